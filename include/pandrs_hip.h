@@ -1,0 +1,279 @@
+/*
+ * pandrs_hip.h — C ABI of libpandrs_hip.so, the MI355X (gfx950) groupby-aggregate /
+ * hash-join engine that sits behind PandRS's GroupBy / agg() / join API.
+ *
+ * The reference (cool-japan/pandrs) exposes NO FFI for this path: the
+ * seams a maintainer would bind are Rust methods.  Every entry point below names the
+ * reference interface it replaces (file:line into the reference tree).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every function returns a pandrs_hip_status (0 = ok); on failure a thread-local
+ *     message is available from pandrs_hip_last_error().  Nothing panics/aborts
+ *     across the ABI (reference: Result<T, pandrs::Error>, src/core/error.rs:6).
+ *   - `mem_space` says where the caller's column / output pointers live:
+ *     PANDRS_HIP_MEM_HOST (library stages H2D/D2H itself) or PANDRS_HIP_MEM_DEVICE
+ *     (pointers are HBM addresses on the context's device; nothing crosses PCIe).
+ *   - caller pointers are never retained past return (reference columns are Arc<[T]>
+ *     borrowed for the call, src/column/int64_column.rs:52-56).
+ *   - a context owns one HIP stream and a workspace arena; calls on ONE context are
+ *     serialised by an internal mutex, distinct contexts run concurrently
+ *     (reference re-entrancy requirement: tests/concurrency_test.rs:351-398).
+ *   - null masks are LSB-first bitmaps, bit = 1 => null (src/core/column.rs:163-177),
+ *     may be NULL (= no nulls).
+ */
+#ifndef PANDRS_HIP_H
+#define PANDRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANDRS_HIP_ABI_VERSION 1
+
+/* status codes; the names map onto pandrs::Error variants (src/core/error.rs) */
+typedef enum pandrs_hip_status {
+    PANDRS_HIP_OK = 0,
+    PANDRS_HIP_ERR_INVALID_ARGUMENT = 1,   /* Error::InvalidInput / ColumnNotFound at the shim */
+    PANDRS_HIP_ERR_TYPE_MISMATCH = 2,      /* Error::ColumnTypeMismatch (join.rs:98-104) */
+    PANDRS_HIP_ERR_OPERATION_FAILED = 3,   /* Error::OperationFailed (aggregation.rs:744-752, lazy.rs:377-382) */
+    PANDRS_HIP_ERR_COMPUTATION = 4,        /* Error::Computation(String) — device failures (src/gpu/mod.rs:206-210) */
+    PANDRS_HIP_ERR_OUT_OF_MEMORY = 5,
+    PANDRS_HIP_ERR_NOT_INITIALIZED = 6
+} pandrs_hip_status;
+
+/* column element types.  Layouts are the reference's own:
+ *   I64      Int64Column.data   Arc<[i64]>  (src/column/int64_column.rs:52-56)
+ *   F64      Float64Column.data Arc<[f64]>  (src/column/float64_column.rs:9-13)
+ *   U32CODE  StringColumn.indices Arc<[u32]> — global string-pool codes, equal string
+ *            <=> equal code (src/column/string_column.rs:26-32, string_pool.rs:28-53)
+ *   BOOLBITS BooleanColumn.data BitMask, LSB-first packed (src/column/boolean_column.rs:10-15) */
+typedef enum pandrs_hip_dtype {
+    PANDRS_HIP_I64 = 0,
+    PANDRS_HIP_F64 = 1,
+    PANDRS_HIP_U32CODE = 2,
+    PANDRS_HIP_BOOLBITS = 3
+} pandrs_hip_dtype;
+
+/* AggregateOp, same order as src/optimized/split_dataframe/group/types.rs:11-34 */
+typedef enum pandrs_hip_agg_op {
+    PANDRS_HIP_AGG_SUM = 0,
+    PANDRS_HIP_AGG_MEAN = 1,
+    PANDRS_HIP_AGG_MIN = 2,
+    PANDRS_HIP_AGG_MAX = 3,
+    PANDRS_HIP_AGG_COUNT = 4,
+    PANDRS_HIP_AGG_STD = 5,
+    PANDRS_HIP_AGG_VAR = 6,
+    PANDRS_HIP_AGG_MEDIAN = 7,
+    PANDRS_HIP_AGG_FIRST = 8,
+    PANDRS_HIP_AGG_LAST = 9,
+    PANDRS_HIP_AGG_CUSTOM = 10   /* always PANDRS_HIP_ERR_OPERATION_FAILED (aggregation.rs:744) */
+} pandrs_hip_agg_op;
+
+/* JoinType, src/optimized/split_dataframe/join.rs:11-20 */
+typedef enum pandrs_hip_join_type {
+    PANDRS_HIP_JOIN_INNER = 0,
+    PANDRS_HIP_JOIN_LEFT = 1,
+    PANDRS_HIP_JOIN_RIGHT = 2,
+    PANDRS_HIP_JOIN_OUTER = 3
+} pandrs_hip_join_type;
+
+typedef enum pandrs_hip_mem_space {
+    PANDRS_HIP_MEM_HOST = 0,
+    PANDRS_HIP_MEM_DEVICE = 1
+} pandrs_hip_mem_space;
+
+/* Mirrors GpuConfig (src/gpu/mod.rs:18-44). */
+typedef struct pandrs_hip_config {
+    int32_t enabled;             /* GpuConfig.enabled */
+    int32_t device_id;           /* GpuConfig.device_id */
+    int64_t memory_limit;        /* GpuConfig.memory_limit, bytes; 0 = no limit */
+    int32_t fallback_to_cpu;     /* GpuConfig.fallback_to_cpu — honoured by the CALLER (shim keeps the
+                                    reference CPU path); this library never computes on the CPU */
+    int32_t use_pinned_memory;   /* GpuConfig.use_pinned_memory: pin host staging buffers */
+    int64_t min_size_threshold;  /* GpuConfig.min_size_threshold (default 10_000, src/gpu/mod.rs:41) */
+} pandrs_hip_config;
+
+/* One typed column view.  `data` element type per `dtype`; `null_mask` may be NULL. */
+typedef struct pandrs_hip_column {
+    const void *data;
+    const uint8_t *null_mask;
+    int32_t dtype;      /* pandrs_hip_dtype */
+    int32_t reserved;
+} pandrs_hip_column;
+
+/* One requested aggregate: (index into vals[], op).  Replaces the
+ * (String column, AggregateOp, String alias) triples of GroupBy::aggregate
+ * (aggregation.rs:763-767); alias naming stays on the host side. */
+typedef struct pandrs_hip_agg_spec {
+    int32_t col;
+    int32_t op;         /* pandrs_hip_agg_op */
+} pandrs_hip_agg_spec;
+
+/* Per-call measurements, for the bench (SURVEY.md §8b "pandrs_hip_get_timings"). */
+#define PANDRS_HIP_MAX_PHASES 12
+typedef struct pandrs_hip_timings {
+    double total_ms;                          /* hipEvent time, whole call on the ctx stream */
+    double phase_ms[PANDRS_HIP_MAX_PHASES];   /* per phase, see PANDRS_HIP_PHASE_* */
+    int64_t algorithmic_bytes;                /* SURVEY.md §8d formula for this call */
+    int64_t n_partitions;                     /* radix fan-out chosen */
+    int64_t table_slots;                      /* LDS hash-table slots per partition */
+    int64_t retries;                          /* overflow retries taken */
+    int64_t estimated_groups;
+} pandrs_hip_timings;
+
+enum {
+    PANDRS_HIP_PHASE_STAGE_IN = 0,    /* H2D staging (host mem_space only) */
+    PANDRS_HIP_PHASE_ESTIMATE = 1,    /* sampled cardinality estimate */
+    PANDRS_HIP_PHASE_HISTOGRAM = 2,   /* radix histogram */
+    PANDRS_HIP_PHASE_SCAN = 3,        /* exclusive scan of bucket counts */
+    PANDRS_HIP_PHASE_SCATTER = 4,     /* LDS-staged radix scatter */
+    PANDRS_HIP_PHASE_AGGREGATE = 5,   /* per-partition LDS hash aggregate + compaction */
+    PANDRS_HIP_PHASE_BUILD = 6,       /* join: build side */
+    PANDRS_HIP_PHASE_PROBE = 7,       /* join: probe count + write */
+    PANDRS_HIP_PHASE_GATHER = 8,
+    PANDRS_HIP_PHASE_OTHER = 9
+};
+
+typedef struct pandrs_hip_ctx pandrs_hip_ctx;
+
+/* ---- library lifetime ----------------------------------------------------------------
+ * Replaces init_gpu / get_gpu_manager (src/gpu/mod.rs:214-282).  Idempotent. */
+int32_t pandrs_hip_abi_version(void);
+int32_t pandrs_hip_init(const pandrs_hip_config *cfg /* NULL = defaults */);
+int32_t pandrs_hip_shutdown(void);
+int32_t pandrs_hip_device_count(int32_t *out_count);
+const char *pandrs_hip_last_error(void);
+
+/* ---- contexts (one stream + workspace per context) ------------------------------------ */
+int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx);
+int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *ctx);
+int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *ctx);
+/* Pre-size the workspace arena (bytes) so the first timed call does not pay hipMalloc. */
+int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *ctx, int64_t workspace_bytes);
+/* Tuning knobs: "groups_hint" (0 = estimate), "scatter_staged" (0/1), "partitions" (0 = auto). */
+int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *ctx, const char *name, int64_t value);
+int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
+
+/* ---- groupby-aggregate ------------------------------------------------------------------
+ * Replaces OptimizedDataFrame::group_by(..)?.aggregate(..)
+ *   (src/optimized/split_dataframe/group/grouping.rs:22-115 +
+ *    src/optimized/split_dataframe/group/aggregation.rs:500-871)
+ * and the inline copy in LazyFrame::execute (src/optimized/lazy.rs:186-404).
+ *
+ * Semantics (bit-for-bit the reference's fold rules):
+ *   - a null key is its own group ("NULL", grouping.rs:74); f64 keys: all NaNs one group,
+ *     0.0 != -0.0 (string equality of val.to_string()).
+ *   - every aggregate is an f64; I64 Sum wraps in i64 then casts; Mean of nothing = 0.0;
+ *     Min/Max whose sentinel is unchanged = 0.0; Count = group size INCLUDING nulls;
+ *     Std/Var = two-pass, Bessel; First/Last = value at first/last row, null => 0.0.
+ *   - group order in the output is unspecified (reference: HashMap order).
+ *   - value dtypes: I64 / F64 for numeric ops; Count accepts any dtype; anything else =>
+ *     PANDRS_HIP_ERR_OPERATION_FAILED (aggregation.rs:748).
+ *
+ * Two steps so that outputs are caller-allocated after a size query:
+ *   1. pandrs_hip_groupby_agg computes on the device and keeps the result in the ctx,
+ *      returning n_groups;
+ *   2. pandrs_hip_groupby_fetch copies it out and may be called repeatedly until the next
+ *      compute call on the same ctx.
+ * out_keys[k]     : n_groups 8-byte cells — i64 value / f64 bits / zero-extended u32 code /
+ *                   0-1 for bool.  Stringification stays host-side (aggregation.rs:856-860).
+ * out_key_null[k] : n_groups bytes, 1 = the NULL group (may be NULL pointer to skip).
+ * out_aggs[a]     : n_groups doubles per requested aggregate, in request order.
+ */
+int32_t pandrs_hip_groupby_agg(pandrs_hip_ctx *ctx, int32_t mem_space,
+                               const pandrs_hip_column *keys, int32_t n_keys,
+                               int64_t n_rows,
+                               const pandrs_hip_column *vals, int32_t n_vals,
+                               const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
+                               int64_t *out_n_groups);
+int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                 uint64_t *const *out_keys, uint8_t *const *out_key_null,
+                                 double *const *out_aggs);
+
+/* ---- mergeable partial aggregates (multi-GPU) -----------------------------
+ * pandrs_hip_groupby_partials: same inputs as groupby_agg, but keeps the un-finalised
+ * per-group states (group size, per value column: sum, non-null count, min, max as the
+ * requested ops need) so that partials from several row-range shards can be merged.
+ * pandrs_hip_partials_layout reports how many 8-byte state columns a group carries.
+ * pandrs_hip_partials_split buckets the retained partial rows by owner rank
+ * (hash of key mod n_ranks) and writes them rank-contiguous into caller buffers, ready for
+ * one all-to-all; counts[r] = rows destined to rank r.
+ * pandrs_hip_groupby_merge consumes concatenated partial rows (from all peers), merges
+ * equal keys and finalises the aggregates; fetch with pandrs_hip_groupby_fetch.
+ * Row format of a partial: key cell (8 B), key_null (1 B), then n_state 8-byte cells. */
+int32_t pandrs_hip_groupby_partials(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                    const pandrs_hip_column *keys, int32_t n_keys,
+                                    int64_t n_rows,
+                                    const pandrs_hip_column *vals, int32_t n_vals,
+                                    const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
+                                    int64_t *out_n_groups, int32_t *out_n_state);
+int32_t pandrs_hip_partials_split(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t n_ranks,
+                                  uint64_t *out_keys, uint8_t *out_key_null,
+                                  uint64_t *out_states /* [n_state][n_groups] */,
+                                  int64_t *out_counts /* host, n_ranks */);
+int32_t pandrs_hip_groupby_merge(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t key_dtype,
+                                 const uint64_t *keys, const uint8_t *key_null,
+                                 const uint64_t *states /* [n_state][n_rows] */,
+                                 int64_t n_rows,
+                                 const int32_t *val_dtypes, int32_t n_vals,
+                                 const uint8_t *val_has_nulls,
+                                 const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
+                                 int64_t *out_n_groups);
+
+/* ---- hash join ------------------------------------------------------------------------------
+ * Replaces OptimizedDataFrame::join_impl (src/optimized/split_dataframe/join.rs:76-555) up to
+ * the join_indices vector (:146-224); the column gathers (:286-552) are pandrs_hip_gather_*.
+ * Order contract = the reference's: left rows ascending; for one left row its matches in
+ * ascending right-row order; left/outer misses in place; right/outer unmatched right rows
+ * appended ascending.  Null keys never match and null LEFT keys are dropped even for
+ * left/outer (join.rs:152).  -1 marks the missing side.  dtype mismatch between the two key
+ * columns => PANDRS_HIP_ERR_TYPE_MISMATCH (join.rs:98-104). */
+int32_t pandrs_hip_join_indices(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                const pandrs_hip_column *left_key, int64_t n_left,
+                                const pandrs_hip_column *right_key, int64_t n_right,
+                                int32_t how, int64_t *out_n_rows);
+int32_t pandrs_hip_join_fetch(pandrs_hip_ctx *ctx, int32_t mem_space,
+                              int64_t *out_left_idx, int64_t *out_right_idx);
+
+/* out[i] = idx[i] >= 0 && !null(src, idx[i]) ? src[idx[i]] : fill
+ * (join.rs:296-357: misses and nulls become 0 / 0.0 / "" / false, not nulls). */
+int32_t pandrs_hip_gather_i64(pandrs_hip_ctx *ctx, int32_t mem_space, const int64_t *src,
+                              const uint8_t *src_null_mask, const int64_t *idx, int64_t n,
+                              int64_t fill, int64_t *out);
+int32_t pandrs_hip_gather_f64(pandrs_hip_ctx *ctx, int32_t mem_space, const double *src,
+                              const uint8_t *src_null_mask, const int64_t *idx, int64_t n,
+                              double fill, double *out);
+int32_t pandrs_hip_gather_u32(pandrs_hip_ctx *ctx, int32_t mem_space, const uint32_t *src,
+                              const uint8_t *src_null_mask, const int64_t *idx, int64_t n,
+                              uint32_t fill, uint32_t *out);
+/* bit-packed source (BooleanColumn), byte-per-row output */
+int32_t pandrs_hip_gather_bool(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *src_bits,
+                               const uint8_t *src_null_mask, const int64_t *idx, int64_t n,
+                               uint8_t fill, uint8_t *out);
+
+/* Fused inner join -> groupby(right payload g).sum(left payload v)  (BASELINE config 5):
+ * never materialises the join rows.  Equivalent to inner_join (join.rs:32) followed by
+ * group_by(g).aggregate([(v, Sum)]) (aggregation.rs:763).  Fetch with groupby_fetch. */
+int32_t pandrs_hip_join_groupby_sum(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                    const pandrs_hip_column *left_key,
+                                    const pandrs_hip_column *left_val, int64_t n_left,
+                                    const pandrs_hip_column *right_key,
+                                    const pandrs_hip_column *right_group, int64_t n_right,
+                                    int64_t *out_n_groups);
+
+/* ---- whole-column reductions ----------------------------------------------
+ * Replaces simd_{sum,mean,min,max}_{f64,i64} (src/optimized/jit/simd.rs:9-112) and
+ * Int64Column/Float64Column::{sum,mean,min,max}.  out[0..3] = sum, mean, min, max as f64;
+ * out_count = number of non-null elements.  Empty input: sum 0, mean 0 (simd.rs), min/max
+ * +inf/-inf for f64 and i64::MAX/MIN (as f64) for i64. */
+int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                 const pandrs_hip_column *col, int64_t n,
+                                 double out[4], int64_t *out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANDRS_HIP_H */
