@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE config 2.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the groupby-aggregate hot path over one batch of synthetic rows that are
+already resident in HBM: 100 M rows per GPU, one sparse i64 key column with 1 M groups, four f64
+value columns, sum/mean/min/max over each (16 aggregates).  N > 1 is weak scaling: every rank
+holds its own 100 M-row shard; per step it pre-aggregates locally, exchanges the partial rows
+with ONE all-to-all (RCCL) keyed on hash(key) mod N, and merges the partitions it owns.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def make_shard(torch, n_rows, n_groups, n_cols, seed, device):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    ids = torch.randint(0, n_groups, (n_rows,), device=device, generator=gen, dtype=torch.int64)
+    # bit-mix dense ids to sparse i64 keys: x * 0x9E3779B97F4A7C15 ^ const, wrapping
+    keys = ids * -7046029254386353131 ^ 0x5555AAAA5555AAAA
+    del ids
+    vals = [torch.randn(n_rows, device=device, generator=gen, dtype=torch.float64) * 10 + 100
+            for _ in range(n_cols)]
+    return keys, vals
+
+
+def cpu_baseline(n_sample, n_groups, n_cols, aggs):
+    """The oracle's faithful restatement of the reference path (string keys + HashMap + per-group
+    gather/fold, lazy.rs:186-404), single thread, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(43)
+    ids = rng.integers(0, n_groups, n_sample).astype(np.uint64)
+    keys = (ids * np.uint64(0x9E3779B97F4A7C15) ^ np.uint64(0x5555AAAA5555AAAA)).view(np.int64)
+    vals = [(rng.normal(100, 10, n_sample), None, O.F64) for _ in range(n_cols)]
+    O.lib()
+    t0 = time.perf_counter()
+    O.groupby_agg([(keys, None, O.I64)], n_sample, vals, aggs, faithful=True)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt / 1e6, "unit": "Mrows/s", "cores": 1, "kind": "port",
+            "sample": "%d rows, %d-group key space, %d f64 cols, same 16 aggregates; string-keyed "
+                      "HashMap restatement of lazy.rs:186-404 (oracle_groupby_agg_ref), %.1f s"
+                      % (n_sample, n_groups, n_cols, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--groups", type=int, default=1_000_000)
+    ap.add_argument("--cols", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=6_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import pandrs_amd as pa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    n, g, ncol = args.rows, args.groups, args.cols
+    keys, vals = make_shard(torch, n, g, ncol, 42 + 1 + 1000 * rank, device)
+    aggs = [(c, op) for c in range(ncol) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)]
+    key_cols = [(keys, None, pa.I64)]
+    val_cols = [(v, None, pa.F64) for v in vals]
+    ctx = pa.Context(local_rank)
+
+    if world > 1:
+        from pandrs_amd.dist import DistributedGroupBy
+        dgb = DistributedGroupBy(ctx, dist, device)
+
+        def step():
+            return dgb.groupby_agg(key_cols, n, val_cols, aggs, fetch=False)
+    else:
+        def step():
+            return ctx.groupby_compute(key_cols, n, val_cols, aggs)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    phase_sum, total_kernel_ms, bytes_alg = {}, 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = ctx.timings() if world == 1 else dgb.last_timings
+        total_kernel_ms += t["total_ms"]
+        bytes_alg = t["algorithmic_bytes"]
+        for k, v in t["phase_ms"].items():
+            phase_sum[k] = phase_sum.get(k, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        k = args.steps
+        ms_per_step = dt / k * 1e3
+        dev_ms = total_kernel_ms / k                    # hipEvent time of the pipeline on its stream
+        achieved = bytes_alg / (dev_ms * 1e-3) / 1e9
+        phases = {p: v / k for p, v in sorted(phase_sum.items())}
+        out = {
+            "metric": "Mrows/sec groupby-agg", "value": n * world / (dt / k) / 1e6, "unit": "Mrows/s",
+            "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: %d rows/GPU, 1 sparse i64 key (%d groups), "
+                                   "sum/mean/min/max over %d f64 cols" % (n, g, ncol),
+                       "rows_per_gpu": n, "groups": g, "value_cols": ncol, "aggregates": len(aggs),
+                       "parallelism": "row-range shards + 1 all-to-all of partials" if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes": bytes_alg, "device_ms": dev_ms, "phase_ms": phases,
+                         "note": "whole groupby pipeline (estimate+histogram+scan+scatter+aggregate) "
+                                 "timed with hipEvents on the library stream; B = N(K+8C)+G(K+8A)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

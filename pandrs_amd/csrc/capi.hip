@@ -1,0 +1,236 @@
+// capi.hip — extern "C" surface of libpandrs_hip.so (declarations: include/pandrs_hip.h).
+#include "common.hpp"
+
+#include <atomic>
+
+namespace {
+std::mutex g_mu;
+bool g_inited = false;
+pandrs_hip_config g_cfg{1, 0, 0, 1, 0, 10000};   // GpuConfig defaults, src/gpu/mod.rs:32-44
+}  // namespace
+
+using pandrs::fail;
+
+extern "C" {
+
+int32_t pandrs_hip_abi_version(void) { return PANDRS_HIP_ABI_VERSION; }
+
+const char *pandrs_hip_last_error(void) { return pandrs::last_error().c_str(); }
+
+int32_t pandrs_hip_init(const pandrs_hip_config *cfg) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (cfg) g_cfg = *cfg;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "no HIP device available: %s",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (g_cfg.device_id < 0 || g_cfg.device_id >= n)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", g_cfg.device_id, n);
+    g_inited = true;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_inited = false;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_device_count(int32_t *out_count) {
+    if (!out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null out_count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *out_count = e == hipSuccess ? n : 0;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx) {
+    if (!out_ctx) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null out_ctx");
+    *out_ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!g_inited) {
+            int n = 0;
+            hipError_t e = hipGetDeviceCount(&n);
+            if (e != hipSuccess || n == 0)
+                return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "no HIP device available");
+            g_inited = true;
+        }
+    }
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0) device_id = g_cfg.device_id;
+    if (device_id >= n) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    auto *c = new pandrs_hip_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_bytes = (int)std::min<size_t>(prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin : prop.sharedMemPerBlock, 160 * 1024);
+    if (c->lds_bytes < 64 * 1024) c->lds_bytes = 64 * 1024;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) {
+        HIP_TRY(hipEventCreate(&c->ev_begin[i]));
+        HIP_TRY(hipEventCreate(&c->ev_end[i]));
+    }
+    HIP_TRY(hipEventCreate(&c->ev_call_begin));
+    HIP_TRY(hipEventCreate(&c->ev_call_end));
+    HIP_TRY(hipHostMalloc(&c->pinned, 1 << 16, hipHostMallocDefault));
+    *out_ctx = c;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
+    if (!c) return PANDRS_HIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->work.release(); c->result.release(); c->staging.release();
+    for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
+    (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *c) {
+    if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *c, int64_t workspace_bytes) {
+    if (!c || workspace_bytes < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return c->work.ensure((size_t)workspace_bytes, c->stream);
+}
+
+int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!std::strcmp(name, "groups_hint")) c->opt.groups_hint = value;
+    else if (!std::strcmp(name, "scatter_staged")) c->opt.scatter_staged = value;
+    else if (!std::strcmp(name, "partitions")) c->opt.partitions = value;
+    else return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_get_timings(pandrs_hip_ctx *c, pandrs_hip_timings *out) {
+    if (!c || !out) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
+    std::lock_guard<std::mutex> lock(c->mu);
+    *out = c->timings;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_groupby_agg(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
+                               int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals,
+                               int32_t n_vals, const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
+                               int64_t *out_n_groups) {
+    return pandrs::groupby_entry(ctx, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs,
+                                 false, out_n_groups, nullptr);
+}
+
+int32_t pandrs_hip_groupby_partials(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
+                                    int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals,
+                                    int32_t n_vals, const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
+                                    int64_t *out_n_groups, int32_t *out_n_state) {
+    return pandrs::groupby_entry(ctx, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs,
+                                 true, out_n_groups, out_n_state);
+}
+
+int32_t pandrs_hip_partials_split(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t n_ranks,
+                                  uint64_t *out_keys, uint8_t *out_key_null, uint64_t *out_states,
+                                  int64_t *out_counts) {
+    return pandrs::partials_split_entry(ctx, mem_space, n_ranks, out_keys, out_key_null, out_states, out_counts);
+}
+
+int32_t pandrs_hip_groupby_merge(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t key_dtype,
+                                 const uint64_t *keys, const uint8_t *key_null, const uint64_t *states,
+                                 int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
+                                 const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
+                                 int32_t n_aggs, int64_t *out_n_groups) {
+    return pandrs::groupby_merge_entry(ctx, mem_space, key_dtype, keys, key_null, states, n_rows,
+                                       val_dtypes, n_vals, val_has_nulls, aggs, n_aggs, out_n_groups);
+}
+
+int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t *const *out_keys,
+                                 uint8_t *const *out_key_null, double *const *out_aggs) {
+    if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+    std::lock_guard<std::mutex> lock(c->mu);
+    pandrs::GroupbyResult &r = c->gb;
+    if (!r.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no groupby result retained in this context");
+    if (r.partials) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "context holds partials; use pandrs_hip_partials_split");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t g = (size_t)r.n_groups;
+    if (g == 0) return PANDRS_HIP_OK;
+    hipMemcpyKind kind = mem_space == PANDRS_HIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    for (int k = 0; k < r.n_keys; k++) {
+        if (out_keys && out_keys[k])
+            HIP_TRY(hipMemcpyAsync(out_keys[k], r.keys + (size_t)k * r.cap, g * 8, kind, c->stream));
+        if (out_key_null && out_key_null[k])
+            HIP_TRY(hipMemcpyAsync(out_key_null[k], r.key_null + (size_t)k * r.cap, g, kind, c->stream));
+    }
+    for (int a = 0; a < r.n_aggs; a++)
+        if (out_aggs && out_aggs[a])
+            HIP_TRY(hipMemcpyAsync(out_aggs[a], r.aggs + (size_t)a * r.cap, g * 8, kind, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_join_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *left_key,
+                                int64_t n_left, const pandrs_hip_column *right_key, int64_t n_right,
+                                int32_t how, int64_t *out_n_rows) {
+    return pandrs::join_entry(ctx, mem_space, left_key, n_left, right_key, n_right, how, out_n_rows);
+}
+
+int32_t pandrs_hip_join_fetch(pandrs_hip_ctx *c, int32_t mem_space, int64_t *out_left_idx,
+                              int64_t *out_right_idx) {
+    if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->jn.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no join result retained in this context");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t n = (size_t)c->jn.n_rows;
+    if (n == 0) return PANDRS_HIP_OK;
+    hipMemcpyKind kind = mem_space == PANDRS_HIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (out_left_idx) HIP_TRY(hipMemcpyAsync(out_left_idx, c->jn.left_idx, n * 8, kind, c->stream));
+    if (out_right_idx) HIP_TRY(hipMemcpyAsync(out_right_idx, c->jn.right_idx, n * 8, kind, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_gather_i64(pandrs_hip_ctx *ctx, int32_t mem_space, const int64_t *src,
+                              const uint8_t *m, const int64_t *idx, int64_t n, int64_t fill, int64_t *out) {
+    return pandrs::gather_entry(ctx, mem_space, 0, src, m, idx, n, (uint64_t)fill, out);
+}
+int32_t pandrs_hip_gather_f64(pandrs_hip_ctx *ctx, int32_t mem_space, const double *src,
+                              const uint8_t *m, const int64_t *idx, int64_t n, double fill, double *out) {
+    uint64_t b;
+    std::memcpy(&b, &fill, 8);
+    return pandrs::gather_entry(ctx, mem_space, 0, src, m, idx, n, b, out);
+}
+int32_t pandrs_hip_gather_u32(pandrs_hip_ctx *ctx, int32_t mem_space, const uint32_t *src,
+                              const uint8_t *m, const int64_t *idx, int64_t n, uint32_t fill, uint32_t *out) {
+    return pandrs::gather_entry(ctx, mem_space, 1, src, m, idx, n, fill, out);
+}
+int32_t pandrs_hip_gather_bool(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *src_bits,
+                               const uint8_t *m, const int64_t *idx, int64_t n, uint8_t fill, uint8_t *out) {
+    return pandrs::gather_entry(ctx, mem_space, 2, src_bits, m, idx, n, fill, out);
+}
+
+int32_t pandrs_hip_join_groupby_sum(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *lk,
+                                    const pandrs_hip_column *lv, int64_t nl, const pandrs_hip_column *rk,
+                                    const pandrs_hip_column *rg, int64_t nr, int64_t *out_n_groups) {
+    return pandrs::join_groupby_sum_entry(ctx, mem_space, lk, lv, nl, rk, rg, nr, out_n_groups);
+}
+
+int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col,
+                                 int64_t n, double out[4], int64_t *out_count) {
+    return pandrs::reduce_entry(ctx, mem_space, col, n, out, out_count);
+}
+
+}  // extern "C"

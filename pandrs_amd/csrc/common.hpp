@@ -1,0 +1,197 @@
+// common.hpp — context, workspace arenas, error plumbing for libpandrs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pandrs_hip.h"
+
+namespace pandrs {
+
+// ---- thread-local error string (pandrs_hip_last_error) ---------------------------------------
+inline std::string &last_error() {
+    thread_local std::string e;
+    return e;
+}
+inline int32_t fail(int32_t status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ::pandrs::fail(e__ == hipErrorOutOfMemory ? PANDRS_HIP_ERR_OUT_OF_MEMORY \
+                                                             : PANDRS_HIP_ERR_COMPUTATION, \
+                                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                  __FILE__, __LINE__);                                    \
+    } while (0)
+#define ST_TRY(expr)               \
+    do {                           \
+        int32_t s__ = (expr);      \
+        if (s__) return s__;       \
+    } while (0)
+
+// ---- bump arena over one hipMalloc block -------------------------------------------------------
+// Sized for 288 GB of HBM: one big block per purpose, grown (never shrunk) between calls, so the
+// steady state performs no hipMalloc/hipFree inside a timed call.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+
+    int32_t ensure(size_t bytes, hipStream_t stream) {
+        off = 0;
+        if (bytes <= cap) return 0;
+        if (base) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipFree(base));
+            base = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + (bytes >> 3) + (1u << 20);
+        HIP_TRY(hipMalloc((void **)&base, want));
+        cap = want;
+        return 0;
+    }
+    template <typename T>
+    T *take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        if (off + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += bytes;
+        return p;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = off = 0;
+    }
+};
+
+// ---- retained results --------------------------------------------------------------------------
+struct GroupbyResult {
+    bool valid = false;
+    bool partials = false;      // states retained instead of finalised aggregates
+    int64_t n_groups = 0;
+    int64_t cap = 0;            // row capacity (stride) of the arrays below
+    int n_keys = 0, n_aggs = 0, n_state = 0;
+    int key_dtype = 0;
+    uint64_t *keys = nullptr;   // [n_keys][cap]
+    uint8_t *key_null = nullptr;// [n_keys][cap]
+    double *aggs = nullptr;     // [n_aggs][cap]
+    uint64_t *states = nullptr; // [n_state][cap]  (partials)
+};
+
+struct JoinResult {
+    bool valid = false;
+    int64_t n_rows = 0;
+    int64_t *left_idx = nullptr, *right_idx = nullptr;
+};
+
+struct Options {
+    int64_t groups_hint = 0;     // 0 = estimate from a sample
+    int64_t scatter_staged = 1;  // stage columns through LDS for coalesced partition writes
+    int64_t partitions = 0;      // 0 = auto
+    int64_t agg_threads = 1024;
+};
+
+}  // namespace pandrs
+
+struct pandrs_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    pandrs::Arena work, result, staging;
+    pandrs::Options opt;
+    pandrs_hip_timings timings{};
+    pandrs::GroupbyResult gb;
+    pandrs::JoinResult jn;
+    // phase timing: pairs of events
+    hipEvent_t ev_begin[PANDRS_HIP_MAX_PHASES]{}, ev_end[PANDRS_HIP_MAX_PHASES]{};
+    bool ev_used[PANDRS_HIP_MAX_PHASES]{};
+    hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
+    void *pinned = nullptr;      // small pinned host block for readbacks
+    int lds_bytes = 0;           // usable LDS per workgroup
+    int n_cu = 0;
+};
+
+namespace pandrs {
+
+struct PhaseTimer {
+    pandrs_hip_ctx *c;
+    int phase;
+    PhaseTimer(pandrs_hip_ctx *ctx, int ph) : c(ctx), phase(ph) {
+        if (!c->ev_used[phase]) {
+            (void)hipEventRecord(c->ev_begin[phase], c->stream);
+            c->ev_used[phase] = true;
+        }
+    }
+    ~PhaseTimer() { (void)hipEventRecord(c->ev_end[phase], c->stream); }
+};
+
+inline void timings_begin(pandrs_hip_ctx *c) {
+    std::memset(&c->timings, 0, sizeof c->timings);
+    for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) c->ev_used[i] = false;
+    (void)hipEventRecord(c->ev_call_begin, c->stream);
+}
+inline int32_t timings_end(pandrs_hip_ctx *c) {
+    HIP_TRY(hipEventRecord(c->ev_call_end, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_call_end));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_call_begin, c->ev_call_end));
+    c->timings.total_ms = ms;
+    for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) {
+        if (!c->ev_used[i]) continue;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+        c->timings.phase_ms[i] = ms;
+    }
+    return 0;
+}
+
+// entry points implemented across the .hip files
+int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys,
+                      int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
+                      const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
+                      int64_t *out_n_groups, int32_t *out_n_state);
+int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
+                            const uint64_t *keys, const uint8_t *key_null, const uint64_t *states,
+                            int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
+                            const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
+                            int32_t n_aggs, int64_t *out_n_groups);
+int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
+                             uint64_t *out_keys, uint8_t *out_key_null, uint64_t *out_states,
+                             int64_t *out_counts);
+int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk, int64_t nl,
+                   const pandrs_hip_column *rk, int64_t nr, int32_t how, int64_t *out_n);
+int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk,
+                               const pandrs_hip_column *lv, int64_t nl,
+                               const pandrs_hip_column *rk, const pandrs_hip_column *rg,
+                               int64_t nr, int64_t *out_n_groups);
+int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void *src,
+                     const uint8_t *mask, const int64_t *idx, int64_t n, uint64_t fill_bits,
+                     void *out);
+int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
+                     double out[4], int64_t *out_count);
+
+inline size_t dtype_bytes(int dtype, int64_t n) {
+    switch (dtype) {
+    case PANDRS_HIP_I64: case PANDRS_HIP_F64: return size_t(n) * 8;
+    case PANDRS_HIP_U32CODE: return size_t(n) * 4;
+    default: return size_t((n + 7) / 8);
+    }
+}
+
+}  // namespace pandrs

@@ -1,0 +1,972 @@
+// groupby.hip — radix-partitioned hash aggregate for MI355X (gfx950, wave64).
+//
+// Replaces the reference's group_by + aggregate hot loops
+//   src/optimized/split_dataframe/group/grouping.rs:62-104   (row -> group)
+//   src/optimized/split_dataframe/group/aggregation.rs:500-754 (per-group fold)
+//   src/optimized/lazy.rs:186-404                             (inline copy)
+// which stringify every key and gather per group on one CPU thread.
+//
+// Pipeline (all kernels on the context's stream, inputs/outputs resident in HBM):
+//   estimate  sampled distinct count -> radix fan-out P so a partition's groups fit one LDS table
+//   histogram per-workgroup counts of hash-partition ids (keys only, coalesced 8-byte scan)
+//   scan      exclusive scan, partition-major, -> exact write cursor per (partition, workgroup)
+//   scatter   tile-local counting sort in LDS, then each column is staged through LDS so a
+//             partition's rows leave the CU as contiguous runs (coalesced HBM writes)
+//   aggregate one workgroup per partition: open-addressing key table + per-state arrays in LDS,
+//             native ds_cmpst_b64 / ds_add_f64 / ds_min_u64 / ds_max_u64 / ds_add_u64, then
+//             ballot + prefix-sum compaction of occupied slots into dense output rows, with the
+//             reference's finalisation rules applied in registers.
+// HBM traffic: keys once (histogram) + all columns read/written once (scatter) + read once
+// (aggregate) + outputs.  No MFMA: the path is integer/byte work bounded by HBM.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace pandrs {
+
+constexpr int MAX_SRC = 16;
+constexpr int MAX_STATES = 40;
+constexpr int MAX_AGGS = 64;
+constexpr int MAX_MOVE = 40;
+constexpr int P_MAX = 4096;
+
+constexpr int SC_THREADS = 1024;   // histogram / scatter workgroup
+constexpr int SC_RPT = 8;          // rows per thread per tile
+constexpr int SC_TILE = SC_THREADS * SC_RPT;
+static_assert(SC_TILE <= (1 << 13), "scatter packs the tile position in 13 bits");
+constexpr int AG_THREADS = 1024;   // aggregate workgroup
+
+enum StateKind : int8_t { SK_ADD_F64 = 0, SK_ADD_I64, SK_MIN_F64, SK_MAX_F64, SK_MIN_I64, SK_MAX_I64 };
+
+struct SrcDev {
+    const uint64_t *vals;   // partitioned 8-byte values
+    const uint8_t *valid;   // partitioned validity bytes (1 = valid) or nullptr
+    int8_t kind;            // 0 = f64, 1 = i64
+    int8_t st_add, st_min, st_max, st_nn;  // LDS state indices, -1 = none
+    int8_t pad[3];
+};
+
+struct FinDev {
+    int8_t op, kind, st_add, st_nn, st_min, st_max;
+};
+
+struct MoveDesc {
+    const void *src;
+    void *dst;
+    int kind;   // 0: 8-byte element, 1: null bitmap -> validity byte, 2: byte copy
+    int pad;
+};
+
+// ------------------------------------------------------------------------------------ estimate
+__global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
+                                uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sample) return;
+    int64_t i = s * stride;
+    if (i >= n_rows) return;
+    if (key_is_null(key, i)) return;
+    uint64_t k = key_cell(key, i);
+    if (k == EMPTY_KEY) return;
+    uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+    for (uint32_t probe = 0; probe <= table_mask; probe++) {
+        uint64_t cur = table[slot];
+        if (cur == k) return;
+        if (cur == EMPTY_KEY) {
+            uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { atomicAdd(distinct, 1u); return; }
+            if (old == k) return;
+        }
+        slot = (slot + 1) & table_mask;
+    }
+}
+
+// ------------------------------------------------------------------------------------ histogram
+// Workgroup b owns rows [b*chunk, (b+1)*chunk).  hist is partition-major: hist[p*NB + b].
+__global__ __launch_bounds__(SC_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
+                                                               int64_t chunk, uint32_t P,
+                                                               uint32_t seed, uint32_t *hist) {
+    extern __shared__ uint32_t cnt[];  // P + 1
+    const uint32_t NB = gridDim.x, b = blockIdx.x;
+    for (uint32_t p = threadIdx.x; p <= P; p += SC_THREADS) cnt[p] = 0;
+    __syncthreads();
+    int64_t beg = (int64_t)b * chunk, end = min(beg + chunk, n_rows);
+    for (int64_t i = beg + threadIdx.x; i < end; i += SC_THREADS) {
+        uint32_t p = key_is_null(key, i) ? P : part_of(hash32(key_cell(key, i), seed), P);
+        atomicAdd(&cnt[p], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p <= P; p += SC_THREADS) hist[(size_t)p * NB + b] = cnt[p];
+}
+
+// ------------------------------------------------------------------------------------ scan
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_IPT = 4;
+constexpr int SCAN_SEG = SCAN_THREADS * SCAN_IPT;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_partial_kernel(const uint32_t *in, size_t n,
+                                                                    uint32_t *seg_sum) {
+    __shared__ uint32_t wt[17];
+    size_t base = (size_t)blockIdx.x * SCAN_SEG + (size_t)threadIdx.x * SCAN_IPT;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) if (base + j < n) s += in[base + j];
+    uint32_t total;
+    block_exclusive_scan<SCAN_THREADS>(s, wt, &total);
+    if (threadIdx.x == 0) seg_sum[blockIdx.x] = total;
+}
+// single workgroup: exclusive scan of up to SCAN_SEG segment sums, in place
+__global__ __launch_bounds__(SCAN_THREADS) void scan_top_kernel(uint32_t *seg_sum, uint32_t n_seg) {
+    __shared__ uint32_t wt[17];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_seg; base += SCAN_THREADS) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_seg ? seg_sum[i] : 0u, total;
+        uint32_t ex = block_exclusive_scan<SCAN_THREADS>(v, wt, &total);
+        uint32_t c = carry;
+        if (i < n_seg) seg_sum[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+// out[i] = exclusive prefix; out[n] = grand total (written by the last segment)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t *in, size_t n,
+                                                                  const uint32_t *seg_base,
+                                                                  uint32_t *out) {
+    __shared__ uint32_t wt[17];
+    size_t base = (size_t)blockIdx.x * SCAN_SEG + (size_t)threadIdx.x * SCAN_IPT;
+    uint32_t v[SCAN_IPT], s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) { v[j] = base + j < n ? in[base + j] : 0u; s += v[j]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan<SCAN_THREADS>(s, wt, &total) + seg_base[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+        if (base + j == n - 1) out[n] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------------ scatter
+struct ScatterArgs {
+    KeyDesc key;
+    uint64_t *pkeys;
+    const uint32_t *offsets;   // partition-major exclusive scan of the histogram
+    int64_t n_rows, chunk;
+    uint32_t P, seed;
+    int n_move;
+    MoveDesc mv[MAX_MOVE];
+};
+
+__device__ __forceinline__ uint64_t move_load(const MoveDesc &m, int64_t i) {
+    if (m.kind == 0) return reinterpret_cast<const uint64_t *>(m.src)[i];
+    if (m.kind == 1) return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 0ull : 1ull;
+    return reinterpret_cast<const uint8_t *>(m.src)[i];
+}
+__device__ __forceinline__ void move_store(const MoveDesc &m, uint32_t dst, uint64_t v) {
+    if (m.kind == 0) reinterpret_cast<uint64_t *>(m.dst)[dst] = v;
+    else reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
+}
+
+// LDS: cursor[P+1] | cnt[P+1] | delta[P+1] | wave_tot[32] | pid[TILE] (u16) | stage[TILE] (u64)
+template <bool STAGED>
+__global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t P1 = a.P + 1;
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cnt = cursor + P1;
+    uint32_t *delta = cnt + P1;
+    uint32_t *wave_tot = delta + P1;
+    uint16_t *pid = reinterpret_cast<uint16_t *>(wave_tot + 32);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(
+        (reinterpret_cast<uintptr_t>(pid + SC_TILE) + 15) & ~uintptr_t(15));
+
+    const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t p = tid; p < P1; p += SC_THREADS) cursor[p] = a.offsets[(size_t)p * NB + b];
+    const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
+    // entries of the partition counters each thread scans (contiguous, <= 5 for P <= 4096)
+    const uint32_t ipt = (P1 + SC_THREADS - 1) / SC_THREADS;
+
+    for (int64_t tbase = beg; tbase < end; tbase += SC_TILE) {
+        const uint32_t tile_n = (uint32_t)min<int64_t>(SC_TILE, end - tbase);
+        for (uint32_t p = tid; p < P1; p += SC_THREADS) cnt[p] = 0;
+        __syncthreads();
+        // per row: key cell + packed (partition << 13 | position); 0xFFFFFFFF = past the tile end
+        uint64_t kc[SC_RPT];
+        uint32_t ps[SC_RPT];
+        constexpr uint32_t INVALID = 0xFFFFFFFFu, SPM = (1u << 13) - 1;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = r * SC_THREADS + tid;
+            ps[r] = INVALID;
+            if (j < tile_n) {
+                int64_t i = tbase + j;
+                bool nul = key_is_null(a.key, i);
+                kc[r] = nul ? 0ull : key_cell(a.key, i);
+                uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
+                ps[r] = (p << 13) | atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
+            }
+        }
+        __syncthreads();
+        // exclusive scan of cnt[] -> delta[] (tile-local partition starts)
+        {
+            uint32_t first = tid * ipt, s = 0;
+            for (uint32_t q = 0; q < ipt; q++) if (first + q < P1) s += cnt[first + q];
+            uint32_t ex = block_exclusive_scan<SC_THREADS>(s, wave_tot, nullptr);
+            for (uint32_t q = 0; q < ipt; q++)
+                if (first + q < P1) { delta[first + q] = ex; ex += cnt[first + q]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) if (ps[r] != INVALID) ps[r] += delta[ps[r] >> 13];
+        __syncthreads();
+        // delta[p] := global cursor - tile-local start, so dst = delta[p] + sorted position
+        for (uint32_t p = tid; p < P1; p += SC_THREADS) {
+            uint32_t c = cursor[p];
+            delta[p] = c - delta[p];
+            cursor[p] = c + cnt[p];
+        }
+        __syncthreads();
+
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if (ps[r] != INVALID) { stage[ps[r] & SPM] = kc[r]; pid[ps[r] & SPM] = (uint16_t)(ps[r] >> 13); }
+            __syncthreads();
+            // from here kc[] is dead; dst[] takes its registers
+            uint32_t dst[SC_RPT];
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) {
+                uint32_t j = r * SC_THREADS + tid;
+                if (j < tile_n) { dst[r] = delta[pid[j]] + j; a.pkeys[dst[r]] = stage[j]; }
+            }
+            for (int m = 0; m < a.n_move; m++) {
+                const MoveDesc mv = a.mv[m];
+                uint64_t v[SC_RPT];
+#pragma unroll
+                for (int r = 0; r < SC_RPT; r++)
+                    if (ps[r] != INVALID) v[r] = move_load(mv, tbase + r * SC_THREADS + tid);
+                __syncthreads();   // previous column's linear reads done
+#pragma unroll
+                for (int r = 0; r < SC_RPT; r++) if (ps[r] != INVALID) stage[ps[r] & SPM] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < SC_RPT; r++) {
+                    uint32_t j = r * SC_THREADS + tid;
+                    if (j < tile_n) move_store(mv, dst[r], stage[j]);
+                }
+            }
+            __syncthreads();
+        } else {
+            uint32_t dst[SC_RPT];
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if (ps[r] != INVALID) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); a.pkeys[dst[r]] = kc[r]; }
+            for (int m = 0; m < a.n_move; m++) {
+                const MoveDesc mv = a.mv[m];
+#pragma unroll
+                for (int r = 0; r < SC_RPT; r++)
+                    if (ps[r] != INVALID)
+                        move_store(mv, dst[r], move_load(mv, tbase + r * SC_THREADS + tid));
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ aggregate
+struct AggArgs {
+    const uint64_t *pkeys;
+    const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
+    const int64_t *pgsize;       // merge mode: partitioned group sizes, else nullptr (=1 per row)
+    uint32_t NB, P, T, seed;
+    int n_src, n_states, n_fin, partials;
+    SrcDev src[MAX_SRC];
+    int8_t kinds[MAX_STATES];
+    FinDev fin[MAX_AGGS];
+    // outputs (row capacity = cap)
+    uint64_t *out_keys;
+    uint8_t *out_null;
+    double *out_aggs;            // [n_fin][cap]
+    uint64_t *out_states;        // [1 + n_states][cap] when partials
+    size_t cap;
+    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag
+};
+
+__device__ __forceinline__ uint64_t state_identity(int8_t kind) {
+    switch (kind) {
+    case SK_MIN_F64: return enc_f64(__longlong_as_double(0x7FF0000000000000ll));
+    case SK_MAX_F64: return enc_f64(__longlong_as_double((long long)0xFFF0000000000000ull));
+    case SK_MIN_I64: return enc_i64(INT64_MAX);
+    case SK_MAX_I64: return enc_i64(INT64_MIN);
+    default: return 0ull;   // +0.0 / 0
+    }
+}
+// natural (ABI / partial) representation of an LDS state cell
+__device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
+    switch (kind) {
+    case SK_MIN_F64: case SK_MAX_F64: return (uint64_t)__double_as_longlong(dec_f64(cell));
+    case SK_MIN_I64: case SK_MAX_I64: return (uint64_t)dec_i64(cell);
+    default: return cell;
+    }
+}
+
+// The reference's finalisation of one aggregate from the group's states
+// (aggregation.rs:507-556, :625-674, :743).
+__device__ __forceinline__ double finalize(const FinDev &f, const uint64_t *st, uint32_t stride,
+                                           uint32_t slot, uint64_t gsize) {
+    auto cell = [&](int8_t s) { return st[(size_t)s * stride + slot]; };
+    switch (f.op) {
+    case PANDRS_HIP_AGG_COUNT: return (double)gsize;
+    case PANDRS_HIP_AGG_SUM:
+        return f.kind == 0 ? __longlong_as_double((long long)cell(f.st_add))
+                           : (double)(int64_t)cell(f.st_add);
+    case PANDRS_HIP_AGG_MEAN: {
+        uint64_t nn = f.st_nn >= 0 ? cell(f.st_nn) : gsize;
+        if (nn == 0) return 0.0;
+        double s = f.kind == 0 ? __longlong_as_double((long long)cell(f.st_add))
+                               : (double)(int64_t)cell(f.st_add);
+        return s / (double)nn;
+    }
+    case PANDRS_HIP_AGG_MIN:
+        if (f.kind == 0) {
+            double v = dec_f64(cell(f.st_min));
+            return v == __longlong_as_double(0x7FF0000000000000ll) ? 0.0 : v;
+        } else {
+            int64_t v = dec_i64(cell(f.st_min));
+            return v == INT64_MAX ? 0.0 : (double)v;
+        }
+    case PANDRS_HIP_AGG_MAX:
+        if (f.kind == 0) {
+            double v = dec_f64(cell(f.st_max));
+            return v == __longlong_as_double((long long)0xFFF0000000000000ull) ? 0.0 : v;
+        } else {
+            int64_t v = dec_i64(cell(f.st_max));
+            return v == INT64_MIN ? 0.0 : (double)v;
+        }
+    }
+    return 0.0;
+}
+
+// LDS: keys[T+1] | gsize[T+1] | states[n_states][T+1] | misc
+template <int NSRC>
+__global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t T = a.T, T1 = T + 1, tid = threadIdx.x;
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *gsz = keys + T1;
+    uint64_t *st = gsz + T1;
+    uint32_t *misc = reinterpret_cast<uint32_t *>(st + (size_t)a.n_states * T1);
+    // misc[0..16] wave totals, [20] overflow, [21] sentinel-key-present, [22] output base
+    const uint32_t p = blockIdx.x;
+    const uint32_t beg = a.offsets[(size_t)p * a.NB];
+    const uint32_t end = a.offsets[(size_t)(p + 1) * a.NB];
+    if (beg == end) return;
+    const int nsrc = NSRC > 0 ? NSRC : a.n_src;
+
+    for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
+    for (int k = 0; k < a.n_states; k++) {
+        uint64_t idv = state_identity(a.kinds[k]);
+        for (uint32_t s = tid; s < T1; s += AG_THREADS) st[(size_t)k * T1 + s] = idv;
+    }
+    if (tid < 32) misc[tid] = 0;
+    __syncthreads();
+
+    for (uint32_t i = beg + tid; i < end; i += AG_THREADS) {
+        const uint64_t k = a.pkeys[i];
+        uint64_t v[NSRC > 0 ? NSRC : MAX_SRC];
+        bool ok[NSRC > 0 ? NSRC : MAX_SRC];
+#pragma unroll
+        for (int c = 0; c < (NSRC > 0 ? NSRC : MAX_SRC); c++) {
+            if (c < nsrc) {
+                v[c] = a.src[c].vals ? a.src[c].vals[i] : 0ull;
+                ok[c] = a.src[c].valid ? a.src[c].valid[i] != 0 : true;
+            }
+        }
+        const uint64_t gs = a.pgsize ? (uint64_t)a.pgsize[i] : 1ull;
+        // find-or-insert
+        uint32_t slot;
+        if (k == EMPTY_KEY) {
+            slot = T;
+            misc[21] = 1;
+        } else {
+            slot = slot_of(hash32(k, a.seed), T);
+            uint32_t probe = 0;
+            for (; probe < T; probe++) {
+                uint64_t cur = keys[slot];
+                if (cur == k) break;
+                if (cur == EMPTY_KEY) {
+                    uint64_t old = atomicCAS((unsigned long long *)&keys[slot], EMPTY_KEY, k);
+                    if (old == EMPTY_KEY || old == k) break;
+                }
+                slot = slot + 1 == T ? 0 : slot + 1;
+            }
+            if (probe == T) { misc[20] = 1; continue; }   // table full: host retries with more partitions
+        }
+        atomicAdd((unsigned long long *)&gsz[slot], gs);
+#pragma unroll
+        for (int c = 0; c < (NSRC > 0 ? NSRC : MAX_SRC); c++) {
+            if (c < nsrc && ok[c]) {
+                const SrcDev &s = a.src[c];
+                if (s.st_nn >= 0) atomicAdd((unsigned long long *)&st[(size_t)s.st_nn * T1 + slot], 1ull);
+                if (s.kind == 0) {
+                    double d = __longlong_as_double((long long)v[c]);
+                    if (s.st_add >= 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)s.st_add * T1 + slot]), d);
+                    if (d == d) {   // Rust f64::min/max ignore NaN operands (aggregation.rs:653,:666)
+                        uint64_t e = enc_f64(d);
+                        if (s.st_min >= 0) atomicMin((unsigned long long *)&st[(size_t)s.st_min * T1 + slot], e);
+                        if (s.st_max >= 0) atomicMax((unsigned long long *)&st[(size_t)s.st_max * T1 + slot], e);
+                    }
+                } else {
+                    if (s.st_add >= 0) atomicAdd((unsigned long long *)&st[(size_t)s.st_add * T1 + slot], v[c]);
+                    uint64_t e = enc_i64((int64_t)v[c]);
+                    if (s.st_min >= 0) atomicMin((unsigned long long *)&st[(size_t)s.st_min * T1 + slot], e);
+                    if (s.st_max >= 0) atomicMax((unsigned long long *)&st[(size_t)s.st_max * T1 + slot], e);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
+
+    // ---- compaction: occupied slots -> dense output rows (ballot + prefix sum) ----
+    const bool sentinel = misc[21] != 0;
+    uint32_t mine = 0;
+    for (uint32_t s = tid; s < T1; s += AG_THREADS)
+        mine += (s < T ? keys[s] != EMPTY_KEY : sentinel) ? 1u : 0u;
+    uint32_t total;
+    block_exclusive_scan<AG_THREADS>(mine, misc, &total);
+    if (tid == 0) misc[22] = atomicAdd(&a.counters[0], total);
+    __syncthreads();
+    uint32_t run = misc[22];
+    __syncthreads();
+    const bool null_part = p == a.P;
+    for (uint32_t sbase = 0; sbase < T1; sbase += AG_THREADS) {
+        uint32_t s = sbase + tid;
+        bool occ = s < T1 && (s < T ? keys[s] != EMPTY_KEY : sentinel);
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<AG_THREADS>(occ ? 1u : 0u, misc, &tot);
+        if (occ) {
+            size_t pos = (size_t)run + ex;
+            a.out_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
+            a.out_null[pos] = null_part ? 1 : 0;
+            uint64_t g = gsz[s];
+            if (a.partials) {
+                a.out_states[pos] = g;
+                for (int k = 0; k < a.n_states; k++)
+                    a.out_states[(size_t)(k + 1) * a.cap + pos] =
+                        state_natural(a.kinds[k], st[(size_t)k * T1 + s]);
+            } else {
+                for (int f = 0; f < a.n_fin; f++)
+                    a.out_aggs[(size_t)f * a.cap + pos] = finalize(a.fin[f], st, T1, s, g);
+            }
+        }
+        run += tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+
+struct Plan {
+    int n_src = 0, n_states = 0, n_fin = 0;
+    int src_col[MAX_SRC];          // index into vals[]
+    int8_t src_kind[MAX_SRC];
+    int8_t st_add[MAX_SRC], st_min[MAX_SRC], st_max[MAX_SRC], st_nn[MAX_SRC];
+    int8_t kinds[MAX_STATES];
+    FinDev fin[MAX_AGGS];
+};
+
+// Builds the state layout from (value dtypes, has-null flags, aggregate specs).  The layout is a
+// pure function of these, so shards on different GPUs produce mergeable partials.
+static int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
+                          const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl) {
+    if (n_aggs > MAX_AGGS) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "more than %d aggregates", MAX_AGGS);
+    int src_of[1024];
+    if (n_vals > 1024) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "too many value columns");
+    for (int i = 0; i < n_vals; i++) src_of[i] = -1;
+    auto new_state = [&](int8_t kind) -> int {
+        if (pl.n_states >= MAX_STATES) return -1;
+        pl.kinds[pl.n_states] = kind;
+        return pl.n_states++;
+    };
+    for (int a = 0; a < n_aggs; a++) {
+        int c = aggs[a].col, op = aggs[a].op;
+        if (c < 0 || c >= n_vals) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "aggregate %d: column %d out of range", a, c);
+        FinDev &f = pl.fin[a];
+        f = FinDev{(int8_t)op, 0, -1, -1, -1, -1};
+        if (op == PANDRS_HIP_AGG_COUNT) continue;   // any dtype (aggregation.rs:743)
+        if (op == PANDRS_HIP_AGG_CUSTOM)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                        "Custom aggregation requires a custom function, use aggregate_custom instead");
+        if (op < 0 || op > PANDRS_HIP_AGG_CUSTOM) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad op %d", op);
+        int dt = val_dtypes[c];
+        if (dt != PANDRS_HIP_I64 && dt != PANDRS_HIP_F64)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                        "Aggregation operation %d is not supported for column type %d", op, dt);
+        if (op > PANDRS_HIP_AGG_COUNT)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                        "aggregate op %d (std/var/median/first/last) is not implemented on the device path yet", op);
+        int s = src_of[c];
+        if (s < 0) {
+            if (pl.n_src >= MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregated columns", MAX_SRC);
+            s = src_of[c] = pl.n_src++;
+            pl.src_col[s] = c;
+            pl.src_kind[s] = dt == PANDRS_HIP_F64 ? 0 : 1;
+            pl.st_add[s] = pl.st_min[s] = pl.st_max[s] = pl.st_nn[s] = -1;
+        }
+        const bool f64 = dt == PANDRS_HIP_F64;
+        f.kind = f64 ? 0 : 1;
+        int need = 0;
+        if ((op == PANDRS_HIP_AGG_SUM || op == PANDRS_HIP_AGG_MEAN) && pl.st_add[s] < 0)
+            need = pl.st_add[s] = (int8_t)new_state(f64 ? SK_ADD_F64 : SK_ADD_I64);
+        if (op == PANDRS_HIP_AGG_MEAN && val_has_nulls[c] && pl.st_nn[s] < 0)
+            need = std::min(need, (int)(pl.st_nn[s] = (int8_t)new_state(SK_ADD_I64)));
+        if (op == PANDRS_HIP_AGG_MIN && pl.st_min[s] < 0)
+            need = pl.st_min[s] = (int8_t)new_state(f64 ? SK_MIN_F64 : SK_MIN_I64);
+        if (op == PANDRS_HIP_AGG_MAX && pl.st_max[s] < 0)
+            need = pl.st_max[s] = (int8_t)new_state(f64 ? SK_MAX_F64 : SK_MAX_I64);
+        if (need < 0) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregate states", MAX_STATES);
+        f.st_add = pl.st_add[s]; f.st_nn = pl.st_nn[s]; f.st_min = pl.st_min[s]; f.st_max = pl.st_max[s];
+    }
+    // st_nn may have been created by a later MEAN than an earlier MEAN's FinDev snapshot: refresh
+    for (int a = 0; a < n_aggs; a++) {
+        int c = aggs[a].col;
+        if (aggs[a].op == PANDRS_HIP_AGG_COUNT) continue;
+        int s = src_of[c];
+        pl.fin[a].st_add = pl.st_add[s]; pl.fin[a].st_nn = pl.st_nn[s];
+        pl.fin[a].st_min = pl.st_min[s]; pl.fin[a].st_max = pl.st_max[s];
+    }
+    pl.n_fin = n_aggs;
+    return 0;
+}
+
+// Row source handed to the engine: device pointers only.
+struct RowSource {
+    KeyDesc key;
+    int64_t n_rows = 0;
+    // raw mode: per plan source, the value column and its null bitmap
+    const void *val_data[MAX_SRC]{};
+    const uint8_t *val_null_bits[MAX_SRC]{};
+    // merge mode: partial state columns [1 + n_states][n_rows] (column 0 = group size)
+    const uint64_t *merge_states = nullptr;
+    size_t merge_stride = 0;
+};
+
+static int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out,
+                                  uint32_t *seg) {
+    uint32_t n_seg = (uint32_t)((n + SCAN_SEG - 1) / SCAN_SEG);
+    hipLaunchKernelGGL(scan_partial_kernel, dim3(n_seg), dim3(SCAN_THREADS), 0, c->stream, in, n, seg);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, c->stream, seg, n_seg);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(n_seg), dim3(SCAN_THREADS), 0, c->stream, in, n, seg, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est) {
+    PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
+    const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
+    const int64_t stride = n_rows / n_sample;
+    uint32_t slots = 1;
+    while (slots < 2 * n_sample) slots <<= 1;
+    uint64_t *table = c->work.take<uint64_t>(slots);
+    uint32_t *distinct = c->work.take<uint32_t>(64);
+    if (!table || !distinct) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (estimate)");
+    HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(slots) * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(distinct, 0, 4, c->stream));
+    hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, c->stream,
+                       key, n_rows, stride, n_sample, table, slots - 1, distinct);
+    HIP_TRY(hipGetLastError());
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    HIP_TRY(hipMemcpyAsync(h, distinct, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double d = std::max<uint32_t>(h[0], 1), s = (double)n_sample;
+    double est;
+    if (n_sample == n_rows) est = d;
+    else if (d >= s * 0.98) est = (double)n_rows;                 // (nearly) all distinct in sample
+    else {
+        // uniform-occupancy model d = G (1 - exp(-s/G)); Newton on G
+        double G = d;
+        for (int it = 0; it < 50; it++) {
+            double e = std::exp(-s / G), f = G * (1 - e) - d, fp = 1 - e - (s / G) * e;
+            if (std::fabs(fp) < 1e-12) break;
+            double Gn = G - f / fp;
+            if (!(Gn > 0)) break;
+            if (std::fabs(Gn - G) < 1e-6 * G) { G = Gn; break; }
+            G = Gn;
+        }
+        est = std::min<double>(std::max(G, d), (double)n_rows);
+    }
+    *out_est = (int64_t)est;
+    return 0;
+}
+
+template <typename K>
+static int32_t set_max_lds(K kernel, int bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int n_src, size_t lds) {
+    dim3 grid(a.P + 1), block(AG_THREADS);
+#define LAUNCH_AG(N)                                                                 \
+    case N:                                                                          \
+        (void)set_max_lds(aggregate_kernel<N>, (int)lds);                            \
+        hipLaunchKernelGGL(aggregate_kernel<N>, grid, block, lds, c->stream, a);     \
+        break;
+    switch (n_src) {
+        LAUNCH_AG(1) LAUNCH_AG(2) LAUNCH_AG(3) LAUNCH_AG(4)
+    default:
+        (void)set_max_lds(aggregate_kernel<0>, (int)lds);
+        hipLaunchKernelGGL(aggregate_kernel<0>, grid, block, lds, c->stream, a);
+    }
+#undef LAUNCH_AG
+}
+
+// Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
+static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
+                          bool partials, int n_aggs, int key_dtype) {
+    GroupbyResult &res = c->gb;
+    res = GroupbyResult{};
+    res.n_keys = 1; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;
+    res.key_dtype = key_dtype;
+    const int64_t N = rs.n_rows;
+    if (N == 0) { res.valid = true; return 0; }
+    if (N >= (int64_t(1) << 32) - SC_TILE)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "n_rows %lld exceeds the 2^32 per-call limit", (long long)N);
+
+    // merge mode: every partial state column is its own single-op source
+    const int n_src = merge ? pl.n_states : pl.n_src;
+    if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
+
+    // LDS table geometry
+    const size_t slot_bytes = 16 + 8 * (size_t)pl.n_states;
+    const size_t lds_budget = (size_t)c->lds_bytes - 256;
+    int64_t T = (int64_t)((lds_budget - 128) / slot_bytes) - 1;
+    if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
+    T = std::min<int64_t>(T, 32768);
+
+    int64_t est = c->opt.groups_hint;
+    // workspace upper bound so that one ensure() covers the whole call (incl. retries at P_MAX)
+    const int NBmax = 1024;
+    size_t n_cols8 = 1 + (size_t)n_src + (merge ? 1 : 0);
+    size_t ws = Arena::padded(size_t(1 << 19) * 8) + 4096                     // estimate table
+              + 2 * Arena::padded((size_t(P_MAX + 1) * NBmax + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64)
+              + n_cols8 * Arena::padded(size_t(N) * 8) + (size_t)n_src * Arena::padded(size_t(N)) + (1 << 16);
+    ST_TRY(c->work.ensure(ws, c->stream));
+    if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
+    c->timings.estimated_groups = est;
+
+    int64_t P = c->opt.partitions;
+    if (P <= 0) {
+        P = (int64_t)std::ceil((double)est / ((double)T * 0.45));
+        int64_t p_par = std::min<int64_t>(1024, N / 8192);       // enough workgroups to fill 256 CUs
+        P = std::max<int64_t>(std::max<int64_t>(P, p_par), 1);
+        P = std::min<int64_t>(P, P_MAX);
+    }
+    P = std::min<int64_t>(std::max<int64_t>(P, 1), P_MAX);
+
+    const uint32_t seed = 0x9E3779B9u;
+    for (int attempt = 0;; attempt++) {
+        c->work.off = 0;
+        c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
+        const uint32_t P1 = (uint32_t)P + 1;
+        int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
+        uint32_t NB = (uint32_t)std::min<int64_t>(n_tiles, NBmax);
+        int64_t chunk = ((n_tiles + NB - 1) / NB) * SC_TILE;
+        NB = (uint32_t)((N + chunk - 1) / chunk);
+        size_t M = (size_t)P1 * NB;
+
+        uint32_t *hist = c->work.take<uint32_t>(M + 8);
+        uint32_t *offsets = c->work.take<uint32_t>(M + 8);
+        uint32_t *seg = c->work.take<uint32_t>(SCAN_SEG + 16);
+        uint32_t *counters = c->work.take<uint32_t>(64);
+        uint64_t *pkeys = c->work.take<uint64_t>(N);
+        if (!hist || !offsets || !seg || !counters || !pkeys)
+            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+        if ((M + SCAN_SEG - 1) / SCAN_SEG > SCAN_SEG)
+            return fail(PANDRS_HIP_ERR_COMPUTATION, "histogram too large for the scan");
+        HIP_TRY(hipMemsetAsync(counters, 0, 64 * 4, c->stream));
+
+        // ---- histogram + scan
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_HISTOGRAM);
+            hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(SC_THREADS), P1 * 4, c->stream,
+                               rs.key, N, chunk, (uint32_t)P, seed, hist);
+            HIP_TRY(hipGetLastError());
+        }
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_SCAN);
+            ST_TRY(exclusive_scan_u32(c, hist, M, offsets, seg));
+        }
+
+        // ---- scatter
+        ScatterArgs sa{};
+        sa.key = rs.key; sa.pkeys = pkeys; sa.offsets = offsets; sa.n_rows = N; sa.chunk = chunk;
+        sa.P = (uint32_t)P; sa.seed = seed;
+        AggArgs aa{};
+        int64_t *pgsize = nullptr;
+        if (merge) {
+            pgsize = c->work.take<int64_t>(N);
+            if (!pgsize) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+            sa.mv[sa.n_move++] = MoveDesc{rs.merge_states, pgsize, 0, 0};
+            for (int s = 0; s < pl.n_states; s++) {
+                uint64_t *pv = c->work.take<uint64_t>(N);
+                if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+                sa.mv[sa.n_move++] = MoveDesc{rs.merge_states + (size_t)(s + 1) * rs.merge_stride, pv, 0, 0};
+                SrcDev &sd = aa.src[s];
+                sd = SrcDev{pv, nullptr, 0, -1, -1, -1, -1, {0, 0, 0}};
+                switch (pl.kinds[s]) {
+                case SK_ADD_F64: sd.kind = 0; sd.st_add = (int8_t)s; break;
+                case SK_ADD_I64: sd.kind = 1; sd.st_add = (int8_t)s; break;
+                case SK_MIN_F64: sd.kind = 0; sd.st_min = (int8_t)s; break;
+                case SK_MAX_F64: sd.kind = 0; sd.st_max = (int8_t)s; break;
+                case SK_MIN_I64: sd.kind = 1; sd.st_min = (int8_t)s; break;
+                case SK_MAX_I64: sd.kind = 1; sd.st_max = (int8_t)s; break;
+                }
+            }
+        } else {
+            for (int s = 0; s < pl.n_src; s++) {
+                uint64_t *pv = c->work.take<uint64_t>(N);
+                if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+                sa.mv[sa.n_move++] = MoveDesc{rs.val_data[s], pv, 0, 0};
+                uint8_t *pvalid = nullptr;
+                if (rs.val_null_bits[s]) {
+                    pvalid = c->work.take<uint8_t>(N);
+                    if (!pvalid) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+                    sa.mv[sa.n_move++] = MoveDesc{rs.val_null_bits[s], pvalid, 1, 0};
+                }
+                aa.src[s] = SrcDev{pv, pvalid, pl.src_kind[s], pl.st_add[s], pl.st_min[s], pl.st_max[s],
+                                   pl.st_nn[s], {0, 0, 0}};
+            }
+        }
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_SCATTER);
+            size_t lds = (size_t)P1 * 12 + 32 * 4 + SC_TILE * 2 + 16 + (c->opt.scatter_staged ? SC_TILE * 8 : 0);
+            if (c->opt.scatter_staged) {
+                ST_TRY(set_max_lds(scatter_kernel<true>, (int)lds));
+                hipLaunchKernelGGL(scatter_kernel<true>, dim3(NB), dim3(SC_THREADS), lds, c->stream, sa);
+            } else {
+                ST_TRY(set_max_lds(scatter_kernel<false>, (int)lds));
+                hipLaunchKernelGGL(scatter_kernel<false>, dim3(NB), dim3(SC_THREADS), lds, c->stream, sa);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+
+        // ---- aggregate
+        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 1));
+        size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
+        ST_TRY(c->result.ensure(Arena::padded(cap * 8) + Arena::padded(cap) + out_cols * Arena::padded(cap * 8) + 4096, c->stream));
+        res.cap = (int64_t)cap;
+        res.keys = c->result.take<uint64_t>(cap);
+        res.key_null = c->result.take<uint8_t>(cap);
+        if (partials) res.states = c->result.take<uint64_t>(cap * out_cols + 32);
+        else res.aggs = c->result.take<double>(cap * std::max<size_t>(out_cols, 1) + 32);
+        aa.pkeys = pkeys; aa.offsets = offsets; aa.pgsize = pgsize; aa.NB = NB; aa.P = (uint32_t)P;
+        aa.T = (uint32_t)T; aa.seed = seed; aa.n_src = n_src; aa.n_states = pl.n_states;
+        aa.n_fin = partials ? 0 : n_aggs; aa.partials = partials ? 1 : 0;
+        std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
+        std::memcpy(aa.fin, pl.fin, sizeof aa.fin);
+        aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
+        aa.out_states = res.states; aa.cap = cap; aa.counters = counters;
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
+            size_t lds = (size_t)(T + 1) * slot_bytes + 128;
+            launch_aggregate(c, aa, n_src, lds);
+            HIP_TRY(hipGetLastError());
+        }
+        uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+        HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[1] == 0) { res.n_groups = h[0]; res.valid = true; return 0; }
+        if (P >= P_MAX)
+            return fail(PANDRS_HIP_ERR_COMPUTATION,
+                        "group cardinality exceeds the single-level radix capacity (%d partitions x %lld slots)",
+                        P_MAX, (long long)T);
+        P = std::min<int64_t>(P * 4, P_MAX);
+    }
+}
+
+// ---- staging helpers (host mem_space) -----------------------------------------------------------
+struct Stager {
+    pandrs_hip_ctx *c;
+    int32_t space;
+    int32_t status = 0;
+    // copies `bytes` from a caller pointer into the staging arena when it lives on the host
+    const void *in(const void *p, size_t bytes) {
+        if (!p || space == PANDRS_HIP_MEM_DEVICE || status) return p;
+        void *d = c->staging.take<uint8_t>(bytes + 16);
+        if (!d) { status = fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small"); return nullptr; }
+        hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) status = fail(PANDRS_HIP_ERR_COMPUTATION, "H2D copy failed: %s", hipGetErrorString(e));
+        return d;
+    }
+};
+
+static int32_t check_cols(const pandrs_hip_column *cols, int n, const char *what) {
+    for (int i = 0; i < n; i++) {
+        if (cols[i].dtype < PANDRS_HIP_I64 || cols[i].dtype > PANDRS_HIP_BOOLBITS)
+            return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "%s column %d: bad dtype %d", what, i, cols[i].dtype);
+    }
+    return 0;
+}
+
+int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys,
+                      int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
+                      const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
+                      int64_t *out_n_groups, int32_t *out_n_state) {
+    if (!c || !out_n_groups || n_rows < 0 || n_keys < 1 || n_vals < 0 || n_aggs < 0 || !keys ||
+        (n_vals && !vals) || (n_aggs && !aggs))
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby: bad arguments");
+    if (n_keys != 1)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                    "multi-key groupby is not on the device path yet (pack the keys host-side)");
+    ST_TRY(check_cols(keys, n_keys, "key"));
+    ST_TRY(check_cols(vals, n_vals, "value"));
+    if (n_rows > 0) {
+        if (!keys[0].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column has no data");
+    }
+    std::vector<int32_t> dts(std::max(n_vals, 1));
+    std::vector<uint8_t> hn(std::max(n_vals, 1));
+    for (int i = 0; i < n_vals; i++) { dts[i] = vals[i].dtype; hn[i] = vals[i].null_mask != nullptr; }
+    Plan pl;
+    ST_TRY(build_plan(dts.data(), hn.data(), n_vals, aggs, n_aggs, pl));
+
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    RowSource rs;
+    rs.n_rows = n_rows;
+    Stager stg{c, mem_space};
+    if (mem_space == PANDRS_HIP_MEM_HOST && n_rows > 0) {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        size_t need = dtype_bytes(keys[0].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
+        for (int s = 0; s < pl.n_src; s++) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
+        ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
+    }
+    rs.key = KeyDesc{stg.in(keys[0].data, dtype_bytes(keys[0].dtype, n_rows)),
+                     (const uint8_t *)stg.in(keys[0].null_mask, (n_rows + 7) / 8), nullptr, keys[0].dtype};
+    for (int s = 0; s < pl.n_src; s++) {
+        const pandrs_hip_column &v = vals[pl.src_col[s]];
+        if (n_rows > 0 && !v.data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "value column %d has no data", pl.src_col[s]);
+        rs.val_data[s] = stg.in(v.data, size_t(n_rows) * 8);
+        rs.val_null_bits[s] = (const uint8_t *)stg.in(v.null_mask, (n_rows + 7) / 8);
+    }
+    if (stg.status) return stg.status;
+    ST_TRY(run_engine(c, rs, pl, /*merge=*/false, partials, n_aggs, keys[0].dtype));
+    // B = N (K + 8 C) + G (K + 8 A) (+ N/8 per masked column)
+    {
+        int64_t K = keys[0].dtype == PANDRS_HIP_U32CODE ? 4 : (keys[0].dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
+        int64_t b = n_rows * (K + 8 * (int64_t)pl.n_src) + c->gb.n_groups * (K + 8 * (int64_t)n_aggs);
+        if (keys[0].null_mask) b += n_rows / 8;
+        for (int s = 0; s < pl.n_src; s++) if (rs.val_null_bits[s]) b += n_rows / 8;
+        c->timings.algorithmic_bytes = b;
+    }
+    ST_TRY(timings_end(c));
+    *out_n_groups = c->gb.n_groups;
+    if (out_n_state) *out_n_state = c->gb.n_state;
+    return 0;
+}
+
+int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
+                            const uint64_t *keys, const uint8_t *key_null, const uint64_t *states,
+                            int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
+                            const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
+                            int32_t n_aggs, int64_t *out_n_groups) {
+    if (!c || !out_n_groups || n_rows < 0 || (n_rows && (!keys || !states)) || n_vals < 0 || n_aggs < 0)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_merge: bad arguments");
+    Plan pl;
+    ST_TRY(build_plan(val_dtypes, val_has_nulls, n_vals, aggs, n_aggs, pl));
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    Stager stg{c, mem_space};
+    size_t n_state = 1 + (size_t)pl.n_states;
+    if (mem_space == PANDRS_HIP_MEM_HOST && n_rows > 0)
+        ST_TRY(c->staging.ensure(size_t(n_rows) * (9 + 8 * n_state) + (1 << 16), c->stream));
+    RowSource rs;
+    rs.n_rows = n_rows;
+    rs.key = KeyDesc{stg.in(keys, size_t(n_rows) * 8), nullptr,
+                     (const uint8_t *)stg.in(key_null, size_t(n_rows)), DT_CELL};
+    rs.merge_states = (const uint64_t *)stg.in(states, size_t(n_rows) * 8 * n_state);
+    rs.merge_stride = (size_t)n_rows;
+    if (stg.status) return stg.status;
+    ST_TRY(run_engine(c, rs, pl, /*merge=*/true, /*partials=*/false, n_aggs, key_dtype));
+    c->timings.algorithmic_bytes = n_rows * (int64_t)(9 + 8 * n_state) + c->gb.n_groups * (8 + 8 * (int64_t)n_aggs);
+    ST_TRY(timings_end(c));
+    *out_n_groups = c->gb.n_groups;
+    return 0;
+}
+
+// ---- partial split for the all-to-all -------------------------------------------------------------
+__global__ void owner_count_kernel(const uint64_t *keys, const uint8_t *knull, int64_t n,
+                                   uint32_t n_ranks, uint32_t *counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = knull[i] ? 0u : owner_of(keys[i], n_ranks);
+    atomicAdd(&counts[r], 1u);
+}
+__global__ void owner_scatter_kernel(const uint64_t *keys, const uint8_t *knull,
+                                     const uint64_t *states, size_t in_stride, int n_state, int64_t n,
+                                     uint32_t n_ranks, uint32_t *cursors, uint64_t *out_keys,
+                                     uint8_t *out_null, uint64_t *out_states, size_t out_stride) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = knull[i] ? 0u : owner_of(keys[i], n_ranks);
+    uint32_t d = atomicAdd(&cursors[r], 1u);
+    out_keys[d] = keys[i];
+    out_null[d] = knull[i];
+    for (int s = 0; s < n_state; s++) out_states[(size_t)s * out_stride + d] = states[(size_t)s * in_stride + i];
+}
+
+int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
+                             uint64_t *out_keys, uint8_t *out_key_null, uint64_t *out_states,
+                             int64_t *out_counts) {
+    if (!c || n_ranks < 1 || n_ranks > 1024 || !out_counts)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "partials_split: bad arguments");
+    std::lock_guard<std::mutex> lock(c->mu);
+    GroupbyResult &res = c->gb;
+    if (!res.valid || !res.partials) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no partials retained in this context");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = res.n_groups;
+    for (int r = 0; r < n_ranks; r++) out_counts[r] = 0;
+    if (n == 0) return 0;
+    if (!out_keys || !out_key_null || !out_states) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null output");
+    c->work.off = 0;
+    size_t need = 4096 + (mem_space == PANDRS_HIP_MEM_HOST ? Arena::padded(n * 8) + Arena::padded(n) + Arena::padded(size_t(n) * 8 * res.n_state) : 0);
+    if (c->work.cap < need) ST_TRY(c->work.ensure(need, c->stream));
+    uint32_t *counts = c->work.take<uint32_t>(2048);
+    uint32_t *cursors = counts + 1024;
+    HIP_TRY(hipMemsetAsync(counts, 0, 2048 * 4, c->stream));
+    unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(owner_count_kernel, dim3(grid), dim3(256), 0, c->stream, res.keys, res.key_null, n,
+                       (uint32_t)n_ranks, counts);
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    HIP_TRY(hipMemcpyAsync(h, counts, n_ranks * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t run = 0;
+    for (int r = 0; r < n_ranks; r++) { out_counts[r] = h[r]; uint32_t t = h[r]; h[r] = run; run += t; }
+    HIP_TRY(hipMemcpyAsync(cursors, h, n_ranks * 4, hipMemcpyHostToDevice, c->stream));
+    uint64_t *dk = out_keys; uint8_t *dn = out_key_null; uint64_t *ds = out_states;
+    if (mem_space == PANDRS_HIP_MEM_HOST) {
+        dk = c->work.take<uint64_t>(n); dn = c->work.take<uint8_t>(n); ds = c->work.take<uint64_t>(size_t(n) * res.n_state);
+        if (!dk || !dn || !ds) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+    }
+    hipLaunchKernelGGL(owner_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, res.keys, res.key_null,
+                       res.states, (size_t)res.cap, res.n_state, n, (uint32_t)n_ranks, cursors, dk, dn, ds, (size_t)n);
+    HIP_TRY(hipGetLastError());
+    if (mem_space == PANDRS_HIP_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out_keys, dk, n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_key_null, dn, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_states, ds, size_t(n) * 8 * res.n_state, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace pandrs

@@ -1,0 +1,294 @@
+"""Thin host wrapper over the C ABI: one `Context` = one HIP stream + workspace on one GPU.
+
+Columns are `(data, null_mask, dtype)` triples.  `data`/`null_mask` are either numpy arrays
+(host memory: the library stages them over PCIe) or torch CUDA tensors (device memory: nothing
+leaves HBM).  torch is used only as the device allocator; no torch op is on the compute path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_NP_OF = {L.I64: np.int64, L.F64: np.float64, L.U32CODE: np.uint32, L.BOOLBITS: np.uint8}
+
+
+class PandrsHipError(RuntimeError):
+    """Maps onto pandrs::Error (reference src/core/error.rs): .status is the C status code."""
+
+    def __init__(self, status, message):
+        super().__init__("[status %d] %s" % (status, message))
+        self.status = status
+        self.message = message
+
+
+class ColumnTypeMismatch(PandrsHipError):
+    pass
+
+
+class OperationFailed(PandrsHipError):
+    pass
+
+
+def _raise(status):
+    msg = L.last_error()
+    if status == L.ERR_TYPE_MISMATCH:
+        raise ColumnTypeMismatch(status, msg)
+    if status == L.ERR_OPERATION_FAILED:
+        raise OperationFailed(status, msg)
+    raise PandrsHipError(status, msg)
+
+
+def _is_torch(x):
+    return x is not None and type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        st = self.lib.pandrs_hip_ctx_create(int(device), C.byref(h))
+        if st:
+            _raise(st)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pandrs_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _cols(self, cols, keep):
+        arr = (L.Column * max(len(cols), 1))()
+        space = None
+        for i, (data, mask, dt) in enumerate(cols):
+            if _is_torch(data):
+                sp = L.MEM_DEVICE
+                if not data.is_contiguous():
+                    data = data.contiguous()
+                if mask is not None and not _is_torch(mask):
+                    raise ValueError("device column with a host null mask")
+            else:
+                sp = L.MEM_HOST
+                data = np.ascontiguousarray(data, dtype=_NP_OF[dt])
+                if mask is not None:
+                    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            if space is None:
+                space = sp
+            elif space != sp:
+                raise ValueError("columns of one call must all be host or all device")
+            keep.extend([data, mask])
+            arr[i].data = _ptr(data)
+            arr[i].null_mask = _ptr(mask)
+            arr[i].dtype = int(dt)
+        return arr, (space if space is not None else L.MEM_HOST)
+
+    @staticmethod
+    def _aggs(aggs):
+        arr = (L.AggSpec * max(len(aggs), 1))()
+        for i, (c, op) in enumerate(aggs):
+            arr[i].col, arr[i].op = int(c), int(op)
+        return arr
+
+    def set_option(self, name, value):
+        st = self.lib.pandrs_hip_ctx_set_option(self.h, name.encode(), int(value))
+        if st:
+            _raise(st)
+
+    def reserve(self, nbytes):
+        st = self.lib.pandrs_hip_ctx_reserve(self.h, int(nbytes))
+        if st:
+            _raise(st)
+
+    def timings(self):
+        t = L.Timings()
+        st = self.lib.pandrs_hip_get_timings(self.h, C.byref(t))
+        if st:
+            _raise(st)
+        return {
+            "total_ms": t.total_ms,
+            "phase_ms": {L.PHASE_NAMES[i]: t.phase_ms[i] for i in range(L.MAX_PHASES)
+                         if L.PHASE_NAMES[i] and t.phase_ms[i] > 0},
+            "algorithmic_bytes": t.algorithmic_bytes, "n_partitions": t.n_partitions,
+            "table_slots": t.table_slots, "retries": t.retries,
+            "estimated_groups": t.estimated_groups,
+        }
+
+    # -- groupby -----------------------------------------------------------------------------------
+    def groupby_compute(self, keys, n_rows, vals, aggs):
+        """Runs the device pipeline and keeps the result in the context.  -> n_groups."""
+        keep = []
+        kc, sp1 = self._cols(keys, keep)
+        vc, sp2 = self._cols(vals, keep) if vals else ((L.Column * 1)(), sp1)
+        if vals and sp1 != sp2:
+            raise ValueError("keys and values must live in the same memory space")
+        ng = C.c_int64(0)
+        st = self.lib.pandrs_hip_groupby_agg(self.h, sp1, kc, len(keys), int(n_rows), vc, len(vals),
+                                             self._aggs(aggs), len(aggs), C.byref(ng))
+        if st:
+            _raise(st)
+        self._last = (len(keys), len(aggs), sp1, ng.value)
+        return ng.value
+
+    def groupby_fetch(self, to_device=None):
+        """-> (key_cells[n_keys, G] u64, key_null[n_keys, G] u8, aggs[n_aggs, G] f64)."""
+        n_keys, n_aggs, space, g = self._last
+        dev = space == L.MEM_DEVICE if to_device is None else to_device
+        if dev:
+            import torch
+            d = "cuda:%d" % self.device
+            kc = torch.empty((n_keys, g), dtype=torch.int64, device=d)
+            kn = torch.empty((n_keys, g), dtype=torch.uint8, device=d)
+            oa = torch.empty((n_aggs, g), dtype=torch.float64, device=d)
+            row = lambda t, i: t[i].data_ptr()
+        else:
+            kc = np.empty((n_keys, g), np.uint64)
+            kn = np.empty((n_keys, g), np.uint8)
+            oa = np.empty((n_aggs, g), np.float64)
+            row = lambda t, i: t[i].ctypes.data
+        pk = (C.c_void_p * max(n_keys, 1))(*[row(kc, i) for i in range(n_keys)])
+        pn = (C.c_void_p * max(n_keys, 1))(*[row(kn, i) for i in range(n_keys)])
+        pa = (C.c_void_p * max(n_aggs, 1))(*[row(oa, i) for i in range(n_aggs)])
+        st = self.lib.pandrs_hip_groupby_fetch(self.h, L.MEM_DEVICE if dev else L.MEM_HOST, pk, pn, pa)
+        if st:
+            _raise(st)
+        return kc, kn, oa
+
+    def groupby_agg(self, keys, n_rows, vals, aggs):
+        self.groupby_compute(keys, n_rows, vals, aggs)
+        return self.groupby_fetch()
+
+    # -- mergeable partials (multi-GPU) --------------------------------------------------------------
+    def groupby_partials(self, keys, n_rows, vals, aggs):
+        """-> (n_groups, n_state); partial rows stay in the context until partials_split."""
+        keep = []
+        kc, sp1 = self._cols(keys, keep)
+        vc, _ = self._cols(vals, keep) if vals else ((L.Column * 1)(), sp1)
+        ng, ns = C.c_int64(0), C.c_int32(0)
+        st = self.lib.pandrs_hip_groupby_partials(self.h, sp1, kc, len(keys), int(n_rows), vc, len(vals),
+                                                  self._aggs(aggs), len(aggs), C.byref(ng), C.byref(ns))
+        if st:
+            _raise(st)
+        self._last_partials = (ng.value, ns.value, sp1)
+        return ng.value, ns.value
+
+    def partials_split(self, n_ranks, device=None):
+        """Buckets the retained partial rows by owner rank.
+        -> (keys[G] , key_null[G], states[n_state, G], counts[n_ranks])  rank-contiguous."""
+        g, ns, space = self._last_partials
+        dev = space == L.MEM_DEVICE if device is None else device
+        counts = (C.c_int64 * n_ranks)()
+        if dev:
+            import torch
+            d = "cuda:%d" % self.device
+            k = torch.empty(g, dtype=torch.int64, device=d)
+            kn = torch.empty(g, dtype=torch.uint8, device=d)
+            s = torch.empty((ns, g), dtype=torch.int64, device=d)
+        else:
+            k = np.empty(g, np.uint64)
+            kn = np.empty(g, np.uint8)
+            s = np.empty((ns, g), np.uint64)
+        st = self.lib.pandrs_hip_partials_split(self.h, L.MEM_DEVICE if dev else L.MEM_HOST, n_ranks,
+                                                _ptr(k), _ptr(kn), _ptr(s), counts)
+        if st:
+            _raise(st)
+        return k, kn, s, [int(c) for c in counts]
+
+    def groupby_merge(self, key_dtype, keys, key_null, states, n_rows, val_dtypes, val_has_nulls, aggs):
+        dev = _is_torch(keys)
+        if not dev:
+            keys = np.ascontiguousarray(keys, np.uint64)
+            key_null = np.ascontiguousarray(key_null, np.uint8)
+            states = np.ascontiguousarray(states, np.uint64)
+        else:
+            keys, key_null, states = keys.contiguous(), key_null.contiguous(), states.contiguous()
+        nv = len(val_dtypes)
+        vd = (C.c_int32 * max(nv, 1))(*[int(x) for x in val_dtypes])
+        vh = (C.c_uint8 * max(nv, 1))(*[1 if x else 0 for x in val_has_nulls])
+        ng = C.c_int64(0)
+        st = self.lib.pandrs_hip_groupby_merge(self.h, L.MEM_DEVICE if dev else L.MEM_HOST, int(key_dtype),
+                                               _ptr(keys), _ptr(key_null), _ptr(states), int(n_rows),
+                                               vd, nv, vh, self._aggs(aggs), len(aggs), C.byref(ng))
+        if st:
+            _raise(st)
+        self._last = (1, len(aggs), L.MEM_DEVICE if dev else L.MEM_HOST, ng.value)
+        return ng.value
+
+    # -- join --------------------------------------------------------------------------------------------
+    def join_indices(self, lkey, n_left, rkey, n_right, how):
+        keep = []
+        lc, sp1 = self._cols([lkey], keep)
+        rc, sp2 = self._cols([rkey], keep)
+        if sp1 != sp2:
+            raise ValueError("both key columns must live in the same memory space")
+        n = C.c_int64(0)
+        st = self.lib.pandrs_hip_join_indices(self.h, sp1, lc, int(n_left), rc, int(n_right), int(how), C.byref(n))
+        if st:
+            _raise(st)
+        n = n.value
+        if sp1 == L.MEM_DEVICE:
+            import torch
+            d = "cuda:%d" % self.device
+            li = torch.empty(n, dtype=torch.int64, device=d)
+            ri = torch.empty(n, dtype=torch.int64, device=d)
+        else:
+            li, ri = np.empty(n, np.int64), np.empty(n, np.int64)
+        st = self.lib.pandrs_hip_join_fetch(self.h, sp1, _ptr(li), _ptr(ri))
+        if st:
+            _raise(st)
+        return li, ri
+
+    def gather(self, src, mask, idx, fill, dtype):
+        """Device tensors only.  -> torch tensor (uint8 per row for BOOLBITS sources)."""
+        import torch
+        n = idx.numel()
+        d = idx.device
+        fn, out = {
+            L.I64: (self.lib.pandrs_hip_gather_i64, torch.empty(n, dtype=torch.int64, device=d)),
+            L.F64: (self.lib.pandrs_hip_gather_f64, torch.empty(n, dtype=torch.float64, device=d)),
+            L.U32CODE: (self.lib.pandrs_hip_gather_u32, torch.empty(n, dtype=torch.int32, device=d)),
+            L.BOOLBITS: (self.lib.pandrs_hip_gather_bool, torch.empty(n, dtype=torch.uint8, device=d)),
+        }[dtype]
+        fill = float(fill) if dtype == L.F64 else int(fill)
+        st = fn(self.h, L.MEM_DEVICE, _ptr(src), _ptr(mask), _ptr(idx), n, fill, _ptr(out))
+        if st:
+            _raise(st)
+        return out
+
+    def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
+        keep = []
+        a, sp = self._cols([lkey], keep)
+        b, _ = self._cols([lval], keep)
+        c, _ = self._cols([rkey], keep)
+        d, _ = self._cols([rgroup], keep)
+        ng = C.c_int64(0)
+        st = self.lib.pandrs_hip_join_groupby_sum(self.h, sp, a, b, int(n_left), c, d, int(n_right), C.byref(ng))
+        if st:
+            _raise(st)
+        self._last = (1, 1, sp, ng.value)
+        return self.groupby_fetch()
+
+    def reduce_column(self, col, n):
+        keep = []
+        cc, sp = self._cols([col], keep)
+        out = (C.c_double * 4)()
+        cnt = C.c_int64(0)
+        st = self.lib.pandrs_hip_reduce_column(self.h, sp, cc, int(n), out, C.byref(cnt))
+        if st:
+            _raise(st)
+        return np.array(list(out)), cnt.value

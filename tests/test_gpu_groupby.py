@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, against the reference's golden vectors, and — at BASELINE scale — through
+size-independent properties.  Tolerances: keys / counts / min / max bit-exact; f64 sums and means
+within 1e-9 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import assert_groupby_equal, codes_of
+
+pytestmark = pytest.mark.gpu
+
+OPS = {"sum": O.SUM, "mean": O.MEAN, "min": O.MIN, "max": O.MAX, "count": O.COUNT}
+FIVE = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT)]
+EXACT5 = (2, 3, 4)      # min, max, count rows of FIVE are bit-exact
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import pandrs_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def sparse_keys(rng, n, g):
+    """keys uniform over g groups, bit-mixed to sparse i64."""
+    ids = rng.integers(0, g, n).astype(np.uint64)
+    return (ids * np.uint64(0x9E3779B97F4A7C15) ^ np.uint64(0x5555AAAA5555AAAA)).view(np.int64)
+
+
+def check(ctx, keys, n, vals, aggs, key_dtypes, exact=(), rtol=1e-9):
+    got = ctx.groupby_agg(keys, n, vals, aggs)
+    want = O.groupby_agg(keys, n, vals, aggs)
+    assert_groupby_equal(got, want, key_dtypes, int_exact_rows=exact, rtol=rtol)
+    return got
+
+
+def test_golden_known_answers(ctx, golden):
+    for case in golden["groupby"]:
+        if "key_strings" in case:
+            codes, pool = codes_of(case["key_strings"])
+            key = (codes, None, O.U32CODE)
+            name_of = lambda cell: pool[int(cell)]
+        else:
+            key = (np.array(case["key_i64"], np.int64), None, O.I64)
+            name_of = lambda cell: str(int(np.int64(np.uint64(cell))))
+        n = len(key[0])
+        if "values_i64" in case:
+            val = (np.array(case["values_i64"], np.int64), None, O.I64)
+        else:
+            mask = O.pack_mask(case["value_nulls"]) if "value_nulls" in case else None
+            val = (np.array(case["values_f64"], np.float64), mask, O.F64)
+        ops = sorted({op for e in case["expect"].values() for op in e if op in OPS})
+        kc, kn, oa = ctx.groupby_agg([key], n, [val], [(0, OPS[o]) for o in ops])
+        assert kc.shape[1] == len(case["expect"]), case["cite"]
+        for g in range(kc.shape[1]):
+            exp = case["expect"][name_of(kc[0, g])]
+            for a, o in enumerate(ops):
+                if o in exp:
+                    assert oa[a, g] == pytest.approx(exp[o], rel=1e-12), (case["cite"], o)
+
+
+@pytest.mark.parametrize("n,g", [(1, 1), (5, 3), (1000, 7), (65_537, 1000), (300_000, 50_000),
+                                 (1_000_000, 1_000), (2_000_000, 1_000_000)])
+def test_i64_key_f64_value(ctx, n, g):
+    rng = np.random.default_rng(n + g)
+    keys = [(sparse_keys(rng, n, g), None, O.I64)]
+    vals = [(rng.normal(100, 10, n), None, O.F64)]
+    check(ctx, keys, n, vals, FIVE, [O.I64], exact=EXACT5)
+
+
+def test_config2_shape_small(ctx):
+    """C2's shape (4 f64 columns x sum/mean/min/max) at a size the oracle finishes in seconds."""
+    rng = np.random.default_rng(42 + 1)
+    n, g = 1_500_000, 40_000
+    keys = [(sparse_keys(rng, n, g), None, O.I64)]
+    vals = [(rng.normal(100, 10, n), None, O.F64) for _ in range(4)]
+    aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)]
+    exact = [i for i, (_, op) in enumerate(aggs) if op in (O.MIN, O.MAX)]
+    check(ctx, keys, n, vals, aggs, [O.I64], exact=exact)
+
+
+def test_nulls_everywhere(ctx):
+    rng = np.random.default_rng(9)
+    n, g = 400_000, 3_000
+    km = O.pack_mask(rng.random(n) < 0.01)
+    keys = [(sparse_keys(rng, n, g), km, O.I64)]
+    vals = [(rng.normal(0, 1, n) + 50, O.pack_mask(rng.random(n) < 0.01), O.F64),
+            (rng.integers(-10**6, 10**6, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.3), O.I64)]
+    aggs = [(c, op) for c in (0, 1) for op in (O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT)]
+    # i64 sums/min/max/count are integer work: bit-exact
+    exact = [i for i, (c, op) in enumerate(aggs) if c == 1 and op != O.MEAN or op in (O.MIN, O.MAX, O.COUNT)]
+    got = check(ctx, keys, n, vals, aggs, [O.I64], exact=exact)
+    assert got[1].sum() == 1            # exactly one NULL group (grouping.rs:74)
+
+
+def test_all_null_groups_and_sentinels(ctx):
+    """Source-derived quirks: empty => 0.0, sentinel min/max => 0.0, count
+    includes nulls, i64 sum wraps, NaN propagates through sum and is ignored by min/max."""
+    key = [(np.array([1, 1, 2, 2, 3, -1, -1], np.int64), None, O.I64)]     # -1 == table sentinel bits
+    vi = (np.array([5, 7, 0, 0, 9, 2**62, 2**62], np.int64), O.pack_mask([0, 0, 1, 1, 0, 0, 0]), O.I64)
+    vf = (np.array([5.0, np.nan, 0, 0, np.inf, -0.0, 0.0]), O.pack_mask([0, 0, 1, 1, 0, 0, 0]), O.F64)
+    aggs = [(c, op) for c in (0, 1) for op in (O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT)]
+    check(ctx, key, 7, [vi, vf], aggs, [O.I64], exact=range(len(aggs)))
+    big = (np.array([2**62] * 4 + [np.iinfo(np.int64).max, np.iinfo(np.int64).min], np.int64), None, O.I64)
+    k2 = [(np.array([0, 0, 0, 0, 1, 2], np.int64), None, O.I64)]
+    check(ctx, k2, 6, [big], FIVE, [O.I64], exact=range(5))
+
+
+def test_other_key_dtypes(ctx):
+    rng = np.random.default_rng(21)
+    n = 200_000
+    v = [(rng.normal(10, 3, n), None, O.F64)]
+    codes = rng.integers(0, 10_000, n).astype(np.uint32)
+    check(ctx, [(codes, O.pack_mask(rng.random(n) < 0.001), O.U32CODE)], n, v, FIVE, [O.U32CODE], exact=EXACT5)
+    kf = rng.choice(np.array([0.0, -0.0, 1.5, np.nan, np.inf, -2.25, 1e300]), n)
+    bits = kf.view(np.uint64).copy()
+    bits[np.isnan(kf) & (rng.random(n) < 0.5)] = 0xFFF8000000000123      # another NaN payload
+    check(ctx, [(bits.view(np.float64), None, O.F64)], n, v, FIVE, [O.F64], exact=EXACT5)
+    kb = np.packbits(rng.random(n) < 0.3, bitorder="little")
+    check(ctx, [(kb, O.pack_mask(rng.random(n) < 0.05), O.BOOLBITS)], n, v, FIVE, [O.BOOLBITS], exact=EXACT5)
+
+
+def test_skew_and_extremes(ctx):
+    rng = np.random.default_rng(33)
+    n = 600_000
+    v = [(rng.normal(100, 10, n), None, O.F64)]
+    # 80/20 skew (reference benches/enhanced_comprehensive_benchmark.rs:53-59)
+    g = 20_000
+    hot = rng.random(n) < 0.8
+    ids = np.where(hot, rng.integers(0, g // 5, n), rng.integers(0, g, n)).astype(np.uint64)
+    keys = (ids * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    check(ctx, [(keys, None, O.I64)], n, v, FIVE, [O.I64], exact=EXACT5)
+    # one key for every row; every row its own key
+    check(ctx, [(np.full(n, 12345, np.int64), None, O.I64)], n, v, FIVE, [O.I64], exact=EXACT5)
+    check(ctx, [(np.arange(n, dtype=np.int64) * 1024, None, O.I64)], n, v, FIVE, [O.I64], exact=EXACT5)
+
+
+def test_empty_and_errors(ctx):
+    import pandrs_amd as pa
+    e = np.zeros(0, np.int64)
+    kc, kn, oa = ctx.groupby_agg([(e, None, O.I64)], 0, [(np.zeros(0), None, O.F64)], FIVE)
+    assert kc.shape == (1, 0) and oa.shape == (5, 0)        # tests/edge_cases_test.rs:46-80
+    k = [(np.array([1, 2, 1], np.int64), None, O.I64)]
+    with pytest.raises(pa.OperationFailed):                # aggregation.rs:748
+        ctx.groupby_agg(k, 3, [(np.zeros(3, np.uint32), None, O.U32CODE)], [(0, O.SUM)])
+    with pytest.raises(pa.OperationFailed):                # aggregation.rs:744
+        ctx.groupby_agg(k, 3, [(np.zeros(3), None, O.F64)], [(0, O.CUSTOM)])
+    with pytest.raises(pa.PandrsHipError):
+        ctx.groupby_agg(k, 3, [(np.zeros(3), None, O.F64)], [(5, O.SUM)])
+    # Count works on any dtype (aggregation.rs:743)
+    kc, kn, oa = ctx.groupby_agg(k, 3, [(np.zeros(3, np.uint32), None, O.U32CODE)], [(0, O.COUNT)])
+    assert sorted(oa[0].tolist()) == [1.0, 2.0]
+
+
+def test_overflow_retry_path(ctx):
+    """A wrong cardinality hint makes LDS tables overflow; the engine must retry with more
+    partitions and still be exact."""
+    rng = np.random.default_rng(5)
+    n, g = 500_000, 200_000
+    keys = [(sparse_keys(rng, n, g), None, O.I64)]
+    vals = [(rng.normal(100, 10, n), None, O.F64)]
+    ctx.set_option("groups_hint", 10)
+    ctx.set_option("partitions", 1)
+    try:
+        check(ctx, keys, n, vals, FIVE, [O.I64], exact=EXACT5)
+        assert ctx.timings()["retries"] >= 1
+    finally:
+        ctx.set_option("groups_hint", 0)
+        ctx.set_option("partitions", 0)
+
+
+def test_unstaged_scatter_variant(ctx):
+    rng = np.random.default_rng(6)
+    n, g = 300_000, 30_000
+    keys = [(sparse_keys(rng, n, g), None, O.I64)]
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.1), O.F64)]
+    ctx.set_option("scatter_staged", 0)
+    try:
+        check(ctx, keys, n, vals, FIVE, [O.I64], exact=EXACT5)
+    finally:
+        ctx.set_option("scatter_staged", 1)
+
+
+def test_device_resident_columns(ctx):
+    import torch
+    rng = np.random.default_rng(8)
+    n, g = 700_000, 9_000
+    k = sparse_keys(rng, n, g)
+    v = rng.normal(100, 10, n)
+    m = O.pack_mask(rng.random(n) < 0.02)
+    d = "cuda:0"
+    got = ctx.groupby_agg([(torch.from_numpy(k).to(d), None, O.I64)], n,
+                          [(torch.from_numpy(v).to(d), torch.from_numpy(m).to(d), O.F64)], FIVE)
+    got = tuple(t.cpu().numpy() for t in got)
+    got = (got[0].view(np.uint64), got[1], got[2])
+    want = O.groupby_agg([(k, None, O.I64)], n, [(v, m, O.F64)], FIVE)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=EXACT5)
+
+
+def test_partials_split_merge_roundtrip(ctx):
+    """Two row-range shards -> partials -> owner split -> merge == oracle on the whole input
+    (the single-process rehearsal of the multi-GPU exchange)."""
+    rng = np.random.default_rng(12)
+    n, g, ranks = 400_000, 25_000, 2
+    k = sparse_keys(rng, n, g)
+    km = O.pack_mask(rng.random(n) < 0.001)
+    v0 = rng.normal(100, 10, n)
+    v1 = rng.integers(-1000, 1000, n).astype(np.int64)
+    m1 = O.pack_mask(rng.random(n) < 0.2)
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT), (1, O.SUM), (1, O.MEAN), (1, O.MIN), (1, O.MAX)]
+    half = n // 2 // 8 * 8
+    inbox = [[] for _ in range(ranks)]
+    for lo, hi in ((0, half), (half, n)):
+        sl = slice(lo, hi)
+        kmask = O.pack_mask(np.unpackbits(km, bitorder="little")[:n][sl])
+        vmask = O.pack_mask(np.unpackbits(m1, bitorder="little")[:n][sl])
+        ng, ns = ctx.groupby_partials([(k[sl], kmask, O.I64)], hi - lo,
+                                      [(v0[sl], None, O.F64), (v1[sl], vmask, O.I64)], aggs)
+        pk, pn, ps, counts = ctx.partials_split(ranks)
+        assert sum(counts) == ng
+        off = 0
+        for r, c in enumerate(counts):
+            inbox[r].append((pk[off:off + c], pn[off:off + c], ps[:, off:off + c]))
+            off += c
+    outs = []
+    for r in range(ranks):
+        pk = np.concatenate([x[0] for x in inbox[r]])
+        pn = np.concatenate([x[1] for x in inbox[r]])
+        ps = np.concatenate([x[2] for x in inbox[r]], axis=1)
+        ctx.groupby_merge(O.I64, pk, pn, ps, len(pk), [O.F64, O.I64], [False, True], aggs)
+        outs.append(ctx.groupby_fetch(to_device=False))
+    got = tuple(np.concatenate([o[i] for o in outs], axis=1) for i in range(3))
+    want = O.groupby_agg([(k, km, O.I64)], n, [(v0, None, O.F64), (v1, m1, O.I64)], aggs)
+    exact = [i for i, (c, op) in enumerate(aggs) if (c == 1 and op != O.MEAN) or op in (O.MIN, O.MAX, O.COUNT)]
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+
+
+def test_reduce_column(ctx, golden):
+    rng = np.random.default_rng(4)
+    n = 1_000_003
+    for col in [(rng.normal(5, 2, n), O.pack_mask(rng.random(n) < 0.1), O.F64),
+                (rng.integers(-10**9, 10**9, n).astype(np.int64), None, O.I64)]:
+        got, gc = ctx.reduce_column(col, n)
+        want, wc = O.reduce_column(col, n)
+        assert gc == wc
+        np.testing.assert_allclose(got[:2], want[:2], rtol=1e-9)
+        assert got[2] == want[2] and got[3] == want[3]
+    for c in golden["reductions"]:
+        if "f64_range" in c:
+            col = (np.arange(c["f64_range"][0], c["f64_range"][1] + 1, dtype=np.float64), None, O.F64)
+        elif "f64" in c:
+            col = (np.array(c["f64"], np.float64), None, O.F64)
+        else:
+            col = (np.array(c["i64"], np.int64), None, O.I64)
+        got, _ = ctx.reduce_column(col, len(col[0]))
+        for i, name in enumerate(("sum", "mean", "min", "max")):
+            if name in c:
+                assert got[i] == pytest.approx(float(c[name]), abs=1e-10), (c["cite"], name)
+
+
+def test_full_size_properties():
+    """BASELINE C2 scale (100 M rows, 1 M groups, 4 f64 columns): too big for the oracle, so
+    check size-independent properties: group count, sum of counts == N, sum of sums == column
+    total (linearity, 1e-9), global min/max == min/max of per-group min/max, mean*count == sum."""
+    import torch
+    import pandrs_amd as pa
+    n, g = 100_000_000, 1_000_000
+    d = "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(43)
+    ids = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64)
+    keys = ids * -7046029254386353131 ^ 0x5555AAAA5555AAAA      # 0x9E3779B97F4A7C15 as i64, wraps
+    vals = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100 for _ in range(4)]
+    aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    c = pa.Context(0)
+    try:
+        ng = c.groupby_compute([(keys, None, O.I64)], n, [(v, None, O.F64) for v in vals], aggs)
+        kc, kn, oa = c.groupby_fetch()
+        assert ng == torch.unique(ids).numel()
+        assert torch.unique(kc[0]).numel() == ng and int(kn.sum()) == 0
+        cnt = oa[16]
+        assert float(cnt.sum()) == n
+        for col in range(4):
+            s, mean, mn, mx = oa[4 * col:4 * col + 4]
+            tot = float(vals[col].sum())
+            assert abs(float(s.sum()) - tot) <= 1e-9 * abs(tot)
+            assert float(mn.min()) == float(vals[col].min()) and float(mx.max()) == float(vals[col].max())
+            assert torch.allclose(mean * cnt, s, rtol=1e-12, atol=0)
+        # idempotence: grouping the group keys again yields every key once
+        ng2 = c.groupby_compute([(kc[0].contiguous(), None, O.I64)], ng, [(oa[0].contiguous(), None, O.F64)], [(0, O.COUNT)])
+        assert ng2 == ng
+    finally:
+        c.close()
