@@ -90,6 +90,24 @@ class LibraryMissing(ImportError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (same soname, libamdhip64.so.7, as /opt/rocm's); when torch is installed we map
+    its copy first so libpandrs_hip.so's DT_NEEDED resolves to it and device pointers, streams and
+    RCCL buffers are shared.  Without torch the system ROCm runtime is used.  torch itself is NOT
+    imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen the in-tree library and type every entry point.  Raises LibraryMissing if the
     HIP extension has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
@@ -100,6 +118,7 @@ def load():
         raise LibraryMissing(
             "%s not found — build the HIP extension first (make -C pandrs_amd/csrc, or "
             "__graft_entry__.build()).  pandrs_amd has no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
