@@ -116,6 +116,12 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     if (!std::strcmp(name, "groups_hint")) c->opt.groups_hint = value;
     else if (!std::strcmp(name, "scatter_staged")) c->opt.scatter_staged = value;
     else if (!std::strcmp(name, "partitions")) c->opt.partitions = value;
+    else if (!std::strcmp(name, "scatter_threads")) c->opt.scatter_threads = value;
+    else if (!std::strcmp(name, "src_per_round")) c->opt.src_per_round = value;
+    else if (!std::strcmp(name, "p_target")) c->opt.p_target = value;
+    else if (!std::strcmp(name, "load_pct")) c->opt.load_pct = value;
+    else if (!std::strcmp(name, "generic_aggregate")) c->opt.generic_aggregate = value;
+    else if (!std::strcmp(name, "shared_cursors")) c->opt.shared_cursors = value;
     else return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return PANDRS_HIP_OK;
 }

@@ -32,11 +32,12 @@ constexpr int MAX_AGGS = 64;
 constexpr int MAX_MOVE = 40;
 constexpr int P_MAX = 4096;
 
-constexpr int SC_THREADS = 1024;   // histogram / scatter workgroup
-constexpr int SC_RPT = 8;          // rows per thread per tile
-constexpr int SC_TILE = SC_THREADS * SC_RPT;
-static_assert(SC_TILE <= (1 << 13), "scatter packs the tile position in 13 bits");
+constexpr int HI_THREADS = 1024;   // histogram workgroup
+constexpr int SC_RPT = 8;          // scatter: rows per thread per tile
+constexpr int SC_TILE_MAX = 1024 * SC_RPT;
+static_assert(SC_TILE_MAX <= (1 << 13), "scatter packs the tile position in 13 bits");
 constexpr int AG_THREADS = 1024;   // aggregate workgroup
+constexpr int MAX_ROUNDS = 16;
 
 enum StateKind : int8_t { SK_ADD_F64 = 0, SK_ADD_I64, SK_MIN_F64, SK_MAX_F64, SK_MIN_I64, SK_MAX_I64 };
 
@@ -49,7 +50,8 @@ struct SrcDev {
 };
 
 struct FinDev {
-    int8_t op, kind, st_add, st_nn, st_min, st_max;
+    int8_t op, kind, st_add, st_nn, st_min, st_max;   // st_*: LDS state index inside its round
+    int8_t round, pad;
 };
 
 struct MoveDesc {
@@ -83,21 +85,32 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
 }
 
 // ------------------------------------------------------------------------------------ histogram
-// Workgroup b owns rows [b*chunk, (b+1)*chunk).  hist is partition-major: hist[p*NB + b].
-__global__ __launch_bounds__(SC_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
+// Workgroup b owns rows [b*chunk, (b+1)*chunk).  hist is partition-major: hist[p*NB + q(b)] with
+// q(b) = (b % 8) * (NB/8) + b / 8, so the workgroups of one group g = b % 8 (the set that shares an
+// XCD under round-robin dispatch; a label, never a correctness assumption) own ONE contiguous
+// region of every partition.  NB is a multiple of 8.
+__device__ __forceinline__ uint32_t group_slot(uint32_t b, uint32_t NB) { return (b & 7) * (NB >> 3) + (b >> 3); }
+
+__global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
                                                                int64_t chunk, uint32_t P,
                                                                uint32_t seed, uint32_t *hist) {
     extern __shared__ uint32_t cnt[];  // P + 1
-    const uint32_t NB = gridDim.x, b = blockIdx.x;
-    for (uint32_t p = threadIdx.x; p <= P; p += SC_THREADS) cnt[p] = 0;
+    const uint32_t NB = gridDim.x, b = blockIdx.x, qb = group_slot(b, NB);
+    for (uint32_t p = threadIdx.x; p <= P; p += HI_THREADS) cnt[p] = 0;
     __syncthreads();
     int64_t beg = (int64_t)b * chunk, end = min(beg + chunk, n_rows);
-    for (int64_t i = beg + threadIdx.x; i < end; i += SC_THREADS) {
+    for (int64_t i = beg + threadIdx.x; i < end; i += HI_THREADS) {
         uint32_t p = key_is_null(key, i) ? P : part_of(hash32(key_cell(key, i), seed), P);
         atomicAdd(&cnt[p], 1u);
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p <= P; p += SC_THREADS) hist[(size_t)p * NB + b] = cnt[p];
+    for (uint32_t p = threadIdx.x; p <= P; p += HI_THREADS) hist[(size_t)p * NB + qb] = cnt[p];
+}
+
+// group cursors: gcur[p*8 + g] = first row of group g's region inside partition p
+__global__ void init_group_cursors_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1, uint32_t *gcur) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P1 * 8) gcur[i] = offsets[(size_t)(i >> 3) * NB + (i & 7) * (NB >> 3)];
 }
 
 // ------------------------------------------------------------------------------------ scan
@@ -157,9 +170,10 @@ struct ScatterArgs {
     KeyDesc key;
     uint64_t *pkeys;
     const uint32_t *offsets;   // partition-major exclusive scan of the histogram
+    uint32_t *gcur;            // [P+1][8] shared write cursors per (partition, group); nullptr = private cursors
     int64_t n_rows, chunk;
     uint32_t P, seed;
-    int n_move;
+    int n_move, n_move8;       // mv[0 .. n_move8) are 8-byte columns, the rest byte-wide
     MoveDesc mv[MAX_MOVE];
 };
 
@@ -173,9 +187,197 @@ __device__ __forceinline__ void move_store(const MoveDesc &m, uint32_t dst, uint
     else reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
 }
 
+// Row r of a thread's tile slice is tile-local index r*THREADS + tid, clamped to the tile's last
+// row so every load below is unconditional (eight back-to-back coalesced loads, no per-row
+// branches).  Bases are wave-uniform (column + tbase), indices 32-bit: saddr + voffset addressing.
+template <int THREADS>
+__device__ __forceinline__ uint32_t tile_idx(uint32_t tid, int r, uint32_t tile_last) {
+    return min((uint32_t)(r * THREADS) + tid, tile_last);
+}
+
+template <int THREADS>
+__device__ __forceinline__ void load_column8(const void *col, int64_t tbase, uint32_t tid, uint32_t tile_last,
+                                             uint64_t (&out)[SC_RPT]) {
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(col) + tbase;
+#pragma unroll
+    for (int r = 0; r < SC_RPT; r++) out[r] = src[tile_idx<THREADS>(tid, r, tile_last)];
+}
+
+// key cells + null flags (bit r of *nulls) for the thread's SC_RPT rows; the dtype switch is
+// wave-uniform and sits outside the unrolled loads.  tbase is a multiple of 8 (tile aligned), so
+// bitmaps are addressed from a byte base.
+template <int THREADS>
+__device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, uint32_t tid, uint32_t tile_last,
+                                               uint64_t (&kc)[SC_RPT], uint32_t *nulls) {
+    switch (k.dtype) {
+    case PANDRS_HIP_U32CODE: {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(k.data) + tbase;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) kc[r] = src[tile_idx<THREADS>(tid, r, tile_last)];
+        break;
+    }
+    case PANDRS_HIP_BOOLBITS: {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(k.data) + (tbase >> 3);
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = tile_idx<THREADS>(tid, r, tile_last);
+            kc[r] = (src[j >> 3] >> (j & 7)) & 1;
+        }
+        break;
+    }
+    default: {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(k.data) + tbase;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) kc[r] = src[tile_idx<THREADS>(tid, r, tile_last)];
+        if (k.dtype == PANDRS_HIP_F64) {
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if ((kc[r] & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) kc[r] = CANON_NAN;
+        }
+    }
+    }
+    uint32_t nm = 0;
+    if (k.null_bits) {
+        const uint8_t *src = k.null_bits + (tbase >> 3);
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = tile_idx<THREADS>(tid, r, tile_last);
+            nm |= ((src[j >> 3] >> (j & 7)) & 1u) << r;
+        }
+    } else if (k.null_bytes) {
+        const uint8_t *src = k.null_bytes + tbase;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) nm |= (src[tile_idx<THREADS>(tid, r, tile_last)] ? 1u : 0u) << r;
+    }
+    *nulls = nm;
+}
+
 // LDS: cursor[P+1] | cnt[P+1] | delta[P+1] | wave_tot[32] | pid[TILE] (u16) | stage[TILE] (u64)
-template <bool STAGED>
-__global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
+// THREADS = 1024: one 8192-row tile per CU (longest per-partition runs);
+// THREADS = 512 : 4096-row tiles, two workgroups per CU (loads of one overlap LDS work of the other).
+// One tile of the scatter.  FULL = the tile has all TILE rows (every tile but the input's last):
+// no per-row predicates anywhere on that path.
+template <int THREADS, bool STAGED, bool FULL>
+__device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase, uint32_t tile_n,
+                                             uint32_t *cursor, uint32_t *cnt, uint32_t *delta,
+                                             uint32_t *wave_tot, uint16_t *pid, uint64_t *stage) {
+    constexpr uint32_t SPM = (1u << 13) - 1;
+    const uint32_t P1 = a.P + 1, tid = threadIdx.x;
+    const uint32_t ipt = (P1 + THREADS - 1) / THREADS;   // partition counters each thread scans
+    const uint32_t tile_last = tile_n - 1;
+    auto live = [&](int r) { return FULL || (uint32_t)(r * THREADS) + tid < tile_n; };
+
+    for (uint32_t p = tid; p < P1; p += THREADS) cnt[p] = 0;
+    __syncthreads();
+    // per row: key cell + packed (partition << 13 | position)
+    uint64_t kc[SC_RPT];
+    uint32_t ps[SC_RPT], nulls;
+    load_key_cells<THREADS>(a.key, tbase, tid, tile_last, kc, &nulls);
+#pragma unroll
+    for (int r = 0; r < SC_RPT; r++) {
+        bool nul = (nulls >> r) & 1;
+        if (nul) kc[r] = 0ull;
+        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
+        ps[r] = p << 13;
+        if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
+    }
+    __syncthreads();
+    // exclusive scan of cnt[] -> delta[] (tile-local partition starts)
+    {
+        uint32_t first = tid * ipt, s = 0;
+        for (uint32_t q = 0; q < ipt; q++) if (first + q < P1) s += cnt[first + q];
+        uint32_t ex = block_exclusive_scan<THREADS>(s, wave_tot, nullptr);
+        for (uint32_t q = 0; q < ipt; q++)
+            if (first + q < P1) { delta[first + q] = ex; ex += cnt[first + q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SC_RPT; r++) ps[r] += delta[ps[r] >> 13];
+    __syncthreads();
+    // delta[p] := global cursor - tile-local start, so dst = delta[p] + sorted position.
+    // Shared cursors: the 32 CUs of an XCD append to the SAME region of each partition, so a
+    // partition's 128-B lines are completed inside that XCD's 4 MiB L2 (frontier = P x columns x
+    // a few lines) instead of leaving it half-written from P x 32 private regions.
+    if (a.gcur) {
+        const uint32_t g = blockIdx.x & 7;
+        for (uint32_t p = tid; p < P1; p += THREADS) {
+            uint32_t n = cnt[p];
+            uint32_t c = n ? atomicAdd(&a.gcur[p * 8 + g], n) : 0u;
+            delta[p] = c - delta[p];
+        }
+    } else {
+        for (uint32_t p = tid; p < P1; p += THREADS) {
+            uint32_t c = cursor[p];
+            delta[p] = c - delta[p];
+            cursor[p] = c + cnt[p];
+        }
+    }
+    __syncthreads();
+
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++)
+            if (live(r)) { stage[ps[r] & SPM] = kc[r]; pid[ps[r] & SPM] = (uint16_t)(ps[r] >> 13); }
+        // from here kc[] is dead: the first value column's loads go out before the barrier.
+        // mv[0 .. n_move8) are 8-byte columns (software-pipelined), the rest byte-wide.
+        uint64_t vnext[SC_RPT];
+        if (a.n_move8 > 0) load_column8<THREADS>(a.mv[0].src, tbase, tid, tile_last, vnext);
+        __syncthreads();
+        uint32_t dst[SC_RPT];
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = r * THREADS + tid;
+            if (live(r)) { dst[r] = delta[pid[j]] + j; a.pkeys[dst[r]] = stage[j]; }
+        }
+        for (int m = 0; m < a.n_move8; m++) {
+            uint64_t *out = reinterpret_cast<uint64_t *>(a.mv[m].dst);
+            uint64_t v[SC_RPT];
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) v[r] = vnext[r];
+            // next column's loads fly under this column's staging
+            if (m + 1 < a.n_move8) load_column8<THREADS>(a.mv[m + 1].src, tbase, tid, tile_last, vnext);
+            __syncthreads();   // previous column's linear reads done
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) if (live(r)) stage[ps[r] & SPM] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) {
+                uint32_t j = r * THREADS + tid;
+                if (live(r)) out[dst[r]] = stage[j];
+            }
+        }
+        for (int m = a.n_move8; m < a.n_move; m++) {      // validity bytes / byte columns
+            const MoveDesc mv = a.mv[m];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if (live(r)) stage[ps[r] & SPM] = move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last));
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) {
+                uint32_t j = r * THREADS + tid;
+                if (live(r)) reinterpret_cast<uint8_t *>(mv.dst)[dst[r]] = (uint8_t)stage[j];
+            }
+        }
+        __syncthreads();
+    } else {
+        uint32_t dst[SC_RPT];
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++)
+            if (live(r)) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); a.pkeys[dst[r]] = kc[r]; }
+        for (int m = 0; m < a.n_move; m++) {
+            const MoveDesc mv = a.mv[m];
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if (live(r)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
+        }
+        __syncthreads();
+    }
+}
+
+template <int THREADS, bool STAGED>
+__global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
+    constexpr int TILE = THREADS * SC_RPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t P1 = a.P + 1;
     uint32_t *cursor = reinterpret_cast<uint32_t *>(smem);
@@ -184,98 +386,17 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     uint32_t *wave_tot = delta + P1;
     uint16_t *pid = reinterpret_cast<uint16_t *>(wave_tot + 32);
     uint64_t *stage = reinterpret_cast<uint64_t *>(
-        (reinterpret_cast<uintptr_t>(pid + SC_TILE) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(pid + TILE) + 15) & ~uintptr_t(15));
 
     const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t p = tid; p < P1; p += SC_THREADS) cursor[p] = a.offsets[(size_t)p * NB + b];
+    if (!a.gcur) for (uint32_t p = tid; p < P1; p += THREADS) cursor[p] = a.offsets[(size_t)p * NB + group_slot(b, NB)];
     const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
-    // entries of the partition counters each thread scans (contiguous, <= 5 for P <= 4096)
-    const uint32_t ipt = (P1 + SC_THREADS - 1) / SC_THREADS;
-
-    for (int64_t tbase = beg; tbase < end; tbase += SC_TILE) {
-        const uint32_t tile_n = (uint32_t)min<int64_t>(SC_TILE, end - tbase);
-        for (uint32_t p = tid; p < P1; p += SC_THREADS) cnt[p] = 0;
-        __syncthreads();
-        // per row: key cell + packed (partition << 13 | position); 0xFFFFFFFF = past the tile end
-        uint64_t kc[SC_RPT];
-        uint32_t ps[SC_RPT];
-        constexpr uint32_t INVALID = 0xFFFFFFFFu, SPM = (1u << 13) - 1;
-#pragma unroll
-        for (int r = 0; r < SC_RPT; r++) {
-            uint32_t j = r * SC_THREADS + tid;
-            ps[r] = INVALID;
-            if (j < tile_n) {
-                int64_t i = tbase + j;
-                bool nul = key_is_null(a.key, i);
-                kc[r] = nul ? 0ull : key_cell(a.key, i);
-                uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
-                ps[r] = (p << 13) | atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
-            }
-        }
-        __syncthreads();
-        // exclusive scan of cnt[] -> delta[] (tile-local partition starts)
-        {
-            uint32_t first = tid * ipt, s = 0;
-            for (uint32_t q = 0; q < ipt; q++) if (first + q < P1) s += cnt[first + q];
-            uint32_t ex = block_exclusive_scan<SC_THREADS>(s, wave_tot, nullptr);
-            for (uint32_t q = 0; q < ipt; q++)
-                if (first + q < P1) { delta[first + q] = ex; ex += cnt[first + q]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SC_RPT; r++) if (ps[r] != INVALID) ps[r] += delta[ps[r] >> 13];
-        __syncthreads();
-        // delta[p] := global cursor - tile-local start, so dst = delta[p] + sorted position
-        for (uint32_t p = tid; p < P1; p += SC_THREADS) {
-            uint32_t c = cursor[p];
-            delta[p] = c - delta[p];
-            cursor[p] = c + cnt[p];
-        }
-        __syncthreads();
-
-        if constexpr (STAGED) {
-#pragma unroll
-            for (int r = 0; r < SC_RPT; r++)
-                if (ps[r] != INVALID) { stage[ps[r] & SPM] = kc[r]; pid[ps[r] & SPM] = (uint16_t)(ps[r] >> 13); }
-            __syncthreads();
-            // from here kc[] is dead; dst[] takes its registers
-            uint32_t dst[SC_RPT];
-#pragma unroll
-            for (int r = 0; r < SC_RPT; r++) {
-                uint32_t j = r * SC_THREADS + tid;
-                if (j < tile_n) { dst[r] = delta[pid[j]] + j; a.pkeys[dst[r]] = stage[j]; }
-            }
-            for (int m = 0; m < a.n_move; m++) {
-                const MoveDesc mv = a.mv[m];
-                uint64_t v[SC_RPT];
-#pragma unroll
-                for (int r = 0; r < SC_RPT; r++)
-                    if (ps[r] != INVALID) v[r] = move_load(mv, tbase + r * SC_THREADS + tid);
-                __syncthreads();   // previous column's linear reads done
-#pragma unroll
-                for (int r = 0; r < SC_RPT; r++) if (ps[r] != INVALID) stage[ps[r] & SPM] = v[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < SC_RPT; r++) {
-                    uint32_t j = r * SC_THREADS + tid;
-                    if (j < tile_n) move_store(mv, dst[r], stage[j]);
-                }
-            }
-            __syncthreads();
-        } else {
-            uint32_t dst[SC_RPT];
-#pragma unroll
-            for (int r = 0; r < SC_RPT; r++)
-                if (ps[r] != INVALID) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); a.pkeys[dst[r]] = kc[r]; }
-            for (int m = 0; m < a.n_move; m++) {
-                const MoveDesc mv = a.mv[m];
-#pragma unroll
-                for (int r = 0; r < SC_RPT; r++)
-                    if (ps[r] != INVALID)
-                        move_store(mv, dst[r], move_load(mv, tbase + r * SC_THREADS + tid));
-            }
-            __syncthreads();
-        }
+    for (int64_t tbase = beg; tbase < end; tbase += TILE) {
+        const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
+        if (tile_n == TILE)
+            scatter_tile<THREADS, STAGED, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+        else
+            scatter_tile<THREADS, STAGED, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
     }
 }
 
@@ -285,9 +406,11 @@ struct AggArgs {
     const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
     const int64_t *pgsize;       // merge mode: partitioned group sizes, else nullptr (=1 per row)
     uint32_t NB, P, T, seed;
-    int n_src, n_states, n_fin, partials;
-    SrcDev src[MAX_SRC];
-    int8_t kinds[MAX_STATES];
+    int n_src, n_states, n_fin, partials, n_rounds, round_states;
+    int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
+    SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
+    int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
+    int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
     FinDev fin[MAX_AGGS];
     // outputs (row capacity = cap)
     uint64_t *out_keys;
@@ -353,120 +476,194 @@ __device__ __forceinline__ double finalize(const FinDev &f, const uint64_t *st, 
     return 0.0;
 }
 
-// LDS: keys[T+1] | gsize[T+1] | states[n_states][T+1] | misc
-template <int NSRC>
+// LDS: keys[T+1] | gsize[T+1] | states[round_states][T+1] | posmap[T+1] (u32) | misc[32]
+// One workgroup per radix partition.  The aggregated columns are processed in `n_rounds` passes
+// over the partition (key table and group sizes persist, the state arrays are reused), which
+// keeps the bytes per slot small => more slots per table => fewer, longer radix partitions.
+// NSRC    compile-time bound on sources per round (0 = runtime)
+// PROFILE -1 = every per-source property is read from the descriptors at run time;
+//         >= 0 = all sources share (kind, ops, validity): bit0 has validity bytes,
+//                bits1-3 ops present (add, min, max), bit4 kind (0 f64, 1 i64); raw rows, one round.
+//         The uniform profiles remove ~300 scalar branches per row pair from the hot loop.
+template <int NSRC, int PROFILE>
 __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = NSRC > 0 ? NSRC : MAX_SRC;
+    constexpr bool GEN = PROFILE < 0;
+    auto f_kind = [](const SrcDev &sd) -> int { return GEN ? sd.kind : ((PROFILE >> 4) & 1); };
+    auto f_add = [](const SrcDev &sd) -> bool { return GEN ? sd.st_add >= 0 : ((PROFILE >> 1) & 1) != 0; };
+    auto f_min = [](const SrcDev &sd) -> bool { return GEN ? sd.st_min >= 0 : ((PROFILE >> 2) & 1) != 0; };
+    auto f_max = [](const SrcDev &sd) -> bool { return GEN ? sd.st_max >= 0 : ((PROFILE >> 3) & 1) != 0; };
+    auto f_valid = [](const SrcDev &sd) -> bool { return GEN ? sd.valid != nullptr : (PROFILE & 1) != 0; };
+    auto f_nn = [](const SrcDev &sd) -> bool { return (GEN || (PROFILE & 1)) ? sd.st_nn >= 0 : false; };
     const uint32_t T = a.T, T1 = T + 1, tid = threadIdx.x;
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *gsz = keys + T1;
     uint64_t *st = gsz + T1;
-    uint32_t *misc = reinterpret_cast<uint32_t *>(st + (size_t)a.n_states * T1);
+    uint32_t *posmap = reinterpret_cast<uint32_t *>(st + (size_t)a.round_states * T1);
+    uint32_t *misc = posmap + ((T1 + 1) & ~1u);
     // misc[0..16] wave totals, [20] overflow, [21] sentinel-key-present, [22] output base
     const uint32_t p = blockIdx.x;
     const uint32_t beg = a.offsets[(size_t)p * a.NB];
     const uint32_t end = a.offsets[(size_t)(p + 1) * a.NB];
     if (beg == end) return;
-    const int nsrc = NSRC > 0 ? NSRC : a.n_src;
 
     for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
-    for (int k = 0; k < a.n_states; k++) {
-        uint64_t idv = state_identity(a.kinds[k]);
-        for (uint32_t s = tid; s < T1; s += AG_THREADS) st[(size_t)k * T1 + s] = idv;
-    }
     if (tid < 32) misc[tid] = 0;
-    __syncthreads();
 
-    for (uint32_t i = beg + tid; i < end; i += AG_THREADS) {
-        const uint64_t k = a.pkeys[i];
-        uint64_t v[NSRC > 0 ? NSRC : MAX_SRC];
-        bool ok[NSRC > 0 ? NSRC : MAX_SRC];
-#pragma unroll
-        for (int c = 0; c < (NSRC > 0 ? NSRC : MAX_SRC); c++) {
-            if (c < nsrc) {
-                v[c] = a.src[c].vals ? a.src[c].vals[i] : 0ull;
-                ok[c] = a.src[c].valid ? a.src[c].valid[i] != 0 : true;
-            }
+    for (int round = 0; round < a.n_rounds; round++) {
+        const int s0 = a.round_src_begin[round], nsrc = a.round_src_begin[round + 1] - s0;
+        for (int k = 0; k < a.n_states; k++) {
+            if (a.st_round[k] != round) continue;
+            uint64_t idv = state_identity(a.kinds[k]);
+            uint64_t *dst = st + (size_t)a.st_lds[k] * T1;
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) dst[s] = idv;
         }
-        const uint64_t gs = a.pgsize ? (uint64_t)a.pgsize[i] : 1ull;
-        // find-or-insert
-        uint32_t slot;
-        if (k == EMPTY_KEY) {
-            slot = T;
-            misc[21] = 1;
-        } else {
-            slot = slot_of(hash32(k, a.seed), T);
-            uint32_t probe = 0;
-            for (; probe < T; probe++) {
-                uint64_t cur = keys[slot];
-                if (cur == k) break;
-                if (cur == EMPTY_KEY) {
-                    uint64_t old = atomicCAS((unsigned long long *)&keys[slot], EMPTY_KEY, k);
-                    if (old == EMPTY_KEY || old == k) break;
-                }
-                slot = slot + 1 == T ? 0 : slot + 1;
-            }
-            if (probe == T) { misc[20] = 1; continue; }   // table full: host retries with more partitions
-        }
-        atomicAdd((unsigned long long *)&gsz[slot], gs);
+        __syncthreads();
+
+        for (uint32_t i0 = beg + tid; i0 < end; i0 += 2 * AG_THREADS) {
+            // two rows per thread in flight: all global loads first, LDS work after
+            const uint32_t i1 = i0 + AG_THREADS;
+            const bool has1 = i1 < end;
+            uint64_t k2[2], v[2][NS], gs[2];
+            bool ok[2][NS];
 #pragma unroll
-        for (int c = 0; c < (NSRC > 0 ? NSRC : MAX_SRC); c++) {
-            if (c < nsrc && ok[c]) {
-                const SrcDev &s = a.src[c];
-                if (s.st_nn >= 0) atomicAdd((unsigned long long *)&st[(size_t)s.st_nn * T1 + slot], 1ull);
-                if (s.kind == 0) {
-                    double d = __longlong_as_double((long long)v[c]);
-                    if (s.st_add >= 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)s.st_add * T1 + slot]), d);
-                    if (d == d) {   // Rust f64::min/max ignore NaN operands (aggregation.rs:653,:666)
-                        uint64_t e = enc_f64(d);
-                        if (s.st_min >= 0) atomicMin((unsigned long long *)&st[(size_t)s.st_min * T1 + slot], e);
-                        if (s.st_max >= 0) atomicMax((unsigned long long *)&st[(size_t)s.st_max * T1 + slot], e);
+            for (int h = 0; h < 2; h++) {
+                const uint32_t i = h ? i1 : i0;
+                if (h && !has1) break;
+                k2[h] = a.pkeys[i];
+                gs[h] = (GEN && round == 0 && a.pgsize) ? (uint64_t)a.pgsize[i] : 1ull;
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    if (c < nsrc) {
+                        const SrcDev &sd = a.src[s0 + c];
+                        v[h][c] = sd.vals[i];
+                        ok[h][c] = f_valid(sd) ? sd.valid[i] != 0 : true;
                     }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (h && !has1) break;
+                const uint64_t k = k2[h];
+                uint32_t slot;
+                if (k == EMPTY_KEY) {
+                    slot = T;
+                    misc[21] = 1;
                 } else {
-                    if (s.st_add >= 0) atomicAdd((unsigned long long *)&st[(size_t)s.st_add * T1 + slot], v[c]);
-                    uint64_t e = enc_i64((int64_t)v[c]);
-                    if (s.st_min >= 0) atomicMin((unsigned long long *)&st[(size_t)s.st_min * T1 + slot], e);
-                    if (s.st_max >= 0) atomicMax((unsigned long long *)&st[(size_t)s.st_max * T1 + slot], e);
+                    // 4-key buckets (32 B, two ds_read_b128): one LDS round trip tests four
+                    // slots, so a wave's longest probe chain stays ~1-3 trips even at 70-80 % load.
+                    const uint32_t NBK = T >> 2;
+                    uint32_t bk = slot_of(hash32(k, a.seed), NBK);
+                    uint32_t probe = 0;
+                    slot = T;
+                    while (probe < NBK) {
+                        const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
+                        ulonglong2 lo = bp[0], hi = bp[1];
+                        uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
+                        int hit = -1, emp = -1;
+#pragma unroll
+                        for (int q = 3; q >= 0; q--) {
+                            if (c4[q] == k) hit = q;
+                            if (c4[q] == EMPTY_KEY) emp = q;
+                        }
+                        if (hit >= 0) { slot = 4 * bk + hit; break; }
+                        if (emp >= 0) {
+                            if (round > 0) break;   // cannot happen: the key was inserted in round 0
+                            uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + emp], EMPTY_KEY, k);
+                            if (old == EMPTY_KEY || old == k) { slot = 4 * bk + emp; break; }
+                            continue;               // lost the race for that slot: re-read this bucket
+                        }
+                        bk = bk + 1 == NBK ? 0 : bk + 1;
+                        probe++;
+                    }
+                    if (slot == T) { misc[20] = 1; continue; }   // table full: host retries with more partitions
+                }
+                if (round == 0) atomicAdd((unsigned long long *)&gsz[slot], gs[h]);
+                // min/max: all current states are read first (back-to-back ds_read_b64, one wait);
+                // an LDS atomic is issued only where the row improves the state.  Skipping on a
+                // stale read is safe: states only move towards the extreme.
+                uint64_t enc[NS], cur_mn[NS], cur_mx[NS];
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    if (c < nsrc) {
+                        const SrcDev &sd = a.src[s0 + c];
+                        enc[c] = f_kind(sd) == 0 ? enc_f64(__longlong_as_double((long long)v[h][c])) : enc_i64((int64_t)v[h][c]);
+                        cur_mn[c] = f_min(sd) ? st[(size_t)sd.st_min * T1 + slot] : 0ull;
+                        cur_mx[c] = f_max(sd) ? st[(size_t)sd.st_max * T1 + slot] : ~0ull;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    if (c < nsrc && ok[h][c]) {
+                        const SrcDev &sd = a.src[s0 + c];
+                        const uint64_t x = v[h][c];
+                        if (f_nn(sd)) atomicAdd((unsigned long long *)&st[(size_t)sd.st_nn * T1 + slot], 1ull);
+                        bool cmp = true;
+                        if (f_kind(sd) == 0) {
+                            double d = __longlong_as_double((long long)x);
+                            if (f_add(sd)) atomicAdd(reinterpret_cast<double *>(&st[(size_t)sd.st_add * T1 + slot]), d);
+                            cmp = d == d;   // Rust f64::min/max ignore NaN operands (aggregation.rs:653,:666)
+                        } else {
+                            if (f_add(sd)) atomicAdd((unsigned long long *)&st[(size_t)sd.st_add * T1 + slot], x);
+                        }
+                        if (cmp && f_min(sd) && enc[c] < cur_mn[c])
+                            atomicMin((unsigned long long *)&st[(size_t)sd.st_min * T1 + slot], enc[c]);
+                        if (cmp && f_max(sd) && enc[c] > cur_mx[c])
+                            atomicMax((unsigned long long *)&st[(size_t)sd.st_max * T1 + slot], enc[c]);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
+        __syncthreads();
+        if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
+        const bool sentinel = misc[21] != 0;
+        const bool null_part = p == a.P;
 
-    // ---- compaction: occupied slots -> dense output rows (ballot + prefix sum) ----
-    const bool sentinel = misc[21] != 0;
-    uint32_t mine = 0;
-    for (uint32_t s = tid; s < T1; s += AG_THREADS)
-        mine += (s < T ? keys[s] != EMPTY_KEY : sentinel) ? 1u : 0u;
-    uint32_t total;
-    block_exclusive_scan<AG_THREADS>(mine, misc, &total);
-    if (tid == 0) misc[22] = atomicAdd(&a.counters[0], total);
-    __syncthreads();
-    uint32_t run = misc[22];
-    __syncthreads();
-    const bool null_part = p == a.P;
-    for (uint32_t sbase = 0; sbase < T1; sbase += AG_THREADS) {
-        uint32_t s = sbase + tid;
-        bool occ = s < T1 && (s < T ? keys[s] != EMPTY_KEY : sentinel);
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan<AG_THREADS>(occ ? 1u : 0u, misc, &tot);
-        if (occ) {
-            size_t pos = (size_t)run + ex;
-            a.out_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
-            a.out_null[pos] = null_part ? 1 : 0;
-            uint64_t g = gsz[s];
+        if (round == 0) {
+            // ---- compaction: occupied slots -> dense output rows (ballot + prefix sum) ----
+            uint32_t mine = 0;
+            for (uint32_t s = tid; s < T1; s += AG_THREADS)
+                mine += (s < T ? keys[s] != EMPTY_KEY : sentinel) ? 1u : 0u;
+            uint32_t total;
+            block_exclusive_scan<AG_THREADS>(mine, misc, &total);
+            if (tid == 0) misc[22] = atomicAdd(&a.counters[0], total);
+            __syncthreads();
+            uint32_t run = misc[22];
+            __syncthreads();
+            for (uint32_t sbase = 0; sbase < T1; sbase += AG_THREADS) {
+                uint32_t s = sbase + tid;
+                bool occ = s < T1 && (s < T ? keys[s] != EMPTY_KEY : sentinel);
+                uint32_t tot;
+                uint32_t ex = block_exclusive_scan<AG_THREADS>(occ ? 1u : 0u, misc, &tot);
+                if (occ) {
+                    uint32_t pos = run + ex;
+                    posmap[s] = pos;
+                    a.out_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
+                    a.out_null[pos] = null_part ? 1 : 0;
+                    if (a.partials) a.out_states[pos] = gsz[s];
+                }
+                run += tot;
+            }
+            __syncthreads();
+        }
+        // ---- this round's outputs ----
+        for (uint32_t s = tid; s < T1; s += AG_THREADS) {
+            if (!(s < T ? keys[s] != EMPTY_KEY : sentinel)) continue;
+            const size_t pos = posmap[s];
             if (a.partials) {
-                a.out_states[pos] = g;
                 for (int k = 0; k < a.n_states; k++)
-                    a.out_states[(size_t)(k + 1) * a.cap + pos] =
-                        state_natural(a.kinds[k], st[(size_t)k * T1 + s]);
+                    if (a.st_round[k] == round)
+                        a.out_states[(size_t)(k + 1) * a.cap + pos] =
+                            state_natural(a.kinds[k], st[(size_t)a.st_lds[k] * T1 + s]);
             } else {
+                const uint64_t g = gsz[s];
                 for (int f = 0; f < a.n_fin; f++)
-                    a.out_aggs[(size_t)f * a.cap + pos] = finalize(a.fin[f], st, T1, s, g);
+                    if (a.fin[f].round == round)
+                        a.out_aggs[(size_t)f * a.cap + pos] = finalize(a.fin[f], st, T1, s, g);
             }
         }
-        run += tot;
+        __syncthreads();
     }
 }
 
@@ -476,9 +673,10 @@ struct Plan {
     int n_src = 0, n_states = 0, n_fin = 0;
     int src_col[MAX_SRC];          // index into vals[]
     int8_t src_kind[MAX_SRC];
-    int8_t st_add[MAX_SRC], st_min[MAX_SRC], st_max[MAX_SRC], st_nn[MAX_SRC];
+    int8_t st_add[MAX_SRC], st_min[MAX_SRC], st_max[MAX_SRC], st_nn[MAX_SRC];   // absolute state ids
     int8_t kinds[MAX_STATES];
-    FinDev fin[MAX_AGGS];
+    int8_t fin_op[MAX_AGGS], fin_kind[MAX_AGGS];
+    int fin_src[MAX_AGGS];         // plan source of each aggregate, -1 for COUNT
 };
 
 // Builds the state layout from (value dtypes, has-null flags, aggregate specs).  The layout is a
@@ -486,24 +684,24 @@ struct Plan {
 static int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
                           const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl) {
     if (n_aggs > MAX_AGGS) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "more than %d aggregates", MAX_AGGS);
-    int src_of[1024];
     if (n_vals > 1024) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "too many value columns");
+    int src_of[1024];
     for (int i = 0; i < n_vals; i++) src_of[i] = -1;
-    auto new_state = [&](int8_t kind) -> int {
-        if (pl.n_states >= MAX_STATES) return -1;
+    bool too_many = false;
+    auto new_state = [&](int8_t kind) -> int8_t {
+        if (pl.n_states >= MAX_STATES) { too_many = true; return -1; }
         pl.kinds[pl.n_states] = kind;
-        return pl.n_states++;
+        return (int8_t)pl.n_states++;
     };
     for (int a = 0; a < n_aggs; a++) {
         int c = aggs[a].col, op = aggs[a].op;
         if (c < 0 || c >= n_vals) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "aggregate %d: column %d out of range", a, c);
-        FinDev &f = pl.fin[a];
-        f = FinDev{(int8_t)op, 0, -1, -1, -1, -1};
+        if (op < 0 || op > PANDRS_HIP_AGG_CUSTOM) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad op %d", op);
+        pl.fin_op[a] = (int8_t)op; pl.fin_kind[a] = 0; pl.fin_src[a] = -1;
         if (op == PANDRS_HIP_AGG_COUNT) continue;   // any dtype (aggregation.rs:743)
         if (op == PANDRS_HIP_AGG_CUSTOM)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                         "Custom aggregation requires a custom function, use aggregate_custom instead");
-        if (op < 0 || op > PANDRS_HIP_AGG_CUSTOM) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad op %d", op);
         int dt = val_dtypes[c];
         if (dt != PANDRS_HIP_I64 && dt != PANDRS_HIP_F64)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
@@ -520,26 +718,17 @@ static int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_null
             pl.st_add[s] = pl.st_min[s] = pl.st_max[s] = pl.st_nn[s] = -1;
         }
         const bool f64 = dt == PANDRS_HIP_F64;
-        f.kind = f64 ? 0 : 1;
-        int need = 0;
+        pl.fin_kind[a] = f64 ? 0 : 1;
+        pl.fin_src[a] = s;
         if ((op == PANDRS_HIP_AGG_SUM || op == PANDRS_HIP_AGG_MEAN) && pl.st_add[s] < 0)
-            need = pl.st_add[s] = (int8_t)new_state(f64 ? SK_ADD_F64 : SK_ADD_I64);
+            pl.st_add[s] = new_state(f64 ? SK_ADD_F64 : SK_ADD_I64);
         if (op == PANDRS_HIP_AGG_MEAN && val_has_nulls[c] && pl.st_nn[s] < 0)
-            need = std::min(need, (int)(pl.st_nn[s] = (int8_t)new_state(SK_ADD_I64)));
+            pl.st_nn[s] = new_state(SK_ADD_I64);
         if (op == PANDRS_HIP_AGG_MIN && pl.st_min[s] < 0)
-            need = pl.st_min[s] = (int8_t)new_state(f64 ? SK_MIN_F64 : SK_MIN_I64);
+            pl.st_min[s] = new_state(f64 ? SK_MIN_F64 : SK_MIN_I64);
         if (op == PANDRS_HIP_AGG_MAX && pl.st_max[s] < 0)
-            need = pl.st_max[s] = (int8_t)new_state(f64 ? SK_MAX_F64 : SK_MAX_I64);
-        if (need < 0) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregate states", MAX_STATES);
-        f.st_add = pl.st_add[s]; f.st_nn = pl.st_nn[s]; f.st_min = pl.st_min[s]; f.st_max = pl.st_max[s];
-    }
-    // st_nn may have been created by a later MEAN than an earlier MEAN's FinDev snapshot: refresh
-    for (int a = 0; a < n_aggs; a++) {
-        int c = aggs[a].col;
-        if (aggs[a].op == PANDRS_HIP_AGG_COUNT) continue;
-        int s = src_of[c];
-        pl.fin[a].st_add = pl.st_add[s]; pl.fin[a].st_nn = pl.st_nn[s];
-        pl.fin[a].st_min = pl.st_min[s]; pl.fin[a].st_max = pl.st_max[s];
+            pl.st_max[s] = new_state(f64 ? SK_MAX_F64 : SK_MAX_I64);
+        if (too_many) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregate states", MAX_STATES);
     }
     pl.n_fin = n_aggs;
     return 0;
@@ -612,21 +801,64 @@ static int32_t set_max_lds(K kernel, int bytes) {
     return 0;
 }
 
-static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int n_src, size_t lds) {
-    dim3 grid(a.P + 1), block(AG_THREADS);
-#define LAUNCH_AG(N)                                                                 \
-    case N:                                                                          \
-        (void)set_max_lds(aggregate_kernel<N>, (int)lds);                            \
-        hipLaunchKernelGGL(aggregate_kernel<N>, grid, block, lds, c->stream, a);     \
-        break;
-    switch (n_src) {
-        LAUNCH_AG(1) LAUNCH_AG(2) LAUNCH_AG(3) LAUNCH_AG(4)
-    default:
-        (void)set_max_lds(aggregate_kernel<0>, (int)lds);
-        hipLaunchKernelGGL(aggregate_kernel<0>, grid, block, lds, c->stream, a);
-    }
-#undef LAUNCH_AG
+template <int NSRC, int PROFILE>
+static void launch_aggregate_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds) {
+    (void)set_max_lds(aggregate_kernel<NSRC, PROFILE>, (int)lds);
+    hipLaunchKernelGGL((aggregate_kernel<NSRC, PROFILE>), dim3(a.P + 1), dim3(AG_THREADS), lds, c->stream, a);
 }
+template <int NSRC>
+static bool launch_aggregate_profile(pandrs_hip_ctx *c, const AggArgs &a, int profile, size_t lds) {
+    // instantiated uniform profiles: {f64, i64} x {sum only, sum+min+max} x {no validity, validity}
+    switch (profile) {
+#define PROF(K, OPS, V) case ((K) << 4 | (OPS) << 1 | (V)): launch_aggregate_one<NSRC, ((K) << 4 | (OPS) << 1 | (V))>(c, a, lds); return true;
+        PROF(0, 1, 0) PROF(0, 1, 1) PROF(0, 7, 0) PROF(0, 7, 1)
+        PROF(1, 1, 0) PROF(1, 1, 1) PROF(1, 7, 0) PROF(1, 7, 1)
+#undef PROF
+    default: return false;
+    }
+}
+static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int max_src_per_round, int profile, size_t lds) {
+    if (profile >= 0) {
+        bool done = false;
+        switch (max_src_per_round) {
+        case 1: done = launch_aggregate_profile<1>(c, a, profile, lds); break;
+        case 2: done = launch_aggregate_profile<2>(c, a, profile, lds); break;
+        case 4: done = launch_aggregate_profile<4>(c, a, profile, lds); break;
+        }
+        if (done) return;
+    }
+    switch (max_src_per_round) {
+    case 1: launch_aggregate_one<1, -1>(c, a, lds); break;
+    case 2: launch_aggregate_one<2, -1>(c, a, lds); break;
+    case 3: launch_aggregate_one<3, -1>(c, a, lds); break;
+    case 4: launch_aggregate_one<4, -1>(c, a, lds); break;
+    default: launch_aggregate_one<0, -1>(c, a, lds);
+    }
+}
+
+template <int THREADS>
+static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t NB, bool staged) {
+    constexpr int TILE = THREADS * SC_RPT;
+    size_t lds = (size_t)(sa.P + 1) * 12 + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
+    if (staged) {
+        ST_TRY(set_max_lds(scatter_kernel<THREADS, true>, (int)lds));
+        hipLaunchKernelGGL((scatter_kernel<THREADS, true>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
+    } else {
+        ST_TRY(set_max_lds(scatter_kernel<THREADS, false>, (int)lds));
+        hipLaunchKernelGGL((scatter_kernel<THREADS, false>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One engine source = one partitioned 8-byte column feeding 1..4 states.
+struct EngSrc {
+    const void *data = nullptr;        // un-partitioned input column
+    const uint8_t *null_bits = nullptr;
+    int8_t kind = 0;
+    int8_t st_add = -1, st_min = -1, st_max = -1, st_nn = -1;   // absolute state ids
+    int n_states() const { return (st_add >= 0) + (st_min >= 0) + (st_max >= 0) + (st_nn >= 0); }
+};
 
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
 static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
@@ -637,37 +869,85 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     res.key_dtype = key_dtype;
     const int64_t N = rs.n_rows;
     if (N == 0) { res.valid = true; return 0; }
-    if (N >= (int64_t(1) << 32) - SC_TILE)
+    const int SCT = c->opt.scatter_threads == 512 ? 512 : 1024;
+    const int SC_TILE = SCT * SC_RPT;
+    if (N >= (int64_t(1) << 32) - SC_TILE_MAX)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "n_rows %lld exceeds the 2^32 per-call limit", (long long)N);
 
-    // merge mode: every partial state column is its own single-op source
-    const int n_src = merge ? pl.n_states : pl.n_src;
+    // ---- engine sources.  merge mode: every partial state column is its own single-op source.
+    std::vector<EngSrc> srcs;
+    if (merge) {
+        for (int s = 0; s < pl.n_states; s++) {
+            EngSrc e;
+            e.data = rs.merge_states + (size_t)(s + 1) * rs.merge_stride;
+            switch (pl.kinds[s]) {
+            case SK_ADD_F64: e.kind = 0; e.st_add = (int8_t)s; break;
+            case SK_ADD_I64: e.kind = 1; e.st_add = (int8_t)s; break;
+            case SK_MIN_F64: e.kind = 0; e.st_min = (int8_t)s; break;
+            case SK_MAX_F64: e.kind = 0; e.st_max = (int8_t)s; break;
+            case SK_MIN_I64: e.kind = 1; e.st_min = (int8_t)s; break;
+            case SK_MAX_I64: e.kind = 1; e.st_max = (int8_t)s; break;
+            }
+            srcs.push_back(e);
+        }
+    } else {
+        for (int s = 0; s < pl.n_src; s++) {
+            EngSrc e;
+            e.data = rs.val_data[s]; e.null_bits = rs.val_null_bits[s]; e.kind = pl.src_kind[s];
+            e.st_add = pl.st_add[s]; e.st_min = pl.st_min[s]; e.st_max = pl.st_max[s]; e.st_nn = pl.st_nn[s];
+            srcs.push_back(e);
+        }
+    }
+    const int n_src = (int)srcs.size();
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
-    // LDS table geometry
-    const size_t slot_bytes = 16 + 8 * (size_t)pl.n_states;
-    const size_t lds_budget = (size_t)c->lds_bytes - 256;
-    int64_t T = (int64_t)((lds_budget - 128) / slot_bytes) - 1;
-    if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
-    T = std::min<int64_t>(T, 32768);
-
-    int64_t est = c->opt.groups_hint;
-    // workspace upper bound so that one ensure() covers the whole call (incl. retries at P_MAX)
+    // ---- workspace upper bound so that one ensure() covers the whole call (incl. retries)
     const int NBmax = 1024;
     size_t n_cols8 = 1 + (size_t)n_src + (merge ? 1 : 0);
     size_t ws = Arena::padded(size_t(1 << 19) * 8) + 4096                     // estimate table
-              + 2 * Arena::padded((size_t(P_MAX + 1) * NBmax + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64)
+              + 2 * Arena::padded((size_t(P_MAX + 1) * (NBmax + 8) + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64) + Arena::padded(size_t(P_MAX + 1) * 32)
               + n_cols8 * Arena::padded(size_t(N) * 8) + (size_t)n_src * Arena::padded(size_t(N)) + (1 << 16);
     ST_TRY(c->work.ensure(ws, c->stream));
+    int64_t est = c->opt.groups_hint;
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
     c->timings.estimated_groups = est;
 
-    int64_t P = c->opt.partitions;
-    if (P <= 0) {
-        P = (int64_t)std::ceil((double)est / ((double)T * 0.45));
-        int64_t p_par = std::min<int64_t>(1024, N / 8192);       // enough workgroups to fill 256 CUs
+    // ---- rounds x table geometry x fan-out.  Fewer sources per round => fewer bytes per slot =>
+    // more slots per LDS table => fewer radix partitions (cheaper scatter), at the price of
+    // re-reading the partition's keys once per extra round.
+    const size_t lds_budget = (size_t)c->lds_bytes - 512;
+    const double LOAD = c->opt.load_pct > 0 ? c->opt.load_pct / 100.0 : 0.70;
+    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : 640;
+    int spr = n_src > 0 ? n_src : 1;           // sources per round
+    int n_rounds = 1, round_states = 0, max_spr = 0;
+    int64_t T = 0, P = 0;
+    int8_t round_begin[MAX_ROUNDS + 1];
+    for (;; spr = (spr + 1) / 2) {
+        if (c->opt.src_per_round > 0) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
+        n_rounds = n_src ? (n_src + spr - 1) / spr : 1;
+        if (n_rounds > MAX_ROUNDS) { spr = (n_src + MAX_ROUNDS - 1) / MAX_ROUNDS; n_rounds = (n_src + spr - 1) / spr; }
+        round_states = 0; max_spr = 0;
+        for (int r = 0; r < n_rounds; r++) {
+            int b0 = r * spr, b1 = std::min(n_src, b0 + spr), ns = 0;
+            round_begin[r] = (int8_t)b0; round_begin[r + 1] = (int8_t)b1;
+            for (int s = b0; s < b1; s++) ns += srcs[s].n_states();
+            round_states = std::max(round_states, ns);
+            max_spr = std::max(max_spr, b1 - b0);
+        }
+        if (n_src == 0) { round_begin[0] = round_begin[1] = 0; }
+        const size_t slot_bytes = 20 + 8 * (size_t)round_states;
+        T = (int64_t)((lds_budget - 160) / slot_bytes) - 2;
+        T = std::min<int64_t>(T, 32768) & ~int64_t(3);   // 4-key buckets
+        P = (int64_t)std::ceil((double)est / ((double)T * LOAD));
+        if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET) break;
+    }
+    if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
+    const size_t slot_bytes = 20 + 8 * (size_t)round_states;
+    if (c->opt.partitions > 0) P = c->opt.partitions;
+    else {
+        int64_t p_par = std::min<int64_t>(512, N / 16384);       // enough workgroups to fill 256 CUs
         P = std::max<int64_t>(std::max<int64_t>(P, p_par), 1);
-        P = std::min<int64_t>(P, P_MAX);
+        if (P > 256) P = (P + 127) / 128 * 128;
     }
     P = std::min<int64_t>(std::max<int64_t>(P, 1), P_MAX);
 
@@ -680,14 +960,16 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
         uint32_t NB = (uint32_t)std::min<int64_t>(n_tiles, NBmax);
         int64_t chunk = ((n_tiles + NB - 1) / NB) * SC_TILE;
         NB = (uint32_t)((N + chunk - 1) / chunk);
+        NB = (NB + 7) & ~7u;                      // 8 groups of NB/8 workgroups (empty ones exit)
         size_t M = (size_t)P1 * NB;
 
         uint32_t *hist = c->work.take<uint32_t>(M + 8);
         uint32_t *offsets = c->work.take<uint32_t>(M + 8);
         uint32_t *seg = c->work.take<uint32_t>(SCAN_SEG + 16);
         uint32_t *counters = c->work.take<uint32_t>(64);
+        uint32_t *gcur = c->work.take<uint32_t>((size_t)P1 * 8);
         uint64_t *pkeys = c->work.take<uint64_t>(N);
-        if (!hist || !offsets || !seg || !counters || !pkeys)
+        if (!hist || !offsets || !seg || !counters || !pkeys || !gcur)
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
         if ((M + SCAN_SEG - 1) / SCAN_SEG > SCAN_SEG)
             return fail(PANDRS_HIP_ERR_COMPUTATION, "histogram too large for the scan");
@@ -696,18 +978,22 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
         // ---- histogram + scan
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_HISTOGRAM);
-            hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(SC_THREADS), P1 * 4, c->stream,
+            hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(HI_THREADS), P1 * 4, c->stream,
                                rs.key, N, chunk, (uint32_t)P, seed, hist);
             HIP_TRY(hipGetLastError());
         }
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_SCAN);
             ST_TRY(exclusive_scan_u32(c, hist, M, offsets, seg));
+            if (c->opt.shared_cursors)
+                hipLaunchKernelGGL(init_group_cursors_kernel, dim3((P1 * 8 + 255) / 256), dim3(256), 0, c->stream,
+                                   offsets, NB, P1, gcur);
         }
 
         // ---- scatter
         ScatterArgs sa{};
         sa.key = rs.key; sa.pkeys = pkeys; sa.offsets = offsets; sa.n_rows = N; sa.chunk = chunk;
+        sa.gcur = c->opt.shared_cursors ? gcur : nullptr;
         sa.P = (uint32_t)P; sa.seed = seed;
         AggArgs aa{};
         int64_t *pgsize = nullptr;
@@ -715,69 +1001,89 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
             pgsize = c->work.take<int64_t>(N);
             if (!pgsize) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
             sa.mv[sa.n_move++] = MoveDesc{rs.merge_states, pgsize, 0, 0};
-            for (int s = 0; s < pl.n_states; s++) {
+        }
+        // LDS index of every state inside its round
+        int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
+        for (int k = 0; k < MAX_STATES; k++) { st_round[k] = -1; st_lds[k] = -1; }
+        for (int r = 0; r < n_rounds; r++) {
+            int next = 0;
+            for (int s = round_begin[r]; s < round_begin[r + 1]; s++) {
+                EngSrc &e = srcs[s];
                 uint64_t *pv = c->work.take<uint64_t>(N);
                 if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-                sa.mv[sa.n_move++] = MoveDesc{rs.merge_states + (size_t)(s + 1) * rs.merge_stride, pv, 0, 0};
-                SrcDev &sd = aa.src[s];
-                sd = SrcDev{pv, nullptr, 0, -1, -1, -1, -1, {0, 0, 0}};
-                switch (pl.kinds[s]) {
-                case SK_ADD_F64: sd.kind = 0; sd.st_add = (int8_t)s; break;
-                case SK_ADD_I64: sd.kind = 1; sd.st_add = (int8_t)s; break;
-                case SK_MIN_F64: sd.kind = 0; sd.st_min = (int8_t)s; break;
-                case SK_MAX_F64: sd.kind = 0; sd.st_max = (int8_t)s; break;
-                case SK_MIN_I64: sd.kind = 1; sd.st_min = (int8_t)s; break;
-                case SK_MAX_I64: sd.kind = 1; sd.st_max = (int8_t)s; break;
-                }
-            }
-        } else {
-            for (int s = 0; s < pl.n_src; s++) {
-                uint64_t *pv = c->work.take<uint64_t>(N);
-                if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-                sa.mv[sa.n_move++] = MoveDesc{rs.val_data[s], pv, 0, 0};
+                sa.mv[sa.n_move++] = MoveDesc{e.data, pv, 0, 0};
                 uint8_t *pvalid = nullptr;
-                if (rs.val_null_bits[s]) {
+                if (e.null_bits) {
                     pvalid = c->work.take<uint8_t>(N);
                     if (!pvalid) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-                    sa.mv[sa.n_move++] = MoveDesc{rs.val_null_bits[s], pvalid, 1, 0};
+                    sa.mv[sa.n_move++] = MoveDesc{e.null_bits, pvalid, 1, 0};
                 }
-                aa.src[s] = SrcDev{pv, pvalid, pl.src_kind[s], pl.st_add[s], pl.st_min[s], pl.st_max[s],
-                                   pl.st_nn[s], {0, 0, 0}};
+                SrcDev &sd = aa.src[s];
+                sd = SrcDev{pv, pvalid, e.kind, -1, -1, -1, -1, {0, 0, 0}};
+                auto place = [&](int8_t abs_id, int8_t &lds_id) {
+                    if (abs_id < 0) return;
+                    st_round[abs_id] = (int8_t)r; st_lds[abs_id] = (int8_t)next; lds_id = (int8_t)next; next++;
+                };
+                place(e.st_add, sd.st_add); place(e.st_min, sd.st_min); place(e.st_max, sd.st_max); place(e.st_nn, sd.st_nn);
             }
+        }
+        {   // 8-byte columns first (the staged kernel pipelines those)
+            std::stable_sort(sa.mv, sa.mv + sa.n_move, [](const MoveDesc &x, const MoveDesc &y) { return (x.kind != 0) < (y.kind != 0); });
+            sa.n_move8 = 0;
+            while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
         }
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_SCATTER);
-            size_t lds = (size_t)P1 * 12 + 32 * 4 + SC_TILE * 2 + 16 + (c->opt.scatter_staged ? SC_TILE * 8 : 0);
-            if (c->opt.scatter_staged) {
-                ST_TRY(set_max_lds(scatter_kernel<true>, (int)lds));
-                hipLaunchKernelGGL(scatter_kernel<true>, dim3(NB), dim3(SC_THREADS), lds, c->stream, sa);
-            } else {
-                ST_TRY(set_max_lds(scatter_kernel<false>, (int)lds));
-                hipLaunchKernelGGL(scatter_kernel<false>, dim3(NB), dim3(SC_THREADS), lds, c->stream, sa);
-            }
-            HIP_TRY(hipGetLastError());
+            if (SCT == 512) ST_TRY(launch_scatter<512>(c, sa, NB, c->opt.scatter_staged != 0));
+            else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
         }
 
         // ---- aggregate
         size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 1));
         size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
-        ST_TRY(c->result.ensure(Arena::padded(cap * 8) + Arena::padded(cap) + out_cols * Arena::padded(cap * 8) + 4096, c->stream));
+        ST_TRY(c->result.ensure(Arena::padded(cap * 8) + Arena::padded(cap) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 4096, c->stream));
         res.cap = (int64_t)cap;
         res.keys = c->result.take<uint64_t>(cap);
         res.key_null = c->result.take<uint8_t>(cap);
         if (partials) res.states = c->result.take<uint64_t>(cap * out_cols + 32);
         else res.aggs = c->result.take<double>(cap * std::max<size_t>(out_cols, 1) + 32);
+        if (!res.keys || !res.key_null || (!res.states && !res.aggs))
+            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
         aa.pkeys = pkeys; aa.offsets = offsets; aa.pgsize = pgsize; aa.NB = NB; aa.P = (uint32_t)P;
         aa.T = (uint32_t)T; aa.seed = seed; aa.n_src = n_src; aa.n_states = pl.n_states;
         aa.n_fin = partials ? 0 : n_aggs; aa.partials = partials ? 1 : 0;
+        aa.n_rounds = n_rounds; aa.round_states = round_states;
+        std::memcpy(aa.round_src_begin, round_begin, sizeof aa.round_src_begin);
         std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
-        std::memcpy(aa.fin, pl.fin, sizeof aa.fin);
+        std::memcpy(aa.st_round, st_round, sizeof st_round);
+        std::memcpy(aa.st_lds, st_lds, sizeof st_lds);
+        for (int f = 0; f < n_aggs && !partials; f++) {
+            FinDev &fd = aa.fin[f];
+            fd = FinDev{pl.fin_op[f], pl.fin_kind[f], -1, -1, -1, -1, 0, 0};
+            int s = pl.fin_src[f];
+            if (s < 0) continue;                                   // COUNT: round 0, group size only
+            auto lds_of = [&](int8_t abs_id) -> int8_t { return abs_id < 0 ? (int8_t)-1 : st_lds[abs_id]; };
+            fd.st_add = lds_of(pl.st_add[s]); fd.st_nn = lds_of(pl.st_nn[s]);
+            fd.st_min = lds_of(pl.st_min[s]); fd.st_max = lds_of(pl.st_max[s]);
+            int8_t any = pl.st_add[s] >= 0 ? pl.st_add[s] : (pl.st_min[s] >= 0 ? pl.st_min[s] : pl.st_max[s]);
+            fd.round = st_round[any];
+        }
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
         aa.out_states = res.states; aa.cap = cap; aa.counters = counters;
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
-            size_t lds = (size_t)(T + 1) * slot_bytes + 128;
-            launch_aggregate(c, aa, n_src, lds);
+            size_t lds = (size_t)(T + 2) * slot_bytes + 160;
+            // uniform profile: raw rows, one round, every source same kind / ops / validity
+            int profile = -1;
+            if (!merge && n_rounds == 1 && n_src > 0 && !c->opt.generic_aggregate) {
+                auto prof_of = [](const EngSrc &e) {
+                    int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
+                    return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
+                };
+                profile = prof_of(srcs[0]);
+                for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != profile) profile = -1;
+            }
+            launch_aggregate(c, aa, max_spr, profile, lds);
             HIP_TRY(hipGetLastError());
         }
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
