@@ -194,16 +194,20 @@ int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *ctx, int32_t mem_space,
                                  double *const *out_aggs);
 
 /* ---- mergeable partial aggregates (multi-GPU) -----------------------------
- * pandrs_hip_groupby_partials: same inputs as groupby_agg, but keeps the un-finalised
- * per-group states (group size, per value column: sum, non-null count, min, max as the
- * requested ops need) so that partials from several row-range shards can be merged.
- * pandrs_hip_partials_layout reports how many 8-byte state columns a group carries.
- * pandrs_hip_partials_split buckets the retained partial rows by owner rank
- * (hash of key mod n_ranks) and writes them rank-contiguous into caller buffers, ready for
- * one all-to-all; counts[r] = rows destined to rank r.
- * pandrs_hip_groupby_merge consumes concatenated partial rows (from all peers), merges
- * equal keys and finalises the aggregates; fetch with pandrs_hip_groupby_fetch.
- * Row format of a partial: key cell (8 B), key_null (1 B), then n_state 8-byte cells. */
+ * The reference has no distributed path for groupby (src/distributed is an in-process DataFusion
+ * wrapper); these three calls are the pieces of the row-range-sharded plan:
+ *   pandrs_hip_groupby_partials : same inputs as groupby_agg, but keeps the un-finalised
+ *     per-group states (group size, then per value column: sum, non-null count, min, max as the
+ *     requested ops need) so that partials from several row-range shards can be merged.  The
+ *     state layout is a pure function of (value dtypes, has-null flags, agg specs): every rank
+ *     computes the same layout.  *out_n_state = 8-byte state cells per group (incl. group size).
+ *   pandrs_hip_partials_split : buckets the retained partial rows by owner rank
+ *     (hash(key) mod n_ranks; the NULL group goes to rank 0) and writes them rank-contiguous as
+ *     packed records of W = 2 + n_state 8-byte cells: [key cell, key_null (0/1), states...],
+ *     ready for ONE all-to-all; out_counts[r] = records destined to rank r (host array).
+ *   pandrs_hip_groupby_merge : consumes concatenated packed records (from all peers), merges
+ *     equal keys and finalises the aggregates exactly like groupby_agg; fetch with
+ *     pandrs_hip_groupby_fetch.  val_dtypes / val_has_nulls / aggs must equal the producers'. */
 int32_t pandrs_hip_groupby_partials(pandrs_hip_ctx *ctx, int32_t mem_space,
                                     const pandrs_hip_column *keys, int32_t n_keys,
                                     int64_t n_rows,
@@ -211,12 +215,10 @@ int32_t pandrs_hip_groupby_partials(pandrs_hip_ctx *ctx, int32_t mem_space,
                                     const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
                                     int64_t *out_n_groups, int32_t *out_n_state);
 int32_t pandrs_hip_partials_split(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t n_ranks,
-                                  uint64_t *out_keys, uint8_t *out_key_null,
-                                  uint64_t *out_states /* [n_state][n_groups] */,
+                                  uint64_t *out_records /* [n_groups][2 + n_state] */,
                                   int64_t *out_counts /* host, n_ranks */);
 int32_t pandrs_hip_groupby_merge(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t key_dtype,
-                                 const uint64_t *keys, const uint8_t *key_null,
-                                 const uint64_t *states /* [n_state][n_rows] */,
+                                 const uint64_t *records /* [n_rows][2 + n_state] */,
                                  int64_t n_rows,
                                  const int32_t *val_dtypes, int32_t n_vals,
                                  const uint8_t *val_has_nulls,

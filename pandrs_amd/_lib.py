@@ -65,8 +65,8 @@ SYMBOLS = {
     "pandrs_hip_groupby_partials": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64,
                                                 C.POINTER(Column), C.c_int32, C.POINTER(AggSpec), C.c_int32,
                                                 C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
-    "pandrs_hip_partials_split": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(C.c_int64)]),
-    "pandrs_hip_groupby_merge": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64,
+    "pandrs_hip_partials_split": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int64)]),
+    "pandrs_hip_groupby_merge": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, C.c_int64,
                                              C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_uint8),
                                              C.POINTER(AggSpec), C.c_int32, C.POINTER(C.c_int64)]),
     "pandrs_hip_join_indices": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64,

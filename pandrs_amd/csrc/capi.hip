@@ -150,17 +150,16 @@ int32_t pandrs_hip_groupby_partials(pandrs_hip_ctx *ctx, int32_t mem_space, cons
 }
 
 int32_t pandrs_hip_partials_split(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t n_ranks,
-                                  uint64_t *out_keys, uint8_t *out_key_null, uint64_t *out_states,
-                                  int64_t *out_counts) {
-    return pandrs::partials_split_entry(ctx, mem_space, n_ranks, out_keys, out_key_null, out_states, out_counts);
+                                  uint64_t *out_records, int64_t *out_counts) {
+    return pandrs::partials_split_entry(ctx, mem_space, n_ranks, out_records, out_counts);
 }
 
 int32_t pandrs_hip_groupby_merge(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t key_dtype,
-                                 const uint64_t *keys, const uint8_t *key_null, const uint64_t *states,
+                                 const uint64_t *records,
                                  int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
                                  const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
                                  int32_t n_aggs, int64_t *out_n_groups) {
-    return pandrs::groupby_merge_entry(ctx, mem_space, key_dtype, keys, key_null, states, n_rows,
+    return pandrs::groupby_merge_entry(ctx, mem_space, key_dtype, records, n_rows,
                                        val_dtypes, n_vals, val_has_nulls, aggs, n_aggs, out_n_groups);
 }
 

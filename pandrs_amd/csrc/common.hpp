@@ -172,13 +172,12 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
                       const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
                       int64_t *out_n_groups, int32_t *out_n_state);
 int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
-                            const uint64_t *keys, const uint8_t *key_null, const uint64_t *states,
+                            const uint64_t *records,
                             int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
                             const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
                             int32_t n_aggs, int64_t *out_n_groups);
 int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
-                             uint64_t *out_keys, uint8_t *out_key_null, uint64_t *out_states,
-                             int64_t *out_counts);
+                             uint64_t *out_records, int64_t *out_counts);
 int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk, int64_t nl,
                    const pandrs_hip_column *rk, int64_t nr, int32_t how, int64_t *out_n);
 int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk,

@@ -1179,31 +1179,52 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     return 0;
 }
 
+// packed partial records [n][W] -> column arrays keys[n] | key_null[n] | states[W-2][n]
+__global__ void unpack_records_kernel(const uint64_t *rec, int64_t n, int W, uint64_t *keys,
+                                      uint8_t *knull, uint64_t *states) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *r = rec + (size_t)i * W;
+    keys[i] = r[0];
+    knull[i] = r[1] != 0;
+    for (int s = 0; s < W - 2; s++) states[(size_t)s * n + i] = r[2 + s];
+}
+
 int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
-                            const uint64_t *keys, const uint8_t *key_null, const uint64_t *states,
+                            const uint64_t *records,
                             int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
                             const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
                             int32_t n_aggs, int64_t *out_n_groups) {
-    if (!c || !out_n_groups || n_rows < 0 || (n_rows && (!keys || !states)) || n_vals < 0 || n_aggs < 0)
+    if (!c || !out_n_groups || n_rows < 0 || (n_rows && !records) || n_vals < 0 || n_aggs < 0)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_merge: bad arguments");
     Plan pl;
     ST_TRY(build_plan(val_dtypes, val_has_nulls, n_vals, aggs, n_aggs, pl));
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     timings_begin(c);
-    Stager stg{c, mem_space};
-    size_t n_state = 1 + (size_t)pl.n_states;
-    if (mem_space == PANDRS_HIP_MEM_HOST && n_rows > 0)
-        ST_TRY(c->staging.ensure(size_t(n_rows) * (9 + 8 * n_state) + (1 << 16), c->stream));
+    const size_t n_state = 1 + (size_t)pl.n_states, W = 2 + n_state;
+    // staging arena: [records (host mode only)] keys | key_null | states
+    ST_TRY(c->staging.ensure(size_t(n_rows) * 8 * W * (mem_space == PANDRS_HIP_MEM_HOST ? 2 : 1) + size_t(n_rows) * 16 + (1 << 16), c->stream));
     RowSource rs;
     rs.n_rows = n_rows;
-    rs.key = KeyDesc{stg.in(keys, size_t(n_rows) * 8), nullptr,
-                     (const uint8_t *)stg.in(key_null, size_t(n_rows)), DT_CELL};
-    rs.merge_states = (const uint64_t *)stg.in(states, size_t(n_rows) * 8 * n_state);
-    rs.merge_stride = (size_t)n_rows;
-    if (stg.status) return stg.status;
+    if (n_rows > 0) {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        Stager stg{c, mem_space};
+        const uint64_t *drec = (const uint64_t *)stg.in(records, size_t(n_rows) * 8 * W);
+        if (stg.status) return stg.status;
+        uint64_t *dk = c->staging.take<uint64_t>(n_rows);
+        uint8_t *dn = c->staging.take<uint8_t>(n_rows);
+        uint64_t *ds = c->staging.take<uint64_t>(size_t(n_rows) * n_state);
+        if (!dk || !dn || !ds) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+        hipLaunchKernelGGL(unpack_records_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                           drec, n_rows, (int)W, dk, dn, ds);
+        HIP_TRY(hipGetLastError());
+        rs.key = KeyDesc{dk, nullptr, dn, DT_CELL};
+        rs.merge_states = ds;
+        rs.merge_stride = (size_t)n_rows;
+    }
     ST_TRY(run_engine(c, rs, pl, /*merge=*/true, /*partials=*/false, n_aggs, key_dtype));
-    c->timings.algorithmic_bytes = n_rows * (int64_t)(9 + 8 * n_state) + c->gb.n_groups * (8 + 8 * (int64_t)n_aggs);
+    c->timings.algorithmic_bytes = n_rows * (int64_t)(8 * W) + c->gb.n_groups * (8 + 8 * (int64_t)n_aggs);
     ST_TRY(timings_end(c));
     *out_n_groups = c->gb.n_groups;
     return 0;
@@ -1217,22 +1238,22 @@ __global__ void owner_count_kernel(const uint64_t *keys, const uint8_t *knull, i
     uint32_t r = knull[i] ? 0u : owner_of(keys[i], n_ranks);
     atomicAdd(&counts[r], 1u);
 }
+// writes packed records [key, key_null, states...] rank-contiguously
 __global__ void owner_scatter_kernel(const uint64_t *keys, const uint8_t *knull,
                                      const uint64_t *states, size_t in_stride, int n_state, int64_t n,
-                                     uint32_t n_ranks, uint32_t *cursors, uint64_t *out_keys,
-                                     uint8_t *out_null, uint64_t *out_states, size_t out_stride) {
+                                     uint32_t n_ranks, uint32_t *cursors, uint64_t *out_records) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t r = knull[i] ? 0u : owner_of(keys[i], n_ranks);
     uint32_t d = atomicAdd(&cursors[r], 1u);
-    out_keys[d] = keys[i];
-    out_null[d] = knull[i];
-    for (int s = 0; s < n_state; s++) out_states[(size_t)s * out_stride + d] = states[(size_t)s * in_stride + i];
+    uint64_t *o = out_records + (size_t)d * (2 + n_state);
+    o[0] = keys[i];
+    o[1] = knull[i];
+    for (int s = 0; s < n_state; s++) o[2 + s] = states[(size_t)s * in_stride + i];
 }
 
 int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
-                             uint64_t *out_keys, uint8_t *out_key_null, uint64_t *out_states,
-                             int64_t *out_counts) {
+                             uint64_t *out_records, int64_t *out_counts) {
     if (!c || n_ranks < 1 || n_ranks > 1024 || !out_counts)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "partials_split: bad arguments");
     std::lock_guard<std::mutex> lock(c->mu);
@@ -1242,10 +1263,11 @@ int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ran
     const int64_t n = res.n_groups;
     for (int r = 0; r < n_ranks; r++) out_counts[r] = 0;
     if (n == 0) return 0;
-    if (!out_keys || !out_key_null || !out_states) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null output");
-    c->work.off = 0;
-    size_t need = 4096 + (mem_space == PANDRS_HIP_MEM_HOST ? Arena::padded(n * 8) + Arena::padded(n) + Arena::padded(size_t(n) * 8 * res.n_state) : 0);
+    if (!out_records) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null output");
+    const size_t W = 2 + (size_t)res.n_state;
+    size_t need = (1 << 16) + (mem_space == PANDRS_HIP_MEM_HOST ? Arena::padded(size_t(n) * 8 * W) : 0);
     if (c->work.cap < need) ST_TRY(c->work.ensure(need, c->stream));
+    c->work.off = 0;
     uint32_t *counts = c->work.take<uint32_t>(2048);
     uint32_t *cursors = counts + 1024;
     HIP_TRY(hipMemsetAsync(counts, 0, 2048 * 4, c->stream));
@@ -1258,19 +1280,16 @@ int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ran
     uint32_t run = 0;
     for (int r = 0; r < n_ranks; r++) { out_counts[r] = h[r]; uint32_t t = h[r]; h[r] = run; run += t; }
     HIP_TRY(hipMemcpyAsync(cursors, h, n_ranks * 4, hipMemcpyHostToDevice, c->stream));
-    uint64_t *dk = out_keys; uint8_t *dn = out_key_null; uint64_t *ds = out_states;
+    uint64_t *drec = out_records;
     if (mem_space == PANDRS_HIP_MEM_HOST) {
-        dk = c->work.take<uint64_t>(n); dn = c->work.take<uint8_t>(n); ds = c->work.take<uint64_t>(size_t(n) * res.n_state);
-        if (!dk || !dn || !ds) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
+        drec = c->work.take<uint64_t>(size_t(n) * W);
+        if (!drec) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
     }
     hipLaunchKernelGGL(owner_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, res.keys, res.key_null,
-                       res.states, (size_t)res.cap, res.n_state, n, (uint32_t)n_ranks, cursors, dk, dn, ds, (size_t)n);
+                       res.states, (size_t)res.cap, res.n_state, n, (uint32_t)n_ranks, cursors, drec);
     HIP_TRY(hipGetLastError());
-    if (mem_space == PANDRS_HIP_MEM_HOST) {
-        HIP_TRY(hipMemcpyAsync(out_keys, dk, n * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(out_key_null, dn, n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(out_states, ds, size_t(n) * 8 * res.n_state, hipMemcpyDeviceToHost, c->stream));
-    }
+    if (mem_space == PANDRS_HIP_MEM_HOST)
+        HIP_TRY(hipMemcpyAsync(out_records, drec, size_t(n) * 8 * W, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -1,0 +1,86 @@
+"""Row-range-sharded groupby across the GPUs of one node: one process per GPU, ONE exchange step.
+
+Plan (the reference has no distributed path for this, src/distributed is an
+in-process DataFusion wrapper):
+
+  1. every rank pre-aggregates its own row range into mergeable partial rows
+     (pandrs_hip_groupby_partials) — with G << N/P this shrinks the exchange from raw rows to
+     at most G records per rank;
+  2. the partial rows are bucketed by owner = hash(key) mod world and written rank-contiguous as
+     packed records (pandrs_hip_partials_split);
+  3. ONE all-to-all moves them (RCCL over xGMI via torch.distributed backend "nccl": grouped
+     send/recv to every peer, all 7 links busy at once — not a ring), preceded by the world x
+     world count exchange;
+  4. every rank merges the records it received — the key sets of different ranks are disjoint —
+     and finalises (pandrs_hip_groupby_merge).  The result stays sharded by key owner.
+
+torch.distributed is transport only.  `engine` is the object that does the local work; in
+production it is a pandrs_amd.Context (HIP).  Tests inject a CPU stand-in so that the exchange
+logic runs under gloo without a GPU.
+"""
+import time
+
+
+class DistributedGroupBy:
+    def __init__(self, engine, dist, device):
+        self.engine = engine
+        self.dist = dist
+        self.device = device
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.last_timings = None
+
+    def _torch(self):
+        import torch
+        return torch
+
+    def exchange(self, records, counts):
+        """records: [G, W] int64 tensor, rank-contiguous by owner; counts: list[world].
+        -> [G_recv, W] tensor of the records this rank owns."""
+        torch = self._torch()
+        dist = self.dist
+        send_counts = torch.tensor(counts, dtype=torch.int64, device=records.device)
+        recv_counts = torch.empty(self.world, dtype=torch.int64, device=records.device)
+        dist.all_to_all_single(recv_counts, send_counts)
+        recv_list = [int(x) for x in recv_counts.tolist()]
+        out = torch.empty((sum(recv_list), records.shape[1]), dtype=records.dtype, device=records.device)
+        dist.all_to_all_single(out, records, output_split_sizes=recv_list, input_split_sizes=list(counts))
+        return out
+
+    def groupby_agg(self, keys, n_rows, vals, aggs, fetch=True):
+        """Same arguments as Context.groupby_agg; every rank passes its own row range.
+        Returns this rank's share of the groups (keys owned by this rank)."""
+        torch = self._torch()
+        eng = self.engine
+        t0 = time.perf_counter()
+        ng_local, n_state = eng.groupby_partials(keys, n_rows, vals, aggs)
+        t_local = eng.timings() if hasattr(eng, "timings") else None
+        records, counts = eng.partials_split(self.world)
+        if not torch.is_tensor(records):
+            records = torch.from_numpy(records.view("int64"))
+        t1 = time.perf_counter()
+        recv = self.exchange(records, counts)
+        if recv.is_cuda:
+            torch.cuda.synchronize(recv.device)
+        t2 = time.perf_counter()
+        val_dtypes = [v[2] for v in vals]
+        val_has_nulls = [v[1] is not None for v in vals]
+        eng.groupby_merge(keys[0][2], recv if recv.is_cuda else recv.numpy().view("uint64"),
+                          val_dtypes, val_has_nulls, aggs)
+        t3 = time.perf_counter()
+        t_merge = eng.timings() if hasattr(eng, "timings") else None
+        if t_local is not None:
+            phases = dict(t_local["phase_ms"])
+            for k, v in t_merge["phase_ms"].items():
+                phases["merge_" + k] = v
+            phases["exchange_wall"] = (t2 - t1) * 1e3
+            self.last_timings = {
+                "total_ms": t_local["total_ms"] + t_merge["total_ms"] + (t2 - t1) * 1e3,
+                "phase_ms": phases,
+                "algorithmic_bytes": t_local["algorithmic_bytes"],
+                "local_groups": ng_local, "records_sent": int(sum(counts)), "records_received": int(recv.shape[0]),
+                "wall_ms": {"local+split": (t1 - t0) * 1e3, "exchange": (t2 - t1) * 1e3, "merge": (t3 - t2) * 1e3},
+            }
+        if fetch:
+            return eng.groupby_fetch()
+        return None

@@ -189,40 +189,36 @@ class Context:
 
     def partials_split(self, n_ranks, device=None):
         """Buckets the retained partial rows by owner rank.
-        -> (keys[G] , key_null[G], states[n_state, G], counts[n_ranks])  rank-contiguous."""
+        -> (records[G, 2 + n_state] int64/uint64: key, key_null, states..., counts[n_ranks]);
+        records are rank-contiguous, ready for one all-to-all."""
         g, ns, space = self._last_partials
         dev = space == L.MEM_DEVICE if device is None else device
         counts = (C.c_int64 * n_ranks)()
         if dev:
             import torch
-            d = "cuda:%d" % self.device
-            k = torch.empty(g, dtype=torch.int64, device=d)
-            kn = torch.empty(g, dtype=torch.uint8, device=d)
-            s = torch.empty((ns, g), dtype=torch.int64, device=d)
+            rec = torch.empty((g, 2 + ns), dtype=torch.int64, device="cuda:%d" % self.device)
         else:
-            k = np.empty(g, np.uint64)
-            kn = np.empty(g, np.uint8)
-            s = np.empty((ns, g), np.uint64)
+            rec = np.empty((g, 2 + ns), np.uint64)
         st = self.lib.pandrs_hip_partials_split(self.h, L.MEM_DEVICE if dev else L.MEM_HOST, n_ranks,
-                                                _ptr(k), _ptr(kn), _ptr(s), counts)
+                                                _ptr(rec), counts)
         if st:
             _raise(st)
-        return k, kn, s, [int(c) for c in counts]
+        return rec, [int(c) for c in counts]
 
-    def groupby_merge(self, key_dtype, keys, key_null, states, n_rows, val_dtypes, val_has_nulls, aggs):
-        dev = _is_torch(keys)
+    def groupby_merge(self, key_dtype, records, val_dtypes, val_has_nulls, aggs):
+        """records: [n, 2 + n_state] packed partial rows gathered from all peers."""
+        dev = _is_torch(records)
         if not dev:
-            keys = np.ascontiguousarray(keys, np.uint64)
-            key_null = np.ascontiguousarray(key_null, np.uint8)
-            states = np.ascontiguousarray(states, np.uint64)
+            records = np.ascontiguousarray(records, np.uint64)
         else:
-            keys, key_null, states = keys.contiguous(), key_null.contiguous(), states.contiguous()
+            records = records.contiguous()
+        n_rows = int(records.shape[0])
         nv = len(val_dtypes)
         vd = (C.c_int32 * max(nv, 1))(*[int(x) for x in val_dtypes])
         vh = (C.c_uint8 * max(nv, 1))(*[1 if x else 0 for x in val_has_nulls])
         ng = C.c_int64(0)
         st = self.lib.pandrs_hip_groupby_merge(self.h, L.MEM_DEVICE if dev else L.MEM_HOST, int(key_dtype),
-                                               _ptr(keys), _ptr(key_null), _ptr(states), int(n_rows),
+                                               _ptr(records) if n_rows else None, n_rows,
                                                vd, nv, vh, self._aggs(aggs), len(aggs), C.byref(ng))
         if st:
             _raise(st)

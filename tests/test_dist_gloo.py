@@ -1,0 +1,73 @@
+"""world_size-2 gloo rehearsal of the multi-GPU groupby exchange (pandrs_amd/dist.py): partials ->
+owner split -> count exchange + ONE all_to_all -> merge.  The local engine is a numpy stand-in
+(tests/cpu_engine.py) because there is no GPU here; the GPU box runs the same driver over
+pandrs_amd.Context in tests/test_gpu_groupby.py::test_partials_split_merge_roundtrip and bench.py."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(n=60_000, g=5_000):
+    rng = np.random.default_rng(77)
+    ids = rng.integers(0, g, n).astype(np.uint64)
+    keys = (ids * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = np.packbits(rng.random(n) < 0.002, bitorder="little")
+    v0 = rng.normal(100, 10, n)
+    v1 = rng.normal(-5, 3, n)
+    m1 = np.packbits(rng.random(n) < 0.1, bitorder="little")
+    return keys, km, v0, v1, m1
+
+
+AGGS = [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1), (1, 2), (1, 3)]
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from pandrs_amd.dist import DistributedGroupBy
+    from tests.cpu_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys, km, v0, v1, m1 = _data()
+    n = len(keys)
+    lo, hi = (n // world // 8 * 8) * rank, n if rank == world - 1 else (n // world // 8 * 8) * (rank + 1)
+    bits = lambda m: np.packbits(np.unpackbits(m, bitorder="little")[:n][lo:hi], bitorder="little")
+    d = DistributedGroupBy(NumpyEngine(), dist, "cpu")
+    kc, kn, oa = d.groupby_agg([(keys[lo:hi], bits(km), 0)], hi - lo,
+                               [(v0[lo:hi], None, 1), (v1[lo:hi], bits(m1), 1)], AGGS)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), kc=kc, kn=kn, oa=oa)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_matches_oracle(world):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from tests.helpers import assert_groupby_equal
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, "r%d.npz" % r)) for r in range(world)]
+    # key ownership is disjoint across ranks
+    allk = np.concatenate([np.stack([p["kn"][0].astype(np.uint64), p["kc"][0]], 1) for p in parts])
+    assert len(np.unique(allk, axis=0)) == len(allk)
+    got = tuple(np.concatenate([p[name] for p in parts], axis=1) for name in ("kc", "kn", "oa"))
+    keys, km, v0, v1, m1 = _data()
+    want = O.groupby_agg([(keys, km, O.I64)], len(keys), [(v0, None, O.F64), (v1, m1, O.F64)], AGGS)
+    exact = [i for i, (_, op) in enumerate(AGGS) if op in (O.MIN, O.MAX, O.COUNT)]
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)

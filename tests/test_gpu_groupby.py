@@ -218,18 +218,15 @@ def test_partials_split_merge_roundtrip(ctx):
         vmask = O.pack_mask(np.unpackbits(m1, bitorder="little")[:n][sl])
         ng, ns = ctx.groupby_partials([(k[sl], kmask, O.I64)], hi - lo,
                                       [(v0[sl], None, O.F64), (v1[sl], vmask, O.I64)], aggs)
-        pk, pn, ps, counts = ctx.partials_split(ranks)
-        assert sum(counts) == ng
+        rec, counts = ctx.partials_split(ranks)
+        assert sum(counts) == ng and rec.shape == (ng, 2 + ns)
         off = 0
         for r, c in enumerate(counts):
-            inbox[r].append((pk[off:off + c], pn[off:off + c], ps[:, off:off + c]))
+            inbox[r].append(rec[off:off + c])
             off += c
     outs = []
     for r in range(ranks):
-        pk = np.concatenate([x[0] for x in inbox[r]])
-        pn = np.concatenate([x[1] for x in inbox[r]])
-        ps = np.concatenate([x[2] for x in inbox[r]], axis=1)
-        ctx.groupby_merge(O.I64, pk, pn, ps, len(pk), [O.F64, O.I64], [False, True], aggs)
+        ctx.groupby_merge(O.I64, np.concatenate(inbox[r]), [O.F64, O.I64], [False, True], aggs)
         outs.append(ctx.groupby_fetch(to_device=False))
     got = tuple(np.concatenate([o[i] for o in outs], axis=1) for i in range(3))
     want = O.groupby_agg([(k, km, O.I64)], n, [(v0, None, O.F64), (v1, m1, O.I64)], aggs)
