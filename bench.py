@@ -148,6 +148,7 @@ def main():
                                  "timed with hipEvents on the library stream; B = N(K+8C)+G(K+8A)"},
         }
         if world > 1 or force_dist:
+            out["roofline"]["wall_ms_last_step"] = dgb.last_timings.get("wall_ms")
             out["roofline"]["note"] = ("local partial aggregation + split + all-to-all + merge; device_ms = hipEvent time of the "
                                        "local and merge pipelines + wall time of the exchange; B = N(K+8C)+G(K+8A) per GPU")
         if not args.no_cpu_baseline and world == 1:

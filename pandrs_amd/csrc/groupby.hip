@@ -917,7 +917,7 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     // re-reading the partition's keys once per extra round.
     const size_t lds_budget = (size_t)c->lds_bytes - 512;
     const double LOAD = c->opt.load_pct > 0 ? c->opt.load_pct / 100.0 : 0.70;
-    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : 640;
+    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : 3072;   // rounds only when one round would need more partitions than this
     int spr = n_src > 0 ? n_src : 1;           // sources per round
     int n_rounds = 1, round_states = 0, max_spr = 0;
     int64_t T = 0, P = 0;
@@ -1231,25 +1231,58 @@ int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dt
 }
 
 // ---- partial split for the all-to-all -------------------------------------------------------------
-__global__ void owner_count_kernel(const uint64_t *keys, const uint8_t *knull, int64_t n,
-                                   uint32_t n_ranks, uint32_t *counts) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t r = knull[i] ? 0u : owner_of(keys[i], n_ranks);
-    atomicAdd(&counts[r], 1u);
+// Owner bucketing with workgroup-level aggregation: LDS counters per rank, ONE global atomic per
+// (workgroup, rank) — a per-record global atomic on n_ranks addresses serialises at the memory side.
+constexpr int OS_THREADS = 256, OS_RPT = 16;
+
+__global__ __launch_bounds__(OS_THREADS) void owner_count_kernel(const uint64_t *keys, const uint8_t *knull,
+                                                                 int64_t n, uint32_t n_ranks, uint32_t *counts) {
+    __shared__ uint32_t cnt[1024];
+    for (uint32_t r = threadIdx.x; r < n_ranks; r += OS_THREADS) cnt[r] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * OS_THREADS * OS_RPT;
+    for (int q = 0; q < OS_RPT; q++) {
+        int64_t i = base + q * OS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[knull[i] ? 0u : owner_of(keys[i], n_ranks)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n_ranks; r += OS_THREADS)
+        if (cnt[r]) atomicAdd(&counts[r], cnt[r]);
 }
 // writes packed records [key, key_null, states...] rank-contiguously
-__global__ void owner_scatter_kernel(const uint64_t *keys, const uint8_t *knull,
-                                     const uint64_t *states, size_t in_stride, int n_state, int64_t n,
-                                     uint32_t n_ranks, uint32_t *cursors, uint64_t *out_records) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t r = knull[i] ? 0u : owner_of(keys[i], n_ranks);
-    uint32_t d = atomicAdd(&cursors[r], 1u);
-    uint64_t *o = out_records + (size_t)d * (2 + n_state);
-    o[0] = keys[i];
-    o[1] = knull[i];
-    for (int s = 0; s < n_state; s++) o[2 + s] = states[(size_t)s * in_stride + i];
+__global__ __launch_bounds__(OS_THREADS) void owner_scatter_kernel(const uint64_t *keys, const uint8_t *knull,
+                                                                   const uint64_t *states, size_t in_stride,
+                                                                   int n_state, int64_t n, uint32_t n_ranks,
+                                                                   uint32_t *cursors, uint64_t *out_records) {
+    __shared__ uint32_t cnt[1024];
+    for (uint32_t r = threadIdx.x; r < n_ranks; r += OS_THREADS) cnt[r] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * OS_THREADS * OS_RPT;
+    uint32_t own[OS_RPT], rank[OS_RPT];
+#pragma unroll
+    for (int q = 0; q < OS_RPT; q++) {
+        int64_t i = base + q * OS_THREADS + threadIdx.x;
+        own[q] = 0xFFFFFFFFu;
+        if (i < n) {
+            own[q] = knull[i] ? 0u : owner_of(keys[i], n_ranks);
+            rank[q] = atomicAdd(&cnt[own[q]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n_ranks; r += OS_THREADS) {
+        uint32_t c = cnt[r];
+        cnt[r] = c ? atomicAdd(&cursors[r], c) : 0u;     // cnt[] now holds this workgroup's base per rank
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < OS_RPT; q++) {
+        if (own[q] == 0xFFFFFFFFu) continue;
+        int64_t i = base + q * OS_THREADS + threadIdx.x;
+        uint64_t *o = out_records + (size_t)(cnt[own[q]] + rank[q]) * (2 + n_state);
+        o[0] = keys[i];
+        o[1] = knull[i];
+        for (int s = 0; s < n_state; s++) o[2 + s] = states[(size_t)s * in_stride + i];
+    }
 }
 
 int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
@@ -1271,8 +1304,8 @@ int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ran
     uint32_t *counts = c->work.take<uint32_t>(2048);
     uint32_t *cursors = counts + 1024;
     HIP_TRY(hipMemsetAsync(counts, 0, 2048 * 4, c->stream));
-    unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(owner_count_kernel, dim3(grid), dim3(256), 0, c->stream, res.keys, res.key_null, n,
+    unsigned grid = (unsigned)((n + OS_THREADS * OS_RPT - 1) / (OS_THREADS * OS_RPT));
+    hipLaunchKernelGGL(owner_count_kernel, dim3(grid), dim3(OS_THREADS), 0, c->stream, res.keys, res.key_null, n,
                        (uint32_t)n_ranks, counts);
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     HIP_TRY(hipMemcpyAsync(h, counts, n_ranks * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1285,7 +1318,7 @@ int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ran
         drec = c->work.take<uint64_t>(size_t(n) * W);
         if (!drec) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
     }
-    hipLaunchKernelGGL(owner_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, res.keys, res.key_null,
+    hipLaunchKernelGGL(owner_scatter_kernel, dim3(grid), dim3(OS_THREADS), 0, c->stream, res.keys, res.key_null,
                        res.states, (size_t)res.cap, res.n_state, n, (uint32_t)n_ranks, cursors, drec);
     HIP_TRY(hipGetLastError());
     if (mem_space == PANDRS_HIP_MEM_HOST)
