@@ -119,7 +119,7 @@ struct pandrs_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    pandrs::Arena work, result, staging;
+    pandrs::Arena work, result, staging, temp;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
     pandrs::GroupbyResult gb;

@@ -1,0 +1,100 @@
+// engine.hpp — declarations shared by groupby.hip and join.hip (radix partitioner + aggregate engine).
+#pragma once
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace pandrs {
+
+constexpr int MAX_SRC = 16;
+constexpr int MAX_STATES = 40;
+constexpr int MAX_AGGS = 64;
+constexpr int MAX_MOVE = 40;
+constexpr int P_MAX = 4096;
+
+constexpr int HI_THREADS = 1024;   // histogram workgroup
+constexpr int SC_RPT = 8;          // scatter: rows per thread per tile
+constexpr int SC_TILE_MAX = 1024 * SC_RPT;
+static_assert(SC_TILE_MAX <= (1 << 13), "scatter packs the tile position in 13 bits");
+constexpr int AG_THREADS = 1024;   // aggregate workgroup
+constexpr int MAX_ROUNDS = 16;
+
+enum StateKind : int8_t { SK_ADD_F64 = 0, SK_ADD_I64, SK_MIN_F64, SK_MAX_F64, SK_MIN_I64, SK_MAX_I64 };
+
+struct SrcDev {
+    const uint64_t *vals;   // partitioned 8-byte values
+    const uint8_t *valid;   // partitioned validity bytes (1 = valid) or nullptr
+    int8_t kind;            // 0 = f64, 1 = i64
+    int8_t st_add, st_min, st_max, st_nn;  // LDS state indices, -1 = none
+    int8_t pad[3];
+};
+
+struct FinDev {
+    int8_t op, kind, st_add, st_nn, st_min, st_max;   // st_*: LDS state index inside its round
+    int8_t round, pad;
+};
+
+struct MoveDesc {
+    const void *src;
+    void *dst;
+    int kind;   // 0: 8-byte element, 1: null bitmap -> validity byte, 2: byte copy
+    int pad;
+};
+
+
+struct ScatterArgs {
+    KeyDesc key;
+    uint64_t *pkeys;
+    const uint32_t *offsets;   // partition-major exclusive scan of the histogram
+    uint32_t *gcur;            // [P+1][8] shared write cursors per (partition, group); nullptr = private cursors
+    int64_t n_rows, chunk;
+    uint32_t P, seed;
+    int n_move, n_move8;       // mv[0 .. n_move8) are 8-byte columns, the rest byte-wide
+    MoveDesc mv[MAX_MOVE];
+};
+
+
+struct Plan {
+    int n_src = 0, n_states = 0, n_fin = 0;
+    int src_col[MAX_SRC];          // index into vals[]
+    int8_t src_kind[MAX_SRC];
+    int8_t st_add[MAX_SRC], st_min[MAX_SRC], st_max[MAX_SRC], st_nn[MAX_SRC];   // absolute state ids
+    int8_t kinds[MAX_STATES];
+    int8_t fin_op[MAX_AGGS], fin_kind[MAX_AGGS];
+    int fin_src[MAX_AGGS];         // plan source of each aggregate, -1 for COUNT
+};
+
+
+// Row source handed to the engine: device pointers only.
+struct RowSource {
+    KeyDesc key;
+    int64_t n_rows = 0;
+    // raw mode: per plan source, the value column and its null bitmap
+    const void *val_data[MAX_SRC]{};
+    const uint8_t *val_null_bits[MAX_SRC]{};
+    // merge mode: partial state columns [1 + n_states][n_rows] (column 0 = group size)
+    const uint64_t *merge_states = nullptr;
+    size_t merge_stride = 0;
+};
+
+
+// Result of one radix partition pass: partition p holds rows [offsets[p*NB], offsets[(p+1)*NB]) of
+// the partitioned arrays; partition P is the null-key partition.
+struct PartInfo {
+    uint32_t P = 0, NB = 0;
+    uint32_t *offsets = nullptr;
+};
+
+// histogram -> scan -> scatter.  The caller fills sa.key, sa.pkeys, sa.mv[0..n_move), sa.n_rows,
+// sa.P, sa.seed; workspace comes from c->work (not reset here).
+int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
+                        int phase_scatter);
+int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out, uint32_t *seg);
+size_t scan_seg_count(size_t n);     // entries the `seg` scratch of exclusive_scan_u32 needs
+
+int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
+                   const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl);
+int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge, bool partials,
+                   int n_aggs, int key_dtype);
+size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
+
+}  // namespace pandrs

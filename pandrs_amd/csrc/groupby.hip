@@ -18,48 +18,12 @@
 //             reference's finalisation rules applied in registers.
 // HBM traffic: keys once (histogram) + all columns read/written once (scatter) + read once
 // (aggregate) + outputs.  No MFMA: the path is integer/byte work bounded by HBM.
-#include "common.hpp"
-#include "device_utils.hpp"
+#include "engine.hpp"
 
 #include <algorithm>
 #include <cmath>
 
 namespace pandrs {
-
-constexpr int MAX_SRC = 16;
-constexpr int MAX_STATES = 40;
-constexpr int MAX_AGGS = 64;
-constexpr int MAX_MOVE = 40;
-constexpr int P_MAX = 4096;
-
-constexpr int HI_THREADS = 1024;   // histogram workgroup
-constexpr int SC_RPT = 8;          // scatter: rows per thread per tile
-constexpr int SC_TILE_MAX = 1024 * SC_RPT;
-static_assert(SC_TILE_MAX <= (1 << 13), "scatter packs the tile position in 13 bits");
-constexpr int AG_THREADS = 1024;   // aggregate workgroup
-constexpr int MAX_ROUNDS = 16;
-
-enum StateKind : int8_t { SK_ADD_F64 = 0, SK_ADD_I64, SK_MIN_F64, SK_MAX_F64, SK_MIN_I64, SK_MAX_I64 };
-
-struct SrcDev {
-    const uint64_t *vals;   // partitioned 8-byte values
-    const uint8_t *valid;   // partitioned validity bytes (1 = valid) or nullptr
-    int8_t kind;            // 0 = f64, 1 = i64
-    int8_t st_add, st_min, st_max, st_nn;  // LDS state indices, -1 = none
-    int8_t pad[3];
-};
-
-struct FinDev {
-    int8_t op, kind, st_add, st_nn, st_min, st_max;   // st_*: LDS state index inside its round
-    int8_t round, pad;
-};
-
-struct MoveDesc {
-    const void *src;
-    void *dst;
-    int kind;   // 0: 8-byte element, 1: null bitmap -> validity byte, 2: byte copy
-    int pad;
-};
 
 // ------------------------------------------------------------------------------------ estimate
 __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
@@ -166,25 +130,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t
 }
 
 // ------------------------------------------------------------------------------------ scatter
-struct ScatterArgs {
-    KeyDesc key;
-    uint64_t *pkeys;
-    const uint32_t *offsets;   // partition-major exclusive scan of the histogram
-    uint32_t *gcur;            // [P+1][8] shared write cursors per (partition, group); nullptr = private cursors
-    int64_t n_rows, chunk;
-    uint32_t P, seed;
-    int n_move, n_move8;       // mv[0 .. n_move8) are 8-byte columns, the rest byte-wide
-    MoveDesc mv[MAX_MOVE];
-};
-
 __device__ __forceinline__ uint64_t move_load(const MoveDesc &m, int64_t i) {
-    if (m.kind == 0) return reinterpret_cast<const uint64_t *>(m.src)[i];
-    if (m.kind == 1) return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 0ull : 1ull;
-    return reinterpret_cast<const uint8_t *>(m.src)[i];
+    switch (m.kind) {
+    case 0: return reinterpret_cast<const uint64_t *>(m.src)[i];
+    case 1: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 0ull : 1ull;
+    case 2: return reinterpret_cast<const uint8_t *>(m.src)[i];
+    case 3: return (uint64_t)i;                                        // row index
+    default: return reinterpret_cast<const uint32_t *>(m.src)[i];      // 4: u32 source
+    }
 }
 __device__ __forceinline__ void move_store(const MoveDesc &m, uint32_t dst, uint64_t v) {
-    if (m.kind == 0) reinterpret_cast<uint64_t *>(m.dst)[dst] = v;
-    else reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
+    switch (m.kind) {
+    case 0: case 4: reinterpret_cast<uint64_t *>(m.dst)[dst] = v; break;
+    case 3: reinterpret_cast<uint32_t *>(m.dst)[dst] = (uint32_t)v; break;
+    default: reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
+    }
 }
 
 // Row r of a thread's tile slice is tile-local index r*THREADS + tid, clamped to the tile's last
@@ -356,7 +316,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++) {
                 uint32_t j = r * THREADS + tid;
-                if (live(r)) reinterpret_cast<uint8_t *>(mv.dst)[dst[r]] = (uint8_t)stage[j];
+                if (live(r)) move_store(mv, dst[r], stage[j]);
             }
         }
         __syncthreads();
@@ -669,19 +629,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
 
 // ------------------------------------------------------------------------------------ host side
 
-struct Plan {
-    int n_src = 0, n_states = 0, n_fin = 0;
-    int src_col[MAX_SRC];          // index into vals[]
-    int8_t src_kind[MAX_SRC];
-    int8_t st_add[MAX_SRC], st_min[MAX_SRC], st_max[MAX_SRC], st_nn[MAX_SRC];   // absolute state ids
-    int8_t kinds[MAX_STATES];
-    int8_t fin_op[MAX_AGGS], fin_kind[MAX_AGGS];
-    int fin_src[MAX_AGGS];         // plan source of each aggregate, -1 for COUNT
-};
-
 // Builds the state layout from (value dtypes, has-null flags, aggregate specs).  The layout is a
 // pure function of these, so shards on different GPUs produce mergeable partials.
-static int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
+int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
                           const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl) {
     if (n_aggs > MAX_AGGS) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "more than %d aggregates", MAX_AGGS);
     if (n_vals > 1024) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "too many value columns");
@@ -734,19 +684,9 @@ static int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_null
     return 0;
 }
 
-// Row source handed to the engine: device pointers only.
-struct RowSource {
-    KeyDesc key;
-    int64_t n_rows = 0;
-    // raw mode: per plan source, the value column and its null bitmap
-    const void *val_data[MAX_SRC]{};
-    const uint8_t *val_null_bits[MAX_SRC]{};
-    // merge mode: partial state columns [1 + n_states][n_rows] (column 0 = group size)
-    const uint64_t *merge_states = nullptr;
-    size_t merge_stride = 0;
-};
+size_t scan_seg_count(size_t n) { return (n + SCAN_SEG - 1) / SCAN_SEG + 16; }
 
-static int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out,
+int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out,
                                   uint32_t *seg) {
     uint32_t n_seg = (uint32_t)((n + SCAN_SEG - 1) / SCAN_SEG);
     hipLaunchKernelGGL(scan_partial_kernel, dim3(n_seg), dim3(SCAN_THREADS), 0, c->stream, in, n, seg);
@@ -851,6 +791,60 @@ static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t
     return 0;
 }
 
+size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1) {
+    const size_t NBmax = 1024 + 8;
+    return Arena::padded(size_t(1 << 19) * 8) + 4096
+         + 2 * Arena::padded((size_t(P_MAX + 1) * NBmax + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64)
+         + Arena::padded(size_t(P_MAX + 1) * 32)
+         + (size_t)n_cols8 * Arena::padded(size_t(n_rows) * 8) + (size_t)n_cols1 * Arena::padded(size_t(n_rows)) + (1 << 16);
+}
+
+int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
+                        int phase_scatter) {
+    const int64_t N = sa.n_rows;
+    const int SCT = c->opt.scatter_threads == 512 ? 512 : 1024;
+    const int SC_TILE = SCT * SC_RPT;
+    const uint32_t P1 = sa.P + 1;
+    int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
+    uint32_t NB = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), 1024);
+    int64_t chunk = ((n_tiles + NB - 1) / NB) * SC_TILE;
+    if (chunk == 0) chunk = SC_TILE;
+    NB = (uint32_t)std::max<int64_t>((N + chunk - 1) / chunk, 1);
+    NB = (NB + 7) & ~7u;                      // 8 groups of NB/8 workgroups (empty ones exit)
+    size_t M = (size_t)P1 * NB;
+    uint32_t *hist = c->work.take<uint32_t>(M + 8);
+    uint32_t *offsets = c->work.take<uint32_t>(M + 8);
+    uint32_t *seg = c->work.take<uint32_t>(scan_seg_count(M));
+    uint32_t *gcur = c->work.take<uint32_t>((size_t)P1 * 8);
+    if (!hist || !offsets || !seg || !gcur) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (partition)");
+    {
+        PhaseTimer pt(c, phase_hist);
+        hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(HI_THREADS), P1 * 4, c->stream,
+                           sa.key, N, chunk, sa.P, sa.seed, hist);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        PhaseTimer pt(c, phase_scan);
+        ST_TRY(exclusive_scan_u32(c, hist, M, offsets, seg));
+        if (c->opt.shared_cursors)
+            hipLaunchKernelGGL(init_group_cursors_kernel, dim3((P1 * 8 + 255) / 256), dim3(256), 0, c->stream,
+                               offsets, NB, P1, gcur);
+    }
+    sa.offsets = offsets; sa.chunk = chunk;
+    sa.gcur = c->opt.shared_cursors ? gcur : nullptr;
+    // 8-byte columns first (the staged kernel pipelines those)
+    std::stable_sort(sa.mv, sa.mv + sa.n_move, [](const MoveDesc &x, const MoveDesc &y) { return (x.kind != 0) < (y.kind != 0); });
+    sa.n_move8 = 0;
+    while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
+    {
+        PhaseTimer pt(c, phase_scatter);
+        if (SCT == 512) ST_TRY(launch_scatter<512>(c, sa, NB, c->opt.scatter_staged != 0));
+        else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
+    }
+    out->P = sa.P; out->NB = NB; out->offsets = offsets;
+    return 0;
+}
+
 // One engine source = one partitioned 8-byte column feeding 1..4 states.
 struct EngSrc {
     const void *data = nullptr;        // un-partitioned input column
@@ -861,7 +855,7 @@ struct EngSrc {
 };
 
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
-static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
+int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
                           bool partials, int n_aggs, int key_dtype) {
     GroupbyResult &res = c->gb;
     res = GroupbyResult{};
@@ -869,8 +863,6 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     res.key_dtype = key_dtype;
     const int64_t N = rs.n_rows;
     if (N == 0) { res.valid = true; return 0; }
-    const int SCT = c->opt.scatter_threads == 512 ? 512 : 1024;
-    const int SC_TILE = SCT * SC_RPT;
     if (N >= (int64_t(1) << 32) - SC_TILE_MAX)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "n_rows %lld exceeds the 2^32 per-call limit", (long long)N);
 
@@ -902,11 +894,7 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
     // ---- workspace upper bound so that one ensure() covers the whole call (incl. retries)
-    const int NBmax = 1024;
-    size_t n_cols8 = 1 + (size_t)n_src + (merge ? 1 : 0);
-    size_t ws = Arena::padded(size_t(1 << 19) * 8) + 4096                     // estimate table
-              + 2 * Arena::padded((size_t(P_MAX + 1) * (NBmax + 8) + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64) + Arena::padded(size_t(P_MAX + 1) * 32)
-              + n_cols8 * Arena::padded(size_t(N) * 8) + (size_t)n_src * Arena::padded(size_t(N)) + (1 << 16);
+    size_t ws = engine_workspace_bytes(N, 1 + n_src + (merge ? 1 : 0), n_src);
     ST_TRY(c->work.ensure(ws, c->stream));
     int64_t est = c->opt.groups_hint;
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
@@ -956,45 +944,13 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
         const uint32_t P1 = (uint32_t)P + 1;
-        int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
-        uint32_t NB = (uint32_t)std::min<int64_t>(n_tiles, NBmax);
-        int64_t chunk = ((n_tiles + NB - 1) / NB) * SC_TILE;
-        NB = (uint32_t)((N + chunk - 1) / chunk);
-        NB = (NB + 7) & ~7u;                      // 8 groups of NB/8 workgroups (empty ones exit)
-        size_t M = (size_t)P1 * NB;
-
-        uint32_t *hist = c->work.take<uint32_t>(M + 8);
-        uint32_t *offsets = c->work.take<uint32_t>(M + 8);
-        uint32_t *seg = c->work.take<uint32_t>(SCAN_SEG + 16);
         uint32_t *counters = c->work.take<uint32_t>(64);
-        uint32_t *gcur = c->work.take<uint32_t>((size_t)P1 * 8);
         uint64_t *pkeys = c->work.take<uint64_t>(N);
-        if (!hist || !offsets || !seg || !counters || !pkeys || !gcur)
-            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-        if ((M + SCAN_SEG - 1) / SCAN_SEG > SCAN_SEG)
-            return fail(PANDRS_HIP_ERR_COMPUTATION, "histogram too large for the scan");
+        if (!counters || !pkeys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
         HIP_TRY(hipMemsetAsync(counters, 0, 64 * 4, c->stream));
 
-        // ---- histogram + scan
-        {
-            PhaseTimer pt(c, PANDRS_HIP_PHASE_HISTOGRAM);
-            hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(HI_THREADS), P1 * 4, c->stream,
-                               rs.key, N, chunk, (uint32_t)P, seed, hist);
-            HIP_TRY(hipGetLastError());
-        }
-        {
-            PhaseTimer pt(c, PANDRS_HIP_PHASE_SCAN);
-            ST_TRY(exclusive_scan_u32(c, hist, M, offsets, seg));
-            if (c->opt.shared_cursors)
-                hipLaunchKernelGGL(init_group_cursors_kernel, dim3((P1 * 8 + 255) / 256), dim3(256), 0, c->stream,
-                                   offsets, NB, P1, gcur);
-        }
-
-        // ---- scatter
         ScatterArgs sa{};
-        sa.key = rs.key; sa.pkeys = pkeys; sa.offsets = offsets; sa.n_rows = N; sa.chunk = chunk;
-        sa.gcur = c->opt.shared_cursors ? gcur : nullptr;
-        sa.P = (uint32_t)P; sa.seed = seed;
+        sa.key = rs.key; sa.pkeys = pkeys; sa.n_rows = N; sa.P = (uint32_t)P; sa.seed = seed;
         AggArgs aa{};
         int64_t *pgsize = nullptr;
         if (merge) {
@@ -1027,16 +983,10 @@ static int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
                 place(e.st_add, sd.st_add); place(e.st_min, sd.st_min); place(e.st_max, sd.st_max); place(e.st_nn, sd.st_nn);
             }
         }
-        {   // 8-byte columns first (the staged kernel pipelines those)
-            std::stable_sort(sa.mv, sa.mv + sa.n_move, [](const MoveDesc &x, const MoveDesc &y) { return (x.kind != 0) < (y.kind != 0); });
-            sa.n_move8 = 0;
-            while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
-        }
-        {
-            PhaseTimer pt(c, PANDRS_HIP_PHASE_SCATTER);
-            if (SCT == 512) ST_TRY(launch_scatter<512>(c, sa, NB, c->opt.scatter_staged != 0));
-            else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
-        }
+        PartInfo part;
+        ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+        const uint32_t NB = part.NB;
+        uint32_t *offsets = part.offsets;
 
         // ---- aggregate
         size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 1));

@@ -1,13 +1,506 @@
-// join.hip — placeholder until the radix-partitioned hash join lands.
-#include "common.hpp"
+// join.hip — radix-partitioned hash join for MI355X (gfx950, wave64).
+//
+// Replaces OptimizedDataFrame::join_impl up to the join_indices vector
+// (reference src/optimized/split_dataframe/join.rs:106-224), which stringifies both key columns,
+// builds HashMap<String, Vec<usize>> over the right side and probes the left side on one thread.
+//
+// Device plan (inputs / outputs resident in HBM):
+//   1. both sides are radix-partitioned on hash(key cell) with the SAME fan-out and seed (the
+//      groupby engine's histogram / scan / LDS-staged scatter), carrying the original row index;
+//      null keys go to a partition of their own and are never probed (join.rs:112, :152);
+//   2. count pass, one workgroup per partition: the right partition is loaded into LDS and
+//      bitonic-sorted by (key, right row) — so a key's matches are already in ascending
+//      right-row order, the reference's per-key Vec<usize> order (join.rs:114, :156-158) — and
+//      written back sorted; every left row binary-searches its run in LDS and stores its match
+//      count at its ORIGINAL row position; matched right rows are flagged for right/outer;
+//   3. exclusive scan of the per-left-row counts = output offsets in reference order
+//      (left rows ascending, join.rs:151);
+//   4. emit pass: sorted right partition back into LDS, each left row writes its (left, right)
+//      index pairs at its offset; left/outer misses write (left, -1) (join.rs:159-162);
+//   5. right/outer: unmatched right rows (null keys included) are compacted ascending behind
+//      the probe output (join.rs:211-224).
+// All of it is HBM-bound integer work: no MFMA.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+
 namespace pandrs {
-int32_t join_entry(pandrs_hip_ctx *, int32_t, const pandrs_hip_column *, int64_t,
-                   const pandrs_hip_column *, int64_t, int32_t, int64_t *) {
-    return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "join: not implemented yet");
+
+constexpr int JN_THREADS = 1024;
+constexpr int JN_RCAP = 8192;           // right rows per partition that fit the LDS sort buffers
+constexpr uint32_t JN_SEED = 0x51ED270Bu;
+
+// ---- LDS bitonic sort of (key, payload) pairs, ascending by key then payload ----------------------
+template <typename PT>
+__device__ __forceinline__ void lds_bitonic_sort(uint64_t *sk, PT *sp, uint32_t n2) {
+    for (uint32_t k = 2; k <= n2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n2; i += JN_THREADS) {
+                uint32_t x = i ^ j;
+                if (x > i) {
+                    uint64_t ka = sk[i], kb = sk[x];
+                    PT pa = sp[i], pb = sp[x];
+                    bool gt = ka > kb || (ka == kb && pa > pb);
+                    bool up = (i & k) == 0;
+                    if (gt == up) { sk[i] = kb; sk[x] = ka; sp[i] = pb; sp[x] = pa; }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
-int32_t join_groupby_sum_entry(pandrs_hip_ctx *, int32_t, const pandrs_hip_column *,
-                               const pandrs_hip_column *, int64_t, const pandrs_hip_column *,
-                               const pandrs_hip_column *, int64_t, int64_t *) {
-    return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "join_groupby_sum: not implemented yet");
+
+__device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t *sk, uint32_t n, uint64_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sk[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
+
+struct JoinArgs {
+    uint64_t *rkeys; uint32_t *rrows;           // partitioned right side (sorted in place by the count pass)
+    const uint64_t *lkeys; const uint32_t *lrows;
+    const uint32_t *roff, *loff;                // partition offsets (PartInfo.offsets)
+    uint32_t rNB, lNB, P;
+    int keep_left;                              // left / outer: a miss still produces one row
+    int flag_right;                             // right / outer: record matched right rows
+    uint32_t *cnt;                              // [n_left] output rows per left row (original order)
+    const uint32_t *out_off;                    // exclusive scan of cnt (emit pass)
+    uint8_t *rmatched;                          // [n_right]
+    int64_t *out_left, *out_right;
+    uint32_t *flags;                            // [0] = a right partition did not fit LDS
+};
+
+// LDS: sk[R2] u64 | sp[R2] u32 | hit[R2] u8
+template <bool EMIT>
+__global__ __launch_bounds__(JN_THREADS) void join_probe_kernel(JoinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
+    const uint32_t lbeg = a.loff[(size_t)p * a.lNB], lend = a.loff[(size_t)(p + 1) * a.lNB];
+    const uint32_t nR = rend - rbeg;
+    if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
+    if (lbeg == lend || (nR == 0 && !a.keep_left)) return;
+    uint32_t n2 = 64;
+    while (n2 < nR) n2 <<= 1;
+    uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *sp = reinterpret_cast<uint32_t *>(sk + JN_RCAP);
+    uint8_t *hit = reinterpret_cast<uint8_t *>(sp + JN_RCAP);
+    for (uint32_t i = tid; i < n2; i += JN_THREADS) {
+        sk[i] = i < nR ? a.rkeys[rbeg + i] : ~0ull;
+        sp[i] = i < nR ? a.rrows[rbeg + i] : 0xFFFFFFFFu;
+        if (!EMIT) hit[i] = 0;
+    }
+    __syncthreads();
+    if (!EMIT) {
+        lds_bitonic_sort<uint32_t>(sk, sp, n2);
+        for (uint32_t i = tid; i < nR; i += JN_THREADS) { a.rkeys[rbeg + i] = sk[i]; a.rrows[rbeg + i] = sp[i]; }
+    }
+    for (uint32_t i = lbeg + tid; i < lend; i += JN_THREADS) {
+        const uint64_t k = a.lkeys[i];
+        const uint32_t lrow = a.lrows[i];
+        uint32_t lb = lds_lower_bound(sk, nR, k);
+        uint32_t m = 0;
+        while (lb + m < nR && sk[lb + m] == k) m++;
+        if (!EMIT) {
+            a.cnt[lrow] = m ? m : (a.keep_left ? 1u : 0u);
+            if (m && a.flag_right) hit[lb] = 1;
+        } else {
+            size_t o = a.out_off[lrow];
+            if (m) {
+                for (uint32_t j = 0; j < m; j++) { a.out_left[o + j] = lrow; a.out_right[o + j] = sp[lb + j]; }
+            } else if (a.keep_left) {
+                a.out_left[o] = lrow; a.out_right[o] = -1;
+            }
+        }
+    }
+    if (!EMIT && a.flag_right) {
+        __syncthreads();
+        for (uint32_t i = tid; i < nR; i += JN_THREADS) {
+            uint32_t s = i;
+            const uint64_t k = sk[i];
+            while (s > 0 && sk[s - 1] == k) s--;        // start of this key's run
+            if (hit[s]) a.rmatched[sp[i]] = 1;
+        }
+    }
+}
+
+__global__ void unmatched_pred_kernel(const uint8_t *rmatched, int64_t n, uint32_t *pred) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pred[i] = rmatched[i] ? 0u : 1u;
+}
+__global__ void append_unmatched_kernel(const uint8_t *rmatched, const uint32_t *off, int64_t n, int64_t base,
+                                        int64_t *out_left, int64_t *out_right) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !rmatched[i]) { out_left[base + off[i]] = -1; out_right[base + off[i]] = i; }
+}
+
+static int32_t stage_key(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n, KeyDesc *out) {
+    const void *d = col->data; const uint8_t *m = col->null_mask;
+    if (mem_space == PANDRS_HIP_MEM_HOST && n > 0) {
+        size_t bytes = dtype_bytes(col->dtype, n);
+        void *dd = c->staging.take<uint8_t>(bytes + 16);
+        if (!dd) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+        HIP_TRY(hipMemcpyAsync(dd, d, bytes, hipMemcpyHostToDevice, c->stream));
+        d = dd;
+        if (m) {
+            uint8_t *dm = c->staging.take<uint8_t>((n + 7) / 8 + 16);
+            if (!dm) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+            HIP_TRY(hipMemcpyAsync(dm, m, (n + 7) / 8, hipMemcpyHostToDevice, c->stream));
+            m = dm;
+        }
+    }
+    *out = KeyDesc{d, m, nullptr, col->dtype};
+    return 0;
+}
+
+int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk, int64_t nl,
+                   const pandrs_hip_column *rk, int64_t nr, int32_t how, int64_t *out_n) {
+    if (!c || !lk || !rk || !out_n || nl < 0 || nr < 0 || how < PANDRS_HIP_JOIN_INNER || how > PANDRS_HIP_JOIN_OUTER)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: bad arguments");
+    if (lk->dtype != rk->dtype)                 // join.rs:98-104
+        return fail(PANDRS_HIP_ERR_TYPE_MISMATCH, "join key columns have different types (%d and %d)", lk->dtype, rk->dtype);
+    if (lk->dtype < PANDRS_HIP_I64 || lk->dtype > PANDRS_HIP_BOOLBITS)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: bad key dtype %d", lk->dtype);
+    if ((nl && !lk->data) || (nr && !rk->data)) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: key column has no data");
+    if (nl >= (int64_t(1) << 32) - 16384 || nr >= (int64_t(1) << 32) - 16384)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: a side exceeds the 2^32-row per-call limit");
+    const bool keep_left = how == PANDRS_HIP_JOIN_LEFT || how == PANDRS_HIP_JOIN_OUTER;
+    const bool keep_right = how == PANDRS_HIP_JOIN_RIGHT || how == PANDRS_HIP_JOIN_OUTER;
+
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    c->jn = JoinResult{};
+    c->gb.valid = false;                        // the result arena is shared
+    KeyDesc lkey{}, rkey{};
+    {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        if (mem_space == PANDRS_HIP_MEM_HOST)
+            ST_TRY(c->staging.ensure(dtype_bytes(lk->dtype, nl) + dtype_bytes(rk->dtype, nr) + (nl + nr) / 8 + (1 << 16), c->stream));
+        ST_TRY(stage_key(c, mem_space, lk, nl, &lkey));
+        ST_TRY(stage_key(c, mem_space, rk, nr, &rkey));
+    }
+    // workspace: two partition passes + per-row arrays
+    size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nl) * 8) + Arena::padded(size_t(nr) * 8)
+              + 3 * Arena::padded(size_t(nl + 2) * 4) + 4 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
+              + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16);
+    ST_TRY(c->work.ensure(ws, c->stream));
+
+    int64_t P = c->opt.partitions > 0 ? c->opt.partitions
+                                     : std::max<int64_t>(1, (int64_t)std::ceil((double)nr / (JN_RCAP * 0.6)));
+    P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, (nl + nr) / 32768)), P_MAX);
+    P = std::max<int64_t>(P, 1);
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    int64_t M1 = 0, M2 = 0;
+    for (int attempt = 0;; attempt++) {
+        c->work.off = 0;
+        c->timings.n_partitions = P; c->timings.retries = attempt; c->timings.table_slots = JN_RCAP;
+        uint32_t *flags = c->work.take<uint32_t>(64);
+        uint64_t *prk = c->work.take<uint64_t>(nr + 1);
+        uint32_t *prr = c->work.take<uint32_t>(nr + 1);
+        uint64_t *plk = c->work.take<uint64_t>(nl + 1);
+        uint32_t *pli = c->work.take<uint32_t>(nl + 1);
+        uint32_t *cnt = c->work.take<uint32_t>(nl + 2);
+        uint32_t *off = c->work.take<uint32_t>(nl + 2);
+        uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)nl + 1));
+        uint8_t *rmatched = c->work.take<uint8_t>(nr + 8);
+        if (!flags || !prk || !prr || !plk || !pli || !cnt || !off || !seg || !rmatched)
+            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
+        HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
+        HIP_TRY(hipMemsetAsync(cnt, 0, size_t(nl + 2) * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(rmatched, 0, size_t(nr) + 8, c->stream));
+
+        PartInfo rpart{}, lpart{};
+        ScatterArgs rs{}, ls{};
+        rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P; rs.seed = JN_SEED;
+        rs.mv[rs.n_move++] = MoveDesc{nullptr, prr, 3, 0};
+        ls.key = lkey; ls.pkeys = plk; ls.n_rows = nl; ls.P = (uint32_t)P; ls.seed = JN_SEED;
+        ls.mv[ls.n_move++] = MoveDesc{nullptr, pli, 3, 0};
+        ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
+        ST_TRY(radix_partition(c, ls, &lpart, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER));
+
+        JoinArgs ja{};
+        ja.rkeys = prk; ja.rrows = prr; ja.lkeys = plk; ja.lrows = pli;
+        ja.roff = rpart.offsets; ja.loff = lpart.offsets; ja.rNB = rpart.NB; ja.lNB = lpart.NB; ja.P = (uint32_t)P;
+        ja.keep_left = keep_left; ja.flag_right = keep_right; ja.cnt = cnt; ja.out_off = off; ja.rmatched = rmatched;
+        ja.flags = flags;
+        const size_t lds = (size_t)JN_RCAP * 13 + 64;
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(join_probe_kernel<false>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ja);
+            HIP_TRY(hipGetLastError());
+            ST_TRY(exclusive_scan_u32(c, cnt, (size_t)nl + 1, off, seg));    // off[nl] = rows from the probe
+        }
+        HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h + 1, off + nl, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[0]) {
+            if (P >= P_MAX)
+                return fail(PANDRS_HIP_ERR_COMPUTATION,
+                            "join build side does not fit: a radix partition holds more than %d right rows at the "
+                            "maximum fan-out (too many rows or one key with too many duplicates)", JN_RCAP);
+            P = std::min<int64_t>(P * 4, P_MAX);
+            continue;
+        }
+        M1 = h[1];
+        // ---- right / outer: unmatched right rows, ascending
+        uint32_t *roff2 = nullptr;
+        if (keep_right && nr > 0) {
+            uint32_t *pred = c->work.take<uint32_t>(nr + 2);
+            roff2 = c->work.take<uint32_t>(nr + 2);
+            uint32_t *seg2 = c->work.take<uint32_t>(scan_seg_count((size_t)nr + 1));
+            if (!pred || !roff2 || !seg2) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
+            HIP_TRY(hipMemsetAsync(pred + nr, 0, 8, c->stream));
+            hipLaunchKernelGGL(unmatched_pred_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, rmatched, nr, pred);
+            ST_TRY(exclusive_scan_u32(c, pred, (size_t)nr + 1, roff2, seg2));
+            HIP_TRY(hipMemcpyAsync(h, roff2 + nr, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            M2 = h[0];
+        }
+        const int64_t M = M1 + M2;
+        ST_TRY(c->result.ensure(2 * Arena::padded(size_t(M + 1) * 8) + 4096, c->stream));
+        c->jn.left_idx = c->result.take<int64_t>(M + 1);
+        c->jn.right_idx = c->result.take<int64_t>(M + 1);
+        if (!c->jn.left_idx || !c->jn.right_idx) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
+        ja.out_left = c->jn.left_idx; ja.out_right = c->jn.right_idx;
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+            if (M1 > 0) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(join_probe_kernel<true>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ja);
+            }
+            if (M2 > 0)
+                hipLaunchKernelGGL(append_unmatched_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
+                                   rmatched, roff2, nr, M1, c->jn.left_idx, c->jn.right_idx);
+            HIP_TRY(hipGetLastError());
+        }
+        c->jn.n_rows = M;
+        c->jn.valid = true;
+        break;
+    }
+    // B_join for index output: both key columns read once, 16 B per output row written
+    int64_t K = lk->dtype == PANDRS_HIP_U32CODE ? 4 : (lk->dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
+    c->timings.algorithmic_bytes = (nl + nr) * K + c->jn.n_rows * 16;
+    ST_TRY(timings_end(c));
+    *out_n = c->jn.n_rows;
+    return 0;
+}
+
+// ================================================================================================
+// Fused inner join -> groupby(right payload g).sum(left payload v)   (BASELINE config 5)
+// Equivalent to inner_join (join.rs:32) + group_by(g).aggregate([(v, Sum)]) (aggregation.rs:763)
+// without materialising the join rows in reference order: matches are emitted partition by
+// partition as (g, v) pairs (coalesced), then fed to the groupby engine.  Null g / null v become
+// 0 / 0.0 and are NOT null afterwards, exactly as the reference's gathers fill them
+// (join.rs:304-307, :319-322).
+// ================================================================================================
+struct FusedArgs {
+    uint64_t *rkeys, *rpay;
+    const uint64_t *lkeys, *lpay;
+    const uint32_t *roff, *loff;
+    uint32_t rNB, lNB, P;
+    uint32_t *pcount;               // [P+1] matches per partition
+    const uint32_t *poff;           // exclusive scan of pcount
+    uint64_t *out_g, *out_v;
+    uint32_t *flags;
+};
+
+// LDS: sk[R] u64 | sg[R] u64 | wave totals
+template <bool EMIT>
+__global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
+    const uint32_t lbeg = a.loff[(size_t)p * a.lNB], lend = a.loff[(size_t)(p + 1) * a.lNB];
+    const uint32_t nR = rend - rbeg;
+    if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
+    if (!EMIT && tid == 0) a.pcount[p] = 0;
+    if (lbeg == lend || nR == 0) return;
+    uint32_t n2 = 64;
+    while (n2 < nR) n2 <<= 1;
+    uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *sg = sk + JN_RCAP;
+    uint32_t *wt = reinterpret_cast<uint32_t *>(sg + JN_RCAP);
+    for (uint32_t i = tid; i < n2; i += JN_THREADS) {
+        sk[i] = i < nR ? a.rkeys[rbeg + i] : ~0ull;
+        sg[i] = i < nR ? a.rpay[rbeg + i] : ~0ull;
+    }
+    __syncthreads();
+    if (!EMIT) {
+        lds_bitonic_sort<uint64_t>(sk, sg, n2);
+        for (uint32_t i = tid; i < nR; i += JN_THREADS) { a.rkeys[rbeg + i] = sk[i]; a.rpay[rbeg + i] = sg[i]; }
+    }
+    uint32_t run = EMIT ? a.poff[p] : 0u, mine = 0;
+    const uint32_t n_iter = (lend - lbeg + JN_THREADS - 1) / JN_THREADS;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t i = lbeg + it * JN_THREADS + tid;
+        uint32_t lb = 0, m = 0;
+        uint64_t v = 0;
+        if (i < lend) {
+            const uint64_t k = a.lkeys[i];
+            lb = lds_lower_bound(sk, nR, k);
+            while (lb + m < nR && sk[lb + m] == k) m++;
+            if (EMIT && m) v = a.lpay[i];
+        }
+        if (!EMIT) { mine += m; continue; }
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<JN_THREADS>(m, wt, &tot);
+        for (uint32_t j = 0; j < m; j++) { a.out_g[run + ex + j] = sg[lb + j]; a.out_v[run + ex + j] = v; }
+        run += tot;
+    }
+    if (!EMIT) {
+        uint32_t tot;
+        block_exclusive_scan<JN_THREADS>(mine, wt, &tot);
+        if (tid == 0) a.pcount[p] = tot;
+    }
+}
+
+// payload with the reference's gather fill: null => 0 (join.rs:304-307); u32 sources widened
+__global__ void clean_payload_kernel(const void *src, const uint8_t *null_bits, int is_u32, int64_t n, uint64_t *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t v = is_u32 ? (uint64_t)reinterpret_cast<const uint32_t *>(src)[i] : reinterpret_cast<const uint64_t *>(src)[i];
+    out[i] = (null_bits && bit_at(null_bits, i)) ? 0ull : v;
+}
+
+int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk,
+                               const pandrs_hip_column *lv, int64_t nl,
+                               const pandrs_hip_column *rk, const pandrs_hip_column *rg,
+                               int64_t nr, int64_t *out_n_groups) {
+    if (!c || !lk || !lv || !rk || !rg || !out_n_groups || nl < 0 || nr < 0)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join_groupby_sum: bad arguments");
+    if (lk->dtype != rk->dtype)
+        return fail(PANDRS_HIP_ERR_TYPE_MISMATCH, "join key columns have different types (%d and %d)", lk->dtype, rk->dtype);
+    if (lv->dtype != PANDRS_HIP_I64 && lv->dtype != PANDRS_HIP_F64)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "Aggregation operation 0 is not supported for column type %d", lv->dtype);
+    if (rg->dtype == PANDRS_HIP_BOOLBITS)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "join_groupby_sum: bit-packed group column is not supported on the device path");
+    if (nl >= (int64_t(1) << 32) - 16384 || nr >= (int64_t(1) << 32) - 16384)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: a side exceeds the 2^32-row per-call limit");
+    int32_t vdt = lv->dtype; uint8_t vhn = 0;
+    pandrs_hip_agg_spec spec{0, PANDRS_HIP_AGG_SUM};
+    Plan pl;
+    ST_TRY(build_plan(&vdt, &vhn, 1, &spec, 1, pl));
+
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    c->jn.valid = false;
+    KeyDesc lkey{}, rkey{}, lval{}, rgrp{};
+    {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        if (mem_space == PANDRS_HIP_MEM_HOST)
+            ST_TRY(c->staging.ensure(dtype_bytes(lk->dtype, nl) + dtype_bytes(rk->dtype, nr) + size_t(nl) * 8 + size_t(nr) * 8 +
+                                     (nl + nr) / 2 + (1 << 16), c->stream));
+        ST_TRY(stage_key(c, mem_space, lk, nl, &lkey));
+        ST_TRY(stage_key(c, mem_space, rk, nr, &rkey));
+        ST_TRY(stage_key(c, mem_space, lv, nl, &lval));
+        ST_TRY(stage_key(c, mem_space, rg, nr, &rgrp));
+    }
+    size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + 3 * Arena::padded(size_t(nl + 1) * 8) + 3 * Arena::padded(size_t(nr + 1) * 8) + (1 << 20);
+    ST_TRY(c->work.ensure(ws, c->stream));
+    int64_t P = c->opt.partitions > 0 ? c->opt.partitions
+                                     : std::max<int64_t>(1, (int64_t)std::ceil((double)nr / (JN_RCAP * 0.6)));
+    P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, (nl + nr) / 32768)), P_MAX);
+    P = std::max<int64_t>(P, 1);
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    int64_t M = 0;
+    uint64_t *out_g = nullptr, *out_v = nullptr;
+    for (int attempt = 0;; attempt++) {
+        c->work.off = 0;
+        c->timings.n_partitions = P; c->timings.retries = attempt;
+        uint32_t *flags = c->work.take<uint32_t>(64);
+        uint64_t *prk = c->work.take<uint64_t>(nr + 1), *prg = c->work.take<uint64_t>(nr + 1);
+        uint64_t *plk = c->work.take<uint64_t>(nl + 1), *plv = c->work.take<uint64_t>(nl + 1);
+        uint32_t *pcount = c->work.take<uint32_t>(P + 2), *poff = c->work.take<uint32_t>(P + 2);
+        uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)P + 1));
+        if (!flags || !prk || !prg || !plk || !plv || !pcount || !poff || !seg)
+            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
+        HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
+        HIP_TRY(hipMemsetAsync(pcount, 0, size_t(P + 2) * 4, c->stream));
+        // payload columns: plain 8-byte columns move as they are; masked / 4-byte ones are cleaned first
+        const void *gsrc = rgrp.data, *vsrc = lval.data;
+        if (nr > 0 && (rgrp.null_bits || rg->dtype == PANDRS_HIP_U32CODE)) {
+            uint64_t *t = c->work.take<uint64_t>(nr + 1);
+            if (!t) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
+            hipLaunchKernelGGL(clean_payload_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
+                               rgrp.data, rgrp.null_bits, rg->dtype == PANDRS_HIP_U32CODE ? 1 : 0, nr, t);
+            gsrc = t;
+        }
+        if (nl > 0 && lval.null_bits) {
+            uint64_t *t = c->work.take<uint64_t>(nl + 1);
+            if (!t) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
+            hipLaunchKernelGGL(clean_payload_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream,
+                               lval.data, lval.null_bits, 0, nl, t);
+            vsrc = t;
+        }
+        PartInfo rpart{}, lpart{};
+        ScatterArgs rs{}, ls{};
+        rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P; rs.seed = JN_SEED;
+        rs.mv[rs.n_move++] = MoveDesc{gsrc, prg, 0, 0};
+        ls.key = lkey; ls.pkeys = plk; ls.n_rows = nl; ls.P = (uint32_t)P; ls.seed = JN_SEED;
+        ls.mv[ls.n_move++] = MoveDesc{vsrc, plv, 0, 0};
+        ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
+        ST_TRY(radix_partition(c, ls, &lpart, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER));
+        FusedArgs fa{};
+        fa.rkeys = prk; fa.rpay = prg; fa.lkeys = plk; fa.lpay = plv;
+        fa.roff = rpart.offsets; fa.loff = lpart.offsets; fa.rNB = rpart.NB; fa.lNB = lpart.NB; fa.P = (uint32_t)P;
+        fa.pcount = pcount; fa.poff = poff; fa.flags = flags;
+        const size_t lds = (size_t)JN_RCAP * 16 + 256;
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_probe_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fused_probe_kernel<false>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, fa);
+            HIP_TRY(hipGetLastError());
+            ST_TRY(exclusive_scan_u32(c, pcount, (size_t)P + 1, poff, seg));
+        }
+        HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h + 1, poff + P, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[0]) {
+            if (P >= P_MAX)
+                return fail(PANDRS_HIP_ERR_COMPUTATION,
+                            "join build side does not fit: a radix partition holds more than %d right rows at the maximum fan-out", JN_RCAP);
+            P = std::min<int64_t>(P * 4, P_MAX);
+            continue;
+        }
+        M = h[1];
+        ST_TRY(c->temp.ensure(2 * Arena::padded(size_t(M + 1) * 8) + 4096, c->stream));
+        out_g = c->temp.take<uint64_t>(M + 1);
+        out_v = c->temp.take<uint64_t>(M + 1);
+        if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
+        fa.out_g = out_g; fa.out_v = out_v;
+        if (M > 0) {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_probe_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fused_probe_kernel<true>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, fa);
+            HIP_TRY(hipGetLastError());
+        }
+        break;
+    }
+    // groupby(g).sum(v) over the matched pairs
+    RowSource rsrc;
+    rsrc.n_rows = M;
+    rsrc.key = KeyDesc{out_g, nullptr, nullptr, rg->dtype == PANDRS_HIP_U32CODE ? DT_CELL : rg->dtype};
+    rsrc.val_data[0] = out_v;
+    rsrc.val_null_bits[0] = nullptr;
+    ST_TRY(run_engine(c, rsrc, pl, /*merge=*/false, /*partials=*/false, 1, rg->dtype));
+    {
+        int64_t K = lk->dtype == PANDRS_HIP_U32CODE ? 4 : 8;
+        c->timings.algorithmic_bytes = nl * (K + 8) + nr * (K + 8) + c->gb.n_groups * 16;   // SURVEY.md §8d, fused form
+    }
+    ST_TRY(timings_end(c));
+    *out_n_groups = c->gb.n_groups;
+    return 0;
+}
+
 }  // namespace pandrs
