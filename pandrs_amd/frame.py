@@ -1,0 +1,528 @@
+"""Host-side mirror of the reference's interface for the hot path — same names, argument meaning and
+error behaviour — so the parity tests read like the reference's own tests.
+
+  reference (file:line)                                               here
+  OptimizedDataFrame  src/optimized/split_dataframe/core.rs:14-25     OptimizedDataFrame
+  Int64Column ...     src/column/*.rs                                 Int64Column / Float64Column / StringColumn / BooleanColumn
+  GLOBAL_STRING_POOL  src/column/string_pool.rs:6-53                  GLOBAL_STRING_POOL
+  group_by            src/optimized/split_dataframe/group/grouping.rs:22      OptimizedDataFrame.group_by
+  GroupBy.aggregate   src/optimized/split_dataframe/group/aggregation.rs:763  GroupBy.aggregate
+  sum/mean/../agg     src/optimized/split_dataframe/group/operations.rs:438-521  GroupBy.sum ... GroupBy.agg
+  *_join / join_impl  src/optimized/split_dataframe/join.rs:32-555    OptimizedDataFrame.inner_join ...
+  LazyFrame           src/optimized/lazy.rs:98-170, :186-425          LazyFrame
+  AggregateOp         src/optimized/split_dataframe/group/types.rs:11-34   AggregateOp
+  JoinType            src/optimized/split_dataframe/join.rs:11-20     JoinType
+
+This is what the Rust call-outs of INTEGRATION.md §3 do: adapt columns to the C ABI, call the
+device engine, stringify group keys, name result columns.  All arithmetic happens in
+libpandrs_hip.so; there is no CPU implementation of groupby or join here.
+"""
+from decimal import Decimal
+from enum import IntEnum
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Context, PandrsHipError, ColumnTypeMismatch, OperationFailed
+
+
+class AggregateOp(IntEnum):          # types.rs:11-34, same order
+    Sum = 0
+    Mean = 1
+    Min = 2
+    Max = 3
+    Count = 4
+    Std = 5
+    Var = 6
+    Median = 7
+    First = 8
+    Last = 9
+    Custom = 10
+
+
+class JoinType(IntEnum):             # join.rs:11-20
+    Inner = 0
+    Left = 1
+    Right = 2
+    Outer = 3
+
+
+class ColumnNotFound(KeyError):      # Error::ColumnNotFound (grouping.rs:55, join.rs:87)
+    pass
+
+
+class DuplicateColumnName(ValueError):
+    pass
+
+
+class InconsistentRowCount(ValueError):
+    pass
+
+
+_OP_NAME = {AggregateOp.Sum: "sum", AggregateOp.Mean: "mean", AggregateOp.Min: "min", AggregateOp.Max: "max",
+            AggregateOp.Count: "count", AggregateOp.Std: "std", AggregateOp.Var: "var",
+            AggregateOp.Median: "median", AggregateOp.First: "first", AggregateOp.Last: "last",
+            AggregateOp.Custom: "custom"}       # operations.rs:501-514
+
+
+# ---------------------------------------------------------------------------------------------- columns
+class StringPool:
+    """Process-global string pool: equal string <=> equal u32 code (string_pool.rs:28-53)."""
+
+    def __init__(self):
+        self._code = {}
+        self._strings = []
+
+    def get_or_insert(self, s):
+        c = self._code.get(s)
+        if c is None:
+            c = len(self._strings)
+            self._code[s] = c
+            self._strings.append(s)
+        return c
+
+    def get(self, code):
+        return self._strings[code]
+
+    def __len__(self):
+        return len(self._strings)
+
+
+GLOBAL_STRING_POOL = StringPool()
+
+
+def create_bitmask(nulls):
+    """bool list -> LSB-first bitmap, 1 = null (src/core/column.rs:163-177)."""
+    return np.packbits(np.asarray(nulls, dtype=bool), bitorder="little")
+
+
+class _Column:
+    dtype = None
+    type_name = None
+
+    def __init__(self, data, null_mask, length):
+        self.data = data
+        self.null_mask = null_mask
+        self.length = length
+
+    def len(self):
+        return self.length
+
+    def __len__(self):
+        return self.length
+
+    def column_type(self):
+        return self.type_name
+
+    def is_null(self, i):
+        return self.null_mask is not None and bool((self.null_mask[i >> 3] >> (i & 7)) & 1)
+
+    def view(self):
+        """(data, null_mask, dtype) triple for the engine."""
+        return (self.data, self.null_mask, self.dtype)
+
+    @staticmethod
+    def _mask(nulls):
+        if nulls is None or not np.any(nulls):
+            return None
+        return create_bitmask(nulls)
+
+
+class Int64Column(_Column):          # src/column/int64_column.rs:52-66
+    dtype, type_name = L.I64, "Int64"
+
+    def __init__(self, data, nulls=None):
+        data = np.ascontiguousarray(data, dtype=np.int64)
+        super().__init__(data, self._mask(nulls), len(data))
+
+    @classmethod
+    def with_nulls(cls, data, nulls):
+        return cls(data, nulls)
+
+    def get(self, i):
+        return None if self.is_null(i) else int(self.data[i])
+
+
+class Float64Column(_Column):        # src/column/float64_column.rs:9-13
+    dtype, type_name = L.F64, "Float64"
+
+    def __init__(self, data, nulls=None):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        super().__init__(data, self._mask(nulls), len(data))
+
+    @classmethod
+    def with_nulls(cls, data, nulls):
+        return cls(data, nulls)
+
+    def get(self, i):
+        return None if self.is_null(i) else float(self.data[i])
+
+
+class StringColumn(_Column):         # src/column/string_column.rs:26-72 (GlobalPool mode)
+    dtype, type_name = L.U32CODE, "String"
+
+    def __init__(self, values, nulls=None, _codes=None):
+        if _codes is None:
+            _codes = np.fromiter((GLOBAL_STRING_POOL.get_or_insert(s) for s in values), dtype=np.uint32,
+                                 count=len(values))
+        super().__init__(np.ascontiguousarray(_codes, dtype=np.uint32), self._mask(nulls), len(_codes))
+
+    @classmethod
+    def with_nulls(cls, values, nulls):
+        return cls(values, nulls)
+
+    @classmethod
+    def from_codes(cls, codes, null_mask=None):
+        c = cls([], _codes=codes)
+        c.null_mask = null_mask
+        return c
+
+    def get(self, i):
+        return None if self.is_null(i) else GLOBAL_STRING_POOL.get(int(self.data[i]))
+
+    def to_list(self):
+        return [self.get(i) for i in range(self.length)]
+
+
+class BooleanColumn(_Column):        # src/column/boolean_column.rs:10-15 (bit-packed)
+    dtype, type_name = L.BOOLBITS, "Boolean"
+
+    def __init__(self, data, nulls=None, _bits=None, _length=None):
+        if _bits is None:
+            data = np.asarray(data, dtype=bool)
+            _bits, _length = np.packbits(data, bitorder="little"), len(data)
+        super().__init__(_bits, self._mask(nulls), _length)
+
+    @classmethod
+    def with_nulls(cls, data, nulls):
+        return cls(data, nulls)
+
+    def get(self, i):
+        return None if self.is_null(i) else bool((self.data[i >> 3] >> (i & 7)) & 1)
+
+
+def rust_f64_to_string(v):
+    """f64::to_string(): shortest round-trip digits, never an exponent ("1", "0.1", "NaN", "inf", "-0")."""
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "inf" if v > 0 else "-inf"
+    s = format(Decimal(repr(float(v))), "f")
+    if "." in s:
+        s = s.rstrip("0").rstrip(".")
+    if s in ("0", "-0"):
+        return "-0" if np.signbit(v) else "0"
+    return s
+
+
+def _key_strings(dtype, cells, nulls):
+    """Group-key cells -> the strings the reference's result frame holds (grouping.rs:69-98)."""
+    out = []
+    for cell, nul in zip(cells.tolist(), nulls.tolist()):
+        if nul:
+            out.append("NULL")
+        elif dtype == L.I64:
+            out.append(str(int(np.int64(np.uint64(cell)))))
+        elif dtype == L.F64:
+            out.append(rust_f64_to_string(float(np.uint64(cell).view(np.float64))))
+        elif dtype == L.U32CODE:
+            out.append(GLOBAL_STRING_POOL.get(int(cell)))
+        else:
+            out.append("true" if cell else "false")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- context
+_default_ctx = None
+
+
+def get_context():
+    """Lazily created process-wide engine context (cf. get_gpu_manager, src/gpu/mod.rs:249-282)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---------------------------------------------------------------------------------------------- frame
+class OptimizedDataFrame:
+    def __init__(self):
+        self.columns = []
+        self.column_names = []
+        self.column_indices = {}
+        self._row_count = 0
+
+    # -- construction / inspection (core.rs) ----------------------------------------------------------
+    def add_column(self, name, column):
+        if name in self.column_indices:
+            raise DuplicateColumnName(name)
+        if self.columns and column.len() != self._row_count:
+            raise InconsistentRowCount("expected %d rows, found %d" % (self._row_count, column.len()))
+        self.column_indices[name] = len(self.columns)
+        self.column_names.append(name)
+        self.columns.append(column)
+        self._row_count = column.len()
+        return self
+
+    def column(self, name):
+        if name not in self.column_indices:
+            raise ColumnNotFound(name)
+        return self.columns[self.column_indices[name]]
+
+    def contains_column(self, name):
+        return name in self.column_indices
+
+    def row_count(self):
+        return self._row_count
+
+    def column_count(self):
+        return len(self.columns)
+
+    # -- groupby (grouping.rs:22-115) -------------------------------------------------------------------
+    def group_by(self, columns):
+        columns = [columns] if isinstance(columns, str) else list(columns)
+        for c in columns:
+            if c not in self.column_indices:
+                raise ColumnNotFound(c)                       # grouping.rs:53-57
+        return GroupBy(self, columns)
+
+    # -- whole-column reductions (K1: split_dataframe/aggregate.rs:21-62) ---------------------------------
+    def _reduce(self, name):
+        col = self.column(name)
+        if col.dtype not in (L.I64, L.F64):
+            raise OperationFailed(L.ERR_OPERATION_FAILED, "column '%s' is not numeric" % name)
+        return get_context().reduce_column(col.view(), col.len())
+
+    def sum(self, name):
+        return float(self._reduce(name)[0][0])
+
+    def mean(self, name):
+        return float(self._reduce(name)[0][1])
+
+    def min(self, name):
+        return float(self._reduce(name)[0][2])
+
+    def max(self, name):
+        return float(self._reduce(name)[0][3])
+
+    # -- joins (join.rs:32-73) -----------------------------------------------------------------------------
+    def inner_join(self, other, left_on, right_on):
+        return self._join_impl(other, left_on, right_on, JoinType.Inner)
+
+    def left_join(self, other, left_on, right_on):
+        return self._join_impl(other, left_on, right_on, JoinType.Left)
+
+    def right_join(self, other, left_on, right_on):
+        return self._join_impl(other, left_on, right_on, JoinType.Right)
+
+    def outer_join(self, other, left_on, right_on):
+        return self._join_impl(other, left_on, right_on, JoinType.Outer)
+
+    def _join_impl(self, other, left_on, right_on, how):
+        if left_on not in self.column_indices:
+            raise ColumnNotFound(left_on)                     # join.rs:84-87
+        if right_on not in other.column_indices:
+            raise ColumnNotFound(right_on)                    # join.rs:89-92
+        lcol, rcol = self.column(left_on), other.column(right_on)
+        ctx = get_context()
+        # dtype mismatch => ColumnTypeMismatch raised by the library (join.rs:98-104)
+        li, ri = ctx.join_indices(lcol.view(), lcol.len(), rcol.view(), rcol.len(), int(how))
+        result = OptimizedDataFrame()
+        if len(li) == 0:
+            # empty result: NON-KEY columns only, suffix decided against the LEFT frame (join.rs:227-284)
+            for name in self.column_names:
+                if name != left_on:
+                    result.add_column(name, _empty_like(self.column(name)))
+            for name in other.column_names:
+                if name != right_on:
+                    new = name + "_right" if name in self.column_indices else name
+                    result.add_column(new, _empty_like(other.column(name)))
+            return result
+        g = _Gatherer(ctx, li, ri)
+        for name in self.column_names:                        # left non-key columns (join.rs:290-361)
+            if name != left_on:
+                result.add_column(name, g.take(self.column(name), left=True))
+        result.add_column(left_on, g.take_key(lcol, rcol))    # key: left value, else right (join.rs:364-472)
+        for name in other.column_names:                       # right non-key columns (join.rs:475-552)
+            if name != right_on:
+                new = name + "_right" if name in result.column_indices else name
+                result.add_column(new, g.take(other.column(name), left=False))
+        return result
+
+
+def _empty_like(col):
+    if isinstance(col, Int64Column):
+        return Int64Column([])
+    if isinstance(col, Float64Column):
+        return Float64Column([])
+    if isinstance(col, StringColumn):
+        return StringColumn([])
+    return BooleanColumn([])
+
+
+class _Gatherer:
+    """Column gathers of join_impl on the device: misses / nulls become 0 / 0.0 / "" / false and the
+    result columns carry NO null mask (join.rs:304-307, :319-322)."""
+
+    def __init__(self, ctx, li, ri):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.dev = "cuda:%d" % ctx.device
+        self.li = torch.from_numpy(np.ascontiguousarray(li)).to(self.dev)
+        self.ri = torch.from_numpy(np.ascontiguousarray(ri)).to(self.dev)
+
+    def _up(self, a):
+        if a is None:
+            return None
+        if a.dtype == np.uint32:
+            a = a.view(np.int32)
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+    def _gather(self, col, idx):
+        fill = GLOBAL_STRING_POOL.get_or_insert("") if col.dtype == L.U32CODE else 0
+        if col.len() == 0:
+            n = idx.numel()
+            return {L.I64: np.zeros(n, np.int64), L.F64: np.zeros(n, np.float64),
+                    L.U32CODE: np.full(n, fill, np.uint32), L.BOOLBITS: np.zeros(n, np.uint8)}[col.dtype]
+        out = self.ctx.gather(self._up(col.data), self._up(col.null_mask), idx, fill, col.dtype).cpu().numpy()
+        return out.view(np.uint32) if col.dtype == L.U32CODE else out
+
+    @staticmethod
+    def _wrap(col, arr):
+        if col.dtype == L.I64:
+            return Int64Column(arr)
+        if col.dtype == L.F64:
+            return Float64Column(arr)
+        if col.dtype == L.U32CODE:
+            return StringColumn.from_codes(arr)
+        return BooleanColumn(None, _bits=np.packbits(arr.astype(bool), bitorder="little"), _length=len(arr))
+
+    def take(self, col, left):
+        return self._wrap(col, self._gather(col, self.li if left else self.ri))
+
+    def take_key(self, lcol, rcol):
+        a = self._gather(lcol, self.li)
+        b = self._gather(rcol, self.ri)
+        from_left = (self.li >= 0).cpu().numpy()
+        return self._wrap(lcol, np.where(from_left, a, b))
+
+
+# ---------------------------------------------------------------------------------------------- GroupBy
+class GroupBy:
+    """GroupBy<'a> (group/types.rs:46-55).  The row-index map `groups` of the reference is not
+    materialised: aggregation runs on the device straight from the columns."""
+
+    def __init__(self, df, group_by_columns):
+        self.df = df
+        self.group_by_columns = group_by_columns
+        self.create_multi_index = len(group_by_columns) > 1
+
+    def aggregate(self, aggregations):
+        """aggregations: iterable of (column, AggregateOp, alias)  (aggregation.rs:763-871)."""
+        aggregations = [(c, AggregateOp(int(op)), alias) for c, op, alias in aggregations]
+        for col_name, _, _ in aggregations:
+            if col_name not in self.df.column_indices:
+                raise ColumnNotFound(col_name)                # aggregation.rs:770-774
+        if len(self.group_by_columns) != 1:
+            raise OperationFailed(L.ERR_OPERATION_FAILED,
+                                  "multi-key group_by is not on the device path yet (SURVEY.md §8f-2)")
+        key_name = self.group_by_columns[0]
+        key_col = self.df.column(key_name)
+        val_names = []
+        for col_name, _, _ in aggregations:
+            if col_name not in val_names:
+                val_names.append(col_name)
+        vals = [self.df.column(n).view() for n in val_names]
+        specs = [(val_names.index(c), int(op)) for c, op, _ in aggregations]
+        ctx = get_context()
+        kc, kn, oa = ctx.groupby_agg([key_col.view()], self.df.row_count(), vals, specs)
+        result = OptimizedDataFrame()
+        # key column as strings (aggregation.rs:856-860), then one Float64Column per alias in
+        # request order (:863-867)
+        result.add_column(key_name, StringColumn(_key_strings(key_col.dtype, kc[0], kn[0])))
+        seen = {}
+        for a, (_, _, alias) in enumerate(aggregations):
+            seen[alias] = a          # the reference keeps one Vec per alias in a HashMap: last writer wins
+        for a, (_, _, alias) in enumerate(aggregations):
+            if alias in result.column_indices:
+                raise DuplicateColumnName(alias)
+            result.add_column(alias, Float64Column(oa[seen[alias]]))
+        return result
+
+    def agg(self, aggs):
+        """[(column, op)] -> aliases "{col}_{op}" (operations.rs:498-521)."""
+        return self.aggregate([(c, op, "%s_%s" % (c, _OP_NAME[AggregateOp(int(op))])) for c, op in aggs])
+
+    par_aggregate = aggregate        # G6: the reference's parallel variant has a known row race
+    par_agg = agg
+
+    def _short(self, column, op):
+        return self.aggregate([(column, op, "%s_%s" % (column, _OP_NAME[op]))])
+
+    def sum(self, column):
+        return self._short(column, AggregateOp.Sum)
+
+    def mean(self, column):
+        return self._short(column, AggregateOp.Mean)
+
+    def min(self, column):
+        return self._short(column, AggregateOp.Min)
+
+    def max(self, column):
+        return self._short(column, AggregateOp.Max)
+
+    def count(self, column):
+        return self._short(column, AggregateOp.Count)
+
+    def std(self, column):
+        return self._short(column, AggregateOp.Std)
+
+    def var(self, column):
+        return self._short(column, AggregateOp.Var)
+
+    def median(self, column):
+        return self._short(column, AggregateOp.Median)
+
+    def first(self, column):
+        return self._short(column, AggregateOp.First)
+
+    def last(self, column):
+        return self._short(column, AggregateOp.Last)
+
+
+# ---------------------------------------------------------------------------------------------- LazyFrame
+class LazyFrame:
+    """LazyFrame (lazy.rs:98-170): only the two operations on the hot path are mirrored."""
+
+    def __init__(self, df):
+        self.source = df
+        self.operations = []
+
+    @classmethod
+    def new(cls, df):
+        return cls(df)
+
+    def aggregate(self, group_by, aggregations):
+        self.operations.append(("aggregate", list(group_by), list(aggregations)))
+        return self
+
+    def join(self, right, left_on, right_on, join_type):
+        self.operations.append(("join", right, left_on, right_on, JoinType(int(join_type))))
+        return self
+
+    def execute(self):
+        df = self.source
+        for op in self.operations:
+            if op[0] == "aggregate":
+                _, group_by, aggregations = op
+                for _, agg_op, _ in aggregations:             # lazy.rs:377-382: only these five ops
+                    if AggregateOp(int(agg_op)) not in (AggregateOp.Sum, AggregateOp.Mean, AggregateOp.Min,
+                                                        AggregateOp.Max, AggregateOp.Count):
+                        raise OperationFailed(L.ERR_OPERATION_FAILED,
+                                              "Aggregation operation %s is not supported" % AggregateOp(int(agg_op)).name)
+                df = df.group_by(group_by).aggregate(aggregations)
+            else:
+                _, right, left_on, right_on, jt = op
+                df = df._join_impl(right, left_on, right_on, jt)     # lazy.rs:405-425
+        return df

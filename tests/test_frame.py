@@ -1,0 +1,182 @@
+"""Host mirror of the reference API (pandrs_amd/frame.py): these read like the reference's own
+tests (tests/optimized_groupby_test.rs, tests/optimized_join_test.rs, tests/optimized_lazy_test.rs,
+examples/optimized_groupby_example.rs) but assert exact values against the oracle / golden data."""
+import numpy as np
+import pytest
+
+from pandrs_amd.frame import (AggregateOp, BooleanColumn, ColumnNotFound, Float64Column, GLOBAL_STRING_POOL,
+                              Int64Column, JoinType, LazyFrame, OptimizedDataFrame, StringColumn,
+                              rust_f64_to_string)
+
+
+def _df_values_keys():
+    df = OptimizedDataFrame()
+    df.add_column("values", Int64Column([10, 20, 30, 40, 50]))
+    df.add_column("keys", StringColumn(["A", "B", "A", "B", "C"]))
+    return df
+
+
+# ------------------------------------------------------------------------------ CPU-side behaviour
+def test_columns_and_pool():
+    a = StringColumn(["x", "y", "x"])
+    b = StringColumn(["y", "x"])
+    assert a.data[0] == a.data[2] == b.data[1] and a.data[1] == b.data[0]    # equal string <=> equal code
+    assert GLOBAL_STRING_POOL.get(int(a.data[1])) == "y"
+    c = Int64Column.with_nulls([1, 2, 3], [False, True, False])
+    assert c.get(1) is None and c.get(2) == 3 and c.null_mask.tolist() == [2]
+    assert Int64Column([1, 2]).null_mask is None
+    bc = BooleanColumn([True, False, True, True, False, False, False, False, True])
+    assert bc.data.tolist() == [0b00001101, 1] and bc.get(8) is True and bc.len() == 9
+    assert [rust_f64_to_string(v) for v in (1.0, 0.1, -0.0, float("nan"), float("inf"), 1e21, 1.5e-7)] == \
+        ["1", "0.1", "-0", "NaN", "inf", "1000000000000000000000", "0.00000015"]
+
+
+def test_errors_before_any_device_work():
+    df = _df_values_keys()
+    with pytest.raises(ColumnNotFound):                   # grouping.rs:53-57
+        df.group_by(["nope"])
+    with pytest.raises(ColumnNotFound):                   # aggregation.rs:770-774
+        df.group_by(["keys"]).aggregate([("nope", AggregateOp.Sum, "s")])
+    with pytest.raises(ColumnNotFound):                   # tests/optimized_join_test.rs:206-212
+        df.inner_join(df, "id", "keys")
+    with pytest.raises(ValueError):
+        df.add_column("values", Int64Column([1, 2, 3, 4, 5]))
+    with pytest.raises(ValueError):
+        df.add_column("short", Int64Column([1]))
+
+
+# ------------------------------------------------------------------------------ device behaviour
+@pytest.mark.gpu
+def test_lazy_aggregate_multiple(golden):
+    """tests/optimized_groupby_test.rs:85-133 (shape) + tests/groupby_test.rs:18-67 (values)."""
+    res = LazyFrame.new(_df_values_keys()).aggregate(
+        ["keys"], [("values", AggregateOp.Count, "count"), ("values", AggregateOp.Sum, "sum"),
+                   ("values", AggregateOp.Mean, "mean"), ("values", AggregateOp.Min, "min"),
+                   ("values", AggregateOp.Max, "max")]).execute()
+    assert res.column_count() == 6 and res.row_count() == 3
+    assert res.column_names == ["keys", "count", "sum", "mean", "min", "max"]
+    rows = {k: i for i, k in enumerate(res.column("keys").to_list())}
+    exp = golden["groupby"][0]["expect"]
+    for k, e in exp.items():
+        assert res.column("count").data[rows[k]] == e["count"]
+        assert res.column("sum").data[rows[k]] == e["sum"]
+        assert res.column("mean").data[rows[k]] == e["mean"]
+    assert res.column("min").data[rows["A"]] == 10 and res.column("max").data[rows["B"]] == 40
+
+
+@pytest.mark.gpu
+def test_groupby_example_and_shortcuts(golden):
+    """examples/optimized_groupby_example.rs:22-33 data; aliases per operations.rs:438-521."""
+    case = golden["groupby"][5]
+    df = OptimizedDataFrame()
+    df.add_column("values", Int64Column(case["values_i64"]))
+    df.add_column("category", StringColumn(case["key_strings"]))
+    gb = df.group_by(["category"])
+    res = gb.agg([("values", AggregateOp.Count), ("values", AggregateOp.Sum), ("values", AggregateOp.Mean),
+                  ("values", AggregateOp.Min), ("values", AggregateOp.Max)])
+    assert res.column_names == ["category", "values_count", "values_sum", "values_mean", "values_min", "values_max"]
+    rows = {k: i for i, k in enumerate(res.column("category").to_list())}
+    for k, e in case["expect"].items():
+        for op in ("count", "sum", "mean", "min", "max"):
+            assert res.column("values_" + op).data[rows[k]] == pytest.approx(e[op], rel=1e-15)
+    assert gb.sum("values").column_names == ["category", "values_sum"]
+    # numeric and null keys are stringified exactly like the reference ("NULL", decimal i64)
+    df2 = OptimizedDataFrame()
+    df2.add_column("k", Int64Column.with_nulls([-5, 7, -5, 0], [False, False, False, True]))
+    df2.add_column("v", Float64Column([1.0, 2.0, 3.0, 4.0]))
+    r2 = df2.group_by("k").sum("v")
+    got = dict(zip(r2.column("k").to_list(), r2.column("v_sum").data.tolist()))
+    assert got == {"-5": 4.0, "7": 2.0, "NULL": 4.0}
+    from pandrs_amd import OperationFailed
+    with pytest.raises(OperationFailed):                  # lazy.rs:377-382
+        LazyFrame.new(df2).aggregate(["k"], [("v", AggregateOp.Median, "m")]).execute()
+
+
+@pytest.mark.gpu
+def test_joins_like_reference_tests(golden):
+    """tests/optimized_join_test.rs:6-232: row / column counts, plus exact contents."""
+    left = OptimizedDataFrame()
+    left.add_column("id", Int64Column([1, 2, 3, 4]))
+    left.add_column("name", StringColumn(["Alice", "Bob", "Charlie", "Dave"]))
+    right = OptimizedDataFrame()
+    right.add_column("id", Int64Column([1, 2, 5, 6]))
+    right.add_column("value", Int64Column([100, 200, 500, 600]))
+    exp = golden["join_optimized"]["rows"]
+    j = left.inner_join(right, "id", "id")
+    assert (j.row_count(), j.column_count()) == (exp["inner"], 3) and j.column_names == ["name", "id", "value"]
+    assert j.column("name").to_list() == ["Alice", "Bob"] and j.column("value").data.tolist() == [100, 200]
+    j = left.left_join(right, "id", "id")
+    assert j.row_count() == exp["left"] and j.column("value").data.tolist() == [100, 200, 0, 0]      # fill 0, not null
+    j = left.right_join(right, "id", "id")
+    assert j.row_count() == exp["right"] and j.column("id").data.tolist() == [1, 2, 5, 6]
+    assert j.column("name").to_list() == ["Alice", "Bob", "", ""]
+    j = left.outer_join(right, "id", "id")
+    assert j.row_count() == exp["outer"] and j.column("id").data.tolist() == [1, 2, 3, 4, 5, 6]
+    # different key names: the key column keeps the LEFT name (optimized_join_test.rs:166-203)
+    r2 = OptimizedDataFrame()
+    r2.add_column("right_id", Int64Column([1, 2, 5, 6]))
+    r2.add_column("name", StringColumn(["a", "b", "c", "d"]))
+    j = left.inner_join(r2, "id", "right_id")
+    assert j.column_names == ["name", "id", "name_right"]                                           # join.rs:478-482
+    # disjoint keys: empty frame WITHOUT the key column (join.rs:227-284)
+    r3 = OptimizedDataFrame()
+    r3.add_column("id", Int64Column([7, 8]))
+    r3.add_column("value", Float64Column([1.0, 2.0]))
+    j = left.inner_join(r3, "id", "id")
+    assert j.row_count() == 0 and j.column_names == ["name", "value"]
+    # key dtype mismatch (join.rs:98-104)
+    from pandrs_amd import ColumnTypeMismatch
+    r4 = OptimizedDataFrame()
+    r4.add_column("id", Float64Column([1.0]))
+    with pytest.raises(ColumnTypeMismatch):
+        left.inner_join(r4, "id", "id")
+    # LazyFrame join dispatch (lazy.rs:405-425)
+    j = LazyFrame.new(left).join(right, "id", "id", JoinType.Outer).execute()
+    assert j.row_count() == exp["outer"]
+
+
+@pytest.mark.gpu
+def test_string_key_merge_vectors(golden):
+    """src/dataframe/pandas_compat/merge.rs:271-411 on the optimized frame (fills are 0.0, not NaN)."""
+    c = golden["join_string_key"]
+    left = OptimizedDataFrame()
+    left.add_column("key", StringColumn(c["left_keys"]))
+    left.add_column("value1", Float64Column(c["left_value1"]))
+    right = OptimizedDataFrame()
+    right.add_column("key", StringColumn(c["right_keys"]))
+    right.add_column("value2", Float64Column(c["right_value2"]))
+    j = left.outer_join(right, "key", "key")
+    assert j.column("key").to_list() == c["outer"]["keys"]
+    assert j.column("value1").data.tolist() == [1.0, 2.0, 3.0, 4.0, 0.0]
+    assert j.column("value2").data.tolist() == [0.0, 20.0, 30.0, 40.0, 50.0]
+    j = left.inner_join(right, "key", "key")
+    assert j.column("key").to_list() == c["inner"]["keys"] and j.column("value2").data.tolist() == [20.0, 30.0, 40.0]
+
+
+@pytest.mark.gpu
+def test_whole_column_reductions():
+    df = OptimizedDataFrame()
+    df.add_column("v", Float64Column(np.arange(1, 1001, dtype=np.float64)))
+    assert df.sum("v") == 500500.0 and df.mean("v") == 500.5 and df.min("v") == 1.0 and df.max("v") == 1000.0
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_share_one_frame():
+    """tests/concurrency_test.rs:351-398: 4 threads x 5 iterations on one shared frame, 4 groups."""
+    import threading
+    rng = np.random.default_rng(1)
+    df = OptimizedDataFrame()
+    df.add_column("k", StringColumn([["a", "b", "c", "d"][i] for i in rng.integers(0, 4, 20_000)]))
+    df.add_column("v", Float64Column(rng.normal(size=20_000)))
+    out, errs = [], []
+
+    def work():
+        try:
+            for _ in range(5):
+                out.append(df.group_by(["k"]).sum("v").row_count())
+        except Exception as e:       # noqa
+            errs.append(e)
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and out == [4] * 20
