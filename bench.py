@@ -36,6 +36,20 @@ def make_shard(torch, n_rows, n_groups, n_cols, seed, device):
     return keys, vals
 
 
+def pmc_traffic(n, g, ncol):
+    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/): counters cannot be read
+    from inside the process, so the corrected per-launch figure is loaded when it was collected on
+    this exact workload; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        if t["config"] == {"rows": n, "groups": g, "value_cols": ncol}:
+            return t["pipeline_hbm_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(n_sample, n_groups, n_cols, aggs):
     """The oracle's faithful restatement of the reference path (string keys + HashMap + per-group
     gather/fold, lazy.rs:186-404), single thread, on a bounded sample of the same workload."""
@@ -142,7 +156,7 @@ def main():
                        "rows_per_gpu": n, "groups": g, "value_cols": ncol, "aggregates": len(aggs),
                        "parallelism": "row-range shards + 1 all-to-all of partials" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(n, g, ncol) if world == 1 else None,
                          "algorithmic_bytes": bytes_alg, "device_ms": dev_ms, "phase_ms": phases,
                          "note": "whole groupby pipeline (estimate+histogram+scan+scatter+aggregate) "
                                  "timed with hipEvents on the library stream; B = N(K+8C)+G(K+8A)"},
