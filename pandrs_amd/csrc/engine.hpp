@@ -25,12 +25,17 @@ struct SrcDev {
     const uint8_t *valid;   // partitioned validity bytes (1 = valid) or nullptr
     int8_t kind;            // 0 = f64, 1 = i64
     int8_t st_add, st_min, st_max, st_nn;  // LDS state indices, -1 = none
-    int8_t pad[3];
+    int8_t st_fadd;         // f64 sum of (double)x for an i64 column's Std/Var (aggregation.rs:559-563)
+    int8_t st_ssq;          // sum of squared deviations from the group mean, filled by the second pass
+    int8_t pad[1];
 };
 
 struct FinDev {
     int8_t op, kind, st_add, st_nn, st_min, st_max;   // st_*: LDS state index inside its round
-    int8_t round, pad;
+    int8_t round, st_ssq;
+    int8_t st_fadd, rowsrc_min, rowsrc_max, pad[5];   // rowsrc_*: LDS state of the first / last row index
+    const void *col_data;       // First/Last: the ORIGINAL (un-partitioned) column and its null bitmap
+    const uint8_t *col_null;
 };
 
 struct MoveDesc {
@@ -58,6 +63,10 @@ struct Plan {
     int src_col[MAX_SRC];          // index into vals[]
     int8_t src_kind[MAX_SRC];
     int8_t st_add[MAX_SRC], st_min[MAX_SRC], st_max[MAX_SRC], st_nn[MAX_SRC];   // absolute state ids
+    int8_t st_fadd[MAX_SRC], st_ssq[MAX_SRC];
+    int8_t st_firstrow = -1, st_lastrow = -1;      // group-level: min / max original row index
+    bool needs_second_pass = false;                // any Std / Var
+    bool mergeable = true;                         // false when Std/Var/First/Last are requested
     int8_t kinds[MAX_STATES];
     int8_t fin_op[MAX_AGGS], fin_kind[MAX_AGGS];
     int fin_src[MAX_AGGS];         // plan source of each aggregate, -1 for COUNT

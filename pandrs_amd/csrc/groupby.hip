@@ -135,13 +135,13 @@ __device__ __forceinline__ uint64_t move_load(const MoveDesc &m, int64_t i) {
     case 0: return reinterpret_cast<const uint64_t *>(m.src)[i];
     case 1: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 0ull : 1ull;
     case 2: return reinterpret_cast<const uint8_t *>(m.src)[i];
-    case 3: return (uint64_t)i;                                        // row index
+    case 3: case 5: return (uint64_t)i;                                // row index
     default: return reinterpret_cast<const uint32_t *>(m.src)[i];      // 4: u32 source
     }
 }
 __device__ __forceinline__ void move_store(const MoveDesc &m, uint32_t dst, uint64_t v) {
     switch (m.kind) {
-    case 0: case 4: reinterpret_cast<uint64_t *>(m.dst)[dst] = v; break;
+    case 0: case 4: case 5: reinterpret_cast<uint64_t *>(m.dst)[dst] = v; break;
     case 3: reinterpret_cast<uint32_t *>(m.dst)[dst] = (uint32_t)v; break;
     default: reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
     }
@@ -366,7 +366,7 @@ struct AggArgs {
     const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
     const int64_t *pgsize;       // merge mode: partitioned group sizes, else nullptr (=1 per row)
     uint32_t NB, P, T, seed;
-    int n_src, n_states, n_fin, partials, n_rounds, round_states;
+    int n_src, n_states, n_fin, partials, n_rounds, round_states, second_pass;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
     SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
     int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
@@ -432,6 +432,19 @@ __device__ __forceinline__ double finalize(const FinDev &f, const uint64_t *st, 
             int64_t v = dec_i64(cell(f.st_max));
             return v == INT64_MIN ? 0.0 : (double)v;
         }
+    case PANDRS_HIP_AGG_STD:
+    case PANDRS_HIP_AGG_VAR: {      // aggregation.rs:881-903: Bessel, n <= 1 => 0.0, empty => 0.0
+        uint64_t nn = f.st_nn >= 0 ? cell(f.st_nn) : gsize;
+        double var = nn > 1 ? __longlong_as_double((long long)cell(f.st_ssq)) / ((double)nn - 1.0) : 0.0;
+        return f.op == PANDRS_HIP_AGG_STD ? sqrt(var) : var;
+    }
+    case PANDRS_HIP_AGG_FIRST:
+    case PANDRS_HIP_AGG_LAST: {     // aggregation.rs:605-624, :723-742: value at the first / last row, null => 0.0
+        int64_t row = dec_i64(cell(f.op == PANDRS_HIP_AGG_FIRST ? f.rowsrc_min : f.rowsrc_max));
+        if (f.col_null && bit_at(f.col_null, row)) return 0.0;
+        return f.kind == 0 ? reinterpret_cast<const double *>(f.col_data)[row]
+                           : (double)reinterpret_cast<const int64_t *>(f.col_data)[row];
+    }
     }
     return 0.0;
 }
@@ -566,6 +579,8 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
                             cmp = d == d;   // Rust f64::min/max ignore NaN operands (aggregation.rs:653,:666)
                         } else {
                             if (f_add(sd)) atomicAdd((unsigned long long *)&st[(size_t)sd.st_add * T1 + slot], x);
+                            if (GEN && sd.st_fadd >= 0)
+                                atomicAdd(reinterpret_cast<double *>(&st[(size_t)sd.st_fadd * T1 + slot]), (double)(int64_t)x);
                         }
                         if (cmp && f_min(sd) && enc[c] < cur_mn[c])
                             atomicMin((unsigned long long *)&st[(size_t)sd.st_min * T1 + slot], enc[c]);
@@ -604,6 +619,42 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
                     if (a.partials) a.out_states[pos] = gsz[s];
                 }
                 run += tot;
+            }
+            __syncthreads();
+        }
+        // ---- second pass (Std / Var): sum of squared deviations from the group mean, the
+        // reference's two-pass variance (aggregation.rs:881-903).  Sums and counts of this (only)
+        // round are still in LDS; the partition's rows are streamed once more.
+        if (GEN && a.second_pass) {
+            const bool sentinel2 = misc[21] != 0;
+            (void)sentinel2;
+            for (uint32_t i = beg + tid; i < end; i += AG_THREADS) {
+                const uint64_t k = a.pkeys[i];
+                uint32_t slot = T;
+                if (k != EMPTY_KEY) {
+                    const uint32_t NBK = T >> 2;
+                    uint32_t bk = slot_of(hash32(k, a.seed), NBK);
+                    for (uint32_t probe = 0; probe < NBK && slot == T; probe++) {
+                        const uint64_t *b4 = keys + 4 * bk;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) if (b4[q] == k) slot = 4 * bk + q;
+                        bk = bk + 1 == NBK ? 0 : bk + 1;
+                    }
+                    if (slot == T) continue;        // unreachable: every key was inserted above
+                }
+                const uint64_t g = gsz[slot];
+                for (int c = 0; c < nsrc; c++) {
+                    const SrcDev &sd = a.src[s0 + c];
+                    if (sd.st_ssq < 0) continue;
+                    if (sd.valid && sd.valid[i] == 0) continue;
+                    const uint64_t x = sd.vals[i];
+                    const double xv = sd.kind == 0 ? __longlong_as_double((long long)x) : (double)(int64_t)x;
+                    const int8_t ssum = sd.kind == 0 ? sd.st_add : sd.st_fadd;
+                    const double sum = __longlong_as_double((long long)st[(size_t)ssum * T1 + slot]);
+                    const uint64_t nn = sd.st_nn >= 0 ? st[(size_t)sd.st_nn * T1 + slot] : g;
+                    const double dlt = xv - sum / (double)nn;
+                    atomicAdd(reinterpret_cast<double *>(&st[(size_t)sd.st_ssq * T1 + slot]), dlt * dlt);
+                }
             }
             __syncthreads();
         }
@@ -656,16 +707,16 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
         if (dt != PANDRS_HIP_I64 && dt != PANDRS_HIP_F64)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                         "Aggregation operation %d is not supported for column type %d", op, dt);
-        if (op > PANDRS_HIP_AGG_COUNT)
+        if (op == PANDRS_HIP_AGG_MEDIAN)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
-                        "aggregate op %d (std/var/median/first/last) is not implemented on the device path yet", op);
+                        "Median needs a per-group sort and is not implemented on the device path yet");
         int s = src_of[c];
         if (s < 0) {
             if (pl.n_src >= MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregated columns", MAX_SRC);
             s = src_of[c] = pl.n_src++;
             pl.src_col[s] = c;
             pl.src_kind[s] = dt == PANDRS_HIP_F64 ? 0 : 1;
-            pl.st_add[s] = pl.st_min[s] = pl.st_max[s] = pl.st_nn[s] = -1;
+            pl.st_add[s] = pl.st_min[s] = pl.st_max[s] = pl.st_nn[s] = pl.st_fadd[s] = pl.st_ssq[s] = -1;
         }
         const bool f64 = dt == PANDRS_HIP_F64;
         pl.fin_kind[a] = f64 ? 0 : 1;
@@ -678,6 +729,18 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
             pl.st_min[s] = new_state(f64 ? SK_MIN_F64 : SK_MIN_I64);
         if (op == PANDRS_HIP_AGG_MAX && pl.st_max[s] < 0)
             pl.st_max[s] = new_state(f64 ? SK_MAX_F64 : SK_MAX_I64);
+        if (op == PANDRS_HIP_AGG_STD || op == PANDRS_HIP_AGG_VAR) {
+            // two-pass variance over the non-null values as f64 (aggregation.rs:557-584, :675-702)
+            if (f64 && pl.st_add[s] < 0) pl.st_add[s] = new_state(SK_ADD_F64);
+            if (!f64 && pl.st_fadd[s] < 0) pl.st_fadd[s] = new_state(SK_ADD_F64);
+            if (val_has_nulls[c] && pl.st_nn[s] < 0) pl.st_nn[s] = new_state(SK_ADD_I64);
+            if (pl.st_ssq[s] < 0) pl.st_ssq[s] = new_state(SK_ADD_F64);
+            pl.needs_second_pass = true; pl.mergeable = false;
+        }
+        if (op == PANDRS_HIP_AGG_FIRST || op == PANDRS_HIP_AGG_LAST) {
+            if (pl.st_firstrow < 0) { pl.st_firstrow = new_state(SK_MIN_I64); pl.st_lastrow = new_state(SK_MAX_I64); }
+            pl.mergeable = false;
+        }
         if (too_many) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregate states", MAX_STATES);
     }
     pl.n_fin = n_aggs;
@@ -850,8 +913,9 @@ struct EngSrc {
     const void *data = nullptr;        // un-partitioned input column
     const uint8_t *null_bits = nullptr;
     int8_t kind = 0;
-    int8_t st_add = -1, st_min = -1, st_max = -1, st_nn = -1;   // absolute state ids
-    int n_states() const { return (st_add >= 0) + (st_min >= 0) + (st_max >= 0) + (st_nn >= 0); }
+    int8_t st_add = -1, st_min = -1, st_max = -1, st_nn = -1, st_fadd = -1, st_ssq = -1;   // absolute state ids
+    bool rowidx = false;               // synthetic source: the original row index (First / Last)
+    int n_states() const { return (st_add >= 0) + (st_min >= 0) + (st_max >= 0) + (st_nn >= 0) + (st_fadd >= 0) + (st_ssq >= 0); }
 };
 
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
@@ -887,9 +951,18 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             EngSrc e;
             e.data = rs.val_data[s]; e.null_bits = rs.val_null_bits[s]; e.kind = pl.src_kind[s];
             e.st_add = pl.st_add[s]; e.st_min = pl.st_min[s]; e.st_max = pl.st_max[s]; e.st_nn = pl.st_nn[s];
+            e.st_fadd = pl.st_fadd[s]; e.st_ssq = pl.st_ssq[s];
+            srcs.push_back(e);
+        }
+        if (pl.st_firstrow >= 0) {
+            EngSrc e;
+            e.kind = 1; e.rowidx = true; e.st_min = pl.st_firstrow; e.st_max = pl.st_lastrow;
             srcs.push_back(e);
         }
     }
+    if ((partials || merge) && !pl.mergeable)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                    "Std/Var/First/Last partial states are not mergeable across shards yet");
     const int n_src = (int)srcs.size();
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
@@ -911,7 +984,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     int64_t T = 0, P = 0;
     int8_t round_begin[MAX_ROUNDS + 1];
     for (;; spr = (spr + 1) / 2) {
-        if (c->opt.src_per_round > 0) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
+        if (c->opt.src_per_round > 0 && !pl.needs_second_pass) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
         n_rounds = n_src ? (n_src + spr - 1) / spr : 1;
         if (n_rounds > MAX_ROUNDS) { spr = (n_src + MAX_ROUNDS - 1) / MAX_ROUNDS; n_rounds = (n_src + spr - 1) / spr; }
         round_states = 0; max_spr = 0;
@@ -927,7 +1000,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         T = (int64_t)((lds_budget - 160) / slot_bytes) - 2;
         T = std::min<int64_t>(T, 32768) & ~int64_t(3);   // 4-key buckets
         P = (int64_t)std::ceil((double)est / ((double)T * LOAD));
-        if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET) break;
+        if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET || pl.needs_second_pass) break;
     }
     if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
     const size_t slot_bytes = 20 + 8 * (size_t)round_states;
@@ -967,7 +1040,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 EngSrc &e = srcs[s];
                 uint64_t *pv = c->work.take<uint64_t>(N);
                 if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-                sa.mv[sa.n_move++] = MoveDesc{e.data, pv, 0, 0};
+                sa.mv[sa.n_move++] = MoveDesc{e.data, pv, e.rowidx ? 5 : 0, 0};
                 uint8_t *pvalid = nullptr;
                 if (e.null_bits) {
                     pvalid = c->work.take<uint8_t>(N);
@@ -975,12 +1048,13 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                     sa.mv[sa.n_move++] = MoveDesc{e.null_bits, pvalid, 1, 0};
                 }
                 SrcDev &sd = aa.src[s];
-                sd = SrcDev{pv, pvalid, e.kind, -1, -1, -1, -1, {0, 0, 0}};
+                sd = SrcDev{pv, pvalid, e.kind, -1, -1, -1, -1, -1, -1, {0}};
                 auto place = [&](int8_t abs_id, int8_t &lds_id) {
                     if (abs_id < 0) return;
                     st_round[abs_id] = (int8_t)r; st_lds[abs_id] = (int8_t)next; lds_id = (int8_t)next; next++;
                 };
                 place(e.st_add, sd.st_add); place(e.st_min, sd.st_min); place(e.st_max, sd.st_max); place(e.st_nn, sd.st_nn);
+                place(e.st_fadd, sd.st_fadd); place(e.st_ssq, sd.st_ssq);
             }
         }
         PartInfo part;
@@ -1002,21 +1076,29 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         aa.pkeys = pkeys; aa.offsets = offsets; aa.pgsize = pgsize; aa.NB = NB; aa.P = (uint32_t)P;
         aa.T = (uint32_t)T; aa.seed = seed; aa.n_src = n_src; aa.n_states = pl.n_states;
         aa.n_fin = partials ? 0 : n_aggs; aa.partials = partials ? 1 : 0;
-        aa.n_rounds = n_rounds; aa.round_states = round_states;
+        aa.n_rounds = n_rounds; aa.round_states = round_states; aa.second_pass = pl.needs_second_pass ? 1 : 0;
         std::memcpy(aa.round_src_begin, round_begin, sizeof aa.round_src_begin);
         std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
         std::memcpy(aa.st_round, st_round, sizeof st_round);
         std::memcpy(aa.st_lds, st_lds, sizeof st_lds);
         for (int f = 0; f < n_aggs && !partials; f++) {
             FinDev &fd = aa.fin[f];
-            fd = FinDev{pl.fin_op[f], pl.fin_kind[f], -1, -1, -1, -1, 0, 0};
+            fd = FinDev{};
+            fd.op = pl.fin_op[f]; fd.kind = pl.fin_kind[f];
+            fd.st_add = fd.st_nn = fd.st_min = fd.st_max = fd.st_ssq = fd.st_fadd = fd.rowsrc_min = fd.rowsrc_max = -1;
             int s = pl.fin_src[f];
             if (s < 0) continue;                                   // COUNT: round 0, group size only
             auto lds_of = [&](int8_t abs_id) -> int8_t { return abs_id < 0 ? (int8_t)-1 : st_lds[abs_id]; };
             fd.st_add = lds_of(pl.st_add[s]); fd.st_nn = lds_of(pl.st_nn[s]);
             fd.st_min = lds_of(pl.st_min[s]); fd.st_max = lds_of(pl.st_max[s]);
-            int8_t any = pl.st_add[s] >= 0 ? pl.st_add[s] : (pl.st_min[s] >= 0 ? pl.st_min[s] : pl.st_max[s]);
-            fd.round = st_round[any];
+            fd.st_ssq = lds_of(pl.st_ssq[s]); fd.st_fadd = lds_of(pl.st_fadd[s]);
+            int8_t any = pl.st_add[s] >= 0 ? pl.st_add[s] : (pl.st_min[s] >= 0 ? pl.st_min[s] : (pl.st_max[s] >= 0 ? pl.st_max[s] : (pl.st_ssq[s] >= 0 ? pl.st_ssq[s] : (int8_t)-1)));
+            fd.round = any >= 0 ? st_round[any] : 0;
+            if (fd.op == PANDRS_HIP_AGG_FIRST || fd.op == PANDRS_HIP_AGG_LAST) {
+                fd.rowsrc_min = st_lds[pl.st_firstrow]; fd.rowsrc_max = st_lds[pl.st_lastrow];
+                fd.round = st_round[pl.st_firstrow];
+                fd.col_data = rs.val_data[s]; fd.col_null = rs.val_null_bits[s];
+            }
         }
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
         aa.out_states = res.states; aa.cap = cap; aa.counters = counters;
@@ -1025,7 +1107,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             size_t lds = (size_t)(T + 2) * slot_bytes + 160;
             // uniform profile: raw rows, one round, every source same kind / ops / validity
             int profile = -1;
-            if (!merge && n_rounds == 1 && n_src > 0 && !c->opt.generic_aggregate) {
+            if (!merge && n_rounds == 1 && n_src > 0 && !c->opt.generic_aggregate && pl.mergeable) {
                 auto prof_of = [](const EngSrc &e) {
                     int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
                     return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);

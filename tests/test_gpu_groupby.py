@@ -137,6 +137,40 @@ def test_skew_and_extremes(ctx):
     check(ctx, [(np.arange(n, dtype=np.int64) * 1024, None, O.I64)], n, v, FIVE, [O.I64], exact=EXACT5)
 
 
+def test_std_var_first_last(ctx, golden):
+    """aggregation.rs:557-624, :675-742 + :881-903: two-pass Bessel variance, value at first/last row."""
+    rng = np.random.default_rng(17)
+    n, g = 500_000, 7_000
+    keys = [(sparse_keys(rng, n, g), O.pack_mask(rng.random(n) < 0.001), O.I64)]
+    vf = (rng.normal(1e6, 3.0, n), O.pack_mask(rng.random(n) < 0.1), O.F64)       # large mean: two-pass matters
+    vi = (rng.integers(-10**5, 10**5, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.3), O.I64)
+    vp = (rng.normal(0, 1, n), None, O.F64)
+    aggs = [(0, O.STD), (0, O.VAR), (0, O.FIRST), (0, O.LAST), (0, O.MEAN),
+            (1, O.STD), (1, O.VAR), (1, O.FIRST), (1, O.LAST), (1, O.SUM),
+            (2, O.VAR), (2, O.FIRST), (2, O.COUNT)]
+    exact = [i for i, (_, op) in enumerate(aggs) if op in (O.FIRST, O.LAST, O.COUNT)] + [9]
+    check(ctx, keys, n, [vf, vi, vp], aggs, [O.I64], exact=exact)
+    # singletons and all-null groups: var/std 0.0, first/last of a null => 0.0
+    k = [(np.array([1, 2, 2, 3, 3, 3], np.int64), None, O.I64)]
+    v = (np.array([5.0, 1.0, 2.0, 0.0, 0.0, 0.0]), O.pack_mask([0, 0, 0, 1, 1, 1]), O.F64)
+    check(ctx, k, 6, [v], [(0, O.STD), (0, O.VAR), (0, O.FIRST), (0, O.LAST)], [O.I64], exact=range(4))
+    # the reference's own known answers: std(A)=20, first 10/20, last 50/40
+    case = golden["groupby"][2]
+    codes, pool = codes_of(case["key_strings"])
+    kc, kn, oa = ctx.groupby_agg([(codes, None, O.U32CODE)], 5, [(np.array(case["values_f64"]), None, O.F64)],
+                                 [(0, O.STD), (0, O.FIRST), (0, O.LAST)])
+    for gi in range(2):
+        e = case["expect"][pool[int(kc[0, gi])]]
+        if "std" in e:
+            assert oa[0, gi] == pytest.approx(e["std"], abs=1e-3)
+        assert oa[1, gi] == e["first"] and oa[2, gi] == e["last"]
+    import pandrs_amd as pa
+    with pytest.raises(pa.OperationFailed):          # Median: not on the device path yet
+        ctx.groupby_agg(k, 6, [v], [(0, O.MEDIAN)])
+    with pytest.raises(pa.OperationFailed):          # non-mergeable ops cannot produce partials
+        ctx.groupby_partials(k, 6, [v], [(0, O.STD)])
+
+
 def test_empty_and_errors(ctx):
     import pandrs_amd as pa
     e = np.zeros(0, np.int64)
