@@ -920,10 +920,10 @@ struct EngSrc {
 
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
-                          bool partials, int n_aggs, int key_dtype) {
+                          bool partials, int n_aggs, int key_dtype, int n_keys_out) {
     GroupbyResult &res = c->gb;
     res = GroupbyResult{};
-    res.n_keys = 1; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;
+    res.n_keys = n_keys_out; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;
     res.key_dtype = key_dtype;
     const int64_t N = rs.n_rows;
     if (N == 0) { res.valid = true; return 0; }
@@ -1065,10 +1065,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // ---- aggregate
         size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 1));
         size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
-        ST_TRY(c->result.ensure(Arena::padded(cap * 8) + Arena::padded(cap) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 4096, c->stream));
+        ST_TRY(c->result.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
         res.cap = (int64_t)cap;
-        res.keys = c->result.take<uint64_t>(cap);
-        res.key_null = c->result.take<uint8_t>(cap);
+        res.keys = c->result.take<uint64_t>(cap * n_keys_out);      // [n_keys][cap]; row 0 holds the engine's cell
+        res.key_null = c->result.take<uint8_t>(cap * n_keys_out);
         if (partials) res.states = c->result.take<uint64_t>(cap * out_cols + 32);
         else res.aggs = c->result.take<double>(cap * std::max<size_t>(out_cols, 1) + 32);
         if (!res.keys || !res.key_null || (!res.states && !res.aggs))
@@ -1154,6 +1154,73 @@ static int32_t check_cols(const pandrs_hip_column *cols, int n, const char *what
     return 0;
 }
 
+// ---- multi-key groupby: composite keys packed into one 8-byte cell -------------------------------
+// The reference groups on Vec<String> (grouping.rs:62-104).  Here every key column is reduced to
+// an order-preserving code  code = sortable(cell) - min + (nullable ? 1 : 0)  (0 = NULL) of just
+// enough bits, the codes are concatenated into one u64 cell, the single-key engine runs on it, and
+// the group keys are unpacked afterwards.  Exact; fails cleanly when the codes need > 64 bits.
+constexpr int MAX_KEYS = 8;
+struct PackDesc {
+    KeyDesc key[MAX_KEYS];
+    uint64_t min_sortable[MAX_KEYS];
+    uint32_t shift[MAX_KEYS], bits[MAX_KEYS], nullable[MAX_KEYS];
+    int n_keys;
+};
+__device__ __forceinline__ uint64_t sortable_cell(int dtype, uint64_t cell) {
+    if (dtype == PANDRS_HIP_I64) return cell ^ 0x8000000000000000ull;
+    if (dtype == PANDRS_HIP_F64) return (cell >> 63) ? ~cell : (cell | 0x8000000000000000ull);
+    return cell;
+}
+__device__ __forceinline__ uint64_t unsortable_cell(int dtype, uint64_t s) {
+    if (dtype == PANDRS_HIP_I64) return s ^ 0x8000000000000000ull;
+    if (dtype == PANDRS_HIP_F64) return (s >> 63) ? (s & 0x7FFFFFFFFFFFFFFFull) : ~s;
+    return s;
+}
+// out[2k] = min sortable cell, out[2k+1] = max, over the non-null rows of key k
+__global__ void key_minmax_kernel(PackDesc d, int64_t n, uint64_t *out) {
+    for (int k = 0; k < d.n_keys; k++) {
+        uint64_t mn = ~0ull, mx = 0;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            if (key_is_null(d.key[k], i)) continue;
+            uint64_t s = sortable_cell(d.key[k].dtype, key_cell(d.key[k], i));
+            mn = s < mn ? s : mn; mx = s > mx ? s : mx;
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            uint64_t a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin((unsigned long long *)&out[2 * k], mn);
+            atomicMax((unsigned long long *)&out[2 * k + 1], mx);
+        }
+    }
+}
+__global__ void pack_keys_kernel(PackDesc d, int64_t n, uint64_t *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t cell = 0;
+    for (int k = 0; k < d.n_keys; k++) {
+        uint64_t code = 0;
+        if (!key_is_null(d.key[k], i))
+            code = sortable_cell(d.key[k].dtype, key_cell(d.key[k], i)) - d.min_sortable[k] + d.nullable[k];
+        cell |= code << d.shift[k];
+    }
+    out[i] = cell;
+}
+// keys[0][g] holds the packed cell; rewrite keys[k][g] / key_null[k][g] for every key column
+__global__ void unpack_keys_kernel(PackDesc d, int64_t g, size_t cap, uint64_t *keys, uint8_t *knull) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g) return;
+    const uint64_t cell = keys[i];
+    for (int k = 0; k < d.n_keys; k++) {
+        uint64_t mask = d.bits[k] >= 64 ? ~0ull : ((1ull << d.bits[k]) - 1);
+        uint64_t code = (cell >> d.shift[k]) & mask;
+        bool nul = d.nullable[k] && code == 0;
+        keys[(size_t)k * cap + i] = nul ? 0ull : unsortable_cell(d.key[k].dtype, code - d.nullable[k] + d.min_sortable[k]);
+        knull[(size_t)k * cap + i] = nul ? 1 : 0;
+    }
+}
+
 int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys,
                       int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
                       const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
@@ -1161,14 +1228,14 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     if (!c || !out_n_groups || n_rows < 0 || n_keys < 1 || n_vals < 0 || n_aggs < 0 || !keys ||
         (n_vals && !vals) || (n_aggs && !aggs))
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby: bad arguments");
-    if (n_keys != 1)
-        return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
-                    "multi-key groupby is not on the device path yet (pack the keys host-side)");
+    if (n_keys > MAX_KEYS)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d key columns", MAX_KEYS);
+    if (n_keys > 1 && partials)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "multi-key partials are not mergeable across shards yet");
     ST_TRY(check_cols(keys, n_keys, "key"));
     ST_TRY(check_cols(vals, n_vals, "value"));
-    if (n_rows > 0) {
-        if (!keys[0].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column has no data");
-    }
+    for (int k = 0; k < n_keys; k++)
+        if (n_rows > 0 && !keys[k].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column %d has no data", k);
     std::vector<int32_t> dts(std::max(n_vals, 1));
     std::vector<uint8_t> hn(std::max(n_vals, 1));
     for (int i = 0; i < n_vals; i++) { dts[i] = vals[i].dtype; hn[i] = vals[i].null_mask != nullptr; }
@@ -1183,7 +1250,8 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     Stager stg{c, mem_space};
     if (mem_space == PANDRS_HIP_MEM_HOST && n_rows > 0) {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
-        size_t need = dtype_bytes(keys[0].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
+        size_t need = 0;
+        for (int k = 0; k < n_keys; k++) need += dtype_bytes(keys[k].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
         for (int s = 0; s < pl.n_src; s++) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
         ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
     }
@@ -1196,10 +1264,61 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         rs.val_null_bits[s] = (const uint8_t *)stg.in(v.null_mask, (n_rows + 7) / 8);
     }
     if (stg.status) return stg.status;
-    ST_TRY(run_engine(c, rs, pl, /*merge=*/false, partials, n_aggs, keys[0].dtype));
+    PackDesc pd{};
+    if (n_keys > 1 && n_rows > 0) {
+        // composite key: per-column code widths from a min/max pass, then one packed cell per row
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+        pd.n_keys = n_keys;
+        for (int k = 0; k < n_keys; k++)
+            pd.key[k] = KeyDesc{k == 0 ? rs.key.data : stg.in(keys[k].data, dtype_bytes(keys[k].dtype, n_rows)),
+                                k == 0 ? rs.key.null_bits : (const uint8_t *)stg.in(keys[k].null_mask, (n_rows + 7) / 8),
+                                nullptr, keys[k].dtype};
+        if (stg.status) return stg.status;
+        ST_TRY(c->temp.ensure(Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
+        uint64_t *mm = c->temp.take<uint64_t>(2 * MAX_KEYS);
+        uint64_t *packed = c->temp.take<uint64_t>(n_rows);
+        if (!mm || !packed) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
+        uint64_t *h = reinterpret_cast<uint64_t *>(c->pinned);
+        for (int k = 0; k < n_keys; k++) { h[2 * k] = ~0ull; h[2 * k + 1] = 0; }
+        HIP_TRY(hipMemcpyAsync(mm, h, 16 * n_keys, hipMemcpyHostToDevice, c->stream));
+        int blocks = (int)std::min<int64_t>(2048, (n_rows + 255) / 256);
+        hipLaunchKernelGGL(key_minmax_kernel, dim3(blocks), dim3(256), 0, c->stream, pd, n_rows, mm);
+        HIP_TRY(hipMemcpyAsync(h, mm, 16 * n_keys, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        uint32_t shift = 0;
+        for (int k = 0; k < n_keys; k++) {
+            uint64_t mn = h[2 * k], mx = h[2 * k + 1];
+            pd.nullable[k] = keys[k].null_mask ? 1u : 0u;
+            if (mn > mx) { mn = mx = 0; }                       // every row null
+            uint64_t span = mx - mn;                            // codes 0..span (+1 when nullable)
+            uint32_t bits = 0;
+            bool wide = span == ~0ull || (pd.nullable[k] && span + 1 == ~0ull);
+            uint64_t top = span + pd.nullable[k];
+            while (bits < 64 && (top >> bits)) bits++;
+            if (wide) bits = 65;
+            if (bits == 0) bits = 1;
+            if (shift + bits > 64)
+                return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                            "multi-key groupby: the key columns need more than 64 bits when packed "
+                            "(column %d needs %u bits after %u); not supported on the device path yet", k, bits, shift);
+            pd.min_sortable[k] = mn; pd.shift[k] = shift; pd.bits[k] = bits;
+            shift += bits;
+        }
+        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, pd, n_rows, packed);
+        HIP_TRY(hipGetLastError());
+        rs.key = KeyDesc{packed, nullptr, nullptr, DT_CELL};
+    }
+    ST_TRY(run_engine(c, rs, pl, /*merge=*/false, partials, n_aggs, keys[0].dtype, n_keys));
+    if (n_keys > 1 && c->gb.n_groups > 0) {
+        hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((c->gb.n_groups + 255) / 256)), dim3(256), 0, c->stream,
+                           pd, c->gb.n_groups, (size_t)c->gb.cap, c->gb.keys, c->gb.key_null);
+        HIP_TRY(hipGetLastError());
+    }
     // B = N (K + 8 C) + G (K + 8 A) (+ N/8 per masked column)
     {
-        int64_t K = keys[0].dtype == PANDRS_HIP_U32CODE ? 4 : (keys[0].dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
+        int64_t K = 0;
+        for (int k = 0; k < n_keys; k++)
+            K += keys[k].dtype == PANDRS_HIP_U32CODE ? 4 : (keys[k].dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
         int64_t b = n_rows * (K + 8 * (int64_t)pl.n_src) + c->gb.n_groups * (K + 8 * (int64_t)n_aggs);
         if (keys[0].null_mask) b += n_rows / 8;
         for (int s = 0; s < pl.n_src; s++) if (rs.val_null_bits[s]) b += n_rows / 8;

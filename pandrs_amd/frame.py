@@ -251,6 +251,8 @@ class OptimizedDataFrame:
         self.column_names = []
         self.column_indices = {}
         self._row_count = 0
+        self.multi_index = None           # list of key tuples when a multi-key group_by built a multi-index
+        self.multi_index_names = None
 
     # -- construction / inspection (core.rs) ----------------------------------------------------------
     def add_column(self, name, column):
@@ -280,11 +282,14 @@ class OptimizedDataFrame:
 
     # -- groupby (grouping.rs:22-115) -------------------------------------------------------------------
     def group_by(self, columns):
+        return self.group_by_with_options(columns, True)      # grouping.rs:22-28
+
+    def group_by_with_options(self, columns, as_multi_index):
         columns = [columns] if isinstance(columns, str) else list(columns)
         for c in columns:
             if c not in self.column_indices:
                 raise ColumnNotFound(c)                       # grouping.rs:53-57
-        return GroupBy(self, columns)
+        return GroupBy(self, columns, as_multi_index and len(columns) > 1)   # grouping.rs:107
 
     # -- whole-column reductions (K1: split_dataframe/aggregate.rs:21-62) ---------------------------------
     def _reduce(self, name):
@@ -413,10 +418,10 @@ class GroupBy:
     """GroupBy<'a> (group/types.rs:46-55).  The row-index map `groups` of the reference is not
     materialised: aggregation runs on the device straight from the columns."""
 
-    def __init__(self, df, group_by_columns):
+    def __init__(self, df, group_by_columns, create_multi_index=False):
         self.df = df
         self.group_by_columns = group_by_columns
-        self.create_multi_index = len(group_by_columns) > 1
+        self.create_multi_index = create_multi_index
 
     def aggregate(self, aggregations):
         """aggregations: iterable of (column, AggregateOp, alias)  (aggregation.rs:763-871)."""
@@ -424,11 +429,7 @@ class GroupBy:
         for col_name, _, _ in aggregations:
             if col_name not in self.df.column_indices:
                 raise ColumnNotFound(col_name)                # aggregation.rs:770-774
-        if len(self.group_by_columns) != 1:
-            raise OperationFailed(L.ERR_OPERATION_FAILED,
-                                  "multi-key group_by is not on the device path yet (SURVEY.md §8f-2)")
-        key_name = self.group_by_columns[0]
-        key_col = self.df.column(key_name)
+        key_cols = [self.df.column(k) for k in self.group_by_columns]
         val_names = []
         for col_name, _, _ in aggregations:
             if col_name not in val_names:
@@ -436,11 +437,19 @@ class GroupBy:
         vals = [self.df.column(n).view() for n in val_names]
         specs = [(val_names.index(c), int(op)) for c, op, _ in aggregations]
         ctx = get_context()
-        kc, kn, oa = ctx.groupby_agg([key_col.view()], self.df.row_count(), vals, specs)
+        kc, kn, oa = ctx.groupby_agg([k.view() for k in key_cols], self.df.row_count(), vals, specs)
         result = OptimizedDataFrame()
-        # key column as strings (aggregation.rs:856-860), then one Float64Column per alias in
-        # request order (:863-867)
-        result.add_column(key_name, StringColumn(_key_strings(key_col.dtype, kc[0], kn[0])))
+        key_strings = [_key_strings(k.dtype, kc[i], kn[i]) for i, k in enumerate(key_cols)]
+        if self.create_multi_index:
+            # > 1 key with the multi-index option: no key columns, a StringMultiIndex of tuples instead
+            # (aggregation.rs:812-853)
+            result.multi_index = list(zip(*key_strings))
+            result.multi_index_names = list(self.group_by_columns)
+        else:
+            # key columns as strings (aggregation.rs:856-860; their relative order is HashMap order in
+            # the reference, group_by order here), then one Float64Column per alias in request order (:863-867)
+            for name, strs in zip(self.group_by_columns, key_strings):
+                result.add_column(name, StringColumn(strs))
         seen = {}
         for a, (_, _, alias) in enumerate(aggregations):
             seen[alias] = a          # the reference keeps one Vec per alias in a HashMap: last writer wins

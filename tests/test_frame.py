@@ -93,6 +93,23 @@ def test_groupby_example_and_shortcuts(golden):
 
 
 @pytest.mark.gpu
+def test_two_key_groupby_like_reference():
+    """tests/optimized_groupby_test.rs:138-186: two keys => 3 columns (no multi-index), 4 groups;
+    group_by() itself builds a multi-index instead of key columns (aggregation.rs:812-853)."""
+    df = OptimizedDataFrame()
+    df.add_column("cat1", StringColumn(["A", "A", "B", "B"]))
+    df.add_column("cat2", StringColumn(["X", "Y", "X", "Y"]))
+    df.add_column("value", Float64Column([1.0, 2.0, 3.0, 4.0]))
+    res = df.group_by_with_options(["cat1", "cat2"], False).aggregate([("value", AggregateOp.Sum, "total")])
+    assert res.column_count() == 3 and res.row_count() == 4
+    got = {(a, b): v for a, b, v in zip(res.column("cat1").to_list(), res.column("cat2").to_list(), res.column("total").data)}
+    assert got == {("A", "X"): 1.0, ("A", "Y"): 2.0, ("B", "X"): 3.0, ("B", "Y"): 4.0}
+    res = df.group_by(["cat1", "cat2"]).sum("value")
+    assert res.column_names == ["value_sum"] and sorted(res.multi_index) == [("A", "X"), ("A", "Y"), ("B", "X"), ("B", "Y")]
+    assert res.multi_index_names == ["cat1", "cat2"]
+
+
+@pytest.mark.gpu
 def test_joins_like_reference_tests(golden):
     """tests/optimized_join_test.rs:6-232: row / column counts, plus exact contents."""
     left = OptimizedDataFrame()

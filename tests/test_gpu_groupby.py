@@ -171,6 +171,30 @@ def test_std_var_first_last(ctx, golden):
         ctx.groupby_partials(k, 6, [v], [(0, O.STD)])
 
 
+def test_multi_key_packed(ctx, golden):
+    """Vec<String> keys of the reference (grouping.rs:62-104) as packed composite cells."""
+    rng = np.random.default_rng(23)
+    n = 300_000
+    k1 = (rng.integers(0, 300, n).astype(np.uint32), O.pack_mask(rng.random(n) < 0.01), O.U32CODE)
+    k2 = (rng.integers(-50, 50, n).astype(np.int64) * 1000 - 7, None, O.I64)
+    k3 = (np.packbits(rng.random(n) < 0.5, bitorder="little"), O.pack_mask(rng.random(n) < 0.05), O.BOOLBITS)
+    v = [(rng.normal(100, 10, n), None, O.F64)]
+    got = ctx.groupby_agg([k1, k2, k3], n, v, FIVE)
+    want = O.groupby_agg([k1, k2, k3], n, v, FIVE)
+    assert_groupby_equal(got, want, [O.U32CODE, O.I64, O.BOOLBITS], int_exact_rows=EXACT5)
+    kf = (rng.choice(np.array([0.5, -0.0, 0.0, np.nan]), n), None, O.F64)     # f64 key spans < 2^64 codes? no: rejected
+    import pandrs_amd as pa
+    with pytest.raises(pa.OperationFailed):
+        ctx.groupby_agg([(rng.integers(-2**62, 2**62, n), None, O.I64), (rng.integers(-2**62, 2**62, n), None, O.I64)], n, v, FIVE)
+    del kf
+    c = golden["groupby_two_keys"]
+    a, _ = codes_of(c["key1_strings"])
+    b, _ = codes_of(c["key2_strings"])
+    kc, kn, oa = ctx.groupby_agg([(a, None, O.U32CODE), (b, None, O.U32CODE)], 4,
+                                 [(np.array(c["values_f64"]), None, O.F64)], [(0, O.SUM)])
+    assert kc.shape == (2, c["expect_n_groups"]) and sorted(oa[0].tolist()) == [1.0, 2.0, 3.0, 4.0]
+
+
 def test_empty_and_errors(ctx):
     import pandrs_amd as pa
     e = np.zeros(0, np.int64)
