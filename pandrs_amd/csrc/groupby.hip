@@ -158,9 +158,11 @@ __device__ __forceinline__ uint32_t tile_idx(uint32_t tid, int r, uint32_t tile_
 template <int THREADS>
 __device__ __forceinline__ void load_column8(const void *col, int64_t tbase, uint32_t tid, uint32_t tile_last,
                                              uint64_t (&out)[SC_RPT]) {
+    // streamed once: non-temporal, so the input does not evict the partially written output lines
+    // that the XCD's L2 is completing (shared-cursor write frontier)
     const uint64_t *src = reinterpret_cast<const uint64_t *>(col) + tbase;
 #pragma unroll
-    for (int r = 0; r < SC_RPT; r++) out[r] = src[tile_idx<THREADS>(tid, r, tile_last)];
+    for (int r = 0; r < SC_RPT; r++) out[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
 }
 
 // key cells + null flags (bit r of *nulls) for the thread's SC_RPT rows; the dtype switch is
@@ -173,7 +175,7 @@ __device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, 
     case PANDRS_HIP_U32CODE: {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(k.data) + tbase;
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) kc[r] = src[tile_idx<THREADS>(tid, r, tile_last)];
+        for (int r = 0; r < SC_RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
         break;
     }
     case PANDRS_HIP_BOOLBITS: {
@@ -188,7 +190,7 @@ __device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, 
     default: {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(k.data) + tbase;
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) kc[r] = src[tile_idx<THREADS>(tid, r, tile_last)];
+        for (int r = 0; r < SC_RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
         if (k.dtype == PANDRS_HIP_F64) {
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++)
@@ -494,27 +496,39 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         }
         __syncthreads();
 
-        for (uint32_t i0 = beg + tid; i0 < end; i0 += 2 * AG_THREADS) {
-            // two rows per thread in flight: all global loads first, LDS work after
-            const uint32_t i1 = i0 + AG_THREADS;
-            const bool has1 = i1 < end;
-            uint64_t k2[2], v[2][NS], gs[2];
-            bool ok[2][NS];
+        // Software pipeline: two rows per thread are processed while the NEXT two rows' global loads
+        // are already in flight (indices are clamped to the partition's last row, so the prefetch
+        // loads are unconditional; a clamped row is simply never processed).
+        auto fetch = [&](uint32_t i0, uint64_t (&k2)[2], uint64_t (&v)[2][NS], uint64_t (&gs)[2], bool (&ok)[2][NS]) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t i = h ? i1 : i0;
-                if (h && !has1) break;
-                k2[h] = a.pkeys[i];
+                const uint32_t i = min(i0 + h * AG_THREADS, end - 1);
+                k2[h] = __builtin_nontemporal_load(a.pkeys + i);
                 gs[h] = (GEN && round == 0 && a.pgsize) ? (uint64_t)a.pgsize[i] : 1ull;
 #pragma unroll
                 for (int c = 0; c < NS; c++) {
                     if (c < nsrc) {
                         const SrcDev &sd = a.src[s0 + c];
-                        v[h][c] = sd.vals[i];
+                        v[h][c] = __builtin_nontemporal_load(sd.vals + i);
                         ok[h][c] = f_valid(sd) ? sd.valid[i] != 0 : true;
                     }
                 }
             }
+        };
+        uint64_t k2n[2], vn[2][NS], gsn[2];
+        bool okn[2][NS];
+        if (beg + tid < end) fetch(beg + tid, k2n, vn, gsn, okn);
+        for (uint32_t i0 = beg + tid; i0 < end; i0 += 2 * AG_THREADS) {
+            const bool has1 = i0 + AG_THREADS < end;
+            uint64_t k2[2], v[2][NS], gs[2];
+            bool ok[2][NS];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                k2[h] = k2n[h]; gs[h] = gsn[h];
+#pragma unroll
+                for (int c = 0; c < NS; c++) { v[h][c] = vn[h][c]; ok[h][c] = okn[h][c]; }
+            }
+            if (i0 + 2 * AG_THREADS < end) fetch(i0 + 2 * AG_THREADS, k2n, vn, gsn, okn);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (h && !has1) break;
@@ -814,8 +828,9 @@ static bool launch_aggregate_profile(pandrs_hip_ctx *c, const AggArgs &a, int pr
     // instantiated uniform profiles: {f64, i64} x {sum only, sum+min+max} x {no validity, validity}
     switch (profile) {
 #define PROF(K, OPS, V) case ((K) << 4 | (OPS) << 1 | (V)): launch_aggregate_one<NSRC, ((K) << 4 | (OPS) << 1 | (V))>(c, a, lds); return true;
-        PROF(0, 1, 0) PROF(0, 1, 1) PROF(0, 7, 0) PROF(0, 7, 1)
-        PROF(1, 1, 0) PROF(1, 1, 1) PROF(1, 7, 0) PROF(1, 7, 1)
+        PROF(0, 1, 0) PROF(0, 1, 1) PROF(0, 7, 0) PROF(0, 7, 1) PROF(0, 6, 0) PROF(0, 6, 1)
+        PROF(0, 2, 0) PROF(0, 4, 0) PROF(0, 3, 0) PROF(0, 5, 0)
+        PROF(1, 1, 0) PROF(1, 1, 1) PROF(1, 7, 0) PROF(1, 7, 1) PROF(1, 6, 0)
 #undef PROF
     default: return false;
     }
@@ -831,6 +846,7 @@ static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int max_src_pe
         if (done) return;
     }
     switch (max_src_per_round) {
+    case 0:     // count-only: no value sources
     case 1: launch_aggregate_one<1, -1>(c, a, lds); break;
     case 2: launch_aggregate_one<2, -1>(c, a, lds); break;
     case 3: launch_aggregate_one<3, -1>(c, a, lds); break;
