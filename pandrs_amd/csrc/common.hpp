@@ -108,6 +108,7 @@ struct Options {
     int64_t scatter_threads = 1024;  // 1024: one 8192-row tile per CU; 512: two 4096-row tiles per CU
     int64_t src_per_round = 0;       // 0 = auto; aggregated columns per pass over a partition
     int64_t shared_cursors = 1;      // scatter: per-(partition, XCD group) shared write cursors
+    int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic

