@@ -108,6 +108,8 @@ struct Options {
     int64_t scatter_threads = 1024;  // 1024: one 8192-row tile per CU; 512: two 4096-row tiles per CU
     int64_t src_per_round = 0;       // 0 = auto; aggregated columns per pass over a partition
     int64_t shared_cursors = 1;      // scatter: per-(partition, XCD group) shared write cursors
+    int64_t no_slice = 0;            // 1 = never split oversized partitions across workgroups
+    int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)
@@ -120,16 +122,17 @@ struct pandrs_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    pandrs::Arena work, result, staging, temp;
+    pandrs::Arena work, result, staging, temp, result2, side;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
-    pandrs::GroupbyResult gb;
+    pandrs::GroupbyResult gb, gb2;   // gb2: secondary result used while merging the slices of oversized partitions
     pandrs::JoinResult jn;
     // phase timing: pairs of events
     hipEvent_t ev_begin[PANDRS_HIP_MAX_PHASES]{}, ev_end[PANDRS_HIP_MAX_PHASES]{};
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
     hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
     void *pinned = nullptr;      // small pinned host block for readbacks
+    int quiet = 0;               // > 0: nested engine runs (slice / direct merges) do not record phase events
     int lds_bytes = 0;           // usable LDS per workgroup
     int n_cu = 0;
 };
@@ -140,12 +143,13 @@ struct PhaseTimer {
     pandrs_hip_ctx *c;
     int phase;
     PhaseTimer(pandrs_hip_ctx *ctx, int ph) : c(ctx), phase(ph) {
+        if (c->quiet) return;
         if (!c->ev_used[phase]) {
             (void)hipEventRecord(c->ev_begin[phase], c->stream);
             c->ev_used[phase] = true;
         }
     }
-    ~PhaseTimer() { (void)hipEventRecord(c->ev_end[phase], c->stream); }
+    ~PhaseTimer() { if (!c->quiet) (void)hipEventRecord(c->ev_end[phase], c->stream); }
 };
 
 inline void timings_begin(pandrs_hip_ctx *c) {

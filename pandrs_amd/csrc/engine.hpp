@@ -103,7 +103,7 @@ size_t scan_seg_count(size_t n);     // entries the `seg` scratch of exclusive_s
 int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
                    const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl);
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge, bool partials,
-                   int n_aggs, int key_dtype, int n_keys_out = 1);
+                   int n_aggs, int key_dtype, int n_keys_out = 1, int res_slot = 0);
 size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
 
 }  // namespace pandrs

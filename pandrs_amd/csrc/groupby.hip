@@ -29,12 +29,27 @@ namespace pandrs {
 __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
                                 uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_sample) return;
-    int64_t i = s * stride;
-    if (i >= n_rows) return;
-    if (key_is_null(key, i)) return;
-    uint64_t k = key_cell(key, i);
-    if (k == EMPTY_KEY) return;
+    bool live = s < n_sample && s * stride < n_rows;
+    uint64_t k = 0;
+    if (live) {
+        int64_t i = s * stride;
+        live = !key_is_null(key, i);
+        if (live) { k = key_cell(key, i); live = k != EMPTY_KEY; }
+    }
+    // a dominant key would make every lane CAS the same address: peel the wave's two most common
+    // leading keys first (one lane inserts for all lanes that hold the same key)
+    bool peeled = false;       // this lane is (or was represented by) a leader already
+    for (int round = 0; round < 2; round++) {
+        unsigned long long m = __ballot(live && !peeled);
+        if (!m) break;
+        int leader = __ffsll((long long)m) - 1;
+        uint64_t lk = __shfl(k, leader, 64);
+        if (live && !peeled && k == lk) {
+            peeled = true;
+            if ((int)(threadIdx.x & 63) != leader) live = false;           // the leader inserts on their behalf
+        }
+    }
+    if (!live) return;
     uint32_t slot = hash32(k, 0x1234567u) & table_mask;
     for (uint32_t probe = 0; probe <= table_mask; probe++) {
         uint64_t cur = table[slot];
@@ -363,6 +378,38 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ aggregate
+struct AggTask { uint32_t part, beg, end, multi; };
+
+// one workgroup: partition sizes -> task list (a partition of more than slice_rows rows becomes
+// ceil(size / slice_rows) tasks flagged `multi`; empty partitions get no task)
+__global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1,
+                                                           uint32_t slice_rows, AggTask *tasks, uint32_t *n_tasks,
+                                                           uint32_t max_tasks) {
+    __shared__ uint32_t wt[17];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < P1; base += 1024) {
+        uint32_t p = base + threadIdx.x, beg = 0, end = 0, ns = 0;
+        if (p < P1) {
+            beg = offsets[(size_t)p * NB]; end = offsets[(size_t)(p + 1) * NB];
+            ns = (end - beg + slice_rows - 1) / slice_rows;
+        }
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<1024>(ns, wt, &tot) + carry;
+        for (uint32_t q = 0; q < ns; q++) {
+            if (ex + q < max_tasks) {
+                uint32_t b = beg + q * slice_rows;
+                tasks[ex + q] = AggTask{p, b, min(b + slice_rows, end), ns > 1 ? 1u : 0u};
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_tasks = min(carry, max_tasks);
+}
+
 struct AggArgs {
     const uint64_t *pkeys;
     const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
@@ -373,6 +420,11 @@ struct AggArgs {
                                  // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) and emits partial records
     KeyDesc dkey;
     uint32_t d_rows, d_chunk, launch_grid, d_task_cap;
+    // oversized partitions are split into row slices handled by different workgroups; their groups
+    // leave as partial records in the side buffers (counters[2]) and are merged afterwards
+    const AggTask *tasks;        // nullptr: workgroup b = partition b
+    const uint32_t *n_tasks;
+    uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
     SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
     int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
@@ -482,11 +534,25 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
     uint32_t *posmap = reinterpret_cast<uint32_t *>(st + (size_t)a.round_states * T1);
     uint32_t *misc = posmap + ((T1 + 1) & ~1u);
     // misc[0..16] wave totals, [20] overflow, [21] sentinel-key-present, [22] output base, [23] NULL-key-present
-    const uint32_t p = blockIdx.x;
+    uint32_t p = blockIdx.x, beg, end;
     const bool direct = a.direct != 0;
-    const uint32_t beg = direct ? min(p * a.d_chunk, a.d_rows) : a.offsets[(size_t)p * a.NB];
-    const uint32_t end = direct ? min(beg + a.d_chunk, a.d_rows) : a.offsets[(size_t)(p + 1) * a.NB];
+    bool multi = false;
+    if (direct) {
+        beg = min(p * a.d_chunk, a.d_rows); end = min(beg + a.d_chunk, a.d_rows);
+    } else if (a.tasks) {
+        if (blockIdx.x >= *a.n_tasks) return;
+        const AggTask t = a.tasks[blockIdx.x];
+        p = t.part; beg = t.beg; end = t.end; multi = t.multi != 0;
+    } else {
+        beg = a.offsets[(size_t)p * a.NB]; end = a.offsets[(size_t)(p + 1) * a.NB];
+    }
     if (beg >= end) return;
+    // a slice of an oversized partition emits partial records into the side buffers
+    uint64_t *const o_keys = multi ? a.side_keys : a.out_keys;
+    uint8_t *const o_null = multi ? a.side_null : a.out_null;
+    uint64_t *const o_states = multi ? a.side_states : a.out_states;
+    const size_t o_cap = multi ? a.side_cap : a.cap;
+    const bool emit_partials = a.partials != 0 || multi;
 
     for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
     if (tid < 32) misc[tid] = 0;
@@ -632,7 +698,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
             uint32_t total;
             block_exclusive_scan<AG_THREADS>(mine, misc, &total);
             if (direct && total > a.d_task_cap) { if (tid == 0) a.counters[1] = 1; return; }   // estimate was too low
-            if (tid == 0) misc[22] = atomicAdd(&a.counters[0], total);
+            if (tid == 0) misc[22] = atomicAdd(&a.counters[multi ? 2 : 0], total);
             __syncthreads();
             uint32_t run = misc[22];
             __syncthreads();
@@ -645,9 +711,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
                     uint32_t pos = run + ex;
                     posmap[s] = pos;
                     const bool isnull = null_part || s == T + 1;
-                    a.out_keys[pos] = isnull ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
-                    a.out_null[pos] = isnull ? 1 : 0;
-                    if (a.partials) a.out_states[pos] = gsz[s];
+                    o_keys[pos] = isnull ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
+                    o_null[pos] = isnull ? 1 : 0;
+                    if (emit_partials) o_states[pos] = gsz[s];
                 }
                 run += tot;
             }
@@ -693,10 +759,10 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         for (uint32_t s = tid; s < T1; s += AG_THREADS) {
             if (!occupied(s)) continue;
             const size_t pos = posmap[s];
-            if (a.partials) {
+            if (emit_partials) {
                 for (int k = 0; k < a.n_states; k++)
                     if (a.st_round[k] == round)
-                        a.out_states[(size_t)(k + 1) * a.cap + pos] =
+                        o_states[(size_t)(k + 1) * o_cap + pos] =
                             state_natural(a.kinds[k], st[(size_t)a.st_lds[k] * T1 + s]);
             } else {
                 const uint64_t g = gsz[s];
@@ -892,7 +958,7 @@ size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1) {
     return Arena::padded(size_t(1 << 19) * 8) + 4096
          + 2 * Arena::padded((size_t(P_MAX + 1) * NBmax + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64)
          + Arena::padded(size_t(P_MAX + 1) * 32)
-         + (size_t)n_cols8 * Arena::padded(size_t(n_rows) * 8) + (size_t)n_cols1 * Arena::padded(size_t(n_rows)) + (1 << 16);
+         + (size_t)n_cols8 * Arena::padded(size_t(n_rows) * 8) + (size_t)n_cols1 * Arena::padded(size_t(n_rows)) + (4 << 20);
 }
 
 int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
@@ -953,8 +1019,9 @@ struct EngSrc {
 
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
-                          bool partials, int n_aggs, int key_dtype, int n_keys_out) {
-    GroupbyResult &res = c->gb;
+                          bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
+    GroupbyResult &res = res_slot ? c->gb2 : c->gb;
+    Arena &rarena = res_slot ? c->result2 : c->result;
     res = GroupbyResult{};
     res.n_keys = n_keys_out; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;
     res.key_dtype = key_dtype;
@@ -1078,8 +1145,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 Options saved = c->opt;
                 c->opt.no_direct = 1;                 // the merge input is tiny; never recurse
                 c->opt.groups_hint = std::max<int64_t>(est, 1);   // cardinality is known: no second estimate
-                int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, n_keys_out);
+                pandrs_hip_timings tsave = c->timings;
+                c->quiet++;
+                int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, n_keys_out, res_slot);
+                c->quiet--;
                 c->opt = saved;
+                c->timings = tsave;
                 c->timings.estimated_groups = est;
                 return st;
             }
@@ -1177,14 +1248,20 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         uint32_t *offsets = part.offsets;
 
         // ---- aggregate
-        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2));
+        // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
+        const bool slicing = !c->opt.no_slice && pl.mergeable && n_rounds == 1;
+        const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
+                                                          : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
+        const int64_t max_slices = slicing ? 2 * (N / slice_rows) + 2 : 0;       // slices of multi-slice partitions
+        const size_t side_cap = (size_t)max_slices * (size_t)(T + 2);
+        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2)) + (slicing ? side_cap : 0);
         size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
-        ST_TRY(c->result.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
+        ST_TRY(rarena.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
         res.cap = (int64_t)cap;
-        res.keys = c->result.take<uint64_t>(cap * n_keys_out);      // [n_keys][cap]; row 0 holds the engine's cell
-        res.key_null = c->result.take<uint8_t>(cap * n_keys_out);
-        if (partials) res.states = c->result.take<uint64_t>(cap * out_cols + 32);
-        else res.aggs = c->result.take<double>(cap * std::max<size_t>(out_cols, 1) + 32);
+        res.keys = rarena.take<uint64_t>(cap * n_keys_out);      // [n_keys][cap]; row 0 holds the engine's cell
+        res.key_null = rarena.take<uint8_t>(cap * n_keys_out);
+        if (partials) res.states = rarena.take<uint64_t>(cap * out_cols + 32);
+        else res.aggs = rarena.take<double>(cap * std::max<size_t>(out_cols, 1) + 32);
         if (!res.keys || !res.key_null || (!res.states && !res.aggs))
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
         aa.pkeys = pkeys; aa.offsets = offsets; aa.pgsize = pgsize; aa.NB = NB; aa.P = (uint32_t)P;
@@ -1216,6 +1293,22 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
         aa.out_states = res.states; aa.cap = cap; aa.counters = counters; aa.launch_grid = (uint32_t)P + 1;
+        if (slicing) {
+            const uint32_t max_tasks = (uint32_t)(P1 + max_slices);
+            const size_t n_state_all = 1 + (size_t)pl.n_states;
+            ST_TRY(c->side.ensure(Arena::padded(side_cap * 8) + Arena::padded(side_cap) + n_state_all * Arena::padded(side_cap * 8 + 256) + 8192, c->stream));
+            aa.side_keys = c->side.take<uint64_t>(side_cap);
+            aa.side_null = c->side.take<uint8_t>(side_cap);
+            aa.side_states = c->side.take<uint64_t>(side_cap * n_state_all + 32);
+            aa.side_cap = side_cap;
+            AggTask *tasks = c->work.take<AggTask>(max_tasks + 8);
+            uint32_t *n_tasks = c->work.take<uint32_t>(64);
+            if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !n_tasks)
+                return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (slices)");
+            hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1,
+                               (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll), tasks, n_tasks, max_tasks);
+            aa.tasks = tasks; aa.n_tasks = n_tasks; aa.launch_grid = max_tasks;
+        }
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
             size_t lds = (size_t)(T + 3) * slot_bytes + 192;
@@ -1233,9 +1326,44 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             HIP_TRY(hipGetLastError());
         }
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-        HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h, counters, 12, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (h[1] == 0) { res.n_groups = h[0]; res.valid = true; return 0; }
+        if (h[1] == 0) {
+            res.n_groups = h[0]; res.valid = true;
+            const int64_t n_side = h[2];
+            if (n_side > 0) {
+                // merge the partial records of the sliced partitions and append their groups
+                RowSource ms;
+                ms.n_rows = n_side;
+                ms.key = KeyDesc{aa.side_keys, nullptr, aa.side_null, DT_CELL};
+                ms.merge_states = aa.side_states;
+                ms.merge_stride = side_cap;
+                Options saved = c->opt;
+                c->opt.no_slice = 1; c->opt.no_direct = 1; c->opt.groups_hint = 0; c->opt.partitions = 0;
+                pandrs_hip_timings tsave = c->timings;
+                c->quiet++;
+                int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot ? 0 : 1);
+                c->quiet--;
+                c->opt = saved;
+                c->timings = tsave;
+                if (st) return st;
+                GroupbyResult &r2 = res_slot ? c->gb : c->gb2;
+                const size_t g2 = (size_t)r2.n_groups, at = (size_t)res.n_groups;
+                if (at + g2 > cap) return fail(PANDRS_HIP_ERR_COMPUTATION, "slice merge produced more groups than reserved");
+                HIP_TRY(hipMemcpyAsync(res.keys + at, r2.keys, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(res.key_null + at, r2.key_null, g2, hipMemcpyDeviceToDevice, c->stream));
+                if (partials) {
+                    for (size_t k = 0; k < 1 + (size_t)pl.n_states; k++)
+                        HIP_TRY(hipMemcpyAsync(res.states + k * cap + at, r2.states + k * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+                } else {
+                    for (int f = 0; f < n_aggs; f++)
+                        HIP_TRY(hipMemcpyAsync(res.aggs + (size_t)f * cap + at, r2.aggs + (size_t)f * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+                }
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                res.n_groups += (int64_t)g2;
+            }
+            return 0;
+        }
         if (P >= P_MAX)
             return fail(PANDRS_HIP_ERR_COMPUTATION,
                         "group cardinality exceeds the single-level radix capacity (%d partitions x %lld slots)",

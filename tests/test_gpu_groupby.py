@@ -159,6 +159,37 @@ def test_low_cardinality_direct_and_partitioned_paths_agree(ctx, no_direct):
         ctx.set_option("no_direct", 0)
 
 
+def test_hot_key_partitions_are_sliced(ctx):
+    """A dominant key inside a high-cardinality column: its radix partition is cut into row slices
+    handled by several workgroups and merged; results must stay exact."""
+    rng = np.random.default_rng(202)
+    n, g = 3_000_000, 400_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.6] = 424242                              # 60 % of the rows share one key
+    k[rng.random(n) < 0.1] = -1                                  # and 10 % the table-sentinel value
+    keys = [(k, O.pack_mask(rng.random(n) < 0.05), O.I64)]       # 5 % null keys: a large NULL partition
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.05), O.F64),
+            (rng.integers(-99, 99, n).astype(np.int64), None, O.I64)]
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT), (1, O.SUM), (1, O.MIN), (1, O.MAX)]
+    for slice_rows in (0, 50_000):
+        ctx.set_option("slice_rows", slice_rows)
+        try:
+            check(ctx, keys, n, vals, aggs, [O.I64], exact=[2, 3, 4, 5, 6, 7])
+        finally:
+            ctx.set_option("slice_rows", 0)
+    # partials of a sliced input stay mergeable
+    ctx.set_option("slice_rows", 50_000)
+    try:
+        ng, ns = ctx.groupby_partials(keys, n, vals, aggs)
+        rec, counts = ctx.partials_split(1)
+        ctx.groupby_merge(O.I64, rec, [O.F64, O.I64], [True, False], aggs)
+        got = ctx.groupby_fetch(to_device=False)
+    finally:
+        ctx.set_option("slice_rows", 0)
+    want = O.groupby_agg(keys, n, vals, aggs)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5, 6, 7])
+
+
 def test_std_var_first_last(ctx, golden):
     """aggregation.rs:557-624, :675-742 + :881-903: two-pass Bessel variance, value at first/last row."""
     rng = np.random.default_rng(17)
