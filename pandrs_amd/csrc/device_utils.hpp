@@ -78,6 +78,14 @@ __device__ __forceinline__ double dec_f64(uint64_t e) {
 __device__ __forceinline__ uint64_t enc_i64(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
 __device__ __forceinline__ int64_t dec_i64(uint64_t e) { return (int64_t)(e ^ 0x8000000000000000ull); }
 
+// Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also drains the
+// vector-memory counter (s_waitcnt vmcnt(0)), i.e. every wave would wait for its in-flight global
+// stores and prefetch loads at each barrier; the kernels here exchange data between waves through
+// LDS alone, so lgkmcnt(0) + s_barrier is sufficient and keeps HBM traffic in flight across barriers.
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- block-wide exclusive scan of one value per thread (THREADS multiple of 64, <= 1024) -------
 // `wave_tot` = 17-entry LDS scratch.  Returns the exclusive prefix; *total gets the block sum.
 template <int THREADS>
@@ -92,7 +100,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
         if (lane >= d) inc += t;
     }
     if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
+    block_sync_lds();
     if (wave == 0) {
         uint32_t w = lane < NW ? wave_tot[lane] : 0u;
         uint32_t winc = w;
@@ -104,11 +112,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
         if (lane < NW) wave_tot[lane] = winc - w;  // exclusive wave base
         if (lane == NW - 1) wave_tot[16] = winc;
     }
-    __syncthreads();
+    block_sync_lds();
     uint32_t base = wave_tot[wave];
     if (total) *total = wave_tot[16];
     uint32_t r = base + inc - v;
-    __syncthreads();  // wave_tot reusable after return
+    block_sync_lds();  // wave_tot reusable after return
     return r;
 }
 

@@ -245,7 +245,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
     auto live = [&](int r) { return FULL || (uint32_t)(r * THREADS) + tid < tile_n; };
 
     for (uint32_t p = tid; p < P1; p += THREADS) cnt[p] = 0;
-    __syncthreads();
+    block_sync_lds();
     // per row: key cell + packed (partition << 13 | position)
     uint64_t kc[SC_RPT];
     uint32_t ps[SC_RPT], nulls;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
         ps[r] = p << 13;
         if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
     }
-    __syncthreads();
+    block_sync_lds();
     // exclusive scan of cnt[] -> delta[] (tile-local partition starts)
     {
         uint32_t first = tid * ipt, s = 0;
@@ -267,10 +267,10 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
         for (uint32_t q = 0; q < ipt; q++)
             if (first + q < P1) { delta[first + q] = ex; ex += cnt[first + q]; }
     }
-    __syncthreads();
+    block_sync_lds();
 #pragma unroll
     for (int r = 0; r < SC_RPT; r++) ps[r] += delta[ps[r] >> 13];
-    __syncthreads();
+    block_sync_lds();
     // delta[p] := global cursor - tile-local start, so dst = delta[p] + sorted position.
     // Shared cursors: the 32 CUs of an XCD append to the SAME region of each partition, so a
     // partition's 128-B lines are completed inside that XCD's 4 MiB L2 (frontier = P x columns x
@@ -289,7 +289,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
             cursor[p] = c + cnt[p];
         }
     }
-    __syncthreads();
+    block_sync_lds();
 
     if constexpr (STAGED) {
 #pragma unroll
@@ -299,7 +299,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
         // mv[0 .. n_move8) are 8-byte columns (software-pipelined), the rest byte-wide.
         uint64_t vnext[SC_RPT];
         if (a.n_move8 > 0) load_column8<THREADS>(a.mv[0].src, tbase, tid, tile_last, vnext);
-        __syncthreads();
+        block_sync_lds();
         uint32_t dst[SC_RPT];
 #pragma unroll
         for (int r = 0; r < SC_RPT; r++) {
@@ -313,10 +313,10 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
             for (int r = 0; r < SC_RPT; r++) v[r] = vnext[r];
             // next column's loads fly under this column's staging
             if (m + 1 < a.n_move8) load_column8<THREADS>(a.mv[m + 1].src, tbase, tid, tile_last, vnext);
-            __syncthreads();   // previous column's linear reads done
+            block_sync_lds();   // previous column's linear reads done
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++) if (live(r)) stage[ps[r] & SPM] = v[r];
-            __syncthreads();
+            block_sync_lds();
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++) {
                 uint32_t j = r * THREADS + tid;
@@ -325,18 +325,18 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
         }
         for (int m = a.n_move8; m < a.n_move; m++) {      // validity bytes / byte columns
             const MoveDesc mv = a.mv[m];
-            __syncthreads();
+            block_sync_lds();
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++)
                 if (live(r)) stage[ps[r] & SPM] = move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last));
-            __syncthreads();
+            block_sync_lds();
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++) {
                 uint32_t j = r * THREADS + tid;
                 if (live(r)) move_store(mv, dst[r], stage[j]);
             }
         }
-        __syncthreads();
+        block_sync_lds();
     } else {
         uint32_t dst[SC_RPT];
 #pragma unroll
@@ -348,7 +348,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
             for (int r = 0; r < SC_RPT; r++)
                 if (live(r)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
         }
-        __syncthreads();
+        block_sync_lds();
     }
 }
 
