@@ -64,34 +64,6 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
 }
 
 // ------------------------------------------------------------------------------------ histogram
-// Workgroup b owns rows [b*chunk, (b+1)*chunk).  hist is partition-major: hist[p*NB + q(b)] with
-// q(b) = (b % 8) * (NB/8) + b / 8, so the workgroups of one group g = b % 8 (the set that shares an
-// XCD under round-robin dispatch; a label, never a correctness assumption) own ONE contiguous
-// region of every partition.  NB is a multiple of 8.
-__device__ __forceinline__ uint32_t group_slot(uint32_t b, uint32_t NB) { return (b & 7) * (NB >> 3) + (b >> 3); }
-
-__global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
-                                                               int64_t chunk, uint32_t P,
-                                                               uint32_t seed, uint32_t *hist) {
-    extern __shared__ uint32_t cnt[];  // P + 1
-    const uint32_t NB = gridDim.x, b = blockIdx.x, qb = group_slot(b, NB);
-    for (uint32_t p = threadIdx.x; p <= P; p += HI_THREADS) cnt[p] = 0;
-    __syncthreads();
-    int64_t beg = (int64_t)b * chunk, end = min(beg + chunk, n_rows);
-    for (int64_t i = beg + threadIdx.x; i < end; i += HI_THREADS) {
-        uint32_t p = key_is_null(key, i) ? P : part_of(hash32(key_cell(key, i), seed), P);
-        atomicAdd(&cnt[p], 1u);
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p <= P; p += HI_THREADS) hist[(size_t)p * NB + qb] = cnt[p];
-}
-
-// group cursors: gcur[p*8 + g] = first row of group g's region inside partition p
-__global__ void init_group_cursors_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1, uint32_t *gcur) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P1 * 8) gcur[i] = offsets[(size_t)(i >> 3) * NB + (i & 7) * (NB >> 3)];
-}
-
 // ------------------------------------------------------------------------------------ scan
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_IPT = 4;
@@ -232,6 +204,45 @@ __device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, 
 // LDS: cursor[P+1] | cnt[P+1] | delta[P+1] | wave_tot[32] | pid[TILE] (u16) | stage[TILE] (u64)
 // THREADS = 1024: one 8192-row tile per CU (longest per-partition runs);
 // THREADS = 512 : 4096-row tiles, two workgroups per CU (loads of one overlap LDS work of the other).
+// Workgroup b owns rows [b*chunk, (b+1)*chunk).  hist is partition-major: hist[p*NB + q(b)] with
+// q(b) = (b % 8) * (NB/8) + b / 8, so the workgroups of one group g = b % 8 (the set that shares an
+// XCD under round-robin dispatch; a label, never a correctness assumption) own ONE contiguous
+// region of every partition.  NB is a multiple of 8.
+__device__ __forceinline__ uint32_t group_slot(uint32_t b, uint32_t NB) { return (b & 7) * (NB >> 3) + (b >> 3); }
+
+__global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
+                                                               int64_t chunk, uint32_t P,
+                                                               uint32_t seed, uint32_t *hist) {
+    extern __shared__ uint32_t cnt[];  // P + 1
+    const uint32_t NB = gridDim.x, b = blockIdx.x, qb = group_slot(b, NB), tid = threadIdx.x;
+    for (uint32_t p = tid; p <= P; p += HI_THREADS) cnt[p] = 0;
+    __syncthreads();
+    const int64_t beg = (int64_t)b * chunk, end = min(beg + chunk, n_rows);
+    // same tiling as the scatter: SC_RPT batched, branch-free key loads per thread and step
+    constexpr int TILE = HI_THREADS * SC_RPT;
+    for (int64_t tbase = beg; tbase < end; tbase += TILE) {
+        const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
+        uint64_t kc[SC_RPT];
+        uint32_t nulls;
+        load_key_cells<HI_THREADS>(key, tbase, tid, tile_n - 1, kc, &nulls);
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            if ((uint32_t)(r * HI_THREADS) + tid < tile_n) {
+                uint32_t p = ((nulls >> r) & 1) ? P : part_of(hash32(kc[r], seed), P);
+                atomicAdd(&cnt[p], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p <= P; p += HI_THREADS) hist[(size_t)p * NB + qb] = cnt[p];
+}
+
+// group cursors: gcur[p*8 + g] = first row of group g's region inside partition p
+__global__ void init_group_cursors_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1, uint32_t *gcur) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P1 * 8) gcur[i] = offsets[(size_t)(i >> 3) * NB + (i & 7) * (NB >> 3)];
+}
+
 // One tile of the scatter.  FULL = the tile has all TILE rows (every tile but the input's last):
 // no per-row predicates anywhere on that path.
 template <int THREADS, bool STAGED, bool FULL>
@@ -1078,7 +1089,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // of the ORIGINAL columns (one HBM pass), emits its groups as partial records, and the few
     // records (<= tasks x G) are merged by the normal engine.  Also the cure for one-hot-key
     // inputs (bool keys, a dominant key), where a radix partition would put all rows on one CU.
-    if (!merge && pl.mergeable && !c->opt.no_direct && n_src <= MAX_SRC) {
+    // (below a few million rows the whole call is launch-bound and the two-stage direct path loses)
+    if (!merge && pl.mergeable && !c->opt.no_direct && n_src <= MAX_SRC && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
         int total_states = 0;
         for (auto &e : srcs) total_states += e.n_states();
         const size_t sb = 20 + 8 * (size_t)total_states;

@@ -142,7 +142,7 @@ def test_low_cardinality_direct_and_partitioned_paths_agree(ctx, no_direct):
     """Few groups: the partition-free direct path (default) and the radix path must both be exact,
     including NULL keys, the sentinel-valued key (-1), null values and one dominant key."""
     rng = np.random.default_rng(101)
-    n = 1_200_000
+    n = 5_000_000
     k = rng.integers(-3, 40, n).astype(np.int64)
     k[rng.random(n) < 0.5] = 7                                   # dominant key
     keys = [(k, O.pack_mask(rng.random(n) < 0.01), O.I64)]
