@@ -65,8 +65,15 @@ class DistributedGroupBy:
         t2 = time.perf_counter()
         val_dtypes = [v[2] for v in vals]
         val_has_nulls = [v[1] is not None for v in vals]
-        eng.groupby_merge(keys[0][2], recv if recv.is_cuda else recv.numpy().view("uint64"),
-                          val_dtypes, val_has_nulls, aggs)
+        # the merge's cardinality is bounded by the records received: no sampling pass needed
+        if hasattr(eng, "set_option"):
+            eng.set_option("groups_hint", max(int(recv.shape[0]), 1))
+        try:
+            eng.groupby_merge(keys[0][2], recv if recv.is_cuda else recv.numpy().view("uint64"),
+                              val_dtypes, val_has_nulls, aggs)
+        finally:
+            if hasattr(eng, "set_option"):
+                eng.set_option("groups_hint", 0)
         t3 = time.perf_counter()
         t_merge = eng.timings() if hasattr(eng, "timings") else None
         if t_local is not None:
