@@ -88,7 +88,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     if (!c) return PANDRS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->side.release();
+    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release();
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -124,6 +124,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "shared_cursors")) c->opt.shared_cursors = value;
     else if (!std::strcmp(name, "no_direct")) c->opt.no_direct = value;
     else if (!std::strcmp(name, "no_slice")) c->opt.no_slice = value;
+    else if (!std::strcmp(name, "p_max")) c->opt.p_max = value;
     else if (!std::strcmp(name, "slice_rows")) c->opt.slice_rows = value;
     else return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return PANDRS_HIP_OK;

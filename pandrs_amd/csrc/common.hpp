@@ -108,6 +108,7 @@ struct Options {
     int64_t scatter_threads = 1024;  // 1024: one 8192-row tile per CU; 512: two 4096-row tiles per CU
     int64_t src_per_round = 0;       // 0 = auto; aggregated columns per pass over a partition
     int64_t shared_cursors = 1;      // scatter: per-(partition, XCD group) shared write cursors
+    int64_t p_max = 0;               // 0 = default (4096); lower values force the two-level path (testing)
     int64_t no_slice = 0;            // 1 = never split oversized partitions across workgroups
     int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
@@ -122,10 +123,10 @@ struct pandrs_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    pandrs::Arena work, result, staging, temp, result2, side;
+    pandrs::Arena work, result, staging, temp, result2, result3, side, super;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
-    pandrs::GroupbyResult gb, gb2;   // gb2: secondary result used while merging the slices of oversized partitions
+    pandrs::GroupbyResult gb, gb2, gb3;   // gb2 / gb3: nested results (slice merges, two-level sub-runs)
     pandrs::JoinResult jn;
     // phase timing: pairs of events
     hipEvent_t ev_begin[PANDRS_HIP_MAX_PHASES]{}, ev_end[PANDRS_HIP_MAX_PHASES]{};

@@ -80,6 +80,14 @@ struct RowSource {
     // raw mode: per plan source, the value column and its null bitmap
     const void *val_data[MAX_SRC]{};
     const uint8_t *val_null_bits[MAX_SRC]{};
+    const uint8_t *val_valid_bytes[MAX_SRC]{};   // alternative to null_bits: one byte per row, 1 = valid
+    // First / Last read the value at the group's first / last ORIGINAL row: the un-partitioned column
+    // (differs from val_data inside a two-level sub-run) and the original row index per row (nullptr = i)
+    const void *fin_data[MAX_SRC]{};
+    const uint8_t *fin_null_bits[MAX_SRC]{};
+    const uint64_t *row_index = nullptr;
+    const int64_t *merge_gsize = nullptr;        // merge mode alternative to merge_states column 0 (with merge_cols)
+    const uint64_t *merge_cols[MAX_STATES]{};    // merge mode alternative: one pointer per state column
     // merge mode: partial state columns [1 + n_states][n_rows] (column 0 = group size)
     const uint64_t *merge_states = nullptr;
     size_t merge_stride = 0;

@@ -1018,10 +1018,39 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
     return 0;
 }
 
+// copies r2's groups (keys row 0, null flags, aggregates or states) behind res's; `cap` = res's stride
+static int32_t append_groups(pandrs_hip_ctx *c, GroupbyResult &res, size_t cap, const GroupbyResult &r2,
+                             bool partials, const Plan &pl, int n_aggs) {
+    const size_t g2 = (size_t)r2.n_groups, at = (size_t)res.n_groups;
+    if (g2 == 0) return 0;
+    if (at + g2 > cap) return fail(PANDRS_HIP_ERR_COMPUTATION, "nested result has more groups than reserved");
+    HIP_TRY(hipMemcpyAsync(res.keys + at, r2.keys, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(res.key_null + at, r2.key_null, g2, hipMemcpyDeviceToDevice, c->stream));
+    if (partials) {
+        for (size_t k = 0; k < 1 + (size_t)pl.n_states; k++)
+            HIP_TRY(hipMemcpyAsync(res.states + k * cap + at, r2.states + k * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        for (int f = 0; f < n_aggs; f++)
+            HIP_TRY(hipMemcpyAsync(res.aggs + (size_t)f * cap + at, r2.aggs + (size_t)f * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    res.n_groups += (int64_t)g2;
+    return 0;
+}
+
+__global__ void gather_part_offsets_kernel(const uint32_t *offsets, uint32_t NB, uint32_t n, uint32_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = offsets[(size_t)i * NB];
+}
+
+struct EngSrc;
+static int32_t run_two_level(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge, bool partials,
+                             int n_aggs, int key_dtype, int n_keys_out, int res_slot, int64_t est, int64_t groups_per_run);
+
 // One engine source = one partitioned 8-byte column feeding 1..4 states.
 struct EngSrc {
     const void *data = nullptr;        // un-partitioned input column
     const uint8_t *null_bits = nullptr;
+    const uint8_t *valid_bytes = nullptr;
     int8_t kind = 0;
     int8_t st_add = -1, st_min = -1, st_max = -1, st_nn = -1, st_fadd = -1, st_ssq = -1;   // absolute state ids
     bool rowidx = false;               // synthetic source: the original row index (First / Last)
@@ -1031,8 +1060,9 @@ struct EngSrc {
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
                           bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
-    GroupbyResult &res = res_slot ? c->gb2 : c->gb;
-    Arena &rarena = res_slot ? c->result2 : c->result;
+    if (res_slot < 0 || res_slot > 2) return fail(PANDRS_HIP_ERR_COMPUTATION, "engine nesting too deep");
+    GroupbyResult &res = res_slot == 0 ? c->gb : (res_slot == 1 ? c->gb2 : c->gb3);
+    Arena &rarena = res_slot == 0 ? c->result : (res_slot == 1 ? c->result2 : c->result3);
     res = GroupbyResult{};
     res.n_keys = n_keys_out; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;
     res.key_dtype = key_dtype;
@@ -1046,7 +1076,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     if (merge) {
         for (int s = 0; s < pl.n_states; s++) {
             EngSrc e;
-            e.data = rs.merge_states + (size_t)(s + 1) * rs.merge_stride;
+            e.data = rs.merge_cols[s] ? rs.merge_cols[s] : rs.merge_states + (size_t)(s + 1) * rs.merge_stride;
             switch (pl.kinds[s]) {
             case SK_ADD_F64: e.kind = 0; e.st_add = (int8_t)s; break;
             case SK_ADD_I64: e.kind = 1; e.st_add = (int8_t)s; break;
@@ -1060,7 +1090,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     } else {
         for (int s = 0; s < pl.n_src; s++) {
             EngSrc e;
-            e.data = rs.val_data[s]; e.null_bits = rs.val_null_bits[s]; e.kind = pl.src_kind[s];
+            e.data = rs.val_data[s]; e.null_bits = rs.val_null_bits[s]; e.valid_bytes = rs.val_valid_bytes[s]; e.kind = pl.src_kind[s];
             e.st_add = pl.st_add[s]; e.st_min = pl.st_min[s]; e.st_max = pl.st_max[s]; e.st_nn = pl.st_nn[s];
             e.st_fadd = pl.st_fadd[s]; e.st_ssq = pl.st_ssq[s];
             srcs.push_back(e);
@@ -1068,6 +1098,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         if (pl.st_firstrow >= 0) {
             EngSrc e;
             e.kind = 1; e.rowidx = true; e.st_min = pl.st_firstrow; e.st_max = pl.st_lastrow;
+            e.data = rs.row_index;             // nullptr: the row's own index
             srcs.push_back(e);
         }
     }
@@ -1090,7 +1121,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // records (<= tasks x G) are merged by the normal engine.  Also the cure for one-hot-key
     // inputs (bool keys, a dominant key), where a radix partition would put all rows on one CU.
     // (below a few million rows the whole call is launch-bound and the two-stage direct path loses)
-    if (!merge && pl.mergeable && !c->opt.no_direct && n_src <= MAX_SRC && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
+    bool has_valid_bytes = false;
+    for (auto &e : srcs) has_valid_bytes |= e.valid_bytes != nullptr;
+    if (!merge && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
         int total_states = 0;
         for (auto &e : srcs) total_states += e.n_states();
         const size_t sb = 20 + 8 * (size_t)total_states;
@@ -1207,7 +1240,13 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         P = std::max<int64_t>(std::max<int64_t>(P, p_par), 1);
         if (P > 256) P = (P + 127) / 128 * 128;
     }
-    P = std::min<int64_t>(std::max<int64_t>(P, 1), P_MAX);
+    const int64_t P_LIMIT = c->opt.p_max > 0 ? std::min<int64_t>(c->opt.p_max, P_MAX) : P_MAX;
+    if (P > P_LIMIT && c->opt.partitions <= 0 && res_slot == 0 && !c->quiet)
+        // more groups than one radix level can hold (P_LIMIT tables of T slots): split by an
+        // independent hash into super-partitions and run the engine on each
+        return run_two_level(c, rs, pl, merge, partials, n_aggs, key_dtype, n_keys_out, res_slot, est,
+                             (int64_t)((double)P_LIMIT * 0.6 * (double)T * LOAD));
+    P = std::min<int64_t>(std::max<int64_t>(P, 1), P_LIMIT);
 
     const uint32_t seed = 0x9E3779B9u;
     for (int attempt = 0;; attempt++) {
@@ -1226,7 +1265,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         if (merge) {
             pgsize = c->work.take<int64_t>(N);
             if (!pgsize) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-            sa.mv[sa.n_move++] = MoveDesc{rs.merge_states, pgsize, 0, 0};
+            sa.mv[sa.n_move++] = MoveDesc{rs.merge_gsize ? (const void *)rs.merge_gsize : (const void *)rs.merge_states, pgsize, 0, 0};
         }
         // LDS index of every state inside its round
         int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
@@ -1237,12 +1276,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 EngSrc &e = srcs[s];
                 uint64_t *pv = c->work.take<uint64_t>(N);
                 if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-                sa.mv[sa.n_move++] = MoveDesc{e.data, pv, e.rowidx ? 5 : 0, 0};
+                sa.mv[sa.n_move++] = MoveDesc{e.data, pv, (e.rowidx && !e.data) ? 5 : 0, 0};
                 uint8_t *pvalid = nullptr;
-                if (e.null_bits) {
+                if (e.null_bits || e.valid_bytes) {
                     pvalid = c->work.take<uint8_t>(N);
                     if (!pvalid) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
-                    sa.mv[sa.n_move++] = MoveDesc{e.null_bits, pvalid, 1, 0};
+                    sa.mv[sa.n_move++] = e.null_bits ? MoveDesc{e.null_bits, pvalid, 1, 0} : MoveDesc{e.valid_bytes, pvalid, 2, 0};
                 }
                 SrcDev &sd = aa.src[s];
                 sd = SrcDev{pv, pvalid, e.kind, -1, -1, -1, -1, -1, -1, {0}};
@@ -1300,7 +1339,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (fd.op == PANDRS_HIP_AGG_FIRST || fd.op == PANDRS_HIP_AGG_LAST) {
                 fd.rowsrc_min = st_lds[pl.st_firstrow]; fd.rowsrc_max = st_lds[pl.st_lastrow];
                 fd.round = st_round[pl.st_firstrow];
-                fd.col_data = rs.val_data[s]; fd.col_null = rs.val_null_bits[s];
+                fd.col_data = rs.fin_data[s] ? rs.fin_data[s] : rs.val_data[s];
+                fd.col_null = rs.fin_data[s] ? rs.fin_null_bits[s] : rs.val_null_bits[s];
             }
         }
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
@@ -1329,7 +1369,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (!merge && n_rounds == 1 && n_src > 0 && !c->opt.generic_aggregate && pl.mergeable) {
                 auto prof_of = [](const EngSrc &e) {
                     int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
-                    return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
+                    return (e.kind << 4) | (ops << 1) | ((e.null_bits || e.valid_bytes) ? 1 : 0);
                 };
                 profile = prof_of(srcs[0]);
                 for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != profile) profile = -1;
@@ -1354,34 +1394,145 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 c->opt.no_slice = 1; c->opt.no_direct = 1; c->opt.groups_hint = 0; c->opt.partitions = 0;
                 pandrs_hip_timings tsave = c->timings;
                 c->quiet++;
-                int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot ? 0 : 1);
+                int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot + 1);
                 c->quiet--;
                 c->opt = saved;
                 c->timings = tsave;
                 if (st) return st;
-                GroupbyResult &r2 = res_slot ? c->gb : c->gb2;
-                const size_t g2 = (size_t)r2.n_groups, at = (size_t)res.n_groups;
-                if (at + g2 > cap) return fail(PANDRS_HIP_ERR_COMPUTATION, "slice merge produced more groups than reserved");
-                HIP_TRY(hipMemcpyAsync(res.keys + at, r2.keys, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
-                HIP_TRY(hipMemcpyAsync(res.key_null + at, r2.key_null, g2, hipMemcpyDeviceToDevice, c->stream));
-                if (partials) {
-                    for (size_t k = 0; k < 1 + (size_t)pl.n_states; k++)
-                        HIP_TRY(hipMemcpyAsync(res.states + k * cap + at, r2.states + k * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
-                } else {
-                    for (int f = 0; f < n_aggs; f++)
-                        HIP_TRY(hipMemcpyAsync(res.aggs + (size_t)f * cap + at, r2.aggs + (size_t)f * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
-                }
+                GroupbyResult &r2 = res_slot == 0 ? c->gb2 : c->gb3;
+                ST_TRY(append_groups(c, res, cap, r2, partials, pl, n_aggs));
                 HIP_TRY(hipStreamSynchronize(c->stream));
-                res.n_groups += (int64_t)g2;
             }
             return 0;
         }
-        if (P >= P_MAX)
+        if (P >= P_LIMIT) {
+            if (c->opt.partitions <= 0 && res_slot == 0 && !c->quiet)      // the estimate was far too low: two-level with a safe bound
+                return run_two_level(c, rs, pl, merge, partials, n_aggs, key_dtype, n_keys_out, res_slot, N,
+                                     (int64_t)((double)P_LIMIT * 0.6 * (double)T * LOAD));
             return fail(PANDRS_HIP_ERR_COMPUTATION,
-                        "group cardinality exceeds the single-level radix capacity (%d partitions x %lld slots)",
-                        P_MAX, (long long)T);
-        P = std::min<int64_t>(P * 4, P_MAX);
+                        "group cardinality exceeds the radix capacity (%lld partitions x %lld slots)",
+                        (long long)P_LIMIT, (long long)T);
+        }
+        P = std::min<int64_t>(P * 4, P_LIMIT);
     }
+}
+
+// ---- two-level path: more groups than P_MAX LDS tables can hold --------------------------------------
+// One extra radix pass with an INDEPENDENT hash splits the rows into K super-partitions (disjoint
+// key sets); the engine then runs on each super-partition in turn and the group lists are
+// concatenated.  Costs one more read + write of every column, only for inputs like a nearly
+// unique key column.
+static int32_t run_two_level(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge, bool partials,
+                             int n_aggs, int key_dtype, int n_keys_out, int res_slot, int64_t est,
+                             int64_t groups_per_run) {
+    const int64_t N = rs.n_rows;
+    int64_t K = (int64_t)std::ceil((double)std::max<int64_t>(est, 1) / (double)std::max<int64_t>(groups_per_run, 1));
+    K = std::min<int64_t>(std::max<int64_t>(K, 2), P_MAX);
+    GroupbyResult &res = c->gb;
+    Arena &rarena = c->result;
+
+    // ---- columns that travel: key cells, every plan source (+ validity bytes), row index, merge columns
+    const int n_src = merge ? 0 : pl.n_src;
+    const int n_mcols = merge ? pl.n_states : 0;
+    size_t need = Arena::padded(size_t(N) * 8) * (size_t)(1 + n_src + n_mcols + (merge ? 1 : 0) + (pl.st_firstrow >= 0 ? 1 : 0))
+                + Arena::padded(size_t(N)) * (size_t)(n_src + 1) + (1 << 20);
+    ST_TRY(c->super.ensure(need, c->stream));
+    ST_TRY(c->work.ensure(engine_workspace_bytes(N, 1 + n_src + n_mcols + 2, n_src), c->stream));
+    ScatterArgs sa{};
+    uint64_t *spk = c->super.take<uint64_t>(N);
+    if (!spk) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+    sa.key = rs.key; sa.pkeys = spk; sa.n_rows = N; sa.P = (uint32_t)K; sa.seed = 0xC2B2AE3Du;
+    uint64_t *spv[MAX_SRC]{}; uint8_t *spvalid[MAX_SRC]{};
+    for (int s2 = 0; s2 < n_src; s2++) {
+        spv[s2] = c->super.take<uint64_t>(N);
+        if (!spv[s2]) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+        sa.mv[sa.n_move++] = MoveDesc{rs.val_data[s2], spv[s2], 0, 0};
+        if (rs.val_null_bits[s2] || rs.val_valid_bytes[s2]) {
+            spvalid[s2] = c->super.take<uint8_t>(N);
+            if (!spvalid[s2]) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+            sa.mv[sa.n_move++] = rs.val_null_bits[s2] ? MoveDesc{rs.val_null_bits[s2], spvalid[s2], 1, 0}
+                                                      : MoveDesc{rs.val_valid_bytes[s2], spvalid[s2], 2, 0};
+        }
+    }
+    uint64_t *sprow = nullptr;
+    if (!merge && pl.st_firstrow >= 0) {
+        sprow = c->super.take<uint64_t>(N);
+        if (!sprow) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+        sa.mv[sa.n_move++] = rs.row_index ? MoveDesc{rs.row_index, sprow, 0, 0} : MoveDesc{nullptr, sprow, 5, 0};
+    }
+    int64_t *spg = nullptr; uint64_t *spm[MAX_STATES]{};
+    if (merge) {
+        spg = c->super.take<int64_t>(N);
+        if (!spg) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+        sa.mv[sa.n_move++] = MoveDesc{rs.merge_gsize ? (const void *)rs.merge_gsize : (const void *)rs.merge_states, spg, 0, 0};
+        for (int k = 0; k < n_mcols; k++) {
+            spm[k] = c->super.take<uint64_t>(N);
+            if (!spm[k]) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+            const uint64_t *src = rs.merge_cols[k] ? rs.merge_cols[k] : rs.merge_states + (size_t)(k + 1) * rs.merge_stride;
+            sa.mv[sa.n_move++] = MoveDesc{src, spm[k], 0, 0};
+        }
+    }
+    uint8_t *ones = c->super.take<uint8_t>(N);           // null flags of the NULL super-partition's rows
+    uint32_t *d_off = c->super.take<uint32_t>(K + 8);
+    if (!ones || !d_off) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "super arena too small");
+    c->work.off = 0;
+    PartInfo part;
+    ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+    hipLaunchKernelGGL(gather_part_offsets_kernel, dim3((unsigned)((K + 2 + 255) / 256)), dim3(256), 0, c->stream,
+                       part.offsets, part.NB, (uint32_t)K + 2, d_off);
+    std::vector<uint32_t> off(K + 2);
+    HIP_TRY(hipMemcpyAsync(off.data(), d_off, (K + 2) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(ones, 1, size_t(N), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    // ---- result arrays for the concatenation (every row could be its own group)
+    const size_t cap = (size_t)N + 8;
+    const size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)std::max(n_aggs, 1);
+    res = GroupbyResult{};
+    res.n_keys = n_keys_out; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;
+    res.key_dtype = key_dtype;
+    ST_TRY(rarena.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + out_cols * Arena::padded(cap * 8 + 256) + 8192, c->stream));
+    res.cap = (int64_t)cap;
+    res.keys = rarena.take<uint64_t>(cap * n_keys_out);
+    res.key_null = rarena.take<uint8_t>(cap * n_keys_out);
+    if (partials) res.states = rarena.take<uint64_t>(cap * out_cols + 32);
+    else res.aggs = rarena.take<double>(cap * out_cols + 32);
+    if (!res.keys || !res.key_null || (!res.states && !res.aggs)) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
+
+    Options saved = c->opt;
+    pandrs_hip_timings tsave = c->timings;
+    c->opt.no_direct = 1; c->opt.groups_hint = 0; c->opt.partitions = 0;
+    int32_t st = 0;
+    for (int64_t sp = 0; sp <= K && !st; sp++) {          // sp == K: the NULL-key rows
+        const uint32_t b = off[sp], e2 = off[sp + 1];
+        if (b == e2) continue;
+        RowSource sub;
+        sub.n_rows = (int64_t)e2 - b;
+        sub.key = KeyDesc{spk + b, nullptr, sp == K ? ones : nullptr, DT_CELL};
+        for (int s2 = 0; s2 < n_src; s2++) {
+            sub.val_data[s2] = spv[s2] + b;
+            sub.val_valid_bytes[s2] = spvalid[s2] ? spvalid[s2] + b : nullptr;
+            sub.fin_data[s2] = rs.fin_data[s2] ? rs.fin_data[s2] : rs.val_data[s2];
+            sub.fin_null_bits[s2] = rs.fin_data[s2] ? rs.fin_null_bits[s2] : rs.val_null_bits[s2];
+        }
+        sub.row_index = sprow ? sprow + b : nullptr;
+        if (merge) {
+            sub.merge_gsize = spg + b;
+            for (int k = 0; k < n_mcols; k++) sub.merge_cols[k] = spm[k] + b;
+            sub.merge_states = spm[0];          // non-null marker only; merge_cols carry the data
+        }
+        c->quiet++;
+        st = run_engine(c, sub, pl, merge, partials, n_aggs, key_dtype, 1, res_slot + 1);
+        c->quiet--;
+        if (!st) st = append_groups(c, res, cap, c->gb2, partials, pl, n_aggs);
+        if (!st) HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->opt = saved;
+    c->timings = tsave;
+    c->timings.n_partitions = K; c->timings.retries = 0; c->timings.estimated_groups = est;
+    if (st) return st;
+    res.valid = true;
+    return 0;
 }
 
 // ---- staging helpers (host mem_space) -----------------------------------------------------------

@@ -190,6 +190,34 @@ def test_hot_key_partitions_are_sliced(ctx):
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5, 6, 7])
 
 
+def test_two_level_for_huge_cardinality(ctx):
+    """More groups than one radix level holds (forced here with a small partition cap): rows are
+    split by an independent hash into super-partitions, the engine runs per super-partition and the
+    group lists are concatenated.  Every op, null keys, null values, and the merge path."""
+    rng = np.random.default_rng(303)
+    n, g = 2_000_000, 1_500_000
+    keys = [(sparse_keys(rng, n, g), O.pack_mask(rng.random(n) < 0.01), O.I64)]
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.05), O.F64),
+            (rng.integers(-99, 99, n).astype(np.int64), None, O.I64)]
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT), (1, O.SUM), (1, O.MIN), (1, O.MAX),
+            (0, O.STD), (0, O.FIRST), (1, O.LAST), (1, O.VAR)]
+    exact = [2, 3, 4, 5, 6, 7, 9, 10]
+    ctx.set_option("p_max", 48)
+    try:
+        got = check(ctx, keys, n, vals, aggs, [O.I64], exact=exact)
+        assert ctx.timings()["n_partitions"] >= 2 and got[1].sum() == 1
+        # mergeable subset through partials -> split -> merge, both stages two-level
+        m_aggs = aggs[:8]
+        ng, ns = ctx.groupby_partials(keys, n, vals, m_aggs)
+        rec, counts = ctx.partials_split(1)
+        ctx.groupby_merge(O.I64, rec, [O.F64, O.I64], [True, False], m_aggs)
+        merged = ctx.groupby_fetch(to_device=False)
+    finally:
+        ctx.set_option("p_max", 0)
+    want = O.groupby_agg(keys, n, vals, aggs[:8])
+    assert_groupby_equal(merged, want, [O.I64], int_exact_rows=[2, 3, 4, 5, 6, 7])
+
+
 def test_std_var_first_last(ctx, golden):
     """aggregation.rs:557-624, :675-742 + :881-903: two-pass Bessel variance, value at first/last row."""
     rng = np.random.default_rng(17)
