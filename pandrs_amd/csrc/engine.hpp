@@ -9,7 +9,7 @@ constexpr int MAX_SRC = 16;
 constexpr int MAX_STATES = 40;
 constexpr int MAX_AGGS = 64;
 constexpr int MAX_MOVE = 40;
-constexpr int P_MAX = 4096;
+constexpr int P_MAX = 8192;      // bounded by the scatter's LDS counters (2 x 4 B x (P+1) beside the 80 KB tile buffers)
 
 constexpr int HI_THREADS = 1024;   // histogram workgroup
 constexpr int SC_RPT = 8;          // scatter: rows per thread per tile

@@ -368,8 +368,9 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     constexpr int TILE = THREADS * SC_RPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t P1 = a.P + 1;
+    // LDS: [cursor[P1] only with private cursors] | cnt[P1] | delta[P1] | wave_tot[32] | pid[TILE] | stage[TILE]
     uint32_t *cursor = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *cnt = cursor + P1;
+    uint32_t *cnt = a.gcur ? cursor : cursor + P1;
     uint32_t *delta = cnt + P1;
     uint32_t *wave_tot = delta + P1;
     uint16_t *pid = reinterpret_cast<uint16_t *>(wave_tot + 32);
@@ -952,7 +953,8 @@ static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int max_src_pe
 template <int THREADS>
 static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t NB, bool staged) {
     constexpr int TILE = THREADS * SC_RPT;
-    size_t lds = (size_t)(sa.P + 1) * 12 + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
+    size_t lds = (size_t)(sa.P + 1) * (sa.gcur ? 8 : 12) + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
+    if (lds > 160 * 1024) return fail(PANDRS_HIP_ERR_COMPUTATION, "radix fan-out %u does not fit the scatter's LDS", sa.P);
     if (staged) {
         ST_TRY(set_max_lds(scatter_kernel<THREADS, true>, (int)lds));
         hipLaunchKernelGGL((scatter_kernel<THREADS, true>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
