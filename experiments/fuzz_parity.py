@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: HIP engine (through the C ABI) vs the CPU oracle over random shapes,
+dtypes, null rates, skews, aggregate sets, join types and engine knobs.  GPU box only.
+usage: fuzz_parity.py [n_cases] [seed]"""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pandrs_amd as pa
+from oracle import oracle as O
+from tests.helpers import assert_groupby_equal
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = pa.Context(0)
+OPS_MERGEABLE = [O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT]
+OPS_ALL = OPS_MERGEABLE + [O.STD, O.VAR, O.FIRST, O.LAST]
+
+def rand_key(rng, n, dtype, g, skew):
+    ids = rng.integers(0, g, n)
+    if skew == "hot":
+        ids[rng.random(n) < 0.6] = 0
+    elif skew == "8020":
+        hot = rng.random(n) < 0.8
+        ids = np.where(hot, rng.integers(0, max(g // 5, 1), n), ids)
+    if dtype == O.I64:
+        k = (ids.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+        if rng.random() < 0.3: k[rng.random(n) < 0.05] = -1          # table sentinel bits
+        return k
+    if dtype == O.F64:
+        pool = np.concatenate([rng.normal(size=max(g - 4, 1)), [0.0, -0.0, np.nan, np.inf]])
+        return pool[ids % len(pool)]
+    if dtype == O.U32CODE:
+        return ids.astype(np.uint32)
+    return np.packbits(ids % 2 == 0, bitorder="little")
+
+def mask(rng, n, p):
+    return O.pack_mask(rng.random(n) < p) if p > 0 else None
+
+fails = 0
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 * 100003 + case)
+    try:
+        if rng.random() < 0.7:      # ---------------- groupby
+            n = int(rng.choice([1, 7, 1000, 70_000, 300_000, 1_200_000, 5_000_000]))
+            kd = int(rng.choice([O.I64, O.I64, O.F64, O.U32CODE, O.BOOLBITS]))
+            g = int(rng.choice([1, 3, 50, 2000, 60_000, 900_000]))
+            skew = rng.choice(["uniform", "hot", "8020"])
+            nk = 1 if rng.random() < 0.8 else 2
+            keys = [(rand_key(rng, n, kd, g, skew), mask(rng, n, rng.choice([0, 0, 0.01, 0.3])), kd)]
+            kdts = [kd]
+            if nk == 2:
+                keys.append((rng.integers(0, 5, n).astype(np.uint32), mask(rng, n, rng.choice([0, 0.05])), O.U32CODE)); kdts.append(O.U32CODE)
+                if kd in (O.I64, O.F64): keys[0] = (rng.integers(-100, 100, n).astype(np.int64), keys[0][1], O.I64); kdts[0] = O.I64
+            nv = int(rng.integers(1, 4))
+            vals = []
+            for _ in range(nv):
+                if rng.random() < 0.6: vals.append((rng.normal(50, 20, n), mask(rng, n, rng.choice([0, 0, 0.1])), O.F64))
+                else: vals.append((rng.integers(-10**6, 10**6, n).astype(np.int64), mask(rng, n, rng.choice([0, 0.2])), O.I64))
+            ops = OPS_ALL if rng.random() < 0.4 else OPS_MERGEABLE
+            aggs = [(int(rng.integers(0, nv)), int(rng.choice(ops))) for _ in range(int(rng.integers(1, 9)))]
+            opts = {"no_direct": int(rng.random() < 0.3), "slice_rows": int(rng.choice([0, 0, 20_000])),
+                    "p_max": int(rng.choice([0, 0, 0, 24])), "generic_aggregate": int(rng.random() < 0.2),
+                    "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9)}
+            for k, v in opts.items(): ctx.set_option(k, v)
+            try:
+                got = ctx.groupby_agg(keys, n, vals, aggs)
+            finally:
+                for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1}.items(): ctx.set_option(k, v)
+            want = O.groupby_agg(keys, n, vals, aggs)
+            exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST) or (vals[c][2] == O.I64 and op == O.SUM)]
+            assert_groupby_equal(got, want, kdts, int_exact_rows=exact, rtol=1e-9)
+            desc = "groupby n=%d kd=%d g=%d %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, nk, aggs, opts)
+        else:                       # ---------------- join
+            nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000]))
+            kd = int(rng.choice([O.I64, O.I64, O.U32CODE, O.F64]))
+            space = int(rng.choice([3, 500, 100_000, 5_000_000]))
+            if kd == O.U32CODE or space >= 500 or max(nl, nr) < 10_000:
+                pass
+            else:
+                space = 100_000          # avoid > 8192 duplicates per key on big build sides
+            lk = (rand_key(rng, nl, kd, space, "uniform"), mask(rng, nl, rng.choice([0, 0.02])), kd)
+            rk = (rand_key(rng, nr, kd, space, "uniform"), mask(rng, nr, rng.choice([0, 0.02])), kd)
+            if nr > 8192 * 4 and space < 200: continue
+            how = int(rng.integers(0, 4))
+            gl, gr = ctx.join_indices(lk, nl, rk, nr, how)
+            wl, wr = O.join_indices(lk, nl, rk, nr, how)
+            np.testing.assert_array_equal(gl, wl); np.testing.assert_array_equal(gr, wr)
+            desc = "join nl=%d nr=%d kd=%d space=%d how=%d -> %d rows" % (nl, nr, kd, space, how, len(gl))
+        print("ok   %3d %s" % (case, desc), flush=True)
+    except pa.PandrsHipError as e:
+        if "does not fit" in str(e) or "more than 64 bits" in str(e):
+            print("skip %3d %s" % (case, str(e)[:100]), flush=True)
+        else:
+            fails += 1; print("FAIL %3d" % case); traceback.print_exc()
+    except Exception:
+        fails += 1; print("FAIL %3d" % case); traceback.print_exc()
+print("fuzz done: %d cases, %d failures" % (n_cases, fails))
+sys.exit(1 if fails else 0)

@@ -123,7 +123,10 @@ struct pandrs_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    pandrs::Arena work, result, staging, temp, result2, result3, side, super;
+    // one arena per lifetime class: buffers that must survive a nested engine run never share an
+    // arena with what that run allocates (work: per-run scratch; temp: direct-path records;
+    // side: slice records; super: two-level columns; packed: multi-key cells; pairs: fused-join pairs)
+    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
     pandrs::GroupbyResult gb, gb2, gb3;   // gb2 / gb3: nested results (slice merges, two-level sub-runs)
@@ -133,6 +136,7 @@ struct pandrs_hip_ctx {
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
     hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
     void *pinned = nullptr;      // small pinned host block for readbacks
+    bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
     int quiet = 0;               // > 0: nested engine runs (slice / direct merges) do not record phase events
     int lds_bytes = 0;           // usable LDS per workgroup
     int n_cu = 0;

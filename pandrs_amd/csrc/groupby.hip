@@ -1411,6 +1411,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (c->opt.partitions <= 0 && res_slot == 0 && !c->quiet)      // the estimate was far too low: two-level with a safe bound
                 return run_two_level(c, rs, pl, merge, partials, n_aggs, key_dtype, n_keys_out, res_slot, N,
                                      (int64_t)((double)P_LIMIT * 0.6 * (double)T * LOAD));
+            c->capacity_exceeded = true;
             return fail(PANDRS_HIP_ERR_COMPUTATION,
                         "group cardinality exceeds the radix capacity (%lld partitions x %lld slots)",
                         (long long)P_LIMIT, (long long)T);
@@ -1430,6 +1431,7 @@ static int32_t run_two_level(pandrs_hip_ctx *c, const RowSource &rs, const Plan 
     const int64_t N = rs.n_rows;
     int64_t K = (int64_t)std::ceil((double)std::max<int64_t>(est, 1) / (double)std::max<int64_t>(groups_per_run, 1));
     K = std::min<int64_t>(std::max<int64_t>(K, 2), P_MAX);
+  for (;; K = std::min<int64_t>(K * 4, P_MAX)) {        // a sub-run that still overflows => finer super-partitions
     GroupbyResult &res = c->gb;
     Arena &rarena = c->result;
 
@@ -1505,6 +1507,7 @@ static int32_t run_two_level(pandrs_hip_ctx *c, const RowSource &rs, const Plan 
     pandrs_hip_timings tsave = c->timings;
     c->opt.no_direct = 1; c->opt.groups_hint = 0; c->opt.partitions = 0;
     int32_t st = 0;
+    c->capacity_exceeded = false;
     for (int64_t sp = 0; sp <= K && !st; sp++) {          // sp == K: the NULL-key rows
         const uint32_t b = off[sp], e2 = off[sp + 1];
         if (b == e2) continue;
@@ -1532,9 +1535,11 @@ static int32_t run_two_level(pandrs_hip_ctx *c, const RowSource &rs, const Plan 
     c->opt = saved;
     c->timings = tsave;
     c->timings.n_partitions = K; c->timings.retries = 0; c->timings.estimated_groups = est;
+    if (st && c->capacity_exceeded && K < P_MAX) { c->capacity_exceeded = false; continue; }
     if (st) return st;
     res.valid = true;
     return 0;
+  }
 }
 
 // ---- staging helpers (host mem_space) -----------------------------------------------------------
@@ -1681,9 +1686,9 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
                                 k == 0 ? rs.key.null_bits : (const uint8_t *)stg.in(keys[k].null_mask, (n_rows + 7) / 8),
                                 nullptr, keys[k].dtype};
         if (stg.status) return stg.status;
-        ST_TRY(c->temp.ensure(Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
-        uint64_t *mm = c->temp.take<uint64_t>(2 * MAX_KEYS);
-        uint64_t *packed = c->temp.take<uint64_t>(n_rows);
+        ST_TRY(c->packed.ensure(Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
+        uint64_t *mm = c->packed.take<uint64_t>(2 * MAX_KEYS);
+        uint64_t *packed = c->packed.take<uint64_t>(n_rows);
         if (!mm || !packed) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
         uint64_t *h = reinterpret_cast<uint64_t *>(c->pinned);
         for (int k = 0; k < n_keys; k++) { h[2 * k] = ~0ull; h[2 * k + 1] = 0; }

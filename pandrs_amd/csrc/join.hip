@@ -473,10 +473,10 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
             continue;
         }
         M = h[1];
-        ST_TRY(c->temp.ensure(2 * Arena::padded(size_t(M + 1) * 8) + 4096, c->stream));
-        out_g = c->temp.take<uint64_t>(M + 1);
-        out_v = c->temp.take<uint64_t>(M + 1);
-        if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
+        ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(M + 1) * 8) + 4096, c->stream));
+        out_g = c->pairs.take<uint64_t>(M + 1);
+        out_v = c->pairs.take<uint64_t>(M + 1);
+        if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
         fa.out_g = out_g; fa.out_v = out_v;
         if (M > 0) {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);

@@ -268,6 +268,14 @@ def test_multi_key_packed(ctx, golden):
     with pytest.raises(pa.OperationFailed):
         ctx.groupby_agg([(rng.integers(-2**62, 2**62, n), None, O.I64), (rng.integers(-2**62, 2**62, n), None, O.I64)], n, v, FIVE)
     del kf
+    # many rows, few composite groups: the packed cells must survive the partition-free direct path
+    n2 = 5_000_000
+    ka = (rng.integers(-100, 100, n2).astype(np.int64), None, O.I64)
+    kb = (rng.integers(0, 5, n2).astype(np.uint32), None, O.U32CODE)
+    v2 = [(rng.normal(50, 20, n2), O.pack_mask(rng.random(n2) < 0.1), O.F64)]
+    got = ctx.groupby_agg([ka, kb], n2, v2, [(0, O.MAX), (0, O.MEAN)])
+    want = O.groupby_agg([ka, kb], n2, v2, [(0, O.MAX), (0, O.MEAN)])
+    assert_groupby_equal(got, want, [O.I64, O.U32CODE], int_exact_rows=[0])
     c = golden["groupby_two_keys"]
     a, _ = codes_of(c["key1_strings"])
     b, _ = codes_of(c["key2_strings"])

@@ -128,6 +128,18 @@ def test_gathers_match_reference_fill(ctx):
     np.testing.assert_array_equal(got, O.gather(bits, None, li, 0, O.BOOLBITS))
 
 
+def test_fused_join_few_groups_uses_direct_path(ctx):
+    """Few distinct group values after the join: the pair buffers must survive the partition-free path."""
+    rng = np.random.default_rng(77)
+    nb, npb = 100_000, 6_000_000
+    rkeys = (rng.permutation(nb * 3)[:nb].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rg = rng.integers(0, 12, nb).astype(np.int64)
+    lkeys = rkeys[rng.integers(0, nb, npb)].copy()
+    lv = rng.normal(100, 10, npb)
+    args = ((lkeys, None, O.I64), (lv, None, O.F64), npb, (rkeys, None, O.I64), (rg, None, O.I64), nb)
+    assert_groupby_equal(ctx.join_groupby_sum(*args), O.join_groupby_sum(*args), [O.I64])
+
+
 @pytest.mark.parametrize("gdtype", [O.I64, O.U32CODE])
 def test_fused_join_groupby_sum(ctx, gdtype):
     rng = np.random.default_rng(5 + gdtype)
