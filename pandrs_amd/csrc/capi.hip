@@ -58,6 +58,8 @@ int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx) {
             g_inited = true;
         }
     }
+    if (!g_cfg.enabled)          // GpuConfig.enabled = false: the caller keeps its CPU path (src/gpu/mod.rs:20)
+        return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "the device path is disabled by configuration (pandrs_hip_config.enabled = 0)");
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device_id < 0) device_id = g_cfg.device_id;
@@ -80,6 +82,7 @@ int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx) {
     HIP_TRY(hipEventCreate(&c->ev_call_begin));
     HIP_TRY(hipEventCreate(&c->ev_call_end));
     HIP_TRY(hipHostMalloc(&c->pinned, 1 << 16, hipHostMallocDefault));
+    pandrs::arena_limit() = g_cfg.memory_limit > 0 ? (size_t)g_cfg.memory_limit : 0;   // GpuConfig.memory_limit
     *out_ctx = c;
     return PANDRS_HIP_OK;
 }

@@ -44,6 +44,12 @@ inline int32_t fail(int32_t status, const char *fmt, ...) {
         if (s__) return s__;       \
     } while (0)
 
+// GpuConfig.memory_limit (src/gpu/mod.rs:22): upper bound for any single arena of the library; 0 = none
+inline size_t &arena_limit() {
+    static size_t limit = 0;
+    return limit;
+}
+
 // ---- bump arena over one hipMalloc block -------------------------------------------------------
 // Sized for 288 GB of HBM: one big block per purpose, grown (never shrunk) between calls, so the
 // steady state performs no hipMalloc/hipFree inside a timed call.
@@ -61,6 +67,9 @@ struct Arena {
             cap = 0;
         }
         size_t want = bytes + (bytes >> 3) + (1u << 20);
+        if (arena_limit() && want > arena_limit())
+            return ::pandrs::fail(PANDRS_HIP_ERR_OUT_OF_MEMORY,
+                                  "workspace of %zu bytes exceeds pandrs_hip_config.memory_limit (%zu)", want, arena_limit());
         HIP_TRY(hipMalloc((void **)&base, want));
         cap = want;
         return 0;

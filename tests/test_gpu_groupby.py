@@ -437,3 +437,30 @@ def test_full_size_properties():
         assert ng2 == ng
     finally:
         c.close()
+
+
+def test_gpu_config_is_honoured():
+    """pandrs_hip_config mirrors GpuConfig (reference src/gpu/mod.rs:18-44): enabled / memory_limit."""
+    import ctypes as C
+    import pandrs_amd as pa
+    from pandrs_amd import _lib as L
+    lib = L.load()
+    try:
+        cfg = L.Config(enabled=0, device_id=0, memory_limit=0, fallback_to_cpu=1, use_pinned_memory=0, min_size_threshold=10_000)
+        assert lib.pandrs_hip_init(C.byref(cfg)) == 0
+        with pytest.raises(pa.PandrsHipError) as e:
+            pa.Context(0)
+        assert e.value.status == L.ERR_NOT_INITIALIZED
+        cfg.enabled, cfg.memory_limit = 1, 8 << 20          # 8 MiB: far too small for 2 M rows
+        assert lib.pandrs_hip_init(C.byref(cfg)) == 0
+        c = pa.Context(0)
+        rng = np.random.default_rng(0)
+        with pytest.raises(pa.PandrsHipError) as e:
+            c.groupby_agg([(rng.integers(0, 10**6, 2_000_000), None, O.I64)], 2_000_000,
+                          [(rng.normal(size=2_000_000), None, O.F64)], [(0, O.SUM)])
+        assert e.value.status == L.ERR_OUT_OF_MEMORY and "memory_limit" in str(e.value)
+        c.close()
+    finally:
+        cfg = L.Config(enabled=1, device_id=0, memory_limit=0, fallback_to_cpu=1, use_pinned_memory=0, min_size_threshold=10_000)
+        lib.pandrs_hip_init(C.byref(cfg))
+        pa.Context(0).close()        # resets the limit
