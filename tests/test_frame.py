@@ -197,3 +197,39 @@ def test_concurrent_callers_share_one_frame():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs and out == [4] * 20
+
+
+@pytest.mark.gpu
+def test_empty_frames_do_not_fail():
+    """tests/edge_cases_test.rs:46-80: joins / groupby on empty frames must not panic."""
+    e1 = OptimizedDataFrame()
+    e1.add_column("id", Int64Column([]))
+    e1.add_column("v", Float64Column([]))
+    e2 = OptimizedDataFrame()
+    e2.add_column("id", Int64Column([]))
+    e2.add_column("w", StringColumn([]))
+    for how in ("inner_join", "left_join", "right_join", "outer_join"):
+        j = getattr(e1, how)(e2, "id", "id")
+        assert j.row_count() == 0 and j.column_names == ["v", "w"]
+    g = e1.group_by(["id"]).agg([("v", AggregateOp.Sum), ("v", AggregateOp.Count)])
+    assert g.row_count() == 0 and g.column_names == ["id", "v_sum", "v_count"]
+    full = OptimizedDataFrame()
+    full.add_column("id", Int64Column([1, 2]))
+    full.add_column("v", Float64Column([1.0, 2.0]))
+    j = full.left_join(e2, "id", "id")
+    assert j.row_count() == 2 and j.column("w").to_list() == ["", ""] and j.column("id").data.tolist() == [1, 2]
+
+
+@pytest.mark.gpu
+def test_lazy_pipeline_join_then_aggregate():
+    """tests/optimized_lazy_test.rs shape: a join followed by an aggregate in one LazyFrame."""
+    left = OptimizedDataFrame()
+    left.add_column("id", Int64Column([1, 2, 3, 4, 5, 6]))
+    left.add_column("amount", Float64Column([10.0, 20.0, 30.0, 40.0, 50.0, 60.0]))
+    right = OptimizedDataFrame()
+    right.add_column("id", Int64Column([1, 2, 3, 4, 5]))
+    right.add_column("dept", StringColumn(["a", "b", "a", "b", "a"]))
+    res = (LazyFrame.new(left).join(right, "id", "id", JoinType.Inner)
+           .aggregate(["dept"], [("amount", AggregateOp.Sum, "total"), ("amount", AggregateOp.Mean, "avg")]).execute())
+    got = {k: (t, a) for k, t, a in zip(res.column("dept").to_list(), res.column("total").data, res.column("avg").data)}
+    assert got == {"a": (90.0, 30.0), "b": (60.0, 30.0)}
