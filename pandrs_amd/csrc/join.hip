@@ -30,6 +30,7 @@ namespace pandrs {
 constexpr int JN_THREADS = 1024;
 constexpr int JN_RCAP = 8192;           // right rows per partition that fit the LDS sort buffers
 constexpr uint32_t JN_SEED = 0x51ED270Bu;
+constexpr uint32_t NO_MATCH = 0xFFFFFFFFu;
 
 // ---- LDS bitonic sort of (key, payload) pairs, ascending by key then payload ----------------------
 template <typename PT>
@@ -67,15 +68,13 @@ struct JoinArgs {
     uint32_t rNB, lNB, P;
     int keep_left;                              // left / outer: a miss still produces one row
     int flag_right;                             // right / outer: record matched right rows
-    uint32_t *cnt;                              // [n_left] output rows per left row (original order)
-    const uint32_t *out_off;                    // exclusive scan of cnt (emit pass)
+    uint2 *match;                               // [n_left], ORIGINAL left order: {first match in the sorted right
+                                                //  arrays or NO_MATCH, output rows of this left row}
     uint8_t *rmatched;                          // [n_right]
-    int64_t *out_left, *out_right;
     uint32_t *flags;                            // [0] = a right partition did not fit LDS
 };
 
-// LDS: sk[R2] u64 | sp[R2] u32 | hit[R2] u8
-template <bool EMIT>
+// Count pass.  LDS: sk[R2] u64 | sp[R2] u32 | hit[R2] u8
 __global__ __launch_bounds__(JN_THREADS) void join_probe_kernel(JoinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
@@ -92,32 +91,22 @@ __global__ __launch_bounds__(JN_THREADS) void join_probe_kernel(JoinArgs a) {
     for (uint32_t i = tid; i < n2; i += JN_THREADS) {
         sk[i] = i < nR ? a.rkeys[rbeg + i] : ~0ull;
         sp[i] = i < nR ? a.rrows[rbeg + i] : 0xFFFFFFFFu;
-        if (!EMIT) hit[i] = 0;
+        hit[i] = 0;
     }
     __syncthreads();
-    if (!EMIT) {
-        lds_bitonic_sort<uint32_t>(sk, sp, n2);
-        for (uint32_t i = tid; i < nR; i += JN_THREADS) { a.rkeys[rbeg + i] = sk[i]; a.rrows[rbeg + i] = sp[i]; }
-    }
+    lds_bitonic_sort<uint32_t>(sk, sp, n2);
+    // the sorted build partition goes back to HBM: the emit pass gathers right rows from it
+    for (uint32_t i = tid; i < nR; i += JN_THREADS) { a.rkeys[rbeg + i] = sk[i]; a.rrows[rbeg + i] = sp[i]; }
     for (uint32_t i = lbeg + tid; i < lend; i += JN_THREADS) {
         const uint64_t k = a.lkeys[i];
         const uint32_t lrow = a.lrows[i];
         uint32_t lb = lds_lower_bound(sk, nR, k);
         uint32_t m = 0;
         while (lb + m < nR && sk[lb + m] == k) m++;
-        if (!EMIT) {
-            a.cnt[lrow] = m ? m : (a.keep_left ? 1u : 0u);
-            if (m && a.flag_right) hit[lb] = 1;
-        } else {
-            size_t o = a.out_off[lrow];
-            if (m) {
-                for (uint32_t j = 0; j < m; j++) { a.out_left[o + j] = lrow; a.out_right[o + j] = sp[lb + j]; }
-            } else if (a.keep_left) {
-                a.out_left[o] = lrow; a.out_right[o] = -1;
-            }
-        }
+        a.match[lrow] = m ? make_uint2(rbeg + lb, m) : make_uint2(NO_MATCH, a.keep_left ? 1u : 0u);
+        if (m && a.flag_right) hit[lb] = 1;
     }
-    if (!EMIT && a.flag_right) {
+    if (a.flag_right) {
         __syncthreads();
         for (uint32_t i = tid; i < nR; i += JN_THREADS) {
             uint32_t s = i;
@@ -126,6 +115,25 @@ __global__ __launch_bounds__(JN_THREADS) void join_probe_kernel(JoinArgs a) {
             if (hit[s]) a.rmatched[sp[i]] = 1;
         }
     }
+}
+
+// per-left-row output counts as a dense array for the scan
+__global__ void match_counts_kernel(const uint2 *match, int64_t n, uint32_t *cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = match[i].y;
+}
+
+// Emit pass, in ORIGINAL left order: coalesced reads of (match, offset), coalesced index-pair writes;
+// the only gather is from the sorted right-row array (n_right x 4 B, cache resident for typical builds).
+__global__ void join_emit_kernel(const uint2 *match, const uint32_t *out_off, const uint32_t *rrows_sorted,
+                                 int64_t n_left, int64_t *out_left, int64_t *out_right) {
+    int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_left) return;
+    const uint2 mt = match[l];
+    if (mt.y == 0) return;
+    size_t o = out_off[l];
+    if (mt.x == NO_MATCH) { out_left[o] = l; out_right[o] = -1; return; }
+    for (uint32_t j = 0; j < mt.y; j++) { out_left[o + j] = l; out_right[o + j] = rrows_sorted[mt.x + j]; }
 }
 
 __global__ void unmatched_pred_kernel(const uint8_t *rmatched, int64_t n, uint32_t *pred) {
@@ -186,7 +194,7 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
     }
     // workspace: two partition passes + per-row arrays
     size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nl) * 8) + Arena::padded(size_t(nr) * 8)
-              + 3 * Arena::padded(size_t(nl + 2) * 4) + 4 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
+              + 5 * Arena::padded(size_t(nl + 2) * 4) + 4 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
               + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16);
     ST_TRY(c->work.ensure(ws, c->stream));
 
@@ -204,14 +212,16 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         uint32_t *prr = c->work.take<uint32_t>(nr + 1);
         uint64_t *plk = c->work.take<uint64_t>(nl + 1);
         uint32_t *pli = c->work.take<uint32_t>(nl + 1);
+        uint2 *match = c->work.take<uint2>(nl + 2);
         uint32_t *cnt = c->work.take<uint32_t>(nl + 2);
         uint32_t *off = c->work.take<uint32_t>(nl + 2);
         uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)nl + 1));
         uint8_t *rmatched = c->work.take<uint8_t>(nr + 8);
-        if (!flags || !prk || !prr || !plk || !pli || !cnt || !off || !seg || !rmatched)
+        if (!flags || !prk || !prr || !plk || !pli || !match || !cnt || !off || !seg || !rmatched)
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
         HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
         HIP_TRY(hipMemsetAsync(cnt, 0, size_t(nl + 2) * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(match, 0, size_t(nl + 2) * 8, c->stream));      // {0, 0}: rows never probed (null keys) emit nothing
         HIP_TRY(hipMemsetAsync(rmatched, 0, size_t(nr) + 8, c->stream));
 
         PartInfo rpart{}, lpart{};
@@ -226,14 +236,16 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         JoinArgs ja{};
         ja.rkeys = prk; ja.rrows = prr; ja.lkeys = plk; ja.lrows = pli;
         ja.roff = rpart.offsets; ja.loff = lpart.offsets; ja.rNB = rpart.NB; ja.lNB = lpart.NB; ja.P = (uint32_t)P;
-        ja.keep_left = keep_left; ja.flag_right = keep_right; ja.cnt = cnt; ja.out_off = off; ja.rmatched = rmatched;
+        ja.keep_left = keep_left; ja.flag_right = keep_right; ja.match = match; ja.rmatched = rmatched;
         ja.flags = flags;
         const size_t lds = (size_t)JN_RCAP * 13 + 64;
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<false>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(join_probe_kernel<false>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ja);
+            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ja);
+            if (nl > 0)
+                hipLaunchKernelGGL(match_counts_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream, match, nl, cnt);
             HIP_TRY(hipGetLastError());
             ST_TRY(exclusive_scan_u32(c, cnt, (size_t)nl + 1, off, seg));    // off[nl] = rows from the probe
         }
@@ -268,14 +280,11 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         c->jn.left_idx = c->result.take<int64_t>(M + 1);
         c->jn.right_idx = c->result.take<int64_t>(M + 1);
         if (!c->jn.left_idx || !c->jn.right_idx) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
-        ja.out_left = c->jn.left_idx; ja.out_right = c->jn.right_idx;
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
-            if (M1 > 0) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(join_probe_kernel<true>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ja);
-            }
+            if (M1 > 0)
+                hipLaunchKernelGGL(join_emit_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream,
+                                   match, off, prr, nl, c->jn.left_idx, c->jn.right_idx);
             if (M2 > 0)
                 hipLaunchKernelGGL(append_unmatched_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
                                    rmatched, roff2, nr, M1, c->jn.left_idx, c->jn.right_idx);
