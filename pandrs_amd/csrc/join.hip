@@ -5,20 +5,21 @@
 // builds HashMap<String, Vec<usize>> over the right side and probes the left side on one thread.
 //
 // Device plan (inputs / outputs resident in HBM):
-//   1. both sides are radix-partitioned on hash(key cell) with the SAME fan-out and seed (the
-//      groupby engine's histogram / scan / LDS-staged scatter), carrying the original row index;
-//      null keys go to a partition of their own and are never probed (join.rs:112, :152);
-//   2. count pass, one workgroup per partition: the right partition is loaded into LDS and
-//      bitonic-sorted by (key, right row) — so a key's matches are already in ascending
-//      right-row order, the reference's per-key Vec<usize> order (join.rs:114, :156-158) — and
-//      written back sorted; every left row binary-searches its run in LDS and stores its match
-//      count at its ORIGINAL row position; matched right rows are flagged for right/outer;
-//   3. exclusive scan of the per-left-row counts = output offsets in reference order
+//   1. the BUILD (right) side is radix-partitioned on hash(key cell) with the groupby engine's
+//      histogram / scan / LDS-staged scatter, carrying the original row index; null keys go to a
+//      partition of their own and are never built (join.rs:112);
+//   2. build pass, one workgroup per partition: bitonic sort in LDS by (key, right row) — so a
+//      key's matches are in ascending right-row order, the reference's per-key Vec<usize> order
+//      (join.rs:114, :156-158) — written back sorted; every run {key -> start, count} is published
+//      in a global open-addressing table of 16-byte entries (cache-resident for typical builds);
+//   3. probe pass over the LEFT rows in their ORIGINAL order (never partitioned): one table lookup
+//      per row -> {first match, output rows}; null left keys emit nothing (join.rs:152);
+//   4. exclusive scan of the per-left-row counts = output offsets in reference order
 //      (left rows ascending, join.rs:151);
-//   4. emit pass: sorted right partition back into LDS, each left row writes its (left, right)
-//      index pairs at its offset; left/outer misses write (left, -1) (join.rs:159-162);
-//   5. right/outer: unmatched right rows (null keys included) are compacted ascending behind
-//      the probe output (join.rs:211-224).
+//   5. emit pass in original left order: coalesced index-pair writes, the only gather is from the
+//      sorted right-row array; left/outer misses write (left, -1) (join.rs:159-162);
+//   6. right/outer: runs hit by the probe mark their right rows; unmatched right rows (null keys
+//      included) are compacted ascending behind the probe output (join.rs:211-224).
 // All of it is HBM-bound integer work: no MFMA.
 #include "engine.hpp"
 
@@ -61,79 +62,145 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t *sk, uint32_t
     return lo;
 }
 
-struct JoinArgs {
-    uint64_t *rkeys; uint32_t *rrows;           // partitioned right side (sorted in place by the count pass)
-    const uint64_t *lkeys; const uint32_t *lrows;
-    const uint32_t *roff, *loff;                // partition offsets (PartInfo.offsets)
-    uint32_t rNB, lNB, P;
-    int keep_left;                              // left / outer: a miss still produces one row
-    int flag_right;                             // right / outer: record matched right rows
-    uint2 *match;                               // [n_left], ORIGINAL left order: {first match in the sorted right
-                                                //  arrays or NO_MATCH, output rows of this left row}
-    uint8_t *rmatched;                          // [n_right]
+// Global open-addressing table over the build side's DISTINCT keys: 16-byte entries
+// {key cell, first position of the key's run in the sorted right arrays, run length}.
+struct __attribute__((aligned(16))) JoinEntry {
+    uint64_t key;
+    uint32_t start, count;
+};
+
+struct BuildArgs {
+    uint64_t *rkeys; uint32_t *rrows;           // partitioned right side, sorted in place per partition
+    const uint32_t *roff;                       // partition offsets (PartInfo.offsets)
+    uint32_t rNB;
+    JoinEntry *table; uint32_t table_mask;      // capacity = table_mask + 1; entry [capacity] serves the key ~0
     uint32_t *flags;                            // [0] = a right partition did not fit LDS
 };
 
-// Count pass.  LDS: sk[R2] u64 | sp[R2] u32 | hit[R2] u8
-__global__ __launch_bounds__(JN_THREADS) void join_probe_kernel(JoinArgs a) {
+// Build pass, one workgroup per right partition.  LDS: sk[R2] u64 | sp[R2] u32.
+// Sort (key, right row) so a key's matches are in ascending right-row order (join.rs:114,
+// :156-158), write the partition back sorted, publish every run {key -> start, count}.
+__global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
-    const uint32_t lbeg = a.loff[(size_t)p * a.lNB], lend = a.loff[(size_t)(p + 1) * a.lNB];
     const uint32_t nR = rend - rbeg;
     if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
-    if (lbeg == lend || (nR == 0 && !a.keep_left)) return;
+    if (nR == 0) return;
     uint32_t n2 = 64;
     while (n2 < nR) n2 <<= 1;
     uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
     uint32_t *sp = reinterpret_cast<uint32_t *>(sk + JN_RCAP);
-    uint8_t *hit = reinterpret_cast<uint8_t *>(sp + JN_RCAP);
     for (uint32_t i = tid; i < n2; i += JN_THREADS) {
         sk[i] = i < nR ? a.rkeys[rbeg + i] : ~0ull;
         sp[i] = i < nR ? a.rrows[rbeg + i] : 0xFFFFFFFFu;
-        hit[i] = 0;
     }
     __syncthreads();
     lds_bitonic_sort<uint32_t>(sk, sp, n2);
-    // the sorted build partition goes back to HBM: the emit pass gathers right rows from it
-    for (uint32_t i = tid; i < nR; i += JN_THREADS) { a.rkeys[rbeg + i] = sk[i]; a.rrows[rbeg + i] = sp[i]; }
-    for (uint32_t i = lbeg + tid; i < lend; i += JN_THREADS) {
-        const uint64_t k = a.lkeys[i];
-        const uint32_t lrow = a.lrows[i];
-        uint32_t lb = lds_lower_bound(sk, nR, k);
-        uint32_t m = 0;
-        while (lb + m < nR && sk[lb + m] == k) m++;
-        a.match[lrow] = m ? make_uint2(rbeg + lb, m) : make_uint2(NO_MATCH, a.keep_left ? 1u : 0u);
-        if (m && a.flag_right) hit[lb] = 1;
-    }
-    if (a.flag_right) {
-        __syncthreads();
-        for (uint32_t i = tid; i < nR; i += JN_THREADS) {
-            uint32_t s = i;
-            const uint64_t k = sk[i];
-            while (s > 0 && sk[s - 1] == k) s--;        // start of this key's run
-            if (hit[s]) a.rmatched[sp[i]] = 1;
+    for (uint32_t i = tid; i < nR; i += JN_THREADS) {
+        const uint64_t k = sk[i];
+        a.rkeys[rbeg + i] = k; a.rrows[rbeg + i] = sp[i];
+        if (i > 0 && sk[i - 1] == k) continue;          // not the start of a run
+        uint32_t m = 1;
+        while (i + m < nR && sk[i + m] == k) m++;
+        if (k == EMPTY_KEY) {                            // the sentinel-valued key has a dedicated entry
+            a.table[a.table_mask + 1].start = rbeg + i; a.table[a.table_mask + 1].count = m;
+            continue;
+        }
+        uint32_t slot = hash32(k, 0x7F4A7C15u) & a.table_mask;
+        for (;;) {                                       // distinct keys only: claim the first empty entry
+            uint64_t old = atomicCAS((unsigned long long *)&a.table[slot].key, EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { a.table[slot].start = rbeg + i; a.table[slot].count = m; break; }
+            slot = (slot + 1) & a.table_mask;
         }
     }
 }
 
-// per-left-row output counts as a dense array for the scan
-__global__ void match_counts_kernel(const uint2 *match, int64_t n, uint32_t *cnt) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cnt[i] = match[i].y;
+// Probe pass over the left rows in ORIGINAL order.  LK_RPT rows per thread: all key loads, then all
+// first-probe table reads (16-byte entries, cache resident for typical builds) are in flight together;
+// only rows whose first entry is neither their key nor empty walk on.
+constexpr int LK_THREADS = 256, LK_RPT = 8;
+__global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, int64_t n_left, const JoinEntry *table,
+                                                                 uint32_t table_mask, int keep_left, int flag_right,
+                                                                 uint2 *match, uint32_t *cnt, uint8_t *hit) {
+    const int64_t base = (int64_t)blockIdx.x * (LK_THREADS * LK_RPT) + threadIdx.x;
+    uint64_t k[LK_RPT];
+    uint32_t slot[LK_RPT];
+    bool nul[LK_RPT];
+#pragma unroll
+    for (int r = 0; r < LK_RPT; r++) {
+        const int64_t l = min(base + (int64_t)r * LK_THREADS, n_left - 1);
+        nul[r] = key_is_null(lkey, l);
+        k[r] = key_cell(lkey, l);
+        slot[r] = k[r] == EMPTY_KEY ? table_mask + 1 : (hash32(k[r], 0x7F4A7C15u) & table_mask);
+    }
+    JoinEntry e[LK_RPT];
+#pragma unroll
+    for (int r = 0; r < LK_RPT; r++) e[r] = table[slot[r]];
+#pragma unroll
+    for (int r = 0; r < LK_RPT; r++) {
+        const int64_t l = base + (int64_t)r * LK_THREADS;
+        if (l >= n_left) continue;
+        uint2 out = make_uint2(NO_MATCH, 0u);           // null left keys are dropped even for left/outer (join.rs:152)
+        if (!nul[r]) {
+            bool found;
+            if (k[r] == EMPTY_KEY) {
+                found = e[r].count != 0;                // the sentinel-valued key's dedicated entry
+            } else {
+                while (e[r].key != k[r] && e[r].key != EMPTY_KEY) {
+                    slot[r] = (slot[r] + 1) & table_mask;
+                    e[r] = table[slot[r]];
+                }
+                found = e[r].key == k[r];
+            }
+            if (found) {
+                out = make_uint2(e[r].start, e[r].count);
+                if (flag_right) hit[slot[r]] = 1;
+            } else if (keep_left) {
+                out.y = 1;
+            }
+        }
+        match[l] = out;
+        cnt[l] = out.y;             // dense per-row output counts for the scan
+    }
+}
+
+// right / outer: every right row of a probed run is matched
+__global__ void mark_matched_kernel(const JoinEntry *table, const uint8_t *hit, uint32_t n_entries,
+                                    const uint32_t *rrows_sorted, uint8_t *rmatched) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_entries || !hit[s]) return;
+    const JoinEntry e = table[s];
+    for (uint32_t j = 0; j < e.count; j++) rmatched[rrows_sorted[e.start + j]] = 1;
 }
 
 // Emit pass, in ORIGINAL left order: coalesced reads of (match, offset), coalesced index-pair writes;
 // the only gather is from the sorted right-row array (n_right x 4 B, cache resident for typical builds).
-__global__ void join_emit_kernel(const uint2 *match, const uint32_t *out_off, const uint32_t *rrows_sorted,
-                                 int64_t n_left, int64_t *out_left, int64_t *out_right) {
-    int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n_left) return;
-    const uint2 mt = match[l];
-    if (mt.y == 0) return;
-    size_t o = out_off[l];
-    if (mt.x == NO_MATCH) { out_left[o] = l; out_right[o] = -1; return; }
-    for (uint32_t j = 0; j < mt.y; j++) { out_left[o + j] = l; out_right[o + j] = rrows_sorted[mt.x + j]; }
+// EM_RPT rows per thread so the gathers of several rows are in flight together.
+constexpr int EM_THREADS = 256, EM_RPT = 4;
+__global__ __launch_bounds__(EM_THREADS) void join_emit_kernel(const uint2 *match, const uint32_t *out_off,
+                                                               const uint32_t *rrows_sorted, int64_t n_left,
+                                                               int64_t *out_left, int64_t *out_right) {
+    const int64_t base = (int64_t)blockIdx.x * (EM_THREADS * EM_RPT) + threadIdx.x;
+    uint2 mt[EM_RPT];
+    uint32_t o[EM_RPT], first[EM_RPT];
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++) {
+        const int64_t l = min(base + (int64_t)r * EM_THREADS, n_left - 1);
+        mt[r] = match[l];
+        o[r] = out_off[l];
+    }
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++)
+        first[r] = (mt[r].y != 0 && mt[r].x != NO_MATCH) ? rrows_sorted[mt[r].x] : 0u;
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++) {
+        const int64_t l = base + (int64_t)r * EM_THREADS;
+        if (l >= n_left || mt[r].y == 0) continue;
+        if (mt[r].x == NO_MATCH) { out_left[o[r]] = l; out_right[o[r]] = -1; continue; }
+        out_left[o[r]] = l; out_right[o[r]] = first[r];
+        for (uint32_t q = 1; q < mt[r].y; q++) { out_left[(size_t)o[r] + q] = l; out_right[(size_t)o[r] + q] = rrows_sorted[mt[r].x + q]; }
+    }
 }
 
 __global__ void unmatched_pred_kernel(const uint8_t *rmatched, int64_t n, uint32_t *pred) {
@@ -192,15 +259,19 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         ST_TRY(stage_key(c, mem_space, lk, nl, &lkey));
         ST_TRY(stage_key(c, mem_space, rk, nr, &rkey));
     }
-    // workspace: two partition passes + per-row arrays
-    size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nl) * 8) + Arena::padded(size_t(nr) * 8)
-              + 5 * Arena::padded(size_t(nl + 2) * 4) + 4 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
+    // workspace: one partition pass over the build side + the table + per-row arrays
+    uint32_t cap_tab = 64;
+    while ((double)cap_tab < 1.3 * (double)nr) cap_tab <<= 1;      // load <= 0.77; 16 B per entry (5 M build rows: 134 MB, cache resident)
+    size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nr + 1) * 8) + Arena::padded(size_t(nr + 1) * 4)
+              + Arena::padded(size_t(cap_tab + 2) * 16) + Arena::padded(size_t(cap_tab) + 16)
+              + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded(size_t(nl + 2) * 4)
+              + 2 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
               + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16);
     ST_TRY(c->work.ensure(ws, c->stream));
 
     int64_t P = c->opt.partitions > 0 ? c->opt.partitions
                                      : std::max<int64_t>(1, (int64_t)std::ceil((double)nr / (JN_RCAP * 0.6)));
-    P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, (nl + nr) / 32768)), P_MAX);
+    P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, nr / 8192)), P_MAX);
     P = std::max<int64_t>(P, 1);
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     int64_t M1 = 0, M2 = 0;
@@ -210,42 +281,46 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         uint32_t *flags = c->work.take<uint32_t>(64);
         uint64_t *prk = c->work.take<uint64_t>(nr + 1);
         uint32_t *prr = c->work.take<uint32_t>(nr + 1);
-        uint64_t *plk = c->work.take<uint64_t>(nl + 1);
-        uint32_t *pli = c->work.take<uint32_t>(nl + 1);
+        JoinEntry *table = c->work.take<JoinEntry>((size_t)cap_tab + 2);
+        uint8_t *hit = c->work.take<uint8_t>((size_t)cap_tab + 16);
         uint2 *match = c->work.take<uint2>(nl + 2);
         uint32_t *cnt = c->work.take<uint32_t>(nl + 2);
         uint32_t *off = c->work.take<uint32_t>(nl + 2);
         uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)nl + 1));
         uint8_t *rmatched = c->work.take<uint8_t>(nr + 8);
-        if (!flags || !prk || !prr || !plk || !pli || !match || !cnt || !off || !seg || !rmatched)
+        if (!flags || !prk || !prr || !table || !hit || !match || !cnt || !off || !seg || !rmatched)
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
         HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
         HIP_TRY(hipMemsetAsync(cnt, 0, size_t(nl + 2) * 4, c->stream));
-        HIP_TRY(hipMemsetAsync(match, 0, size_t(nl + 2) * 8, c->stream));      // {0, 0}: rows never probed (null keys) emit nothing
         HIP_TRY(hipMemsetAsync(rmatched, 0, size_t(nr) + 8, c->stream));
+        HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(cap_tab + 2) * 16, c->stream));      // keys = EMPTY
+        HIP_TRY(hipMemsetAsync(&table[cap_tab], 0, 32, c->stream));                     // entry [capacity] (the key ~0's own): count 0
+        if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(cap_tab) + 16, c->stream));
 
-        PartInfo rpart{}, lpart{};
-        ScatterArgs rs{}, ls{};
+        // ---- build side: radix partition (null keys -> their own partition, never built), sort, publish
+        PartInfo rpart{};
+        ScatterArgs rs{};
         rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P; rs.seed = JN_SEED;
         rs.mv[rs.n_move++] = MoveDesc{nullptr, prr, 3, 0};
-        ls.key = lkey; ls.pkeys = plk; ls.n_rows = nl; ls.P = (uint32_t)P; ls.seed = JN_SEED;
-        ls.mv[ls.n_move++] = MoveDesc{nullptr, pli, 3, 0};
         ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
-        ST_TRY(radix_partition(c, ls, &lpart, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER));
-
-        JoinArgs ja{};
-        ja.rkeys = prk; ja.rrows = prr; ja.lkeys = plk; ja.lrows = pli;
-        ja.roff = rpart.offsets; ja.loff = lpart.offsets; ja.rNB = rpart.NB; ja.lNB = lpart.NB; ja.P = (uint32_t)P;
-        ja.keep_left = keep_left; ja.flag_right = keep_right; ja.match = match; ja.rmatched = rmatched;
-        ja.flags = flags;
-        const size_t lds = (size_t)JN_RCAP * 13 + 64;
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_BUILD);
+            BuildArgs ba{};
+            ba.rkeys = prk; ba.rrows = prr; ba.roff = rpart.offsets; ba.rNB = rpart.NB;
+            ba.table = table; ba.table_mask = cap_tab - 1; ba.flags = flags;
+            const size_t lds = (size_t)JN_RCAP * 12 + 64;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_build_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(join_build_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ba);
+            HIP_TRY(hipGetLastError());
+        }
+        // ---- probe in original left order, scan of the per-row output counts
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_probe_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(join_probe_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ja);
-            if (nl > 0)
-                hipLaunchKernelGGL(match_counts_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream, match, nl, cnt);
+            if (nl > 0) {
+                hipLaunchKernelGGL(join_lookup_kernel, dim3((unsigned)((nl + LK_THREADS * LK_RPT - 1) / (LK_THREADS * LK_RPT))), dim3(LK_THREADS), 0, c->stream,
+                                   lkey, nl, table, cap_tab - 1, keep_left ? 1 : 0, keep_right ? 1 : 0, match, cnt, hit);
+            }
             HIP_TRY(hipGetLastError());
             ST_TRY(exclusive_scan_u32(c, cnt, (size_t)nl + 1, off, seg));    // off[nl] = rows from the probe
         }
@@ -264,6 +339,8 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         // ---- right / outer: unmatched right rows, ascending
         uint32_t *roff2 = nullptr;
         if (keep_right && nr > 0) {
+            hipLaunchKernelGGL(mark_matched_kernel, dim3((cap_tab + 2 + 255) / 256), dim3(256), 0, c->stream,
+                               table, hit, cap_tab + 2, prr, rmatched);
             uint32_t *pred = c->work.take<uint32_t>(nr + 2);
             roff2 = c->work.take<uint32_t>(nr + 2);
             uint32_t *seg2 = c->work.take<uint32_t>(scan_seg_count((size_t)nr + 1));
@@ -283,7 +360,7 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
             if (M1 > 0)
-                hipLaunchKernelGGL(join_emit_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(join_emit_kernel, dim3((unsigned)((nl + EM_THREADS * EM_RPT - 1) / (EM_THREADS * EM_RPT))), dim3(EM_THREADS), 0, c->stream,
                                    match, off, prr, nl, c->jn.left_idx, c->jn.right_idx);
             if (M2 > 0)
                 hipLaunchKernelGGL(append_unmatched_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,

@@ -70,6 +70,22 @@ def test_random_i64_with_dups_and_nulls(ctx, nl, nr, space):
     check_join(ctx, lk, nl, rk, nr)
 
 
+def test_sentinel_valued_key_on_either_side(ctx):
+    """i64 -1 has the bit pattern of the hash tables' empty marker: it owns a dedicated entry that must
+    read as "absent" when only the probe side holds the key (found by the randomised sweep)."""
+    rng = np.random.default_rng(88)
+    nl, nr = 200_000, 60_000
+    base_l = rng.integers(0, 5000, nl).astype(np.int64)
+    base_r = rng.integers(0, 5000, nr).astype(np.int64)
+    for left_has, right_has in ((True, False), (False, True), (True, True)):
+        l, r = base_l.copy(), base_r.copy()
+        if left_has:
+            l[rng.random(nl) < 0.05] = -1
+        if right_has:
+            r[rng.random(nr) < 0.0005] = -1
+        check_join(ctx, (l, None, O.I64), nl, (r, None, O.I64), nr)
+
+
 def test_unique_build_side_large(ctx):
     """C5's shape scaled down: unique build keys, probe keys uniform over them (+10 % misses)."""
     rng = np.random.default_rng(55)
