@@ -40,7 +40,7 @@ fails = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     try:
-        if rng.random() < 0.7:      # ---------------- groupby
+        if rng.random() < float(os.environ.get("FUZZ_GROUPBY_FRAC", "0.7")):      # ---------------- groupby
             n = int(rng.choice([1, 7, 1000, 70_000, 300_000, 1_200_000, 5_000_000]))
             kd = int(rng.choice([O.I64, O.I64, O.F64, O.U32CODE, O.BOOLBITS]))
             g = int(rng.choice([1, 3, 50, 2000, 60_000, 900_000]))
