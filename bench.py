@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--cols", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["groupby", "join"], default="groupby",
+                    help="groupby = BASELINE config 2 (the headline line); join = config 5 shape "
+                         "(probe --rows per GPU, build rows/10 per GPU, inner join -> groupby(g).sum(v))")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +99,9 @@ def main():
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
+
+    if args.workload == "join":
+        return bench_join(args, torch, pa, dist, rank, local_rank, world, device)
 
     n, g, ncol = args.rows, args.groups, args.cols
     keys, vals = make_shard(torch, n, g, ncol, 42 + 1 + 1000 * rank, device)
@@ -168,6 +174,80 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
         print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def bench_join(args, torch, pa, dist, rank, local_rank, world, device):
+    """BASELINE config 5 shape per GPU: probe rows (i64 key, f64 v) x build rows/10 (unique i64 key,
+    i64 g in [0, 100 000)), inner join then groupby(g).sum(v) through the fused entry point.
+    N > 1: build side all-gathered, probe side stays local (pandrs_amd/dist.py)."""
+    nl, nr, g = args.rows, max(args.rows // 10, 1), 100_000
+    gen = torch.Generator(device=device)
+    gen.manual_seed(42 + 5 + 1000 * rank)
+    mix = lambda ids: ids * (-7046029254386353131)          # odd multiplier: a bijection on i64
+    base = rank * nr
+    rkey = mix(torch.randperm(nr, device=device, generator=gen) + base)
+    rgrp = torch.randint(0, g, (nr,), device=device, generator=gen, dtype=torch.int64)
+    lkey = mix(torch.randint(0, nr * world, (nl,), device=device, generator=gen, dtype=torch.int64))
+    lval = torch.randn(nl, device=device, generator=gen, dtype=torch.float64) * 10 + 100
+    ctx = pa.Context(local_rank)
+    cols = ((lkey, None, pa.I64), (lval, None, pa.F64), nl, (rkey, None, pa.I64), (rgrp, None, pa.I64), nr)
+    if world > 1 or (os.environ.get("PANDRS_BENCH_FORCE_DIST") == "1" and dist is not None):
+        from pandrs_amd.dist import DistributedJoinGroupBy
+        djg = DistributedJoinGroupBy(ctx, dist, device)
+        step = lambda: djg.join_groupby_sum(*cols)
+    else:
+        djg = None
+        step = lambda: ctx.join_groupby_sum(*cols)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    dev_ms, phases = 0.0, {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        if djg is None:
+            t = ctx.timings()
+            dev_ms += t["total_ms"]
+            for k, v in t["phase_ms"].items():
+                phases[k] = phases.get(k, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        k = args.steps
+        n_groups = int(out[0].shape[1])
+        bytes_alg = nl * 16 + nr * world * 16 + n_groups * 16      # SURVEY 8(d): fused join->groupby
+        ms = dt / k * 1e3
+        dms = dev_ms / k if djg is None else ms
+        res = {"metric": "Mrows/sec hash-join (probe rows, fused join->groupby-sum)",
+               "value": nl * world / (dt / k) / 1e6, "unit": "Mrows/s", "n_gpus": world, "steps": k,
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE config 5 shape: %d probe rows/GPU x %d build rows/GPU, "
+                                      "inner join -> groupby(g in [0,100000)).sum(v)" % (nl, nr),
+                          "parallelism": "all-gather build side + local fused join + 1 all-to-all of partial sums"
+                          if world > 1 else "1 GPU"},
+               "roofline": {"bound": "hbm", "achieved": bytes_alg / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": bytes_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                            "algorithmic_bytes": bytes_alg, "device_ms": dms,
+                            "phase_ms": {p: v / k for p, v in sorted(phases.items())}}}
+        if djg is not None:
+            res["roofline"]["wall_ms_last_step"] = djg.last_wall_ms
+        print(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -91,3 +91,113 @@ class DistributedGroupBy:
         if fetch:
             return eng.groupby_fetch()
         return None
+
+
+def _pack_bits(flags):
+    """byte-per-row flags (numpy or torch, 0/1) -> LSB-first bitmap of the same kind
+    (reference mask layout: src/core/column.rs:163-177)."""
+    n = int(flags.shape[0])
+    pad = (-n) % 8
+    if hasattr(flags, "numpy") or hasattr(flags, "is_cuda"):
+        import torch
+        f = flags.to(torch.int32)
+        if pad:
+            f = torch.cat([f, torch.zeros(pad, dtype=torch.int32, device=f.device)])
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=f.device)
+        return (f.view(-1, 8) * w).sum(dim=1).to(torch.uint8)
+    import numpy as np
+    return np.packbits(np.asarray(flags, dtype=np.uint8), bitorder="little")
+
+
+class DistributedJoinGroupBy:
+    """BASELINE config 5 across the GPUs of one node: inner join of a row-range-sharded probe side
+    with a row-range-sharded build side, then groupby(g).sum(v) (reference path
+    src/optimized/split_dataframe/join.rs:76-224 followed by group/aggregation.rs:763).
+
+    Plan — the probe side (10 x the build side in C5) never leaves its GPU:
+      1. all-gather the build side (key, g): 0.8 GB in total for C5, one RCCL all-gather per
+         column with every xGMI link busy; shards are padded to a common length with NULL-key
+         rows, which the join skips by its own semantics (join.rs:107-142), so no trimming pass;
+      2. local fused join -> groupby-sum (pandrs_hip_join_groupby_sum): <= G partial sums per rank;
+      3. the partial sums go through DistributedGroupBy (owner split -> ONE all-to-all -> merge).
+    The result stays sharded by owner of g.  Radix-shuffling both sides by key instead would move
+    the 8 GB probe side over xGMI; it only pays when the build side does not fit one GPU."""
+
+    def __init__(self, engine, dist, device):
+        self.engine = engine
+        self.dist = dist
+        self.device = device
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.groupby = DistributedGroupBy(engine, dist, device)
+        self.last_wall_ms = None
+
+    def _gather_build(self, data, mask, n, pad_null):
+        """-> (data[world * n_pad], bitmap[world * n_pad / 8] or None) of every rank's shard.
+        `pad_null` marks the padding rows null (join key) or leaves them valid (payload)."""
+        import numpy as np
+        import torch
+        dist = self.dist
+        is_t = torch.is_tensor(data)
+        t = data if is_t else torch.from_numpy(np.ascontiguousarray(data))
+        sizes = torch.tensor([int(n)], dtype=torch.int64, device=t.device)
+        all_sizes = torch.empty(self.world, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(all_sizes, sizes)
+        n_pad = (int(all_sizes.max().item()) + 7) // 8 * 8
+        send = torch.zeros(n_pad, dtype=t.dtype, device=t.device)
+        send[:n] = t[:n]
+        out = torch.empty(self.world * n_pad, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, send)
+        need_mask = mask is not None or (pad_null and any(int(s) != n_pad for s in all_sizes.tolist()))
+        flags = torch.tensor([1 if need_mask else 0], dtype=torch.int64, device=t.device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        bits = None
+        if int(flags.item()):
+            mb = torch.zeros(n_pad // 8, dtype=torch.uint8, device=t.device)
+            if mask is not None:
+                m = mask if torch.is_tensor(mask) else torch.from_numpy(np.ascontiguousarray(mask))
+                nb = (n + 7) // 8
+                mb[:nb] = m[:nb].to(t.device)
+                if n % 8:   # bits past n inside the last byte are undefined in the caller's bitmap
+                    mb[nb - 1] &= (1 << (n % 8)) - 1
+            if pad_null and n < n_pad:
+                first = n // 8
+                if n % 8:
+                    mb[first] |= (0xFF << (n % 8)) & 0xFF
+                    first += 1
+                mb[first:] = 0xFF
+            bits = torch.empty(self.world * (n_pad // 8), dtype=torch.uint8, device=t.device)
+            dist.all_gather_into_tensor(bits, mb)
+        if not is_t:
+            out = out.numpy()
+            bits = None if bits is None else bits.numpy()
+        return out, bits, self.world * n_pad
+
+    def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
+        """Columns are (data, mask, dtype) like Context.join_groupby_sum; every rank passes its own
+        row ranges of both sides.  -> this rank's share of (g cells, g null flags, sums)."""
+        t0 = time.perf_counter()
+        rk, rk_bits, n_all = self._gather_build(rkey[0], rkey[1], n_right, pad_null=True)
+        rg, rg_bits, _ = self._gather_build(rgroup[0], rgroup[1], n_right, pad_null=False)
+        t1 = time.perf_counter()
+        kc, kn, sums = self.engine.join_groupby_sum(lkey, lval, n_left, (rk, rk_bits, rkey[2]),
+                                                    (rg, rg_bits, rgroup[2]), n_all)
+        t2 = time.perf_counter()
+        g = int(kc.shape[1])
+        cells, nulls, part = kc[0], kn[0], sums[0]
+        if hasattr(cells, "is_cuda"):
+            import torch
+            cells = cells.contiguous().view(torch.int64)
+            has_null = bool(nulls.any().item()) if g else False
+        else:
+            import numpy as np
+            cells = np.ascontiguousarray(cells).view(np.int64)
+            has_null = bool(nulls.any()) if g else False
+        # group cells are merged as plain 8-byte keys whatever g's dtype was: cell equality is
+        # the reference's key equality (device_utils.hpp key_cell)
+        out = self.groupby.groupby_agg([(cells, _pack_bits(nulls) if has_null else None, 0)], g,
+                                       [(part, None, 1)], [(0, 0)])
+        t3 = time.perf_counter()
+        self.last_wall_ms = {"allgather_build": (t1 - t0) * 1e3, "local_join_groupby": (t2 - t1) * 1e3,
+                             "exchange_merge": (t3 - t2) * 1e3}
+        return out

@@ -1,5 +1,5 @@
 """CPU stand-in for pandrs_amd.Context used ONLY by the gloo tests of the multi-GPU exchange logic
-(tests/test_dist_gloo.py).  It implements the four calls DistributedGroupBy needs with numpy so
+(tests/test_dist_gloo.py).  It implements the calls DistributedGroupBy / DistributedJoinGroupBy need with numpy so
 that the routing / count-exchange / all-to-all / merge plumbing can run with world_size 2 on a
 box without GPUs.  It is test infrastructure (like oracle/): never imported by pandrs_amd/."""
 import numpy as np
@@ -80,3 +80,8 @@ class NumpyEngine:
 
     def groupby_fetch(self):
         return self._r
+
+    def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
+        """The fused C5 call, answered by the oracle (test infrastructure on both sides)."""
+        from oracle import oracle as O
+        return O.join_groupby_sum(lkey, lval, n_left, rkey, rgroup, n_right)

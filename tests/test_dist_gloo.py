@@ -71,3 +71,61 @@ def test_exchange_matches_oracle(world):
     want = O.groupby_agg([(keys, km, O.I64)], len(keys), [(v0, None, O.F64), (v1, m1, O.F64)], AGGS)
     exact = [i for i, (_, op) in enumerate(AGGS) if op in (O.MIN, O.MAX, O.COUNT)]
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+
+
+# ---- config 5 across ranks: all-gather the build side, local fused join->groupby, exchange ----------
+def _join_data(nl=50_003, nr=6_001, g=300):
+    rng = np.random.default_rng(91)
+    rkeys = (rng.permutation(4 * nr)[:nr].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rgrp = rng.integers(0, g, nr).astype(np.int64)
+    rk_null = rng.random(nr) < 0.01
+    rg_null = rng.random(nr) < 0.01
+    pick = rng.integers(0, nr, nl)
+    lkeys = np.where(rng.random(nl) < 0.9, rkeys[pick], rng.integers(1, 1 << 40, nl))
+    lk_null = rng.random(nl) < 0.005
+    lval = rng.normal(10, 3, nl)
+    return lkeys, lk_null, lval, rkeys, rk_null, rgrp, rg_null
+
+
+def _shard(n, rank, world):
+    # deliberately not byte-aligned: exercises the null-key padding of the build shards
+    cut = [n * r // world for r in range(world + 1)]
+    return cut[rank], cut[rank + 1]
+
+
+def _join_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from pandrs_amd.dist import DistributedJoinGroupBy
+    from tests.cpu_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lkeys, lk_null, lval, rkeys, rk_null, rgrp, rg_null = _join_data()
+    pb = lambda m: np.packbits(m, bitorder="little")
+    l0, l1 = _shard(len(lkeys), rank, world)
+    r0, r1 = _shard(len(rkeys), rank, world)
+    d = DistributedJoinGroupBy(NumpyEngine(), dist, "cpu")
+    kc, kn, oa = d.join_groupby_sum((lkeys[l0:l1], pb(lk_null[l0:l1]), 0), (lval[l0:l1], None, 1), l1 - l0,
+                                    (rkeys[r0:r1], pb(rk_null[r0:r1]), 0), (rgrp[r0:r1], pb(rg_null[r0:r1]), 0),
+                                    r1 - r0)
+    np.savez(os.path.join(outdir, "j%d.npz" % rank), kc=kc, kn=kn, oa=oa)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_join_groupby_matches_oracle(world):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from tests.helpers import assert_groupby_equal
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_join_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, "j%d.npz" % r)) for r in range(world)]
+    got = tuple(np.concatenate([p[name] for p in parts], axis=1) for name in ("kc", "kn", "oa"))
+    lkeys, lk_null, lval, rkeys, rk_null, rgrp, rg_null = _join_data()
+    pb = lambda m: np.packbits(m, bitorder="little")
+    want = O.join_groupby_sum((lkeys, pb(lk_null), O.I64), (lval, None, O.F64), len(lkeys),
+                              (rkeys, pb(rk_null), O.I64), (rgrp, pb(rg_null), O.I64), len(rkeys))
+    assert got[0].shape[1] == want[0].shape[1]
+    assert_groupby_equal(got, want, [O.I64])
