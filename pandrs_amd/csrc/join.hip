@@ -388,63 +388,108 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
 // (join.rs:304-307, :319-322).
 // ================================================================================================
 struct FusedArgs {
-    uint64_t *rkeys, *rpay;
-    const uint64_t *lkeys, *lpay;
+    const uint64_t *rkeys, *rpay;   // partitioned build side: key cells, group payload g
+    const uint64_t *lkeys, *lpay;   // partitioned probe side: key cells, value payload v
     const uint32_t *roff, *loff;
     uint32_t rNB, lNB, P;
-    uint32_t *pcount;               // [P+1] matches per partition
-    const uint32_t *poff;           // exclusive scan of pcount
+    unsigned long long *cursor;     // pairs emitted so far (keeps counting past `cap`)
+    uint64_t cap;                   // capacity of out_g / out_v
     uint64_t *out_g, *out_v;
     uint32_t *flags;
 };
 
-// LDS: sk[R] u64 | sg[R] u64 | wave totals
-template <bool EMIT>
+constexpr uint32_t FJ_SLOTS = 8192;                 // LDS multimap slots per partition
+constexpr uint32_t FJ_BUCKETS = FJ_SLOTS / 4;       // 4-slot buckets: one 32-byte LDS read compares 4 keys
+constexpr uint32_t FJ_MAXROWS = FJ_SLOTS * 7 / 8;   // build rows a partition may hold
+constexpr int FJ_RPT = 8;
+
+// One workgroup per partition.  LDS: keys[FJ_SLOTS] u64 | g[FJ_SLOTS] u64 | fill[FJ_BUCKETS] u32.
+// Build: a right row takes the next slot of its bucket (fill counter, so no key value is reserved
+// and duplicate keys simply take several slots); a full bucket spills to the next one, and the
+// counter keeps counting so that fill > 4 tells a reader to walk on.  Probe: a left row compares
+// the 4 keys of its bucket at once and walks on only past an over-full bucket — the walk length is
+// nearly uniform across a wave, unlike linear probing.  A sum does not depend on the order of its
+// terms, so pairs are appended at a cursor reserved with one atomic per workgroup and
+// FJ_RPT x 1024 rows — no count pass, no sort.
 __global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
     const uint32_t lbeg = a.loff[(size_t)p * a.lNB], lend = a.loff[(size_t)(p + 1) * a.lNB];
     const uint32_t nR = rend - rbeg;
-    if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
-    if (!EMIT && tid == 0) a.pcount[p] = 0;
+    if (nR > FJ_MAXROWS) { if (tid == 0) a.flags[0] = 1; return; }
     if (lbeg == lend || nR == 0) return;
-    uint32_t n2 = 64;
-    while (n2 < nR) n2 <<= 1;
     uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *sg = sk + JN_RCAP;
-    uint32_t *wt = reinterpret_cast<uint32_t *>(sg + JN_RCAP);
-    for (uint32_t i = tid; i < n2; i += JN_THREADS) {
-        sk[i] = i < nR ? a.rkeys[rbeg + i] : ~0ull;
-        sg[i] = i < nR ? a.rpay[rbeg + i] : ~0ull;
+    uint64_t *sg = sk + FJ_SLOTS;
+    uint32_t *fill = reinterpret_cast<uint32_t *>(sg + FJ_SLOTS);
+    uint32_t *wt = fill + FJ_BUCKETS;                                    // 17 words of scan scratch
+    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(wt + 18);
+    for (uint32_t i = tid; i < FJ_BUCKETS; i += JN_THREADS) fill[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < nR; i += JN_THREADS) {
+        const uint64_t k = a.rkeys[rbeg + i], g = a.rpay[rbeg + i];
+        uint32_t b = hash32(k, 0x7F4A7C15u) & (FJ_BUCKETS - 1);
+        for (;;) {
+            const uint32_t c = atomicAdd(&fill[b], 1u);
+            if (c < 4) { sk[b * 4 + c] = k; sg[b * 4 + c] = g; break; }
+            b = (b + 1) & (FJ_BUCKETS - 1);
+        }
     }
     __syncthreads();
-    if (!EMIT) {
-        lds_bitonic_sort<uint64_t>(sk, sg, n2);
-        for (uint32_t i = tid; i < nR; i += JN_THREADS) { a.rkeys[rbeg + i] = sk[i]; a.rpay[rbeg + i] = sg[i]; }
-    }
-    uint32_t run = EMIT ? a.poff[p] : 0u, mine = 0;
-    const uint32_t n_iter = (lend - lbeg + JN_THREADS - 1) / JN_THREADS;
+    const uint32_t n_iter = (lend - lbeg + JN_THREADS * FJ_RPT - 1) / (JN_THREADS * FJ_RPT);
     for (uint32_t it = 0; it < n_iter; it++) {
-        const uint32_t i = lbeg + it * JN_THREADS + tid;
-        uint32_t lb = 0, m = 0;
-        uint64_t v = 0;
-        if (i < lend) {
-            const uint64_t k = a.lkeys[i];
-            lb = lds_lower_bound(sk, nR, k);
-            while (lb + m < nR && sk[lb + m] == k) m++;
-            if (EMIT && m) v = a.lpay[i];
+        const uint32_t i0 = lbeg + it * (JN_THREADS * FJ_RPT) + tid;
+        uint64_t k[FJ_RPT], v[FJ_RPT];
+#pragma unroll
+        for (int r = 0; r < FJ_RPT; r++) {
+            const uint32_t i = min(i0 + (uint32_t)r * JN_THREADS, lend - 1);
+            k[r] = __builtin_nontemporal_load(&a.lkeys[i]);
+            v[r] = __builtin_nontemporal_load(&a.lpay[i]);
         }
-        if (!EMIT) { mine += m; continue; }
+        uint32_t m[FJ_RPT], first[FJ_RPT], mine = 0;
+#pragma unroll
+        for (int r = 0; r < FJ_RPT; r++) {
+            m[r] = 0; first[r] = 0;
+            if (i0 + (uint32_t)r * JN_THREADS >= lend) continue;
+            uint32_t b = hash32(k[r], 0x7F4A7C15u) & (FJ_BUCKETS - 1);
+            for (;;) {
+                const uint32_t c = fill[b];
+                const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(&sk[b * 4]);
+                const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(&sk[b * 4 + 2]);
+                const uint32_t hit = (uint32_t)(c > 0 && lo.x == k[r]) | ((uint32_t)(c > 1 && lo.y == k[r]) << 1) |
+                                     ((uint32_t)(c > 2 && hi.x == k[r]) << 2) | ((uint32_t)(c > 3 && hi.y == k[r]) << 3);
+                if (hit) {
+                    if (m[r] == 0) first[r] = b * 4 + (uint32_t)__builtin_ctz(hit);
+                    m[r] += (uint32_t)__builtin_popcount(hit);
+                }
+                if (c <= 4) break;
+                b = (b + 1) & (FJ_BUCKETS - 1);
+            }
+            mine += m[r];
+        }
+        // compaction of the workgroup's pairs: ONE global atomic per workgroup and FJ_RPT x 1024 rows
+        // (same-address atomics retire at well under 100 M/s on this chip: never one per wave)
         uint32_t tot;
-        uint32_t ex = block_exclusive_scan<JN_THREADS>(m, wt, &tot);
-        for (uint32_t j = 0; j < m; j++) { a.out_g[run + ex + j] = sg[lb + j]; a.out_v[run + ex + j] = v; }
-        run += tot;
-    }
-    if (!EMIT) {
-        uint32_t tot;
-        block_exclusive_scan<JN_THREADS>(mine, wt, &tot);
-        if (tid == 0) a.pcount[p] = tot;
+        const uint32_t ex = block_exclusive_scan<JN_THREADS>(mine, wt, &tot);
+        if (tot == 0) continue;                         // uniform
+        if (tid == 0) *s_base = atomicAdd(a.cursor, (unsigned long long)tot);
+        __syncthreads();
+        const unsigned long long base = *s_base;
+        if (base + tot > a.cap) continue;               // uniform; host grows the buffer and runs the pass again
+        uint64_t pos = base + ex;
+#pragma unroll
+        for (int r = 0; r < FJ_RPT; r++) {
+            if (m[r] == 0) continue;
+            uint32_t slot = first[r];
+            a.out_g[pos] = sg[slot]; a.out_v[pos] = v[r]; pos++;
+            for (uint32_t q = 1; q < m[r]; q++) {       // further rows of a duplicated build key, in slot order
+                for (;;) {
+                    slot = (slot + 1) & (FJ_SLOTS - 1);
+                    if ((slot & 3) < min(fill[slot >> 2], 4u) && sk[slot] == k[r]) break;
+                }
+                a.out_g[pos] = sg[slot]; a.out_v[pos] = v[r]; pos++;
+            }
+        }
     }
 }
 
@@ -499,18 +544,16 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     int64_t M = 0;
     uint64_t *out_g = nullptr, *out_v = nullptr;
+    uint64_t cap_pairs = (uint64_t)std::max<int64_t>(nl, 1);    // exact bound for unique build keys
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.retries = attempt;
-        uint32_t *flags = c->work.take<uint32_t>(64);
+        uint32_t *flags = c->work.take<uint32_t>(64);               // [0] partition overflow, [2..3] pair cursor
         uint64_t *prk = c->work.take<uint64_t>(nr + 1), *prg = c->work.take<uint64_t>(nr + 1);
         uint64_t *plk = c->work.take<uint64_t>(nl + 1), *plv = c->work.take<uint64_t>(nl + 1);
-        uint32_t *pcount = c->work.take<uint32_t>(P + 2), *poff = c->work.take<uint32_t>(P + 2);
-        uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)P + 1));
-        if (!flags || !prk || !prg || !plk || !plv || !pcount || !poff || !seg)
+        if (!flags || !prk || !prg || !plk || !plv)
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
         HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
-        HIP_TRY(hipMemsetAsync(pcount, 0, size_t(P + 2) * 4, c->stream));
         // payload columns: plain 8-byte columns move as they are; masked / 4-byte ones are cleaned first
         const void *gsrc = rgrp.data, *vsrc = lval.data;
         if (nr > 0 && (rgrp.null_bits || rg->dtype == PANDRS_HIP_U32CODE)) {
@@ -535,42 +578,48 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         ls.mv[ls.n_move++] = MoveDesc{vsrc, plv, 0, 0};
         ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
         ST_TRY(radix_partition(c, ls, &lpart, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER));
+        ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(cap_pairs + 1) * 8) + 4096, c->stream));
+        out_g = c->pairs.take<uint64_t>(cap_pairs + 1);
+        out_v = c->pairs.take<uint64_t>(cap_pairs + 1);
+        if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
         FusedArgs fa{};
         fa.rkeys = prk; fa.rpay = prg; fa.lkeys = plk; fa.lpay = plv;
         fa.roff = rpart.offsets; fa.loff = lpart.offsets; fa.rNB = rpart.NB; fa.lNB = lpart.NB; fa.P = (uint32_t)P;
-        fa.pcount = pcount; fa.poff = poff; fa.flags = flags;
-        const size_t lds = (size_t)JN_RCAP * 16 + 256;
-        {
-            PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_probe_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fused_probe_kernel<false>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, fa);
-            HIP_TRY(hipGetLastError());
-            ST_TRY(exclusive_scan_u32(c, pcount, (size_t)P + 1, poff, seg));
+        fa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); fa.cap = cap_pairs;
+        fa.out_g = out_g; fa.out_v = out_v; fa.flags = flags;
+        const size_t lds = (size_t)FJ_SLOTS * 16 + FJ_BUCKETS * 4 + 128;
+        uint64_t total = 0;
+        for (;;) {
+            {
+                PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_probe_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(fused_probe_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, fa);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+            if (h[0] || total <= fa.cap) break;
+            // duplicate build keys produced more pairs than probe rows: size the buffer exactly, probe again
+            if (total >= (1ull << 32) - 16384)
+                return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: output exceeds the 2^32-row per-call limit");
+            cap_pairs = total;
+            ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(cap_pairs + 1) * 8) + 4096, c->stream));
+            fa.out_g = out_g = c->pairs.take<uint64_t>(cap_pairs + 1);
+            fa.out_v = out_v = c->pairs.take<uint64_t>(cap_pairs + 1);
+            if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
+            fa.cap = cap_pairs;
+            HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
         }
-        HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h + 1, poff + P, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
         if (h[0]) {
             if (P >= P_MAX)
                 return fail(PANDRS_HIP_ERR_COMPUTATION,
-                            "join build side does not fit: a radix partition holds more than %d right rows at the maximum fan-out", JN_RCAP);
+                            "join build side does not fit: a radix partition holds more than %u right rows at the maximum fan-out", FJ_MAXROWS);
             P = std::min<int64_t>(P * 4, P_MAX);
             continue;
         }
-        M = h[1];
-        ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(M + 1) * 8) + 4096, c->stream));
-        out_g = c->pairs.take<uint64_t>(M + 1);
-        out_v = c->pairs.take<uint64_t>(M + 1);
-        if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
-        fa.out_g = out_g; fa.out_v = out_v;
-        if (M > 0) {
-            PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_probe_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fused_probe_kernel<true>, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, fa);
-            HIP_TRY(hipGetLastError());
-        }
+        M = (int64_t)total;
         break;
     }
     // groupby(g).sum(v) over the matched pairs

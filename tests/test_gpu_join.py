@@ -171,3 +171,20 @@ def test_fused_join_groupby_sum(ctx, gdtype):
     got = ctx.join_groupby_sum(*args)
     want = O.join_groupby_sum(*args)
     assert_groupby_equal(got, want, [gdtype])
+
+
+def test_fused_join_duplicate_build_keys_and_sentinel(ctx):
+    """Duplicate build keys give more pairs than probe rows (the pair buffer is re-sized and the probe
+    repeated); the key equal to the table sentinel (-1) and null build keys take part as well."""
+    rng = np.random.default_rng(321)
+    nb, npb = 150_000, 700_000
+    rkeys = rng.integers(0, 40_000, nb).astype(np.int64)       # ~3.75 duplicates per key
+    rkeys[rng.random(nb) < 0.01] = -1
+    rg = rng.integers(-50, 50, nb).astype(np.int64)
+    lkeys = rng.integers(-1, 45_000, npb).astype(np.int64)
+    lv = rng.integers(-1000, 1000, npb).astype(np.int64)       # i64 payload: sums must be bit-exact
+    args = ((lkeys, O.pack_mask(rng.random(npb) < 0.01), O.I64), (lv, None, O.I64), npb,
+            (rkeys, O.pack_mask(rng.random(nb) < 0.02), O.I64), (rg, None, O.I64), nb)
+    got = ctx.join_groupby_sum(*args)
+    want = O.join_groupby_sum(*args)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0])
