@@ -2,7 +2,11 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pandrs_amd as pa
 ctx = pa.Context(0); d = "cuda:0"
-for nb, npb in [(5_000_000, 50_000_000), (30_000_000, 60_000_000), (1_000_000, 100_000_000)]:
+import sys as _s
+CASES = [(5_000_000, 50_000_000), (30_000_000, 60_000_000), (1_000_000, 100_000_000)]
+if len(_s.argv) > 1 and _s.argv[1] == 'big':      # beyond one LDS partition per build bucket: general segmented sort
+    CASES = [(100_000_000, 100_000_000), (200_000_000, 50_000_000)]
+for nb, npb in CASES:
     rk = torch.randperm(nb * 2, device=d)[:nb].to(torch.int64) * -7046029254386353131
     pick = torch.randint(0, nb, (npb,), device=d)
     lk = rk[pick]

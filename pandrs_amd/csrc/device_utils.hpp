@@ -120,4 +120,18 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     return r;
 }
 
+// Length of the run of equal keys that starts at i in a sorted array of n keys: gallop, then
+// binary search — O(log run) reads, whatever the run length.
+__device__ __forceinline__ uint32_t sorted_run_length(const uint64_t *keys, uint32_t i, uint32_t n) {
+    const uint64_t k = keys[i];
+    uint32_t lo = i, step = 1;
+    while (lo + step < n && keys[lo + step] == k) { lo += step; step <<= 1; }
+    uint32_t hi = lo + step < n ? lo + step : n;        // keys[hi] != k, or hi == n
+    while (lo + 1 < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] == k) lo = mid; else hi = mid;
+    }
+    return lo + 1 - i;
+}
+
 }  // namespace pandrs

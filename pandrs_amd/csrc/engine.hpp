@@ -41,7 +41,8 @@ struct FinDev {
 struct MoveDesc {
     const void *src;
     void *dst;
-    int kind;   // 0: 8-byte element, 1: null bitmap -> validity byte, 2: byte copy
+    int kind;   // 0: 8-byte element, 1: null bitmap -> validity byte, 2: byte copy, 3: row index -> u32,
+                // 4: u32 source -> u64, 5: row index -> u64
     int pad;
 };
 
@@ -113,5 +114,14 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge, bool partials,
                    int n_aggs, int key_dtype, int n_keys_out = 1, int res_slot = 0);
 size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
+
+// segsort.hip: sorts every partition [0, n_parts) of (keys, payload) ascending by (key, payload),
+// in place, whatever the partition sizes.  `enc`: 0 = payload compared as is, 1 = f64 bits and
+// 2 = i64 rewritten to their order-preserving u64 encodings (and left encoded).
+int32_t segmented_sort_u32(pandrs_hip_ctx *c, uint64_t *keys, uint32_t *pay, const uint32_t *offsets, uint32_t NB,
+                           uint32_t n_parts, int64_t n_rows);
+int32_t segmented_sort_u64(pandrs_hip_ctx *c, uint64_t *keys, uint64_t *pay, const uint32_t *offsets, uint32_t NB,
+                           uint32_t n_parts, int64_t n_rows, int enc);
+size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_bytes);
 
 }  // namespace pandrs

@@ -116,6 +116,25 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
     }
 }
 
+// General build path (a partition larger than the LDS sort buffers: very many build rows, or one
+// key with thousands of duplicates): the partitions were sorted by segmented_sort_u32; the sorted
+// non-null rows [0, *n_bound) form one array in which equal keys are adjacent (a key lives in
+// exactly one partition), so runs are published without looking at partition boundaries.
+__global__ void publish_runs_kernel(const uint64_t *rkeys, const uint32_t *n_bound, JoinEntry *table, uint32_t table_mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = *n_bound;
+    if (i >= n) return;
+    const uint64_t k = rkeys[i];
+    if (i > 0 && rkeys[i - 1] == k) return;
+    const uint32_t m = sorted_run_length(rkeys, i, n);
+    if (k == EMPTY_KEY) { table[table_mask + 1].start = i; table[table_mask + 1].count = m; return; }
+    uint32_t slot = hash32(k, 0x7F4A7C15u) & table_mask;
+    for (;;) {
+        uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
+        if (old == EMPTY_KEY) { table[slot].start = i; table[slot].count = m; break; }
+        slot = (slot + 1) & table_mask;
+    }
+}
+
 // Probe pass over the left rows in ORIGINAL order.  LK_RPT rows per thread: all key loads, then all
 // first-probe table reads (16-byte entries, cache resident for typical builds) are in flight together;
 // only rows whose first entry is neither their key nor empty walk on.
@@ -266,7 +285,8 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
               + Arena::padded(size_t(cap_tab + 2) * 16) + Arena::padded(size_t(cap_tab) + 16)
               + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded(size_t(nl + 2) * 4)
               + 2 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
-              + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16);
+              + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16)
+              + segsort_workspace_bytes(nr, P_MAX + 1, 4);
     ST_TRY(c->work.ensure(ws, c->stream));
 
     int64_t P = c->opt.partitions > 0 ? c->opt.partitions
@@ -275,6 +295,8 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
     P = std::max<int64_t>(P, 1);
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     int64_t M1 = 0, M2 = 0;
+    // the LDS build cannot work when even the maximum fan-out leaves partitions above its capacity
+    bool generic = c->opt.join_generic != 0 || (double)nr / (double)P > JN_RCAP * 0.95;
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.retries = attempt; c->timings.table_slots = JN_RCAP;
@@ -311,7 +333,16 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
             const size_t lds = (size_t)JN_RCAP * 12 + 64;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_build_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(join_build_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ba);
+            if (!generic) {
+                hipLaunchKernelGGL(join_build_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, ba);
+            } else {
+                // a partition does not fit the LDS sort buffers (very many build rows, or one key with
+                // thousands of duplicates): general segmented sort, runs published from the sorted array
+                ST_TRY(segmented_sort_u32(c, prk, prr, rpart.offsets, rpart.NB, (uint32_t)P, nr));
+                if (nr > 0)
+                    hipLaunchKernelGGL(publish_runs_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
+                                       prk, rpart.offsets + (size_t)P * rpart.NB, table, cap_tab - 1);
+            }
             HIP_TRY(hipGetLastError());
         }
         // ---- probe in original left order, scan of the per-row output counts
@@ -328,11 +359,9 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         HIP_TRY(hipMemcpyAsync(h + 1, off + nl, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (h[0]) {
-            if (P >= P_MAX)
-                return fail(PANDRS_HIP_ERR_COMPUTATION,
-                            "join build side does not fit: a radix partition holds more than %d right rows at the "
-                            "maximum fan-out (too many rows or one key with too many duplicates)", JN_RCAP);
-            P = std::min<int64_t>(P * 4, P_MAX);
+            // first overflow: more partitions (unlucky hashing); second: the general sort handles any size
+            if (attempt == 0 && P < P_MAX) P = std::min<int64_t>(P * 4, P_MAX);
+            else generic = true;
             continue;
         }
         M1 = h[1];

@@ -112,14 +112,35 @@ def test_other_key_dtypes_and_heavy_dups(ctx):
     check_join(ctx, (lb, None, O.BOOLBITS), 500, (rb, None, O.BOOLBITS), 3)
 
 
-def test_build_side_overflow_is_reported(ctx):
-    """One key with more duplicates than an LDS partition holds: a clear error, never a wrong answer."""
-    import pandrs_amd as pa
-    lk = (np.zeros(10, np.int64), None, O.I64)
-    rk = (np.zeros(20_000, np.int64), None, O.I64)
-    with pytest.raises(pa.PandrsHipError) as e:
-        ctx.join_indices(lk, 10, rk, 20_000, O.INNER)
-    assert "does not fit" in str(e.value)
+def test_hot_build_key_beyond_one_lds_partition(ctx):
+    """One build key with more duplicates than an LDS partition holds (20 000 > 8192): the general
+    segmented sort (chunk sort + merge passes) takes over; matches stay in ascending right-row order."""
+    rng = np.random.default_rng(8)
+    nl, nr = 300, 60_000
+    rk = rng.integers(0, 1000, nr).astype(np.int64)
+    rk[rng.random(nr) < 0.35] = 77                              # ~21 000 duplicates of one key
+    rk[rng.random(nr) < 0.2] = -1                               # and ~9 000 of the sentinel-valued key
+    lk = rng.integers(-1, 1100, nl).astype(np.int64)
+    lk[:5] = 77
+    check_join(ctx, (lk, O.pack_mask(rng.random(nl) < 0.02), O.I64), nl, (rk, O.pack_mask(rng.random(nr) < 0.01), O.I64), nr)
+    assert ctx.timings()["retries"] >= 1
+
+
+@pytest.mark.parametrize("parts", [1, 5, 64])
+def test_general_segmented_sort_build_path(ctx, parts):
+    """The general build path forced on ordinary inputs, with few partitions so that every partition
+    spans many 8192-row tiles (1 partition of 200 000 rows = 25 tiles, 5 merge passes)."""
+    rng = np.random.default_rng(100 + parts)
+    nl, nr = 150_000, 200_000
+    rk = rng.integers(0, 120_000, nr).astype(np.int64) * 1_000_003
+    lk = rng.integers(0, 130_000, nl).astype(np.int64) * 1_000_003
+    ctx.set_option("join_generic", 1)
+    ctx.set_option("partitions", parts)
+    try:
+        check_join(ctx, (lk, O.pack_mask(rng.random(nl) < 0.01), O.I64), nl, (rk, O.pack_mask(rng.random(nr) < 0.01), O.I64), nr)
+    finally:
+        ctx.set_option("join_generic", 0)
+        ctx.set_option("partitions", 0)
 
 
 def test_gathers_match_reference_fill(ctx):
