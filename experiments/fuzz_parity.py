@@ -13,7 +13,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = pa.Context(0)
 OPS_MERGEABLE = [O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT]
-OPS_ALL = OPS_MERGEABLE + [O.STD, O.VAR, O.FIRST, O.LAST]
+OPS_ALL = OPS_MERGEABLE + [O.STD, O.VAR, O.FIRST, O.LAST, O.MEDIAN, O.MEDIAN]
 
 def rand_key(rng, n, dtype, g, skew):
     ids = rng.integers(0, g, n)
@@ -67,25 +67,26 @@ for case in range(n_cases):
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
-            exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST) or (vals[c][2] == O.I64 and op == O.SUM)]
+            exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN) or (vals[c][2] == O.I64 and op == O.SUM)]
             assert_groupby_equal(got, want, kdts, int_exact_rows=exact, rtol=1e-9)
             desc = "groupby n=%d kd=%d g=%d %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, nk, aggs, opts)
         else:                       # ---------------- join
             nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000]))
             kd = int(rng.choice([O.I64, O.I64, O.U32CODE, O.F64]))
             space = int(rng.choice([3, 500, 100_000, 5_000_000]))
-            if kd == O.U32CODE or space >= 500 or max(nl, nr) < 10_000:
-                pass
-            else:
-                space = 100_000          # avoid > 8192 duplicates per key on big build sides
+            if nl * nr / max(space, 1) > 3e7: space = 100_000     # keep the output (and the oracle's run time) bounded
             lk = (rand_key(rng, nl, kd, space, "uniform"), mask(rng, nl, rng.choice([0, 0.02])), kd)
             rk = (rand_key(rng, nr, kd, space, "uniform"), mask(rng, nr, rng.choice([0, 0.02])), kd)
-            if nr > 8192 * 4 and space < 200: continue
             how = int(rng.integers(0, 4))
-            gl, gr = ctx.join_indices(lk, nl, rk, nr, how)
+            jg = int(rng.random() < 0.25)
+            ctx.set_option("join_generic", jg)
+            try:
+                gl, gr = ctx.join_indices(lk, nl, rk, nr, how)
+            finally:
+                ctx.set_option("join_generic", 0)
             wl, wr = O.join_indices(lk, nl, rk, nr, how)
             np.testing.assert_array_equal(gl, wl); np.testing.assert_array_equal(gr, wr)
-            desc = "join nl=%d nr=%d kd=%d space=%d how=%d -> %d rows" % (nl, nr, kd, space, how, len(gl))
+            desc = "join nl=%d nr=%d kd=%d space=%d how=%d generic=%d -> %d rows" % (nl, nr, kd, space, how, jg, len(gl))
         print("ok   %3d %s" % (case, desc), flush=True)
     except pa.PandrsHipError as e:
         if "does not fit" in str(e) or "more than 64 bits" in str(e):

@@ -14,6 +14,9 @@
  *   - `mem_space` says where the caller's column / output pointers live:
  *     PANDRS_HIP_MEM_HOST (library stages H2D/D2H itself) or PANDRS_HIP_MEM_DEVICE
  *     (pointers are HBM addresses on the context's device; nothing crosses PCIe).
+ *     Device inputs must be COMPLETE when a call starts: the context's stream is
+ *     non-blocking, so a caller that produced them on another stream synchronises that
+ *     stream first.  Device outputs are complete when the call returns.
  *   - caller pointers are never retained past return (reference columns are Arc<[T]>
  *     borrowed for the call, src/column/int64_column.rs:52-56).
  *   - a context owns one HIP stream and a workspace arena; calls on ONE context are

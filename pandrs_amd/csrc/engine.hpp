@@ -68,6 +68,7 @@ struct Plan {
     int8_t st_firstrow = -1, st_lastrow = -1;      // group-level: min / max original row index
     bool needs_second_pass = false;                // any Std / Var
     bool mergeable = true;                         // false when Std/Var/First/Last are requested
+    bool has_median = false;                       // Median aggregates are filled by median_pass after the engine run
     int8_t kinds[MAX_STATES];
     int8_t fin_op[MAX_AGGS], fin_kind[MAX_AGGS];
     int fin_src[MAX_AGGS];         // plan source of each aggregate, -1 for COUNT
@@ -123,5 +124,10 @@ int32_t segmented_sort_u32(pandrs_hip_ctx *c, uint64_t *keys, uint32_t *pay, con
 int32_t segmented_sort_u64(pandrs_hip_ctx *c, uint64_t *keys, uint64_t *pay, const uint32_t *offsets, uint32_t NB,
                            uint32_t n_parts, int64_t n_rows, int enc);
 size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_bytes);
+
+// median.hip: fills aggregate `fin_index` of c->gb with the groups' medians of one value column
+// (kind 0 = f64, 1 = i64); `key` is the key source the engine ran on.
+int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const void *vdata, const uint8_t *vnull,
+                    int kind, int fin_index);
 
 }  // namespace pandrs

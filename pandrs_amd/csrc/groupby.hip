@@ -816,9 +816,11 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
         if (dt != PANDRS_HIP_I64 && dt != PANDRS_HIP_F64)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                         "Aggregation operation %d is not supported for column type %d", op, dt);
-        if (op == PANDRS_HIP_AGG_MEDIAN)
-            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
-                        "Median needs a per-group sort and is not implemented on the device path yet");
+        if (op == PANDRS_HIP_AGG_MEDIAN) {      // no engine state: filled by median_pass after the run
+            pl.fin_kind[a] = dt == PANDRS_HIP_F64 ? 0 : 1;
+            pl.has_median = true;
+            continue;
+        }
         int s = src_of[c];
         if (s < 0) {
             if (pl.n_src >= MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d aggregated columns", MAX_SRC);
@@ -1106,7 +1108,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     }
     if ((partials || merge) && !pl.mergeable)
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
-                    "Std/Var/First/Last partial states are not mergeable across shards yet");
+                    "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
     const int n_src = (int)srcs.size();
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
@@ -1653,6 +1655,9 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     for (int i = 0; i < n_vals; i++) { dts[i] = vals[i].dtype; hn[i] = vals[i].null_mask != nullptr; }
     Plan pl;
     ST_TRY(build_plan(dts.data(), hn.data(), n_vals, aggs, n_aggs, pl));
+    if (partials && pl.has_median)      // (nested merges of slices keep the Median slots as placeholders)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                    "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
 
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
@@ -1665,6 +1670,8 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         size_t need = 0;
         for (int k = 0; k < n_keys; k++) need += dtype_bytes(keys[k].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
         for (int s = 0; s < pl.n_src; s++) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
+        for (int a = 0; a < n_aggs; a++)
+            if (aggs[a].op == PANDRS_HIP_AGG_MEDIAN) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
         ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
     }
     rs.key = KeyDesc{stg.in(keys[0].data, dtype_bytes(keys[0].dtype, n_rows)),
@@ -1674,6 +1681,23 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         if (n_rows > 0 && !v.data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "value column %d has no data", pl.src_col[s]);
         rs.val_data[s] = stg.in(v.data, size_t(n_rows) * 8);
         rs.val_null_bits[s] = (const uint8_t *)stg.in(v.null_mask, (n_rows + 7) / 8);
+    }
+    // Median columns: device views of the original columns (shared with the plan's sources when the
+    // column is also aggregated otherwise)
+    const void *med_data[MAX_AGGS]{};
+    const uint8_t *med_null[MAX_AGGS]{};
+    for (int a = 0; a < n_aggs && pl.has_median; a++) {
+        if (aggs[a].op != PANDRS_HIP_AGG_MEDIAN) continue;
+        const int col = aggs[a].col;
+        for (int s = 0; s < pl.n_src; s++)
+            if (pl.src_col[s] == col) { med_data[a] = rs.val_data[s]; med_null[a] = rs.val_null_bits[s]; }
+        for (int b = 0; b < a && !med_data[a]; b++)
+            if (aggs[b].op == PANDRS_HIP_AGG_MEDIAN && aggs[b].col == col) { med_data[a] = med_data[b]; med_null[a] = med_null[b]; }
+        if (!med_data[a]) {
+            if (n_rows > 0 && !vals[col].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "value column %d has no data", col);
+            med_data[a] = stg.in(vals[col].data, size_t(n_rows) * 8);
+            med_null[a] = (const uint8_t *)stg.in(vals[col].null_mask, (n_rows + 7) / 8);
+        }
     }
     if (stg.status) return stg.status;
     PackDesc pd{};
@@ -1721,6 +1745,9 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         rs.key = KeyDesc{packed, nullptr, nullptr, DT_CELL};
     }
     ST_TRY(run_engine(c, rs, pl, /*merge=*/false, partials, n_aggs, keys[0].dtype, n_keys));
+    for (int a = 0; a < n_aggs && pl.has_median; a++)       // Median: a per-group sort, one pass per column
+        if (aggs[a].op == PANDRS_HIP_AGG_MEDIAN)
+            ST_TRY(median_pass(c, rs.key, n_rows, med_data[a], med_null[a], pl.fin_kind[a], a));
     if (n_keys > 1 && c->gb.n_groups > 0) {
         hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((c->gb.n_groups + 255) / 256)), dim3(256), 0, c->stream,
                            pd, c->gb.n_groups, (size_t)c->gb.cap, c->gb.keys, c->gb.key_null);
@@ -1762,6 +1789,9 @@ int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dt
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_merge: bad arguments");
     Plan pl;
     ST_TRY(build_plan(val_dtypes, val_has_nulls, n_vals, aggs, n_aggs, pl));
+    if (pl.has_median)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                    "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     timings_begin(c);

@@ -232,6 +232,17 @@ __global__ void append_unmatched_kernel(const uint8_t *rmatched, const uint32_t 
     if (i < n && !rmatched[i]) { out_left[base + off[i]] = -1; out_right[base + off[i]] = i; }
 }
 
+// 64-bit total of the per-left-row output counts: the u32 scan would wrap silently past 2^32 rows
+__global__ __launch_bounds__(256) void sum_counts_kernel(const uint32_t *cnt, int64_t n, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += cnt[i];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ unsigned long long ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
 static int32_t stage_key(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n, KeyDesc *out) {
     const void *d = col->data; const uint8_t *m = col->null_mask;
     if (mem_space == PANDRS_HIP_MEM_HOST && n > 0) {
@@ -354,7 +365,11 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
             }
             HIP_TRY(hipGetLastError());
             ST_TRY(exclusive_scan_u32(c, cnt, (size_t)nl + 1, off, seg));    // off[nl] = rows from the probe
+            if (nl > 0)
+                hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)std::min<int64_t>(1024, (nl + 255) / 256)), dim3(256), 0, c->stream,
+                                   cnt, nl, reinterpret_cast<unsigned long long *>(flags + 2));
         }
+        HIP_TRY(hipMemcpyAsync(h + 2, flags + 2, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h + 1, off + nl, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -365,6 +380,8 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
             continue;
         }
         M1 = h[1];
+        if (((uint64_t)h[2] | ((uint64_t)h[3] << 32)) + (uint64_t)nr >= (1ull << 32) - 16384)
+            return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: the output exceeds the 2^32-row per-call limit");
         // ---- right / outer: unmatched right rows, ascending
         uint32_t *roff2 = nullptr;
         if (keep_right && nr > 0) {

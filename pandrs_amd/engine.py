@@ -96,7 +96,16 @@ class Context:
             arr[i].data = _ptr(data)
             arr[i].null_mask = _ptr(mask)
             arr[i].dtype = int(dt)
+        if space == L.MEM_DEVICE:
+            self._wait_for_producer()
         return arr, (space if space is not None else L.MEM_HOST)
+
+    def _wait_for_producer(self):
+        """The library runs on its own non-blocking stream and (like any C ABI over raw device
+        pointers) requires its device inputs to be complete when the call starts.  Tensors handed
+        over from torch may still be being written by kernels queued on torch's current stream."""
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
 
     @staticmethod
     def _aggs(aggs):

@@ -29,7 +29,12 @@ def sparse_keys(rng, n, g):
     return (ids * np.uint64(0x9E3779B97F4A7C15) ^ np.uint64(0x5555AAAA5555AAAA)).view(np.int64)
 
 
+def sparse_keys_from(ids):
+    return (np.asarray(ids).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+
+
 def check(ctx, keys, n, vals, aggs, key_dtypes, exact=(), rtol=1e-9):
+    keys = keys if isinstance(keys, list) else [keys]
     got = ctx.groupby_agg(keys, n, vals, aggs)
     want = O.groupby_agg(keys, n, vals, aggs)
     assert_groupby_equal(got, want, key_dtypes, int_exact_rows=exact, rtol=rtol)
@@ -246,10 +251,46 @@ def test_std_var_first_last(ctx, golden):
             assert oa[0, gi] == pytest.approx(e["std"], abs=1e-3)
         assert oa[1, gi] == e["first"] and oa[2, gi] == e["last"]
     import pandrs_amd as pa
-    with pytest.raises(pa.OperationFailed):          # Median: not on the device path yet
-        ctx.groupby_agg(k, 6, [v], [(0, O.MEDIAN)])
     with pytest.raises(pa.OperationFailed):          # non-mergeable ops cannot produce partials
         ctx.groupby_partials(k, 6, [v], [(0, O.STD)])
+    with pytest.raises(pa.OperationFailed):
+        ctx.groupby_partials(k, 6, [v], [(0, O.MEDIAN)])
+
+
+def test_median_small_and_edge_cases(ctx):
+    """aggregation.rs:585-604 / :703-722: middle of the sorted non-null values; even count = mean of the
+    two middles, for Int64 with the ADD IN i64 (wraps); no non-null value => 0.0; null keys are a group."""
+    k = (np.array([1, 1, 1, 2, 2, 3, 3, 3, 3, -1, 9, 9], np.int64), O.pack_mask([0] * 10 + [1, 1]), O.I64)
+    vf = (np.array([5.0, 1.0, 3.0, 2.0, 8.0, 7.0, 7.0, -1.0, 4.0, 6.5, 10.0, 20.0]), None, O.F64)
+    vi = (np.array([5, 1, 3, 2, 9, 7, 7, -1, 4, 6, 2**62, 2**62], np.int64),
+          O.pack_mask([0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]), O.I64)       # group 2: all null -> 0.0; NULL group: i64 add wraps
+    got = check(ctx, k, 12, [vf, vi], [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.SUM), (1, O.COUNT)], [O.I64], exact=[0, 1, 3])
+    by_key = {(int(np.int64(c)), int(nl)): (a, b) for c, nl, a, b in zip(got[0][0], got[1][0], got[2][0], got[2][1])}
+    assert by_key[(1, 0)] == (3.0, 3.0) and by_key[(2, 0)] == (5.0, 0.0) and by_key[(3, 0)] == (5.5, 5.5)
+    assert [v for (c, nl), v in by_key.items() if nl == 1] == [(15.0, float(np.int64(-2**63)) / 2.0)]
+
+
+@pytest.mark.parametrize("n,g,skew", [(200_000, 1_000, False), (3_000_000, 40_000, False), (2_000_000, 50, True)])
+def test_median_random(ctx, n, g, skew):
+    """Groups from a few rows to far beyond one LDS tile (the skewed case: 50 groups, one with ~60 % of
+    the rows => multi-tile partitions, merge passes), f64 and masked i64 columns, next to other ops."""
+    rng = np.random.default_rng(n % 1000 + g)
+    ids = rng.integers(0, g, n)
+    if skew:
+        ids[rng.random(n) < 0.6] = 7
+    k = (sparse_keys_from(ids), O.pack_mask(rng.random(n) < 0.001), O.I64)
+    vf = (np.round(rng.normal(0, 100, n), 1), None, O.F64)                   # rounded: many ties
+    vi = (rng.integers(-10**6, 10**6, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.1), O.I64)
+    check(ctx, k, n, [vf, vi], [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.MEAN), (1, O.MAX), (1, O.COUNT)], [O.I64], exact=[0, 1, 3, 4])
+
+
+def test_median_multi_key_and_string_codes(ctx):
+    rng = np.random.default_rng(99)
+    n = 300_000
+    k0 = (rng.integers(0, 30, n).astype(np.uint32), None, O.U32CODE)
+    k1 = (rng.integers(-5, 5, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.05), O.I64)
+    v = (rng.normal(5, 2, n), O.pack_mask(rng.random(n) < 0.3), O.F64)
+    check(ctx, [k0, k1], n, [v], [(0, O.MEDIAN), (0, O.COUNT)], [O.U32CODE, O.I64], exact=[0, 1])
 
 
 def test_multi_key_packed(ctx, golden):

@@ -209,3 +209,13 @@ def test_fused_join_duplicate_build_keys_and_sentinel(ctx):
     got = ctx.join_groupby_sum(*args)
     want = O.join_groupby_sum(*args)
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0])
+
+
+def test_join_output_beyond_row_limit_is_reported(ctx):
+    """300 000 x 20 000 rows of one key = 6e9 output rows: a clear error, never a wrapped 32-bit count."""
+    import pandrs_amd as pa
+    lk = (np.zeros(300_000, np.int64), None, O.I64)
+    rk = (np.zeros(20_000, np.int64), None, O.I64)
+    with pytest.raises(pa.PandrsHipError) as e:
+        ctx.join_indices(lk, 300_000, rk, 20_000, O.INNER)
+    assert "2^32" in str(e.value)
