@@ -228,6 +228,24 @@ int32_t pandrs_hip_groupby_merge(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t
                                  const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
                                  int64_t *out_n_groups);
 
+/* ---- group_by's row -> group assignment ----------------------------------
+ * Replaces the body of OptimizedDataFrame::group_by (src/optimized/split_dataframe/group/
+ * grouping.rs:22-115), which builds HashMap<Vec<String>, Vec<usize>>: per group, the ascending list
+ * of its row indices (:98-103).  GroupBy.groups is a pub field (group/types.rs:52) that filter /
+ * transform / aggregate_custom (group/operations.rs:51-435, aggregation.rs:391-497) and
+ * par_groupby's sub-frame gathers (grouping.rs:286-328) read.  Device form = CSR:
+ * group g has key cells out_keys[k][g] (+ null flags) and rows out_rows[out_offsets[g] ..
+ * out_offsets[g+1]), ascending.  Null keys form one group per distinct combination, like the
+ * reference's "NULL" strings (grouping.rs:74).  Group order is unspecified (HashMap order there). */
+int32_t pandrs_hip_groupby_indices(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                   const pandrs_hip_column *keys, int32_t n_keys, int64_t n_rows,
+                                   int64_t *out_n_groups);
+/* out_keys[k] / out_key_null[k]: n_groups entries each; out_offsets: n_groups + 1; out_rows: n_rows.
+ * Any pointer may be NULL to skip that output. */
+int32_t pandrs_hip_groupby_indices_fetch(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                         uint64_t *const *out_keys, uint8_t *const *out_key_null,
+                                         int64_t *out_offsets, int64_t *out_rows);
+
 /* ---- hash join ------------------------------------------------------------------------------
  * Replaces OptimizedDataFrame::join_impl (src/optimized/split_dataframe/join.rs:76-555) up to
  * the join_indices vector (:146-224); the column gathers (:286-552) are pandrs_hip_gather_*.

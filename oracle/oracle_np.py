@@ -192,6 +192,35 @@ def groupby_agg(keys, n_rows, vals, aggs, pools=None):
     return out
 
 
+def group_indices(keys, n_rows, pools=None):
+    """group_by's result (grouping.rs:62-104): tuple(key strings) -> its row indices, ascending
+    (rows are visited in order and pushed, :98-103); a null key is the string "NULL" (:74)."""
+    groups = {}
+    for r in range(n_rows):
+        k = tuple(_key_string(c, r, pools[i] if pools else None) for i, c in enumerate(keys))
+        groups.setdefault(k, []).append(r)
+    return groups
+
+
+def key_cells(col, n_rows):
+    """Vectorised (null flag, 8-byte cell) of every row of one key column: equal cells <=> equal key
+    strings (NaNs collapsed, 0.0 != -0.0, grouping.rs:72-79); null rows get cell 0."""
+    data, mask, dt = col
+    nul = np.zeros(n_rows, np.uint8) if mask is None else np.unpackbits(np.asarray(mask, np.uint8), bitorder="little")[:n_rows]
+    if dt == I64:
+        cell = np.asarray(data, np.int64)[:n_rows].view(np.uint64).copy()
+    elif dt == F64:
+        d = np.asarray(data, np.float64)[:n_rows]
+        cell = d.view(np.uint64).copy()
+        cell[np.isnan(d)] = np.uint64(0x7FF8000000000000)
+    elif dt == U32CODE:
+        cell = np.asarray(data, np.uint32)[:n_rows].astype(np.uint64)
+    else:
+        cell = np.unpackbits(np.asarray(data, np.uint8), bitorder="little")[:n_rows].astype(np.uint64)
+    cell[nul.astype(bool)] = 0
+    return nul, cell
+
+
 def groupby_agg_arrays(keys, n_rows, vals, aggs):
     """Same result as oracle.groupby_agg(..., faithful=True) layout, first-seen order."""
     res = groupby_agg(keys, n_rows, vals, aggs)

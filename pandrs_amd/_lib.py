@@ -69,6 +69,9 @@ SYMBOLS = {
     "pandrs_hip_groupby_merge": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, C.c_int64,
                                              C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_uint8),
                                              C.POINTER(AggSpec), C.c_int32, C.POINTER(C.c_int64)]),
+    "pandrs_hip_groupby_indices": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64,
+                                               C.POINTER(C.c_int64)]),
+    "pandrs_hip_groupby_indices_fetch": (C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "pandrs_hip_join_indices": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64,
                                             C.POINTER(Column), C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     "pandrs_hip_join_fetch": (C.c_int32, [_P, C.c_int32, _P, _P]),

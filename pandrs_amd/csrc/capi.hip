@@ -91,7 +91,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     if (!c) return PANDRS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release();
+    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release();
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -191,6 +191,32 @@ int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t 
     for (int a = 0; a < r.n_aggs; a++)
         if (out_aggs && out_aggs[a])
             HIP_TRY(hipMemcpyAsync(out_aggs[a], r.aggs + (size_t)a * r.cap, g * 8, kind, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_groupby_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
+                                   int32_t n_keys, int64_t n_rows, int64_t *out_n_groups) {
+    return pandrs::groupby_indices_entry(ctx, mem_space, keys, n_keys, n_rows, out_n_groups);
+}
+
+int32_t pandrs_hip_groupby_indices_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t *const *out_keys,
+                                         uint8_t *const *out_key_null, int64_t *out_offsets, int64_t *out_rows) {
+    if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+    std::lock_guard<std::mutex> lock(c->mu);
+    pandrs::GroupsResult &r = c->gr;
+    if (!r.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no group index retained in this context");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t g = (size_t)r.n_groups, n = (size_t)r.n_rows;
+    hipMemcpyKind kind = mem_space == PANDRS_HIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    for (int k = 0; k < r.n_keys && g > 0; k++) {
+        if (out_keys && out_keys[k])
+            HIP_TRY(hipMemcpyAsync(out_keys[k], r.keys + (size_t)k * r.cap, g * 8, kind, c->stream));
+        if (out_key_null && out_key_null[k])
+            HIP_TRY(hipMemcpyAsync(out_key_null[k], r.key_null + (size_t)k * r.cap, g, kind, c->stream));
+    }
+    if (out_offsets) HIP_TRY(hipMemcpyAsync(out_offsets, r.offsets, (g + 1) * 8, kind, c->stream));
+    if (out_rows && n > 0) HIP_TRY(hipMemcpyAsync(out_rows, r.rows, n * 8, kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
 }

@@ -104,6 +104,17 @@ struct GroupbyResult {
     uint64_t *states = nullptr; // [n_state][cap]  (partials)
 };
 
+// group_by's row -> group assignment in CSR form: group g = rows[offsets[g] .. offsets[g+1]), ascending
+struct GroupsResult {
+    bool valid = false;
+    int64_t n_groups = 0, n_rows = 0, cap = 0;
+    int n_keys = 0;
+    uint64_t *keys = nullptr;    // [n_keys][cap]
+    uint8_t *key_null = nullptr; // [n_keys][cap]
+    int64_t *offsets = nullptr;  // [n_groups + 1]
+    int64_t *rows = nullptr;     // [n_rows]
+};
+
 struct JoinResult {
     bool valid = false;
     int64_t n_rows = 0;
@@ -136,11 +147,12 @@ struct pandrs_hip_ctx {
     // one arena per lifetime class: buffers that must survive a nested engine run never share an
     // arena with what that run allocates (work: per-run scratch; temp: direct-path records;
     // side: slice records; super: two-level columns; packed: multi-key cells; pairs: fused-join pairs)
-    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs;
+    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
     pandrs::GroupbyResult gb, gb2, gb3;   // gb2 / gb3: nested results (slice merges, two-level sub-runs)
     pandrs::JoinResult jn;
+    pandrs::GroupsResult gr;
     // phase timing: pairs of events
     hipEvent_t ev_begin[PANDRS_HIP_MAX_PHASES]{}, ev_end[PANDRS_HIP_MAX_PHASES]{};
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
@@ -191,6 +203,8 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
                       int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
                       const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
                       int64_t *out_n_groups, int32_t *out_n_state);
+int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
+                              int64_t n_rows, int64_t *out_n_groups);
 int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
                             const uint64_t *records,
                             int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,

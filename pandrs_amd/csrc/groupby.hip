@@ -1635,6 +1635,54 @@ __global__ void unpack_keys_kernel(PackDesc d, int64_t g, size_t cap, uint64_t *
     }
 }
 
+// Stages the remaining key columns, measures the code widths and replaces `key` (on entry: key
+// column 0) by the packed cells.  `pd` is kept for unpack_keys_kernel.
+static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_column *keys, int n_keys, int64_t n_rows,
+                              KeyDesc &key, PackDesc &pd) {
+    // composite key: per-column code widths from a min/max pass, then one packed cell per row
+    PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+    pd.n_keys = n_keys;
+    for (int k = 0; k < n_keys; k++)
+        pd.key[k] = KeyDesc{k == 0 ? key.data : stg.in(keys[k].data, dtype_bytes(keys[k].dtype, n_rows)),
+                            k == 0 ? key.null_bits : (const uint8_t *)stg.in(keys[k].null_mask, (n_rows + 7) / 8),
+                            nullptr, keys[k].dtype};
+    if (stg.status) return stg.status;
+    ST_TRY(c->packed.ensure(Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
+    uint64_t *mm = c->packed.take<uint64_t>(2 * MAX_KEYS);
+    uint64_t *packed = c->packed.take<uint64_t>(n_rows);
+    if (!mm || !packed) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
+    uint64_t *h = reinterpret_cast<uint64_t *>(c->pinned);
+    for (int k = 0; k < n_keys; k++) { h[2 * k] = ~0ull; h[2 * k + 1] = 0; }
+    HIP_TRY(hipMemcpyAsync(mm, h, 16 * n_keys, hipMemcpyHostToDevice, c->stream));
+    int blocks = (int)std::min<int64_t>(2048, (n_rows + 255) / 256);
+    hipLaunchKernelGGL(key_minmax_kernel, dim3(blocks), dim3(256), 0, c->stream, pd, n_rows, mm);
+    HIP_TRY(hipMemcpyAsync(h, mm, 16 * n_keys, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t shift = 0;
+    for (int k = 0; k < n_keys; k++) {
+        uint64_t mn = h[2 * k], mx = h[2 * k + 1];
+        pd.nullable[k] = keys[k].null_mask ? 1u : 0u;
+        if (mn > mx) { mn = mx = 0; }                       // every row null
+        uint64_t span = mx - mn;                            // codes 0..span (+1 when nullable)
+        uint32_t bits = 0;
+        bool wide = span == ~0ull || (pd.nullable[k] && span + 1 == ~0ull);
+        uint64_t top = span + pd.nullable[k];
+        while (bits < 64 && (top >> bits)) bits++;
+        if (wide) bits = 65;
+        if (bits == 0) bits = 1;
+        if (shift + bits > 64)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                        "multi-key groupby: the key columns need more than 64 bits when packed "
+                        "(column %d needs %u bits after %u); not supported on the device path yet", k, bits, shift);
+        pd.min_sortable[k] = mn; pd.shift[k] = shift; pd.bits[k] = bits;
+        shift += bits;
+    }
+    hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, pd, n_rows, packed);
+    HIP_TRY(hipGetLastError());
+    key = KeyDesc{packed, nullptr, nullptr, DT_CELL};
+    return 0;
+}
+
 int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys,
                       int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
                       const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
@@ -1701,49 +1749,7 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     }
     if (stg.status) return stg.status;
     PackDesc pd{};
-    if (n_keys > 1 && n_rows > 0) {
-        // composite key: per-column code widths from a min/max pass, then one packed cell per row
-        PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
-        pd.n_keys = n_keys;
-        for (int k = 0; k < n_keys; k++)
-            pd.key[k] = KeyDesc{k == 0 ? rs.key.data : stg.in(keys[k].data, dtype_bytes(keys[k].dtype, n_rows)),
-                                k == 0 ? rs.key.null_bits : (const uint8_t *)stg.in(keys[k].null_mask, (n_rows + 7) / 8),
-                                nullptr, keys[k].dtype};
-        if (stg.status) return stg.status;
-        ST_TRY(c->packed.ensure(Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
-        uint64_t *mm = c->packed.take<uint64_t>(2 * MAX_KEYS);
-        uint64_t *packed = c->packed.take<uint64_t>(n_rows);
-        if (!mm || !packed) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
-        uint64_t *h = reinterpret_cast<uint64_t *>(c->pinned);
-        for (int k = 0; k < n_keys; k++) { h[2 * k] = ~0ull; h[2 * k + 1] = 0; }
-        HIP_TRY(hipMemcpyAsync(mm, h, 16 * n_keys, hipMemcpyHostToDevice, c->stream));
-        int blocks = (int)std::min<int64_t>(2048, (n_rows + 255) / 256);
-        hipLaunchKernelGGL(key_minmax_kernel, dim3(blocks), dim3(256), 0, c->stream, pd, n_rows, mm);
-        HIP_TRY(hipMemcpyAsync(h, mm, 16 * n_keys, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        uint32_t shift = 0;
-        for (int k = 0; k < n_keys; k++) {
-            uint64_t mn = h[2 * k], mx = h[2 * k + 1];
-            pd.nullable[k] = keys[k].null_mask ? 1u : 0u;
-            if (mn > mx) { mn = mx = 0; }                       // every row null
-            uint64_t span = mx - mn;                            // codes 0..span (+1 when nullable)
-            uint32_t bits = 0;
-            bool wide = span == ~0ull || (pd.nullable[k] && span + 1 == ~0ull);
-            uint64_t top = span + pd.nullable[k];
-            while (bits < 64 && (top >> bits)) bits++;
-            if (wide) bits = 65;
-            if (bits == 0) bits = 1;
-            if (shift + bits > 64)
-                return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
-                            "multi-key groupby: the key columns need more than 64 bits when packed "
-                            "(column %d needs %u bits after %u); not supported on the device path yet", k, bits, shift);
-            pd.min_sortable[k] = mn; pd.shift[k] = shift; pd.bits[k] = bits;
-            shift += bits;
-        }
-        hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, pd, n_rows, packed);
-        HIP_TRY(hipGetLastError());
-        rs.key = KeyDesc{packed, nullptr, nullptr, DT_CELL};
-    }
+    if (n_keys > 1 && n_rows > 0) ST_TRY(pack_multi_key(c, stg, keys, n_keys, n_rows, rs.key, pd));
     ST_TRY(run_engine(c, rs, pl, /*merge=*/false, partials, n_aggs, keys[0].dtype, n_keys));
     for (int a = 0; a < n_aggs && pl.has_median; a++)       // Median: a per-group sort, one pass per column
         if (aggs[a].op == PANDRS_HIP_AGG_MEDIAN)
@@ -1766,6 +1772,126 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     ST_TRY(timings_end(c));
     *out_n_groups = c->gb.n_groups;
     if (out_n_state) *out_n_state = c->gb.n_state;
+    return 0;
+}
+
+// ================================================================================================
+// group_by's own result: the row -> group assignment (reference grouping.rs:22-115 builds
+// HashMap<Vec<String>, Vec<usize>> with every group's row indices ascending, :98-103; GroupBy.groups
+// is a pub field, types.rs:52, read by filter / transform / custom aggregations and par_groupby).
+// Device form: CSR — group keys, offsets[G+1], rows[N] with each group's rows ascending.
+//   radix partition of (key cell, row) -> segmented sort by (key, row) -> run starts -> scan -> emit.
+// ================================================================================================
+__global__ void zero_range_kernel(uint64_t *a, const uint32_t *beg, const uint32_t *end) {
+    const uint32_t b = *beg, e = *end;
+    for (uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) a[i] = 0ull;
+}
+__global__ void run_start_flags_kernel(const uint64_t *keys, const uint32_t *null_beg, uint32_t n, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || i == *null_beg || keys[i - 1] != keys[i]) ? 1u : 0u;
+}
+__global__ void emit_groups_kernel(const uint64_t *keys, const uint32_t *prow, const uint32_t *null_beg, uint32_t n,
+                                   const uint32_t *flag, const uint32_t *gid, uint64_t *out_keys, uint8_t *out_null,
+                                   int64_t *out_off, int64_t *out_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_rows[i] = prow[i];
+    if (flag[i]) {
+        const uint32_t g = gid[i];
+        const bool nul = i >= *null_beg;
+        out_keys[g] = nul ? 0ull : keys[i];
+        out_null[g] = nul ? 1 : 0;
+        out_off[g] = i;
+    }
+    if (i == 0) out_off[gid[n]] = n;
+}
+
+int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
+                              int64_t n_rows, int64_t *out_n_groups) {
+    if (!c || !out_n_groups || n_rows < 0 || n_keys < 1 || !keys)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_indices: bad arguments");
+    if (n_keys > MAX_KEYS) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d key columns", MAX_KEYS);
+    ST_TRY(check_cols(keys, n_keys, "key"));
+    for (int k = 0; k < n_keys; k++)
+        if (n_rows > 0 && !keys[k].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column %d has no data", k);
+    if (n_rows >= (int64_t(1) << 32) - 16384)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_indices: more than 2^32 rows per call");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    c->gr = GroupsResult{};
+    Stager stg{c, mem_space};
+    if (mem_space == PANDRS_HIP_MEM_HOST && n_rows > 0) {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        size_t need = 0;
+        for (int k = 0; k < n_keys; k++) need += dtype_bytes(keys[k].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
+        ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
+    }
+    KeyDesc key{stg.in(keys[0].data, dtype_bytes(keys[0].dtype, n_rows)),
+                (const uint8_t *)stg.in(keys[0].null_mask, (n_rows + 7) / 8), nullptr, keys[0].dtype};
+    if (stg.status) return stg.status;
+    PackDesc pd{};
+    if (n_keys > 1 && n_rows > 0) ST_TRY(pack_multi_key(c, stg, keys, n_keys, n_rows, key, pd));
+    int64_t G = 0;
+    if (n_rows > 0) {
+        const size_t ws = engine_workspace_bytes(n_rows, 1, 0) + 3 * Arena::padded(size_t(n_rows + 2) * 4)
+                        + Arena::padded(scan_seg_count((size_t)n_rows + 1) * 4) + segsort_workspace_bytes(n_rows, P_MAX + 2, 4) + (1 << 20);
+        ST_TRY(c->work.ensure(ws, c->stream));
+        uint64_t *pk = c->work.take<uint64_t>(n_rows + 1);
+        uint32_t *prow = c->work.take<uint32_t>(n_rows + 2), *flag = c->work.take<uint32_t>(n_rows + 2), *gid = c->work.take<uint32_t>(n_rows + 2);
+        uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)n_rows + 1));
+        if (!pk || !prow || !flag || !gid || !seg) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (groupby_indices)");
+        int64_t P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)n_rows / 4900.0)), P_MAX);
+        PartInfo part{};
+        ScatterArgs sa{};
+        sa.key = key; sa.pkeys = pk; sa.n_rows = n_rows; sa.P = (uint32_t)P; sa.seed = 0x6A09E667u;
+        sa.mv[sa.n_move++] = MoveDesc{nullptr, prow, 3, 0};
+        ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+        const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
+        {
+            PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+            hipLaunchKernelGGL(zero_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end);
+            ST_TRY(segmented_sort_u32(c, pk, prow, part.offsets, part.NB, (uint32_t)P + 1, n_rows));
+            const unsigned nb = (unsigned)((n_rows + 255) / 256);
+            hipLaunchKernelGGL(run_start_flags_kernel, dim3(nb), dim3(256), 0, c->stream, pk, null_beg, (uint32_t)n_rows, flag);
+            HIP_TRY(hipMemsetAsync(flag + n_rows, 0, 8, c->stream));
+            ST_TRY(exclusive_scan_u32(c, flag, (size_t)n_rows + 1, gid, seg));
+            uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+            HIP_TRY(hipMemcpyAsync(h, gid + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            G = h[0];
+            ST_TRY(c->groups.ensure((size_t)n_keys * (Arena::padded(size_t(G) * 8) + Arena::padded(size_t(G))) +
+                                    Arena::padded(size_t(G + 1) * 8) + Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
+            GroupsResult &r = c->gr;
+            r.cap = G; r.n_keys = n_keys; r.n_rows = n_rows; r.n_groups = G;
+            r.keys = c->groups.take<uint64_t>((size_t)n_keys * G);
+            r.key_null = c->groups.take<uint8_t>((size_t)n_keys * G);
+            r.offsets = c->groups.take<int64_t>(G + 1);
+            r.rows = c->groups.take<int64_t>(n_rows);
+            if (!r.keys || !r.key_null || !r.offsets || !r.rows) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "groups arena too small");
+            hipLaunchKernelGGL(emit_groups_kernel, dim3(nb), dim3(256), 0, c->stream, pk, prow, null_beg, (uint32_t)n_rows,
+                               flag, gid, r.keys, r.key_null, r.offsets, r.rows);
+            if (n_keys > 1)
+                hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,
+                                   pd, G, (size_t)G, r.keys, r.key_null);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        ST_TRY(c->groups.ensure(4096, c->stream));
+        c->gr.offsets = c->groups.take<int64_t>(1);
+        HIP_TRY(hipMemsetAsync(c->gr.offsets, 0, 8, c->stream));
+        c->gr.n_keys = n_keys;
+    }
+    c->gr.valid = true;
+    {
+        int64_t K = 0;
+        for (int k = 0; k < n_keys; k++)
+            K += keys[k].dtype == PANDRS_HIP_U32CODE ? 4 : (keys[k].dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
+        c->timings.algorithmic_bytes = n_rows * (K + 8) + G * (K + 8);
+    }
+    ST_TRY(timings_end(c));
+    *out_n_groups = G;
     return 0;
 }
 

@@ -182,6 +182,38 @@ class Context:
         self.groupby_compute(keys, n_rows, vals, aggs)
         return self.groupby_fetch()
 
+    def groupby_indices(self, keys, n_rows):
+        """group_by's row -> group assignment (grouping.rs:22-115) in CSR form.
+        -> (key_cells[n_keys, G] u64, key_null[n_keys, G] u8, offsets[G + 1] i64, rows[n_rows] i64);
+        group g = rows[offsets[g]:offsets[g + 1]], ascending."""
+        keep = []
+        kc, sp = self._cols(keys, keep)
+        ng = C.c_int64(0)
+        st = self.lib.pandrs_hip_groupby_indices(self.h, sp, kc, len(keys), int(n_rows), C.byref(ng))
+        if st:
+            _raise(st)
+        g, nk = ng.value, len(keys)
+        if sp == L.MEM_DEVICE:
+            import torch
+            d = "cuda:%d" % self.device
+            cells = torch.empty((nk, g), dtype=torch.int64, device=d)
+            nulls = torch.empty((nk, g), dtype=torch.uint8, device=d)
+            off = torch.empty(g + 1, dtype=torch.int64, device=d)
+            rows = torch.empty(int(n_rows), dtype=torch.int64, device=d)
+            row = lambda t, i: t[i].data_ptr()
+        else:
+            cells = np.empty((nk, g), np.uint64)
+            nulls = np.empty((nk, g), np.uint8)
+            off = np.empty(g + 1, np.int64)
+            rows = np.empty(int(n_rows), np.int64)
+            row = lambda t, i: t[i].ctypes.data
+        pk = (C.c_void_p * nk)(*[row(cells, i) for i in range(nk)])
+        pn = (C.c_void_p * nk)(*[row(nulls, i) for i in range(nk)])
+        st = self.lib.pandrs_hip_groupby_indices_fetch(self.h, sp, pk, pn, _ptr(off), _ptr(rows))
+        if st:
+            _raise(st)
+        return cells, nulls, off, rows
+
     # -- mergeable partials (multi-GPU) --------------------------------------------------------------
     def groupby_partials(self, keys, n_rows, vals, aggs):
         """-> (n_groups, n_state); partial rows stay in the context until partials_split."""

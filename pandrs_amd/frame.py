@@ -215,12 +215,12 @@ def rust_f64_to_string(v):
     return s
 
 
-def _key_strings(dtype, cells, nulls):
+def _key_strings(dtype, cells, nulls, null_string="NULL"):
     """Group-key cells -> the strings the reference's result frame holds (grouping.rs:69-98)."""
     out = []
     for cell, nul in zip(cells.tolist(), nulls.tolist()):
         if nul:
-            out.append("NULL")
+            out.append(null_string)
         elif dtype == L.I64:
             out.append(str(int(np.int64(np.uint64(cell)))))
         elif dtype == L.F64:
@@ -290,6 +290,38 @@ class OptimizedDataFrame:
             if c not in self.column_indices:
                 raise ColumnNotFound(c)                       # grouping.rs:53-57
         return GroupBy(self, columns, as_multi_index and len(columns) > 1)   # grouping.rs:107
+
+    def par_groupby(self, group_by_columns):
+        """par_groupby (grouping.rs:124-331): {joined key -> sub-frame}.  Keys are the parts joined
+        with "_" (:186), a null part is "NA" (:158); tuples that collide after joining share a
+        group, as in the reference.  The row lists come from the device (groupby_indices), every
+        sub-frame is a device gather of all columns (:286-328)."""
+        cols = [group_by_columns] if isinstance(group_by_columns, str) else list(group_by_columns)
+        for c in cols:
+            if c not in self.column_indices:
+                raise ColumnNotFound(c)
+        gb = GroupBy(self, cols, False)
+        merged = {}
+        for key, rows in gb._group_rows(null_string="NA").items():
+            name = "_".join(key)
+            if name in merged:
+                merged[name] = np.sort(np.concatenate([merged[name], rows]))
+            else:
+                merged[name] = rows
+        return {name: self.filter_by_indices(rows) for name, rows in merged.items()}
+
+    def filter_by_indices(self, indices):
+        """data_ops.rs:124-209: row gather of every column; nulls become 0 / 0.0 / "" / false and the
+        result carries no masks; out-of-range indices are dropped."""
+        idx = np.asarray(indices, dtype=np.int64)
+        idx = idx[(idx >= 0) & (idx < self._row_count)]
+        result = OptimizedDataFrame()
+        if not self.columns:
+            return result
+        g = _Gatherer(get_context(), idx, idx)
+        for name in self.column_names:
+            result.add_column(name, g.take(self.column(name), left=True))
+        return result
 
     # -- whole-column reductions (K1: split_dataframe/aggregate.rs:21-62) ---------------------------------
     def _reduce(self, name):
@@ -415,13 +447,74 @@ class _Gatherer:
 
 # ---------------------------------------------------------------------------------------------- GroupBy
 class GroupBy:
-    """GroupBy<'a> (group/types.rs:46-55).  The row-index map `groups` of the reference is not
-    materialised: aggregation runs on the device straight from the columns."""
+    """GroupBy<'a> (group/types.rs:46-55).  Aggregations run on the device straight from the
+    columns; the row-index map `groups` (a pub field in the reference, types.rs:52) is built on the
+    device too, but only when something reads it (closures: filter / custom aggregations)."""
 
     def __init__(self, df, group_by_columns, create_multi_index=False):
         self.df = df
         self.group_by_columns = group_by_columns
         self.create_multi_index = create_multi_index
+        self._groups = None
+
+    def _group_rows(self, null_string="NULL"):
+        """{tuple(key strings) -> ascending row indices (numpy)} from pandrs_hip_groupby_indices."""
+        key_cols = [self.df.column(k) for k in self.group_by_columns]
+        cells, nulls, off, rows = get_context().groupby_indices([k.view() for k in key_cols], self.df.row_count())
+        strs = [_key_strings(k.dtype, cells[i], nulls[i], null_string) for i, k in enumerate(key_cols)]
+        return {key: rows[off[g]:off[g + 1]] for g, key in enumerate(zip(*strs))}
+
+    @property
+    def groups(self):
+        """HashMap<Vec<String>, Vec<usize>> of the reference (grouping.rs:62-104)."""
+        if self._groups is None:
+            self._groups = {k: v.tolist() for k, v in self._group_rows().items()}
+        return self._groups
+
+    def _values(self, column, rows):
+        """The group's non-null values of a numeric column as f64 (aggregation.rs:440-455)."""
+        col = self.df.column(column)
+        if col.dtype not in (L.I64, L.F64):
+            raise OperationFailed(L.ERR_OPERATION_FAILED, "column '%s' is not numeric" % column)
+        out = []
+        for r in rows:
+            v = col.get(r)
+            if v is not None:
+                out.append(float(v))
+        return out
+
+    def aggregate_custom(self, aggregations):
+        """aggregations: iterable of (column, fn(list[float]) -> float, result_name)
+        (CustomAggregation, types.rs:58-67; aggregate_custom, aggregation.rs:391-497): the closure
+        runs on the host over the group's non-null values (Int64 cast to f64), groups from the device."""
+        aggregations = list(aggregations)
+        for column, fn, _ in aggregations:
+            if fn is None:
+                raise OperationFailed(L.ERR_OPERATION_FAILED,
+                                      "Custom aggregation function is required for AggregateOp::Custom")
+            if column not in self.df.column_indices:
+                raise ColumnNotFound(column)
+        result = OptimizedDataFrame()
+        groups = self.groups
+        for i, name in enumerate(self.group_by_columns):
+            result.add_column(name, StringColumn([k[i] for k in groups]))
+        for column, fn, result_name in aggregations:
+            result.add_column(result_name, Float64Column([float(fn(self._values(column, rows))) for rows in groups.values()]))
+        return result
+
+    def custom(self, column, result_name, func):          # operations.rs:606
+        return self.aggregate_custom([(column, func, result_name)])
+
+    par_custom = custom
+    par_aggregate_custom = aggregate_custom
+
+    def filter(self, filter_fn):
+        """operations.rs:51-74: keep the rows of the groups whose sub-frame passes filter_fn."""
+        keep = [np.asarray(rows, np.int64) for rows in self.groups.values()
+                if filter_fn(self.df.filter_by_indices(rows))]
+        return self.df.filter_by_indices(np.concatenate(keep) if keep else np.zeros(0, np.int64))
+
+    par_filter = filter
 
     def aggregate(self, aggregations):
         """aggregations: iterable of (column, AggregateOp, alias)  (aggregation.rs:763-871)."""
@@ -498,6 +591,10 @@ class GroupBy:
 
     def last(self, column):
         return self._short(column, AggregateOp.Last)
+
+    # operations.rs:550-594: the par_* shortcuts share the exact path (see par_aggregate above)
+    par_sum, par_mean, par_min, par_max, par_count = sum, mean, min, max, count
+    par_std, par_var, par_median = std, var, median
 
 
 # ---------------------------------------------------------------------------------------------- LazyFrame

@@ -233,3 +233,31 @@ def test_lazy_pipeline_join_then_aggregate():
            .aggregate(["dept"], [("amount", AggregateOp.Sum, "total"), ("amount", AggregateOp.Mean, "avg")]).execute())
     got = {k: (t, a) for k, t, a in zip(res.column("dept").to_list(), res.column("total").data, res.column("avg").data)}
     assert got == {"a": (90.0, 30.0), "b": (60.0, 30.0)}
+
+
+@pytest.mark.gpu
+def test_groups_median_custom_filter_par_groupby():
+    """group_by's own result and its closure-based consumers: GroupBy.groups (grouping.rs:62-104),
+    median (operations.rs:480), custom aggregation (aggregation.rs:391-497, jit/groupby.rs tests use
+    closures over &[f64]), filter (operations.rs:51-74), par_groupby (grouping.rs:124-331)."""
+    df = _df_values_keys()
+    gb = df.group_by(["keys"])
+    assert gb.groups == {("A",): [0, 2], ("B",): [1, 3], ("C",): [4]}       # tests/groupby_test.rs:18-40 sizes 2/2/1
+    med = gb.median("values")
+    assert dict(zip(med.column("keys").to_list(), med.column("values_median").data.tolist())) == {"A": 20.0, "B": 30.0, "C": 50.0}
+    rng_ = gb.custom("values", "range", lambda v: max(v) - min(v))
+    assert dict(zip(rng_.column("keys").to_list(), rng_.column("range").data.tolist())) == {"A": 20.0, "B": 20.0, "C": 0.0}
+    big = gb.filter(lambda g: g.row_count() >= 2)
+    assert big.row_count() == 4 and sorted(big.column("values").data.tolist()) == [10, 20, 30, 40]
+    assert set(big.column("keys").to_list()) == {"A", "B"}
+    # par_groupby: parts joined with "_", a null part is "NA"; sub-frames hold every column, nulls filled
+    df2 = OptimizedDataFrame()
+    df2.add_column("k1", StringColumn(["x", "y", "x", "y", "x"]))
+    df2.add_column("k2", Int64Column.with_nulls([1, 2, 1, 0, 3], [False, False, False, True, False]))
+    df2.add_column("v", Float64Column.with_nulls([1.0, 2.0, 3.0, 4.0, 5.0], [False, False, True, False, False]))
+    parts = df2.par_groupby(["k1", "k2"])
+    assert set(parts) == {"x_1", "y_2", "y_NA", "x_3"}
+    assert parts["x_1"].row_count() == 2 and parts["x_1"].column("v").data.tolist() == [1.0, 0.0]
+    assert parts["x_1"].column_names == ["k1", "k2", "v"] and parts["y_NA"].column("k2").data.tolist() == [0]
+    with pytest.raises(ColumnNotFound):
+        df2.par_groupby(["nope"])

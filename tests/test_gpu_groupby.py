@@ -505,3 +505,66 @@ def test_gpu_config_is_honoured():
         cfg = L.Config(enabled=1, device_id=0, memory_limit=0, fallback_to_cpu=1, use_pinned_memory=0, min_size_threshold=10_000)
         lib.pandrs_hip_init(C.byref(cfg))
         pa.Context(0).close()        # resets the limit
+
+
+# ---- group_by's own result: row -> group assignment (G1, grouping.rs:22-115) -------------------------
+def check_group_indices(ctx, keys, n):
+    """Complete characterisation of the reference's HashMap<key, Vec<usize>>: the rows are a
+    permutation of 0..n, every group's rows are ascending and all carry the group's key, and there
+    are exactly as many groups as distinct keys."""
+    from oracle import oracle_np as ONP
+    cells, nulls, off, rows = ctx.groupby_indices(keys, n)
+    g = cells.shape[1]
+    assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) > 0)
+    np.testing.assert_array_equal(np.sort(rows), np.arange(n))
+    gid = np.repeat(np.arange(g), np.diff(off))
+    inner = np.ones(n, bool)
+    inner[off[:-1]] = False                                  # first row of every group
+    assert np.all(np.diff(rows)[inner[1:]] > 0), "rows of a group must ascend"
+    comp = []
+    for k, col in enumerate(keys):
+        nul, cell = ONP.key_cells(col, n)
+        np.testing.assert_array_equal(nulls[k][gid], nul[rows])
+        np.testing.assert_array_equal(np.where(nulls[k][gid] == 1, 0, cells[k][gid]), cell[rows])
+        comp += [nul.astype(np.uint64), cell]
+    assert len(np.unique(np.stack(comp, 1), axis=0)) == g
+    return cells, nulls, off, rows
+
+
+def test_group_indices_small_matches_reference_semantics(ctx, golden):
+    from oracle import oracle_np as ONP
+    case = golden["groupby"][0]
+    codes, pool = codes_of(case["key_strings"])                # tests/groupby_test.rs:18-82: sizes A 2, B 2, C 1
+    cells, nulls, off, rows = ctx.groupby_indices([(codes, None, O.U32CODE)], len(codes))
+    want = ONP.group_indices([(codes, None, O.U32CODE)], len(codes), pools=[pool])
+    got = {(pool[int(cells[0, g])],): rows[off[g]:off[g + 1]].tolist() for g in range(cells.shape[1])}
+    assert got == want
+    k = (np.array([5, -1, 5, 0, -1, 7, 0], np.int64), O.pack_mask([0, 0, 0, 1, 0, 0, 1]), O.I64)
+    cells, nulls, off, rows = check_group_indices(ctx, [k], 7)
+    got = {("NULL" if nulls[0, g] else str(int(np.int64(cells[0, g]))),): rows[off[g]:off[g + 1]].tolist() for g in range(cells.shape[1])}
+    assert got == ONP.group_indices([k], 7) == {("5",): [0, 2], ("-1",): [1, 4], ("NULL",): [3, 6], ("7",): [5]}
+    check_group_indices(ctx, [(np.zeros(0, np.int64), None, O.I64)], 0)
+
+
+@pytest.mark.parametrize("n,g,kd", [(300_000, 2_000, O.I64), (2_000_000, 700_000, O.I64), (1_500_000, 40, O.F64),
+                                    (1_000_000, 3, O.U32CODE), (500_000, 2, O.BOOLBITS)])
+def test_group_indices_random(ctx, n, g, kd):
+    rng = np.random.default_rng(n // 1000 + g)
+    ids = rng.integers(0, g, n)
+    if kd == O.I64:
+        data = sparse_keys_from(ids)
+    elif kd == O.F64:
+        data = np.concatenate([rng.normal(size=g - 4), [0.0, -0.0, np.nan, np.inf]])[ids]
+    elif kd == O.U32CODE:
+        data = ids.astype(np.uint32)
+    else:
+        data = np.packbits(ids % 2 == 0, bitorder="little")
+    check_group_indices(ctx, [(data, O.pack_mask(rng.random(n) < 0.01), kd)], n)
+
+
+def test_group_indices_multi_key(ctx):
+    rng = np.random.default_rng(31)
+    n = 400_000
+    k0 = (rng.integers(0, 30, n).astype(np.uint32), None, O.U32CODE)
+    k1 = (rng.integers(-5, 5, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.05), O.I64)
+    check_group_indices(ctx, [k0, k1], n)
