@@ -38,6 +38,14 @@ if "c3" in which:
     v = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) for _ in range(2)]
     aggs = [(c, op) for c in range(2) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)] + [(0, pa.COUNT)]
     run("C3 100M/u32 codes 10K groups 80-20/9 aggs", n, lambda: ctx.groupby_compute([(k, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
+    if "c3u" in which:      # same shape, uniform keys: how much of C3's aggregate time is hot-key LDS contention?
+        k2 = torch.randint(0, g, (n,), device=d, generator=gen).to(torch.int32)
+        run("C3-uniform 100M/u32 codes 10K groups uniform/9 aggs", n, lambda: ctx.groupby_compute([(k2, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
+        for P in (64, 128, 256, 1024):
+            ctx.set_option("partitions", P)
+            run("C3 80-20 P=%d" % P, n, lambda: ctx.groupby_compute([(k, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
+        ctx.set_option("partitions", 0)
+        del k2
     del k, v, hot
 if "c4" in which:
     n, g = 125_000_000, 10_000_000

@@ -201,6 +201,23 @@ def join_groupby_sum(lkey, lval, n_left, rkey, rgroup, n_right):
             _take(pa.value, (1, g), np.float64))
 
 
+def groupby_typed_mt(keys_i64, vals_f64, n_threads):
+    """Fair typed CPU baseline, NOT the reference's algorithm: one i64 key, f64
+    columns, all cores.  -> (keys u64[G], stats[G, 1 + 3 * n_vals]: count, then sum/min/max per column)."""
+    keys_i64 = np.ascontiguousarray(keys_i64, np.int64)
+    vals = [np.ascontiguousarray(v, np.float64) for v in vals_f64]
+    n, nv = len(keys_i64), len(vals)
+    ptrs = (C.c_void_p * max(nv, 1))(*[v.ctypes.data for v in vals])
+    ng = C.c_int64(0)
+    pk, ps = C.c_void_p(), C.c_void_p()
+    rc = lib().oracle_groupby_typed_mt(C.c_void_p(keys_i64.ctypes.data), C.c_int64(n), ptrs, C.c_int(nv),
+                                       C.c_int(int(n_threads)), C.byref(ng), C.byref(pk), C.byref(ps))
+    if rc:
+        raise OracleError(rc)
+    g = ng.value
+    return _take(pk.value, (g,), np.uint64), _take(ps.value, (g, 1 + 3 * nv), np.float64)
+
+
 def pack_mask(nulls):
     """bool array -> LSB-first bitmap (reference: create_bitmask, src/core/column.rs:163-177)."""
     nulls = np.asarray(nulls, dtype=bool)

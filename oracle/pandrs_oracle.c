@@ -537,3 +537,107 @@ int oracle_join_groupby_sum(const ocol *lkey, const ocol *lval, int64_t n_left,
     free(v); free(vi); free(g); free(li); free(ri);
     return rc;
 }
+
+/* ---------------------------------------------------------------- fair typed CPU baseline
+ * "a fair typed CPU baseline (i64 open-addressing hash, all cores) so the
+ * speed-up is not just 'removed the strings'".  NOT the reference's algorithm (that is
+ * oracle_groupby_agg_ref above) — it is what a good CPU implementation of the same operator does:
+ * one i64 key, f64 value columns, {count, sum, min, max} per column kept per group (mean = sum /
+ * count).  Every thread owns the keys whose hash falls in its slice, scans the key column, and
+ * aggregates its rows in a private open-addressing table: no locks, no merge.  Used only by
+ * bench.py's cpu_baseline leg and checked against oracle_groupby_agg in tests/. */
+#include <omp.h>
+typedef struct { uint64_t key; int64_t n; int used; } tslot;
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33; return x;
+}
+int oracle_groupby_typed_mt(const int64_t *keys, int64_t n_rows, const double *const *vals, int n_vals,
+                            int n_threads, int64_t *out_n_groups, uint64_t **out_keys,
+                            double **out_stats /* [n_groups][1 + 3 * n_vals]: count, then sum,min,max per column */) {
+    if (n_threads < 1) n_threads = 1;
+    const int W = 1 + 3 * n_vals;
+    uint64_t **tk = (uint64_t **)calloc((size_t)n_threads, sizeof(*tk));
+    double **ts = (double **)calloc((size_t)n_threads, sizeof(*ts));
+    int64_t *tn = (int64_t *)calloc((size_t)n_threads, sizeof(*tn));
+    int failed = 0;
+    /* phase 1: the owner thread of every row (hash once per row, all cores) */
+    uint8_t *owner = (uint8_t *)malloc((size_t)(n_rows ? n_rows : 1));
+    if (n_threads > 255) n_threads = 255;
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int64_t i = 0; i < n_rows; i++) owner[i] = (uint8_t)((mix64((uint64_t)keys[i]) >> 40) % (uint64_t)n_threads);
+    /* phase 2: every thread aggregates the rows it owns in a private table */
+#pragma omp parallel num_threads(n_threads)
+    {
+        const int t = omp_get_thread_num();
+        int64_t cap = 1 << 12, ng = 0;
+        tslot *slots = (tslot *)calloc((size_t)cap, sizeof(tslot));
+        int64_t *slot_group = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+        int64_t gcap = 1 << 11;
+        uint64_t *gk = (uint64_t *)malloc(8 * (size_t)gcap);
+        double *gs = (double *)malloc(8 * (size_t)gcap * (size_t)W);
+        for (int64_t i = 0; i < n_rows && slots && gk && gs; i++) {
+            if (owner[i] != (uint8_t)t) continue;
+            const uint64_t k = (uint64_t)keys[i], h = mix64(k);
+            int64_t p = (int64_t)(h & (uint64_t)(cap - 1));
+            while (slots[p].used && slots[p].key != k) p = (p + 1) & (cap - 1);
+            int64_t g;
+            if (!slots[p].used) {
+                if (ng == gcap) {
+                    gcap *= 2;
+                    gk = (uint64_t *)realloc(gk, 8 * (size_t)gcap);
+                    gs = (double *)realloc(gs, 8 * (size_t)gcap * (size_t)W);
+                }
+                g = ng++;
+                slots[p].used = 1; slots[p].key = k; slot_group[p] = g;
+                gk[g] = k;
+                double *st = gs + (size_t)g * (size_t)W;
+                st[0] = 0.0;
+                for (int c = 0; c < n_vals; c++) { st[1 + 3 * c] = 0.0; st[2 + 3 * c] = INFINITY; st[3 + 3 * c] = -INFINITY; }
+                if (ng * 2 > cap) {                          /* grow + rehash */
+                    int64_t ncap = cap * 2;
+                    tslot *ns = (tslot *)calloc((size_t)ncap, sizeof(tslot));
+                    int64_t *nsg = (int64_t *)malloc(sizeof(int64_t) * (size_t)ncap);
+                    for (int64_t q = 0; q < cap; q++) if (slots[q].used) {
+                        int64_t r = (int64_t)(mix64(slots[q].key) & (uint64_t)(ncap - 1));
+                        while (ns[r].used) r = (r + 1) & (ncap - 1);
+                        ns[r] = slots[q]; nsg[r] = slot_group[q];
+                    }
+                    free(slots); free(slot_group); slots = ns; slot_group = nsg; cap = ncap;
+                }
+            } else {
+                g = slot_group[p];
+            }
+            double *st = gs + (size_t)g * (size_t)W;
+            st[0] += 1.0;
+            for (int c = 0; c < n_vals; c++) {
+                const double v = vals[c][i];
+                st[1 + 3 * c] += v;
+                if (v < st[2 + 3 * c]) st[2 + 3 * c] = v;
+                if (v > st[3 + 3 * c]) st[3 + 3 * c] = v;
+            }
+        }
+        if (!slots || !gk || !gs) {
+#pragma omp atomic write
+            failed = 1;
+        }
+        free(slots); free(slot_group);
+        tk[t] = gk; ts[t] = gs; tn[t] = ng;
+    }
+    int64_t G = 0;
+    for (int t = 0; t < n_threads; t++) G += tn[t];
+    uint64_t *ok = (uint64_t *)malloc(8 * (size_t)(G ? G : 1));
+    double *os = (double *)malloc(8 * (size_t)(G ? G : 1) * (size_t)W);
+    int64_t o = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (tn[t] && tk[t] && ts[t]) {
+            memcpy(ok + o, tk[t], 8 * (size_t)tn[t]);
+            memcpy(os + (size_t)o * (size_t)W, ts[t], 8 * (size_t)tn[t] * (size_t)W);
+            o += tn[t];
+        }
+        free(tk[t]); free(ts[t]);
+    }
+    free(tk); free(ts); free(tn); free(owner);
+    if (failed) { free(ok); free(os); return PANDRS_HIP_ERR_OUT_OF_MEMORY; }
+    *out_n_groups = G; *out_keys = ok; *out_stats = os;
+    return 0;
+}

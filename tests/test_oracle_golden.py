@@ -258,3 +258,19 @@ def test_fused_join_groupby_matches_composition():
             sums[lut[k]] = sums.get(lut[k], 0.0) + v
     assert kc[0].astype(np.int64).tolist() == sorted(sums)
     np.testing.assert_allclose(oa[0], [sums[k] for k in sorted(sums)], rtol=1e-12)
+
+
+def test_typed_multithreaded_baseline_agrees_with_oracle():
+    """bench.py's second CPU baseline (typed keys, all cores) computes the same
+    aggregates as the oracle on the C2 shape."""
+    rng = np.random.default_rng(3)
+    n, g = 200_000, 5_000
+    keys = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    vals = [rng.normal(100, 10, n) for _ in range(2)]
+    k, st = O.groupby_typed_mt(keys, vals, 4)
+    aggs = [(0, O.COUNT)] + [(c, op) for c in range(2) for op in (O.SUM, O.MIN, O.MAX)]
+    wk, wn, wa = O.groupby_agg([(keys, None, O.I64)], n, [(v, None, O.F64) for v in vals], aggs)
+    assert len(k) == wk.shape[1] == len(np.unique(keys))
+    o1, o2 = np.argsort(k), np.argsort(wk[0])
+    np.testing.assert_array_equal(k[o1], wk[0][o2])
+    np.testing.assert_allclose(st[o1], wa[:, o2].T, rtol=1e-12)
