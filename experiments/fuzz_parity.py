@@ -50,7 +50,7 @@ for case in range(n_cases):
             kdts = [kd]
             if nk == 2:
                 keys.append((rng.integers(0, 5, n).astype(np.uint32), mask(rng, n, rng.choice([0, 0.05])), O.U32CODE)); kdts.append(O.U32CODE)
-                if kd in (O.I64, O.F64): keys[0] = (rng.integers(-100, 100, n).astype(np.int64), keys[0][1], O.I64); kdts[0] = O.I64
+                if kd in (O.I64, O.F64) and rng.random() < 0.6: keys[0] = (rng.integers(-100, 100, n).astype(np.int64), keys[0][1], O.I64); kdts[0] = O.I64
             nv = int(rng.integers(1, 4))
             vals = []
             for _ in range(nv):

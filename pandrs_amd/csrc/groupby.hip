@@ -1568,6 +1568,79 @@ static int32_t check_cols(const pandrs_hip_column *cols, int n, const char *what
     return 0;
 }
 
+// ================================================================================================
+// group_by's own result: the row -> group assignment (reference grouping.rs:22-115 builds
+// HashMap<Vec<String>, Vec<usize>> with every group's row indices ascending, :98-103; GroupBy.groups
+// is a pub field, types.rs:52, read by filter / transform / custom aggregations and par_groupby).
+// Device form: CSR — group keys, offsets[G+1], rows[N] with each group's rows ascending.
+//   radix partition of (key cell, row) -> segmented sort by (key, row) -> run starts -> scan -> emit.
+// ================================================================================================
+__global__ void zero_range_kernel(uint64_t *a, const uint32_t *beg, const uint32_t *end) {
+    const uint32_t b = *beg, e = *end;
+    for (uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) a[i] = 0ull;
+}
+__global__ void run_start_flags_kernel(const uint64_t *keys, const uint32_t *null_beg, uint32_t n, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || i == *null_beg || keys[i - 1] != keys[i]) ? 1u : 0u;
+}
+__global__ void emit_groups_kernel(const uint64_t *keys, const uint32_t *prow, const uint32_t *null_beg, uint32_t n,
+                                   const uint32_t *flag, const uint32_t *gid, uint64_t *out_keys, uint8_t *out_null,
+                                   int64_t *out_off, int64_t *out_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_rows[i] = prow[i];
+    if (flag[i]) {
+        const uint32_t g = gid[i];
+        const bool nul = i >= *null_beg;
+        out_keys[g] = nul ? 0ull : keys[i];
+        out_null[g] = nul ? 1 : 0;
+        out_off[g] = i;
+    }
+    if (i == 0) out_off[gid[n]] = n;
+}
+
+// Rows sorted by (radix partition, key cell, row) with the run starts marked: the common first half
+// of groupby_indices and of the dictionary encoding of wide multi-key columns.  Everything lives in
+// c->work (which is re-sized here); synchronises the stream to learn the number of groups.
+struct SortedGroups {
+    uint64_t *pk = nullptr;         // key cells in sorted order (NULL-key rows last, cells zeroed)
+    uint32_t *prow = nullptr;       // original row of every sorted position
+    uint32_t *flag = nullptr;       // 1 at the first position of a group
+    uint32_t *gid = nullptr;        // exclusive scan of flag; gid[n] = number of groups
+    const uint32_t *null_beg = nullptr;   // device: first position of the NULL-key group
+    int64_t G = 0;
+};
+static int32_t build_sorted_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, SortedGroups *o) {
+    const size_t ws = engine_workspace_bytes(n_rows, 1, 0) + 3 * Arena::padded(size_t(n_rows + 2) * 4)
+                    + Arena::padded(scan_seg_count((size_t)n_rows + 1) * 4) + segsort_workspace_bytes(n_rows, P_MAX + 2, 4) + (1 << 20);
+    ST_TRY(c->work.ensure(ws, c->stream));
+    o->pk = c->work.take<uint64_t>(n_rows + 1);
+    o->prow = c->work.take<uint32_t>(n_rows + 2); o->flag = c->work.take<uint32_t>(n_rows + 2); o->gid = c->work.take<uint32_t>(n_rows + 2);
+    uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)n_rows + 1));
+    if (!o->pk || !o->prow || !o->flag || !o->gid || !seg) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (group index)");
+    int64_t P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)n_rows / 4900.0)), P_MAX);
+    PartInfo part{};
+    ScatterArgs sa{};
+    sa.key = key; sa.pkeys = o->pk; sa.n_rows = n_rows; sa.P = (uint32_t)P; sa.seed = 0x6A09E667u;
+    sa.mv[sa.n_move++] = MoveDesc{nullptr, o->prow, 3, 0};
+    ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+    o->null_beg = part.offsets + (size_t)P * part.NB;
+    const uint32_t *null_end = part.offsets + (size_t)(P + 1) * part.NB;
+    PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+    hipLaunchKernelGGL(zero_range_kernel, dim3(256), dim3(256), 0, c->stream, o->pk, o->null_beg, null_end);
+    ST_TRY(segmented_sort_u32(c, o->pk, o->prow, part.offsets, part.NB, (uint32_t)P + 1, n_rows));
+    hipLaunchKernelGGL(run_start_flags_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                       o->pk, o->null_beg, (uint32_t)n_rows, o->flag);
+    HIP_TRY(hipMemsetAsync(o->flag + n_rows, 0, 8, c->stream));
+    ST_TRY(exclusive_scan_u32(c, o->flag, (size_t)n_rows + 1, o->gid, seg));
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    HIP_TRY(hipMemcpyAsync(h, o->gid + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    o->G = h[0];
+    return 0;
+}
+
 // ---- multi-key groupby: composite keys packed into one 8-byte cell -------------------------------
 // The reference groups on Vec<String> (grouping.rs:62-104).  Here every key column is reduced to
 // an order-preserving code  code = sortable(cell) - min + (nullable ? 1 : 0)  (0 = NULL) of just
@@ -1578,6 +1651,11 @@ struct PackDesc {
     KeyDesc key[MAX_KEYS];
     uint64_t min_sortable[MAX_KEYS];
     uint32_t shift[MAX_KEYS], bits[MAX_KEYS], nullable[MAX_KEYS];
+    // dictionary-encoded columns (too wide for their share of the 64 bits): dense[k][row] = the row's
+    // group id in column k alone, dict[k][id] / dict_null[k][id] = that group's cell / null flag
+    const uint32_t *dense[MAX_KEYS];
+    const uint64_t *dict[MAX_KEYS];
+    const uint8_t *dict_null[MAX_KEYS];
     int n_keys;
 };
 __device__ __forceinline__ uint64_t sortable_cell(int dtype, uint64_t cell) {
@@ -1615,7 +1693,8 @@ __global__ void pack_keys_kernel(PackDesc d, int64_t n, uint64_t *out) {
     uint64_t cell = 0;
     for (int k = 0; k < d.n_keys; k++) {
         uint64_t code = 0;
-        if (!key_is_null(d.key[k], i))
+        if (d.dense[k]) code = d.dense[k][i];
+        else if (!key_is_null(d.key[k], i))
             code = sortable_cell(d.key[k].dtype, key_cell(d.key[k], i)) - d.min_sortable[k] + d.nullable[k];
         cell |= code << d.shift[k];
     }
@@ -1629,9 +1708,28 @@ __global__ void unpack_keys_kernel(PackDesc d, int64_t g, size_t cap, uint64_t *
     for (int k = 0; k < d.n_keys; k++) {
         uint64_t mask = d.bits[k] >= 64 ? ~0ull : ((1ull << d.bits[k]) - 1);
         uint64_t code = (cell >> d.shift[k]) & mask;
+        if (d.dense[k]) {
+            keys[(size_t)k * cap + i] = d.dict[k][code];
+            knull[(size_t)k * cap + i] = d.dict_null[k][code];
+            continue;
+        }
         bool nul = d.nullable[k] && code == 0;
         keys[(size_t)k * cap + i] = nul ? 0ull : unsortable_cell(d.key[k].dtype, code - d.nullable[k] + d.min_sortable[k]);
         knull[(size_t)k * cap + i] = nul ? 1 : 0;
+    }
+}
+
+// dictionary encoding of one key column from its sorted group structure
+__global__ void dense_emit_kernel(const uint64_t *pk, const uint32_t *prow, const uint32_t *null_beg, uint32_t n,
+                                  const uint32_t *flag, const uint32_t *gid, uint32_t *code, uint64_t *dict, uint8_t *dict_null) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = gid[i] + flag[i] - 1;      // gid = starts before i; a start opens group gid[i]
+    code[prow[i]] = g;
+    if (flag[i]) {
+        const bool nul = i >= *null_beg;
+        dict[g] = nul ? 0ull : pk[i];
+        dict_null[g] = nul ? 1 : 0;
     }
 }
 
@@ -1647,10 +1745,9 @@ static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_c
                             k == 0 ? key.null_bits : (const uint8_t *)stg.in(keys[k].null_mask, (n_rows + 7) / 8),
                             nullptr, keys[k].dtype};
     if (stg.status) return stg.status;
-    ST_TRY(c->packed.ensure(Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
-    uint64_t *mm = c->packed.take<uint64_t>(2 * MAX_KEYS);
-    uint64_t *packed = c->packed.take<uint64_t>(n_rows);
-    if (!mm || !packed) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small");
+    ST_TRY(c->work.ensure(1 << 16, c->stream));
+    uint64_t *mm = c->work.take<uint64_t>(2 * MAX_KEYS);
+    if (!mm) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (multi-key)");
     uint64_t *h = reinterpret_cast<uint64_t *>(c->pinned);
     for (int k = 0; k < n_keys; k++) { h[2 * k] = ~0ull; h[2 * k + 1] = 0; }
     HIP_TRY(hipMemcpyAsync(mm, h, 16 * n_keys, hipMemcpyHostToDevice, c->stream));
@@ -1658,7 +1755,7 @@ static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_c
     hipLaunchKernelGGL(key_minmax_kernel, dim3(blocks), dim3(256), 0, c->stream, pd, n_rows, mm);
     HIP_TRY(hipMemcpyAsync(h, mm, 16 * n_keys, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    uint32_t shift = 0;
+    uint32_t need[MAX_KEYS], total = 0;
     for (int k = 0; k < n_keys; k++) {
         uint64_t mn = h[2 * k], mx = h[2 * k + 1];
         pd.nullable[k] = keys[k].null_mask ? 1u : 0u;
@@ -1670,13 +1767,48 @@ static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_c
         while (bits < 64 && (top >> bits)) bits++;
         if (wide) bits = 65;
         if (bits == 0) bits = 1;
-        if (shift + bits > 64)
-            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
-                        "multi-key groupby: the key columns need more than 64 bits when packed "
-                        "(column %d needs %u bits after %u); not supported on the device path yet", k, bits, shift);
-        pd.min_sortable[k] = mn; pd.shift[k] = shift; pd.bits[k] = bits;
-        shift += bits;
+        pd.min_sortable[k] = mn; need[k] = bits; total += bits;
     }
+    {   // packed cells + (only when the codes do not fit) room for the dictionaries of the widest columns
+        uint32_t t = total, n_dict = 0, nd[MAX_KEYS];
+        for (int k = 0; k < n_keys; k++) nd[k] = need[k];
+        while (t > 64 && n_dict < (uint32_t)n_keys) {       // every encoded column needs at most 32 bits
+            int w = 0;
+            for (int k = 1; k < n_keys; k++) if (nd[k] > nd[w]) w = k;
+            t -= nd[w]; nd[w] = 0; t += 32; n_dict++;
+        }
+        ST_TRY(c->packed.ensure(Arena::padded(size_t(n_rows) * 8) + (size_t)n_dict * (Arena::padded(size_t(n_rows) * 4) +
+                                Arena::padded(size_t(n_rows) * 8) + Arena::padded(size_t(n_rows))) + 8192, c->stream));
+    }
+    uint64_t *packed = c->packed.take<uint64_t>(n_rows);
+    if (!packed) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "packed arena too small");
+    // Too wide for one 64-bit cell (e.g. two hashed i64 ids): the widest columns are dictionary-encoded
+    // — a column cannot have more distinct values than rows, so its dense group id needs <= 32 bits —
+    // until the codes fit.  One group-index pass (partition + segmented sort) per encoded column.
+    while (total > 64) {
+        int w = -1;
+        for (int k = 0; k < n_keys; k++)
+            if (!pd.dense[k] && (w < 0 || need[k] > need[w])) w = k;
+        if (w < 0 || need[w] <= 1)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                        "multi-key groupby: the key columns need more than 64 bits even with every column "
+                        "dictionary-encoded (%u bits); not supported on the device path", total);
+        SortedGroups sg;
+        ST_TRY(build_sorted_groups(c, pd.key[w], n_rows, &sg));
+        uint32_t *code = c->packed.take<uint32_t>(n_rows);
+        uint64_t *dict = c->packed.take<uint64_t>(sg.G);
+        uint8_t *dnull = c->packed.take<uint8_t>(sg.G);
+        if (!code || !dict || !dnull) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "packed arena too small (dictionary)");
+        hipLaunchKernelGGL(dense_emit_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                           sg.pk, sg.prow, sg.null_beg, (uint32_t)n_rows, sg.flag, sg.gid, code, dict, dnull);
+        HIP_TRY(hipGetLastError());
+        pd.dense[w] = code; pd.dict[w] = dict; pd.dict_null[w] = dnull;
+        uint32_t bits = 1;
+        while (bits < 32 && ((uint64_t)(sg.G - 1) >> bits)) bits++;
+        total -= need[w]; need[w] = bits; total += bits;
+    }
+    uint32_t shift = 0;
+    for (int k = 0; k < n_keys; k++) { pd.shift[k] = shift; pd.bits[k] = need[k]; shift += need[k]; }
     hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, pd, n_rows, packed);
     HIP_TRY(hipGetLastError());
     key = KeyDesc{packed, nullptr, nullptr, DT_CELL};
@@ -1775,38 +1907,6 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     return 0;
 }
 
-// ================================================================================================
-// group_by's own result: the row -> group assignment (reference grouping.rs:22-115 builds
-// HashMap<Vec<String>, Vec<usize>> with every group's row indices ascending, :98-103; GroupBy.groups
-// is a pub field, types.rs:52, read by filter / transform / custom aggregations and par_groupby).
-// Device form: CSR — group keys, offsets[G+1], rows[N] with each group's rows ascending.
-//   radix partition of (key cell, row) -> segmented sort by (key, row) -> run starts -> scan -> emit.
-// ================================================================================================
-__global__ void zero_range_kernel(uint64_t *a, const uint32_t *beg, const uint32_t *end) {
-    const uint32_t b = *beg, e = *end;
-    for (uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) a[i] = 0ull;
-}
-__global__ void run_start_flags_kernel(const uint64_t *keys, const uint32_t *null_beg, uint32_t n, uint32_t *flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    flag[i] = (i == 0 || i == *null_beg || keys[i - 1] != keys[i]) ? 1u : 0u;
-}
-__global__ void emit_groups_kernel(const uint64_t *keys, const uint32_t *prow, const uint32_t *null_beg, uint32_t n,
-                                   const uint32_t *flag, const uint32_t *gid, uint64_t *out_keys, uint8_t *out_null,
-                                   int64_t *out_off, int64_t *out_rows) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out_rows[i] = prow[i];
-    if (flag[i]) {
-        const uint32_t g = gid[i];
-        const bool nul = i >= *null_beg;
-        out_keys[g] = nul ? 0ull : keys[i];
-        out_null[g] = nul ? 1 : 0;
-        out_off[g] = i;
-    }
-    if (i == 0) out_off[gid[n]] = n;
-}
-
 int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
                               int64_t n_rows, int64_t *out_n_groups) {
     if (!c || !out_n_groups || n_rows < 0 || n_keys < 1 || !keys)
@@ -1835,48 +1935,25 @@ int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs
     if (n_keys > 1 && n_rows > 0) ST_TRY(pack_multi_key(c, stg, keys, n_keys, n_rows, key, pd));
     int64_t G = 0;
     if (n_rows > 0) {
-        const size_t ws = engine_workspace_bytes(n_rows, 1, 0) + 3 * Arena::padded(size_t(n_rows + 2) * 4)
-                        + Arena::padded(scan_seg_count((size_t)n_rows + 1) * 4) + segsort_workspace_bytes(n_rows, P_MAX + 2, 4) + (1 << 20);
-        ST_TRY(c->work.ensure(ws, c->stream));
-        uint64_t *pk = c->work.take<uint64_t>(n_rows + 1);
-        uint32_t *prow = c->work.take<uint32_t>(n_rows + 2), *flag = c->work.take<uint32_t>(n_rows + 2), *gid = c->work.take<uint32_t>(n_rows + 2);
-        uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)n_rows + 1));
-        if (!pk || !prow || !flag || !gid || !seg) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (groupby_indices)");
-        int64_t P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)n_rows / 4900.0)), P_MAX);
-        PartInfo part{};
-        ScatterArgs sa{};
-        sa.key = key; sa.pkeys = pk; sa.n_rows = n_rows; sa.P = (uint32_t)P; sa.seed = 0x6A09E667u;
-        sa.mv[sa.n_move++] = MoveDesc{nullptr, prow, 3, 0};
-        ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
-        const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
-        {
-            PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
-            hipLaunchKernelGGL(zero_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end);
-            ST_TRY(segmented_sort_u32(c, pk, prow, part.offsets, part.NB, (uint32_t)P + 1, n_rows));
-            const unsigned nb = (unsigned)((n_rows + 255) / 256);
-            hipLaunchKernelGGL(run_start_flags_kernel, dim3(nb), dim3(256), 0, c->stream, pk, null_beg, (uint32_t)n_rows, flag);
-            HIP_TRY(hipMemsetAsync(flag + n_rows, 0, 8, c->stream));
-            ST_TRY(exclusive_scan_u32(c, flag, (size_t)n_rows + 1, gid, seg));
-            uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-            HIP_TRY(hipMemcpyAsync(h, gid + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            G = h[0];
-            ST_TRY(c->groups.ensure((size_t)n_keys * (Arena::padded(size_t(G) * 8) + Arena::padded(size_t(G))) +
-                                    Arena::padded(size_t(G + 1) * 8) + Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
-            GroupsResult &r = c->gr;
-            r.cap = G; r.n_keys = n_keys; r.n_rows = n_rows; r.n_groups = G;
-            r.keys = c->groups.take<uint64_t>((size_t)n_keys * G);
-            r.key_null = c->groups.take<uint8_t>((size_t)n_keys * G);
-            r.offsets = c->groups.take<int64_t>(G + 1);
-            r.rows = c->groups.take<int64_t>(n_rows);
-            if (!r.keys || !r.key_null || !r.offsets || !r.rows) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "groups arena too small");
-            hipLaunchKernelGGL(emit_groups_kernel, dim3(nb), dim3(256), 0, c->stream, pk, prow, null_beg, (uint32_t)n_rows,
-                               flag, gid, r.keys, r.key_null, r.offsets, r.rows);
-            if (n_keys > 1)
-                hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,
-                                   pd, G, (size_t)G, r.keys, r.key_null);
-            HIP_TRY(hipGetLastError());
-        }
+        SortedGroups sg;
+        ST_TRY(build_sorted_groups(c, key, n_rows, &sg));
+        G = sg.G;
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+        ST_TRY(c->groups.ensure((size_t)n_keys * (Arena::padded(size_t(G) * 8) + Arena::padded(size_t(G))) +
+                                Arena::padded(size_t(G + 1) * 8) + Arena::padded(size_t(n_rows) * 8) + 4096, c->stream));
+        GroupsResult &r = c->gr;
+        r.cap = G; r.n_keys = n_keys; r.n_rows = n_rows; r.n_groups = G;
+        r.keys = c->groups.take<uint64_t>((size_t)n_keys * G);
+        r.key_null = c->groups.take<uint8_t>((size_t)n_keys * G);
+        r.offsets = c->groups.take<int64_t>(G + 1);
+        r.rows = c->groups.take<int64_t>(n_rows);
+        if (!r.keys || !r.key_null || !r.offsets || !r.rows) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "groups arena too small");
+        hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                           sg.pk, sg.prow, sg.null_beg, (uint32_t)n_rows, sg.flag, sg.gid, r.keys, r.key_null, r.offsets, r.rows);
+        if (n_keys > 1)
+            hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,
+                               pd, G, (size_t)G, r.keys, r.key_null);
+        HIP_TRY(hipGetLastError());
     } else {
         ST_TRY(c->groups.ensure(4096, c->stream));
         c->gr.offsets = c->groups.take<int64_t>(1);

@@ -304,11 +304,9 @@ def test_multi_key_packed(ctx, golden):
     got = ctx.groupby_agg([k1, k2, k3], n, v, FIVE)
     want = O.groupby_agg([k1, k2, k3], n, v, FIVE)
     assert_groupby_equal(got, want, [O.U32CODE, O.I64, O.BOOLBITS], int_exact_rows=EXACT5)
-    kf = (rng.choice(np.array([0.5, -0.0, 0.0, np.nan]), n), None, O.F64)     # f64 key spans < 2^64 codes? no: rejected
-    import pandrs_amd as pa
-    with pytest.raises(pa.OperationFailed):
-        ctx.groupby_agg([(rng.integers(-2**62, 2**62, n), None, O.I64), (rng.integers(-2**62, 2**62, n), None, O.I64)], n, v, FIVE)
-    del kf
+    # two full-range i64 keys do not fit 64 bits of codes: dictionary-encoded (every row its own group here)
+    kw = [(rng.integers(-2**62, 2**62, n), None, O.I64), (rng.integers(-2**62, 2**62, n), None, O.I64)]
+    assert_groupby_equal(ctx.groupby_agg(kw, n, v, FIVE), O.groupby_agg(kw, n, v, FIVE), [O.I64, O.I64], int_exact_rows=EXACT5)
     # many rows, few composite groups: the packed cells must survive the partition-free direct path
     n2 = 5_000_000
     ka = (rng.integers(-100, 100, n2).astype(np.int64), None, O.I64)
@@ -568,3 +566,20 @@ def test_group_indices_multi_key(ctx):
     k0 = (rng.integers(0, 30, n).astype(np.uint32), None, O.U32CODE)
     k1 = (rng.integers(-5, 5, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.05), O.I64)
     check_group_indices(ctx, [k0, k1], n)
+
+
+def test_multi_key_wider_than_64_bits_is_dictionary_encoded(ctx):
+    """Two hashed i64 ids (each spans the full 64-bit range) + a small nullable key: 129+ bits of codes.
+    The widest columns get dense per-column group ids (<= 32 bits) until the packed cell fits."""
+    rng = np.random.default_rng(2024)
+    n = 600_000
+    a = sparse_keys_from(rng.integers(0, 3_000, n))
+    b = sparse_keys_from(rng.integers(0, 700, n) + 10_000)
+    k0 = (a, O.pack_mask(rng.random(n) < 0.01), O.I64)
+    k1 = (b, None, O.I64)
+    k2 = (rng.integers(0, 3, n).astype(np.uint32), O.pack_mask(rng.random(n) < 0.1), O.U32CODE)
+    v = (rng.normal(1, 2, n), None, O.F64)
+    check(ctx, [k0, k1, k2], n, [v], [(0, O.SUM), (0, O.MIN), (0, O.COUNT), (0, O.MEDIAN)], [O.I64, O.I64, O.U32CODE], exact=[1, 2, 3])
+    check_group_indices(ctx, [k0, k1], n)
+    f = (rng.choice(np.array([0.0, -0.0, np.nan, 1e300, -1e300, 5e-324]), n), None, O.F64)   # full-range f64 key
+    check(ctx, [f, k1], n, [v], [(0, O.MAX), (0, O.COUNT)], [O.F64, O.I64], exact=[0, 1])
