@@ -262,6 +262,8 @@ static int32_t stage_key(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_
     return 0;
 }
 
+static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, const KeyDesc &rkey, int64_t nr, int32_t how);
+
 int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk, int64_t nl,
                    const pandrs_hip_column *rk, int64_t nr, int32_t how, int64_t *out_n) {
     if (!c || !lk || !rk || !out_n || nl < 0 || nr < 0 || how < PANDRS_HIP_JOIN_INNER || how > PANDRS_HIP_JOIN_OUTER)
@@ -273,14 +275,10 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
     if ((nl && !lk->data) || (nr && !rk->data)) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: key column has no data");
     if (nl >= (int64_t(1) << 32) - 16384 || nr >= (int64_t(1) << 32) - 16384)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: a side exceeds the 2^32-row per-call limit");
-    const bool keep_left = how == PANDRS_HIP_JOIN_LEFT || how == PANDRS_HIP_JOIN_OUTER;
-    const bool keep_right = how == PANDRS_HIP_JOIN_RIGHT || how == PANDRS_HIP_JOIN_OUTER;
 
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     timings_begin(c);
-    c->jn = JoinResult{};
-    c->gb.valid = false;                        // the result arena is shared
     KeyDesc lkey{}, rkey{};
     {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
@@ -289,6 +287,22 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         ST_TRY(stage_key(c, mem_space, lk, nl, &lkey));
         ST_TRY(stage_key(c, mem_space, rk, nr, &rkey));
     }
+    ST_TRY(join_core(c, lkey, nl, rkey, nr, how));
+    // B_join (SURVEY.md §8d) for index output: both key columns read once, 16 B per output row written
+    int64_t K = lk->dtype == PANDRS_HIP_U32CODE ? 4 : (lk->dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
+    c->timings.algorithmic_bytes = (nl + nr) * K + c->jn.n_rows * 16;
+    ST_TRY(timings_end(c));
+    *out_n = c->jn.n_rows;
+    return 0;
+}
+
+// The join proper on device-resident key columns; the caller holds the context's mutex.
+// Leaves the index pairs in c->jn (result arena).
+static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, const KeyDesc &rkey, int64_t nr, int32_t how) {
+    const bool keep_left = how == PANDRS_HIP_JOIN_LEFT || how == PANDRS_HIP_JOIN_OUTER;
+    const bool keep_right = how == PANDRS_HIP_JOIN_RIGHT || how == PANDRS_HIP_JOIN_OUTER;
+    c->jn = JoinResult{};
+    c->gb.valid = false;                        // the result arena is shared
     // workspace: one partition pass over the build side + the table + per-row arrays
     uint32_t cap_tab = 64;
     while ((double)cap_tab < 1.3 * (double)nr) cap_tab <<= 1;      // load <= 0.77; 16 B per entry (5 M build rows: 134 MB, cache resident)
@@ -417,11 +431,6 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         c->jn.valid = true;
         break;
     }
-    // B_join (SURVEY.md §8d) for index output: both key columns read once, 16 B per output row written
-    int64_t K = lk->dtype == PANDRS_HIP_U32CODE ? 4 : (lk->dtype == PANDRS_HIP_BOOLBITS ? 0 : 8);
-    c->timings.algorithmic_bytes = (nl + nr) * K + c->jn.n_rows * 16;
-    ST_TRY(timings_end(c));
-    *out_n = c->jn.n_rows;
     return 0;
 }
 
@@ -539,6 +548,18 @@ __global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
     }
 }
 
+// General fallback of the fused path: (g, v) pairs from materialised join indices, with the
+// reference's gather fill (null => 0, join.rs:304-307, :319-322); u32 group codes widened.
+__global__ void pairs_from_indices_kernel(const int64_t *li, const int64_t *ri, int64_t n, KeyDesc g, int g_is_u32,
+                                          KeyDesc v, uint64_t *out_g, uint64_t *out_v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t l = li[i], r = ri[i];
+    const uint64_t gv = g_is_u32 ? (uint64_t)reinterpret_cast<const uint32_t *>(g.data)[r] : reinterpret_cast<const uint64_t *>(g.data)[r];
+    out_g[i] = (g.null_bits && bit_at(g.null_bits, r)) ? 0ull : gv;
+    out_v[i] = (v.null_bits && bit_at(v.null_bits, l)) ? 0ull : reinterpret_cast<const uint64_t *>(v.data)[l];
+}
+
 // payload with the reference's gather fill: null => 0 (join.rs:304-307); u32 sources widened
 __global__ void clean_payload_kernel(const void *src, const uint8_t *null_bits, int is_u32, int64_t n, uint64_t *out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -591,7 +612,27 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     int64_t M = 0;
     uint64_t *out_g = nullptr, *out_v = nullptr;
     uint64_t cap_pairs = (uint64_t)std::max<int64_t>(nl, 1);    // exact bound for unique build keys
+    // the LDS multimaps cannot hold the build side when even the maximum fan-out leaves partitions too large
+    bool general = c->opt.join_generic != 0 || (double)nr / (double)P > FJ_MAXROWS * 0.95;
     for (int attempt = 0;; attempt++) {
+        if (general) {
+            // materialise the inner join with the general (table-based, segmented-sort) join, then
+            // gather the (g, v) pairs: slower than the fused probe but without any size limit
+            ST_TRY(join_core(c, lkey, nl, rkey, nr, PANDRS_HIP_JOIN_INNER));
+            M = c->jn.n_rows;
+            ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(M + 1) * 8) + 4096, c->stream));
+            out_g = c->pairs.take<uint64_t>(M + 1);
+            out_v = c->pairs.take<uint64_t>(M + 1);
+            if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
+            if (M > 0) {
+                PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+                hipLaunchKernelGGL(pairs_from_indices_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->jn.left_idx, c->jn.right_idx, M, rgrp, rg->dtype == PANDRS_HIP_U32CODE ? 1 : 0, lval, out_g, out_v);
+                HIP_TRY(hipGetLastError());
+            }
+            c->jn.valid = false;                    // the result arena is about to hold the groupby result
+            break;
+        }
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.retries = attempt;
         uint32_t *flags = c->work.take<uint32_t>(64);               // [0] partition overflow, [2..3] pair cursor
@@ -659,10 +700,9 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
             HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
         }
         if (h[0]) {
-            if (P >= P_MAX)
-                return fail(PANDRS_HIP_ERR_COMPUTATION,
-                            "join build side does not fit: a radix partition holds more than %u right rows at the maximum fan-out", FJ_MAXROWS);
-            P = std::min<int64_t>(P * 4, P_MAX);
+            // first overflow: more partitions (unlucky hashing); then the general path (hot build keys, huge builds)
+            if (attempt == 0 && P < P_MAX) P = std::min<int64_t>(P * 4, P_MAX);
+            else general = true;
             continue;
         }
         M = (int64_t)total;

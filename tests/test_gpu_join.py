@@ -219,3 +219,33 @@ def test_join_output_beyond_row_limit_is_reported(ctx):
     with pytest.raises(pa.PandrsHipError) as e:
         ctx.join_indices(lk, 300_000, rk, 20_000, O.INNER)
     assert "2^32" in str(e.value)
+
+
+def test_fused_join_general_fallback(ctx):
+    """A build key with 20 000 duplicates does not fit a workgroup's LDS multimap: the fused entry falls
+    back to the general join + pair gather; same for a forced run on ordinary data with null g / v."""
+    rng = np.random.default_rng(55)
+    nb, npb = 60_000, 40_000
+    rkeys = rng.integers(0, 5000, nb).astype(np.int64)
+    rkeys[rng.random(nb) < 0.34] = 4242
+    rg = rng.integers(0, 40, nb).astype(np.int64)
+    lkeys = rng.integers(0, 6000, npb).astype(np.int64)
+    lkeys[:50] = 4242
+    lv = rng.integers(-100, 100, npb).astype(np.int64)
+    args = ((lkeys, None, O.I64), (lv, None, O.I64), npb, (rkeys, None, O.I64), (rg, None, O.I64), nb)
+    assert_groupby_equal(ctx.join_groupby_sum(*args), O.join_groupby_sum(*args), [O.I64], int_exact_rows=[0])
+    ctx.set_option("join_generic", 1)
+    try:
+        nb, npb = 50_000, 400_000
+        rkeys = sparse(rng.permutation(nb * 2)[:nb])
+        rgc = rng.integers(0, 300, nb).astype(np.uint32)
+        lkeys = rkeys[rng.integers(0, nb, npb)].copy()
+        args = ((lkeys, O.pack_mask(rng.random(npb) < 0.01), O.I64), (rng.normal(3, 1, npb), O.pack_mask(rng.random(npb) < 0.1), O.F64), npb,
+                (rkeys, None, O.I64), (rgc, O.pack_mask(rng.random(nb) < 0.02), O.U32CODE), nb)
+        assert_groupby_equal(ctx.join_groupby_sum(*args), O.join_groupby_sum(*args), [O.U32CODE])
+    finally:
+        ctx.set_option("join_generic", 0)
+
+
+def sparse(ids):
+    return (np.asarray(ids).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
