@@ -52,12 +52,16 @@ typedef enum pandrs_hip_status {
  *   F64      Float64Column.data Arc<[f64]>  (src/column/float64_column.rs:9-13)
  *   U32CODE  StringColumn.indices Arc<[u32]> — global string-pool codes, equal string
  *            <=> equal code (src/column/string_column.rs:26-32, string_pool.rs:28-53)
- *   BOOLBITS BooleanColumn.data BitMask, LSB-first packed (src/column/boolean_column.rs:10-15) */
+ *   BOOLBITS BooleanColumn.data BitMask, LSB-first packed (src/column/boolean_column.rs:10-15)
+ *   CELL64   (no reference counterpart; KEY columns only) already-normalised 8-byte key cells — the form
+ *            group keys are returned in and pandrs_hip_shuffle_fetch delivers: i64 value / canonical
+ *            f64 bits / zero-extended code / bool bit.  Equal cells <=> equal keys. */
 typedef enum pandrs_hip_dtype {
     PANDRS_HIP_I64 = 0,
     PANDRS_HIP_F64 = 1,
     PANDRS_HIP_U32CODE = 2,
-    PANDRS_HIP_BOOLBITS = 3
+    PANDRS_HIP_BOOLBITS = 3,
+    PANDRS_HIP_CELL64 = 4
 } pandrs_hip_dtype;
 
 /* AggregateOp, same order as src/optimized/split_dataframe/group/types.rs:11-34 */
@@ -245,6 +249,30 @@ int32_t pandrs_hip_groupby_indices(pandrs_hip_ctx *ctx, int32_t mem_space,
 int32_t pandrs_hip_groupby_indices_fetch(pandrs_hip_ctx *ctx, int32_t mem_space,
                                          uint64_t *const *out_keys, uint8_t *const *out_key_null,
                                          int64_t *out_offsets, int64_t *out_rows);
+
+/* ---- multi-GPU: row shuffle by key owner ("radix all-to-all ... on key") -------------
+ * The general exchange for what pre-aggregated partials cannot express (Std/Var/Median, or both
+ * sides of a join): every row goes to the rank that owns its key, owner = f(key cell) mod n_ranks,
+ * the same function on every rank and for every column that shares the key.  This call buckets ONE
+ * shard's rows by owner and keeps them rank-contiguous in the context: key cells, one null byte per
+ * row, and every payload column (I64 / F64 as is, U32CODE zero-extended to 8 bytes) with one null
+ * byte per row for masked payloads.  out_counts[r] = rows for rank r.  Rows with a NULL key go to
+ * the last rank (they form one group, grouping.rs:74) or are dropped when drop_null_keys != 0
+ * (they never match in a join, join.rs:112, :152).  After the all-to-all the receiver turns the null
+ * bytes into bitmaps (pandrs_hip_bytes_to_bitmap) and calls the ordinary entry points with key
+ * dtype PANDRS_HIP_CELL64. */
+int32_t pandrs_hip_shuffle_split(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *key,
+                                 const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows,
+                                 int32_t n_ranks, int32_t drop_null_keys, int64_t *out_counts,
+                                 int64_t *out_n_rows);
+/* out_cells / out_key_null: out_n_rows entries; out_payload[c] (8 bytes per row) / out_payload_null[c]
+ * (1 byte per row; ignored for payloads without a mask).  Any pointer may be NULL to skip it. */
+int32_t pandrs_hip_shuffle_fetch(pandrs_hip_ctx *ctx, int32_t mem_space, uint64_t *out_cells,
+                                 uint8_t *out_key_null, uint64_t *const *out_payload,
+                                 uint8_t *const *out_payload_null);
+/* one byte per row (non-zero = set) -> LSB-first bitmap of (n + 7) / 8 bytes (src/core/column.rs:163-177) */
+int32_t pandrs_hip_bytes_to_bitmap(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *bytes, int64_t n,
+                                   uint8_t *out_bitmap);
 
 /* ---- hash join ------------------------------------------------------------------------------
  * Replaces OptimizedDataFrame::join_impl (src/optimized/split_dataframe/join.rs:76-555) up to

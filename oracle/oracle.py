@@ -14,7 +14,7 @@ import subprocess
 
 import numpy as np
 
-I64, F64, U32CODE, BOOLBITS = 0, 1, 2, 3
+I64, F64, U32CODE, BOOLBITS, CELL64 = 0, 1, 2, 3, 4
 SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM = range(11)
 INNER, LEFT, RIGHT, OUTER = range(4)
 
@@ -53,7 +53,7 @@ def lib():
     return _lib
 
 
-_NP_OF = {I64: np.int64, F64: np.float64, U32CODE: np.uint32, BOOLBITS: np.uint8}
+_NP_OF = {I64: np.int64, F64: np.float64, U32CODE: np.uint32, BOOLBITS: np.uint8, CELL64: np.uint64}
 
 
 def _cols(cols, keep):

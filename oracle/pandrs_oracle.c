@@ -61,6 +61,7 @@ static inline uint64_t key_cell(const ocol *c, int64_t i) {
     }
     case PANDRS_HIP_U32CODE: return ((const uint32_t *)c->data)[i];
     case PANDRS_HIP_BOOLBITS: return (((const uint8_t *)c->data)[i >> 3] >> (i & 7)) & 1;
+    case PANDRS_HIP_CELL64: return ((const uint64_t *)c->data)[i];   /* already a cell (multi-GPU shuffle output) */
     }
     return 0;
 }

@@ -15,7 +15,7 @@ PHASE_NAMES = ["stage_in", "estimate", "histogram", "scan", "scatter", "aggregat
                "build", "probe", "gather", "other", "", ""]
 
 # enums (include/pandrs_hip.h)
-I64, F64, U32CODE, BOOLBITS = 0, 1, 2, 3
+I64, F64, U32CODE, BOOLBITS, CELL64 = 0, 1, 2, 3, 4
 SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM = range(11)
 INNER, LEFT, RIGHT, OUTER = range(4)
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -72,6 +72,10 @@ SYMBOLS = {
     "pandrs_hip_groupby_indices": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64,
                                                C.POINTER(C.c_int64)]),
     "pandrs_hip_groupby_indices_fetch": (C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
+    "pandrs_hip_shuffle_split": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.POINTER(Column), C.c_int32, C.c_int64,
+                                             C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pandrs_hip_shuffle_fetch": (C.c_int32, [_P, C.c_int32, _P, _P, C.POINTER(_P), C.POINTER(_P)]),
+    "pandrs_hip_bytes_to_bitmap": (C.c_int32, [_P, C.c_int32, _P, C.c_int64, _P]),
     "pandrs_hip_join_indices": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64,
                                             C.POINTER(Column), C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     "pandrs_hip_join_fetch": (C.c_int32, [_P, C.c_int32, _P, _P]),

@@ -91,7 +91,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     if (!c) return PANDRS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release();
+    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release(); c->shuf.release();
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -219,6 +219,39 @@ int32_t pandrs_hip_groupby_indices_fetch(pandrs_hip_ctx *c, int32_t mem_space, u
     if (out_rows && n > 0) HIP_TRY(hipMemcpyAsync(out_rows, r.rows, n * 8, kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_shuffle_split(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *key,
+                                 const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows,
+                                 int32_t n_ranks, int32_t drop_null_keys, int64_t *out_counts, int64_t *out_n_rows) {
+    return pandrs::shuffle_split_entry(ctx, mem_space, key, payload, n_payload, n_rows, n_ranks, drop_null_keys,
+                                       out_counts, out_n_rows);
+}
+
+int32_t pandrs_hip_shuffle_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t *out_cells, uint8_t *out_key_null,
+                                 uint64_t *const *out_payload, uint8_t *const *out_payload_null) {
+    if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+    std::lock_guard<std::mutex> lock(c->mu);
+    pandrs::ShuffleResult &r = c->sh;
+    if (!r.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no shuffle result retained in this context");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)r.n_rows;
+    if (n == 0) return PANDRS_HIP_OK;
+    hipMemcpyKind kind = mem_space == PANDRS_HIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (out_cells) HIP_TRY(hipMemcpyAsync(out_cells, r.cells, n * 8, kind, c->stream));
+    if (out_key_null) HIP_TRY(hipMemcpyAsync(out_key_null, r.key_null, n, kind, c->stream));
+    for (int p = 0; p < r.n_payload; p++) {
+        if (out_payload && out_payload[p]) HIP_TRY(hipMemcpyAsync(out_payload[p], r.pay[p], n * 8, kind, c->stream));
+        if (out_payload_null && out_payload_null[p] && r.pay_null[p])
+            HIP_TRY(hipMemcpyAsync(out_payload_null[p], r.pay_null[p], n, kind, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_bytes_to_bitmap(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *bytes, int64_t n,
+                                   uint8_t *out_bitmap) {
+    return pandrs::bytes_to_bitmap_entry(ctx, mem_space, bytes, n, out_bitmap);
 }
 
 int32_t pandrs_hip_join_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *left_key,

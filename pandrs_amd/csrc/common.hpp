@@ -115,6 +115,17 @@ struct GroupsResult {
     int64_t *rows = nullptr;     // [n_rows]
 };
 
+// rows of one shard bucketed by owner rank (pandrs_hip_shuffle_split)
+struct ShuffleResult {
+    bool valid = false;
+    int64_t n_rows = 0;
+    int n_payload = 0;
+    uint64_t *cells = nullptr;
+    uint8_t *key_null = nullptr;
+    uint64_t *pay[16]{};
+    uint8_t *pay_null[16]{};     // nullptr for payloads without a mask
+};
+
 struct JoinResult {
     bool valid = false;
     int64_t n_rows = 0;
@@ -147,12 +158,13 @@ struct pandrs_hip_ctx {
     // one arena per lifetime class: buffers that must survive a nested engine run never share an
     // arena with what that run allocates (work: per-run scratch; temp: direct-path records;
     // side: slice records; super: two-level columns; packed: multi-key cells; pairs: fused-join pairs)
-    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups;
+    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups, shuf;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
     pandrs::GroupbyResult gb, gb2, gb3;   // gb2 / gb3: nested results (slice merges, two-level sub-runs)
     pandrs::JoinResult jn;
     pandrs::GroupsResult gr;
+    pandrs::ShuffleResult sh;
     // phase timing: pairs of events
     hipEvent_t ev_begin[PANDRS_HIP_MAX_PHASES]{}, ev_end[PANDRS_HIP_MAX_PHASES]{};
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
@@ -205,6 +217,10 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
                       int64_t *out_n_groups, int32_t *out_n_state);
 int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
                               int64_t n_rows, int64_t *out_n_groups);
+int32_t shuffle_split_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *key,
+                            const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows, int32_t n_ranks,
+                            int32_t drop_null_keys, int64_t *out_counts, int64_t *out_n_rows);
+int32_t bytes_to_bitmap_entry(pandrs_hip_ctx *c, int32_t mem_space, const uint8_t *bytes, int64_t n, uint8_t *out);
 int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
                             const uint64_t *records,
                             int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
@@ -226,7 +242,7 @@ int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_colu
 
 inline size_t dtype_bytes(int dtype, int64_t n) {
     switch (dtype) {
-    case PANDRS_HIP_I64: case PANDRS_HIP_F64: return size_t(n) * 8;
+    case PANDRS_HIP_I64: case PANDRS_HIP_F64: case PANDRS_HIP_CELL64: return size_t(n) * 8;
     case PANDRS_HIP_U32CODE: return size_t(n) * 4;
     default: return size_t((n + 7) / 8);
     }

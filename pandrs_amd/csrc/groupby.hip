@@ -122,6 +122,7 @@ __device__ __forceinline__ uint64_t move_load(const MoveDesc &m, int64_t i) {
     case 0: return reinterpret_cast<const uint64_t *>(m.src)[i];
     case 1: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 0ull : 1ull;
     case 2: return reinterpret_cast<const uint8_t *>(m.src)[i];
+    case 6: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 1ull : 0ull;   // null bitmap -> null byte
     case 3: case 5: return (uint64_t)i;                                // row index
     default: return reinterpret_cast<const uint32_t *>(m.src)[i];      // 4: u32 source
     }
@@ -1560,9 +1561,9 @@ struct Stager {
     }
 };
 
-static int32_t check_cols(const pandrs_hip_column *cols, int n, const char *what) {
+static int32_t check_cols(const pandrs_hip_column *cols, int n, const char *what, bool keys = false) {
     for (int i = 0; i < n; i++) {
-        if (cols[i].dtype < PANDRS_HIP_I64 || cols[i].dtype > PANDRS_HIP_BOOLBITS)
+        if (cols[i].dtype < PANDRS_HIP_I64 || cols[i].dtype > (keys ? PANDRS_HIP_CELL64 : PANDRS_HIP_BOOLBITS))
             return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "%s column %d: bad dtype %d", what, i, cols[i].dtype);
     }
     return 0;
@@ -1826,7 +1827,7 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d key columns", MAX_KEYS);
     if (n_keys > 1 && partials)
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "multi-key partials are not mergeable across shards yet");
-    ST_TRY(check_cols(keys, n_keys, "key"));
+    ST_TRY(check_cols(keys, n_keys, "key", true));
     ST_TRY(check_cols(vals, n_vals, "value"));
     for (int k = 0; k < n_keys; k++)
         if (n_rows > 0 && !keys[k].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column %d has no data", k);
@@ -1912,7 +1913,7 @@ int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs
     if (!c || !out_n_groups || n_rows < 0 || n_keys < 1 || !keys)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_indices: bad arguments");
     if (n_keys > MAX_KEYS) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "more than %d key columns", MAX_KEYS);
-    ST_TRY(check_cols(keys, n_keys, "key"));
+    ST_TRY(check_cols(keys, n_keys, "key", true));
     for (int k = 0; k < n_keys; k++)
         if (n_rows > 0 && !keys[k].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column %d has no data", k);
     if (n_rows >= (int64_t(1) << 32) - 16384)
@@ -1970,6 +1971,116 @@ int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs
     ST_TRY(timings_end(c));
     *out_n_groups = G;
     return 0;
+}
+
+// ================================================================================================
+// Row shuffle by key owner (multi-GPU): the radix partitioner with P = n_ranks.
+// ================================================================================================
+constexpr uint32_t OWNER_SEED = 0x1B873593u;    // independent of every partition seed used locally
+
+__global__ void bytes_to_bitmap_kernel(const uint8_t *bytes, int64_t n, uint8_t *out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b * 8 >= n) return;
+    uint32_t v = 0;
+    for (int j = 0; j < 8; j++)
+        if (b * 8 + j < n && bytes[b * 8 + j]) v |= 1u << j;
+    out[b] = (uint8_t)v;
+}
+
+int32_t bytes_to_bitmap_entry(pandrs_hip_ctx *c, int32_t mem_space, const uint8_t *bytes, int64_t n, uint8_t *out) {
+    if (!c || n < 0 || (n && (!bytes || !out))) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bytes_to_bitmap: bad arguments");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint8_t *src = bytes; uint8_t *dst = out;
+    const size_t nb = (size_t)(n + 7) / 8;
+    if (mem_space == PANDRS_HIP_MEM_HOST) {
+        ST_TRY(c->staging.ensure((size_t)n + nb + 4096, c->stream));
+        uint8_t *d = c->staging.take<uint8_t>(n); dst = c->staging.take<uint8_t>(nb);
+        if (!d || !dst) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+        HIP_TRY(hipMemcpyAsync(d, bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        src = d;
+    }
+    hipLaunchKernelGGL(bytes_to_bitmap_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, src, n, dst);
+    HIP_TRY(hipGetLastError());
+    if (mem_space == PANDRS_HIP_MEM_HOST) HIP_TRY(hipMemcpyAsync(out, dst, nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t shuffle_split_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *key,
+                            const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows, int32_t n_ranks,
+                            int32_t drop_null_keys, int64_t *out_counts, int64_t *out_n_rows) {
+    if (!c || !key || !out_counts || !out_n_rows || n_rows < 0 || n_payload < 0 || n_payload > 16 || (n_payload && !payload) ||
+        n_ranks < 1 || n_ranks > 1024)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "shuffle_split: bad arguments");
+    ST_TRY(check_cols(key, 1, "key", true));
+    for (int p = 0; p < n_payload; p++)
+        if (payload[p].dtype != PANDRS_HIP_I64 && payload[p].dtype != PANDRS_HIP_F64 && payload[p].dtype != PANDRS_HIP_U32CODE)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "shuffle_split: payload column %d has dtype %d (i64, f64 or u32 codes only)", p, payload[p].dtype);
+    if (n_rows >= (int64_t(1) << 32) - 16384)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "shuffle_split: more than 2^32 rows per call");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    c->sh = ShuffleResult{};
+    for (int r = 0; r < n_ranks; r++) out_counts[r] = 0;
+    *out_n_rows = 0;
+    if (n_rows == 0) { c->sh.valid = true; c->sh.n_payload = n_payload; return timings_end(c); }
+    Stager stg{c, mem_space};
+    if (mem_space == PANDRS_HIP_MEM_HOST) {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        size_t need = dtype_bytes(key->dtype, n_rows) + (n_rows + 7) / 8 + 1024;
+        for (int p = 0; p < n_payload; p++) need += dtype_bytes(payload[p].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
+        ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
+    }
+    if (!key->data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "shuffle_split: key column has no data");
+    KeyDesc kd{stg.in(key->data, dtype_bytes(key->dtype, n_rows)), (const uint8_t *)stg.in(key->null_mask, (n_rows + 7) / 8), nullptr, key->dtype};
+    ST_TRY(c->work.ensure(engine_workspace_bytes(n_rows, 0, 0) + (1 << 20), c->stream));
+    size_t out_bytes = Arena::padded(size_t(n_rows) * 8) + Arena::padded(size_t(n_rows)) + 4096;
+    for (int p = 0; p < n_payload; p++) out_bytes += Arena::padded(size_t(n_rows) * 8) + Arena::padded(size_t(n_rows));
+    ST_TRY(c->shuf.ensure(out_bytes, c->stream));
+    ShuffleResult &r = c->sh;
+    r.n_payload = n_payload;
+    r.cells = c->shuf.take<uint64_t>(n_rows);
+    r.key_null = c->shuf.take<uint8_t>(n_rows);
+    if (!r.cells || !r.key_null) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "shuffle arena too small");
+    ScatterArgs sa{};
+    sa.key = kd; sa.pkeys = r.cells; sa.n_rows = n_rows; sa.P = (uint32_t)n_ranks; sa.seed = OWNER_SEED;
+    if (kd.null_bits) sa.mv[sa.n_move++] = MoveDesc{kd.null_bits, r.key_null, 6, 0};
+    else HIP_TRY(hipMemsetAsync(r.key_null, 0, (size_t)n_rows, c->stream));
+    for (int p = 0; p < n_payload; p++) {
+        if (!payload[p].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "shuffle_split: payload column %d has no data", p);
+        const void *d = stg.in(payload[p].data, dtype_bytes(payload[p].dtype, n_rows));
+        const uint8_t *m = (const uint8_t *)stg.in(payload[p].null_mask, (n_rows + 7) / 8);
+        r.pay[p] = c->shuf.take<uint64_t>(n_rows);
+        if (!r.pay[p]) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "shuffle arena too small");
+        sa.mv[sa.n_move++] = MoveDesc{d, r.pay[p], payload[p].dtype == PANDRS_HIP_U32CODE ? 4 : 0, 0};
+        if (m) {
+            r.pay_null[p] = c->shuf.take<uint8_t>(n_rows);
+            if (!r.pay_null[p]) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "shuffle arena too small");
+            sa.mv[sa.n_move++] = MoveDesc{m, r.pay_null[p], 6, 0};
+        }
+    }
+    if (stg.status) return stg.status;
+    PartInfo part{};
+    ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+    uint32_t *bounds = c->work.take<uint32_t>(n_ranks + 2);
+    if (!bounds) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (shuffle)");
+    hipLaunchKernelGGL(gather_part_offsets_kernel, dim3((unsigned)((n_ranks + 2 + 255) / 256)), dim3(256), 0, c->stream,
+                       part.offsets, part.NB, (uint32_t)n_ranks + 2, bounds);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> hb((size_t)n_ranks + 2);
+    HIP_TRY(hipMemcpyAsync(hb.data(), bounds, ((size_t)n_ranks + 2) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int q = 0; q < n_ranks; q++) out_counts[q] = (int64_t)hb[q + 1] - (int64_t)hb[q];
+    const int64_t n_null = (int64_t)hb[n_ranks + 1] - (int64_t)hb[n_ranks];
+    if (!drop_null_keys) out_counts[n_ranks - 1] += n_null;     // the NULL-key partition sits right behind the last rank's rows
+    r.n_rows = drop_null_keys ? (int64_t)hb[n_ranks] : (int64_t)hb[n_ranks + 1];
+    r.valid = true;
+    *out_n_rows = r.n_rows;
+    c->timings.algorithmic_bytes = n_rows * (8 + 8 * (int64_t)n_payload) * 2;
+    return timings_end(c);
 }
 
 // packed partial records [n][W] -> column arrays keys[n] | key_null[n] | states[W-2][n]

@@ -270,7 +270,7 @@ int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: bad arguments");
     if (lk->dtype != rk->dtype)                 // join.rs:98-104
         return fail(PANDRS_HIP_ERR_TYPE_MISMATCH, "join key columns have different types (%d and %d)", lk->dtype, rk->dtype);
-    if (lk->dtype < PANDRS_HIP_I64 || lk->dtype > PANDRS_HIP_BOOLBITS)
+    if (lk->dtype < PANDRS_HIP_I64 || lk->dtype > PANDRS_HIP_CELL64)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: bad key dtype %d", lk->dtype);
     if ((nl && !lk->data) || (nr && !rk->data)) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: key column has no data");
     if (nl >= (int64_t(1) << 32) - 16384 || nr >= (int64_t(1) << 32) - 16384)

@@ -21,6 +21,11 @@ logic runs under gloo without a GPU.
 import time
 
 
+def np_contig(a):
+    import numpy as np
+    return np.ascontiguousarray(a)
+
+
 class DistributedGroupBy:
     def __init__(self, engine, dist, device):
         self.engine = engine
@@ -47,9 +52,65 @@ class DistributedGroupBy:
         dist.all_to_all_single(out, records, output_split_sizes=recv_list, input_split_sizes=list(counts))
         return out
 
+    MERGEABLE_OPS = (0, 1, 2, 3, 4)      # Sum, Mean, Min, Max, Count: pre-aggregate, exchange partial states
+
+    def exchange_columns(self, columns, counts):
+        """All-to-all of several row-aligned columns that share the same rank-contiguous split."""
+        torch = self._torch()
+        dist = self.dist
+        first = next(c for c in columns if c is not None)
+        was_numpy = not torch.is_tensor(first)
+        def as_t(a):        # 64-bit unsigned words travel as int64 (gloo / RCCL have no uint64)
+            if torch.is_tensor(a):
+                return a
+            a = np_contig(a)
+            return torch.from_numpy(a.view("int64") if a.dtype.name == "uint64" else a)
+        first = as_t(first)
+        send_counts = torch.tensor(counts, dtype=torch.int64, device=first.device)
+        recv_counts = torch.empty(self.world, dtype=torch.int64, device=first.device)
+        dist.all_to_all_single(recv_counts, send_counts)
+        recv_list = [int(x) for x in recv_counts.tolist()]
+        out = []
+        for c in columns:
+            if c is None:
+                out.append(None)
+                continue
+            t = as_t(c)
+            r = torch.empty(sum(recv_list), dtype=t.dtype, device=t.device)
+            dist.all_to_all_single(r, t, output_split_sizes=recv_list, input_split_sizes=list(counts))
+            out.append(r.numpy().view(c.dtype) if was_numpy else r)
+        return out
+
+    def groupby_by_shuffle(self, keys, n_rows, vals, aggs):
+        """The general path (any aggregate except First/Last, which need the global row order): every
+        row goes to the owner of its key — pandrs_hip_shuffle_split, one all-to-all per column — and
+        the owner runs the ordinary groupby on the rows it received (key dtype CELL64)."""
+        eng = self.engine
+        if len(keys) != 1:
+            raise NotImplementedError("multi-key groupby is not sharded yet (per-shard key packing differs)")
+        if any(op in (8, 9) for _, op in aggs):
+            raise NotImplementedError("First/Last need the global row order and are not sharded")
+        cells, knull, pays, pnull, counts = eng.shuffle_split(keys[0], vals, n_rows, self.world, drop_null_keys=False)
+        got = self.exchange_columns([cells, knull] + pays + pnull, counts)
+        rc, rn = got[0], got[1]
+        rp, rpn = got[2:2 + len(vals)], got[2 + len(vals):]
+        n_recv = int(rc.shape[0])
+        kmask = eng.bytes_to_bitmap(rn) if keys[0][1] is not None else None
+        vals2 = []
+        for i, v in enumerate(vals):
+            data = rp[i]
+            if v[2] == 1:       # f64 payload travels as raw 8-byte words
+                data = data.view(self._torch().float64) if hasattr(data, "is_cuda") else data.view("float64")
+            elif not hasattr(data, "is_cuda"):
+                data = data.view("int64")
+            vals2.append((data, None if rpn[i] is None else eng.bytes_to_bitmap(rpn[i]), v[2]))
+        return eng.groupby_agg([(rc, kmask, 4)], n_recv, vals2, aggs)
+
     def groupby_agg(self, keys, n_rows, vals, aggs, fetch=True):
         """Same arguments as Context.groupby_agg; every rank passes its own row range.
         Returns this rank's share of the groups (keys owned by this rank)."""
+        if any(op not in self.MERGEABLE_OPS for _, op in aggs):
+            return self.groupby_by_shuffle(keys, n_rows, vals, aggs)
         torch = self._torch()
         eng = self.engine
         t0 = time.perf_counter()
@@ -173,15 +234,36 @@ class DistributedJoinGroupBy:
             bits = None if bits is None else bits.numpy()
         return out, bits, self.world * n_pad
 
-    def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
+    def _shuffled_side(self, key, payload, n_rows):
+        """One side of the join after the row shuffle by key owner: (key column, payload column, rows)."""
+        eng = self.engine
+        cells, _, (pay,), (pnull,), counts = eng.shuffle_split(key, [payload], n_rows, self.world, drop_null_keys=True)
+        rc, rp, rpn = self.groupby.exchange_columns([cells, pay, pnull], counts)
+        if payload[2] == 1:
+            rp = rp.view(self.groupby._torch().float64) if hasattr(rp, "is_cuda") else rp.view("float64")
+        elif not hasattr(rp, "is_cuda"):
+            rp = rp.view("int64") if payload[2] == 0 else rp
+        pdt = 4 if payload[2] == 2 else payload[2]      # u32 codes travel zero-extended: 8-byte cells
+        return (rc, None, 4), (rp, None if rpn is None else eng.bytes_to_bitmap(rpn), pdt), int(rc.shape[0])
+
+    def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right, strategy="allgather"):
         """Columns are (data, mask, dtype) like Context.join_groupby_sum; every rank passes its own
-        row ranges of both sides.  -> this rank's share of (g cells, g null flags, sums)."""
+        row ranges of both sides.  -> this rank's share of (g cells, g null flags, sums).
+        strategy "allgather": the build side is replicated, the probe side stays put (small builds);
+        "shuffle": both sides go to the owner of their join key (SURVEY.md 8e's radix all-to-all) —
+        every GPU then builds only 1/world of the build side, at the price of moving the probe rows."""
         t0 = time.perf_counter()
-        rk, rk_bits, n_all = self._gather_build(rkey[0], rkey[1], n_right, pad_null=True)
-        rg, rg_bits, _ = self._gather_build(rgroup[0], rgroup[1], n_right, pad_null=False)
-        t1 = time.perf_counter()
-        kc, kn, sums = self.engine.join_groupby_sum(lkey, lval, n_left, (rk, rk_bits, rkey[2]),
-                                                    (rg, rg_bits, rgroup[2]), n_all)
+        if strategy == "shuffle":
+            lk2, lv2, nl2 = self._shuffled_side(lkey, lval, n_left)
+            rk2, rg2, nr2 = self._shuffled_side(rkey, rgroup, n_right)
+            t1 = time.perf_counter()
+            kc, kn, sums = self.engine.join_groupby_sum(lk2, lv2, nl2, rk2, rg2, nr2)
+        else:
+            rk, rk_bits, n_all = self._gather_build(rkey[0], rkey[1], n_right, pad_null=True)
+            rg, rg_bits, _ = self._gather_build(rgroup[0], rgroup[1], n_right, pad_null=False)
+            t1 = time.perf_counter()
+            kc, kn, sums = self.engine.join_groupby_sum(lkey, lval, n_left, (rk, rk_bits, rkey[2]),
+                                                        (rg, rg_bits, rgroup[2]), n_all)
         t2 = time.perf_counter()
         g = int(kc.shape[1])
         cells, nulls, part = kc[0], kn[0], sums[0]
@@ -198,6 +280,6 @@ class DistributedJoinGroupBy:
         out = self.groupby.groupby_agg([(cells, _pack_bits(nulls) if has_null else None, 0)], g,
                                        [(part, None, 1)], [(0, 0)])
         t3 = time.perf_counter()
-        self.last_wall_ms = {"allgather_build": (t1 - t0) * 1e3, "local_join_groupby": (t2 - t1) * 1e3,
+        self.last_wall_ms = {("shuffle_rows" if strategy == "shuffle" else "allgather_build"): (t1 - t0) * 1e3, "local_join_groupby": (t2 - t1) * 1e3,
                              "exchange_merge": (t3 - t2) * 1e3}
         return out

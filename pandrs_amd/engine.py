@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 
-_NP_OF = {L.I64: np.int64, L.F64: np.float64, L.U32CODE: np.uint32, L.BOOLBITS: np.uint8}
+_NP_OF = {L.I64: np.int64, L.F64: np.float64, L.U32CODE: np.uint32, L.BOOLBITS: np.uint8, L.CELL64: np.uint64}
 
 
 class PandrsHipError(RuntimeError):
@@ -213,6 +213,59 @@ class Context:
         if st:
             _raise(st)
         return cells, nulls, off, rows
+
+    # -- row shuffle by key owner (multi-GPU) ------------------------------------------------------------
+    def shuffle_split(self, key, payload, n_rows, n_ranks, drop_null_keys=False):
+        """Buckets this shard's rows by the owner rank of their key, rank-contiguous.
+        -> (cells[n] u64, key_null[n] u8, [payload u64/i64 [n]], [payload null bytes [n] or None], counts[n_ranks])"""
+        keep = []
+        kc, sp = self._cols([key], keep)
+        pc, sp2 = self._cols(payload, keep) if payload else ((L.Column * 1)(), sp)
+        if payload and sp != sp2:
+            raise ValueError("key and payload must live in the same memory space")
+        counts = (C.c_int64 * n_ranks)()
+        n_out = C.c_int64(0)
+        st = self.lib.pandrs_hip_shuffle_split(self.h, sp, kc, pc, len(payload), int(n_rows), int(n_ranks),
+                                               1 if drop_null_keys else 0, counts, C.byref(n_out))
+        if st:
+            _raise(st)
+        n, npay = n_out.value, len(payload)
+        masked = [p[1] is not None for p in payload]
+        if sp == L.MEM_DEVICE:
+            import torch
+            d = "cuda:%d" % self.device
+            new = lambda dt: torch.empty(n, dtype=dt, device=d)
+            cells, knull = new(torch.int64), new(torch.uint8)
+            pays = [new(torch.int64) for _ in range(npay)]
+            pnull = [new(torch.uint8) if m else None for m in masked]
+        else:
+            cells, knull = np.empty(n, np.uint64), np.empty(n, np.uint8)
+            pays = [np.empty(n, np.uint64) for _ in range(npay)]
+            pnull = [np.empty(n, np.uint8) if m else None for m in masked]
+        pp = (C.c_void_p * max(npay, 1))(*[_ptr(a) for a in pays])
+        pn = (C.c_void_p * max(npay, 1))(*[_ptr(a) for a in pnull])
+        st = self.lib.pandrs_hip_shuffle_fetch(self.h, sp, _ptr(cells), _ptr(knull), pp, pn)
+        if st:
+            _raise(st)
+        return cells, knull, pays, pnull, [int(x) for x in counts]
+
+    def bytes_to_bitmap(self, flags):
+        """One byte per row (non-zero = set) -> LSB-first bitmap, same kind (numpy / torch) as the input."""
+        n = int(flags.shape[0])
+        if _is_torch(flags):
+            import torch
+            self._wait_for_producer()
+            flags = flags.contiguous()
+            out = torch.empty((n + 7) // 8, dtype=torch.uint8, device=flags.device)
+            sp = L.MEM_DEVICE
+        else:
+            flags = np.ascontiguousarray(flags, np.uint8)
+            out = np.empty((n + 7) // 8, np.uint8)
+            sp = L.MEM_HOST
+        st = self.lib.pandrs_hip_bytes_to_bitmap(self.h, sp, _ptr(flags), n, _ptr(out))
+        if st:
+            _raise(st)
+        return out
 
     # -- mergeable partials (multi-GPU) --------------------------------------------------------------
     def groupby_partials(self, keys, n_rows, vals, aggs):

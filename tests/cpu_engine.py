@@ -81,6 +81,30 @@ class NumpyEngine:
     def groupby_fetch(self):
         return self._r
 
+    # ---- the shuffle path: rows to the owner of their key, then ordinary calls on the received rows
+    def shuffle_split(self, key, payload, n_rows, n_ranks, drop_null_keys=False):
+        from oracle import oracle_np as ONP
+        nul, cell = ONP.key_cells(key, n_rows)
+        owner = ((cell * np.uint64(0xD6E8FEB86659FD93)) >> np.uint64(33)) % np.uint64(n_ranks)
+        owner = np.where(nul.astype(bool), n_ranks - 1, owner).astype(np.int64)
+        keep = np.ones(n_rows, bool) if not drop_null_keys else ~nul.astype(bool)
+        order = np.argsort(owner, kind="stable")
+        order = order[keep[order]]
+        pays, pnull = [], []
+        for data, mask, dt in payload:
+            pays.append(np.asarray(data)[:n_rows][order].astype(np.int64 if dt != 1 else np.float64).view(np.uint64)
+                        if dt != 2 else np.asarray(data, np.uint32)[:n_rows][order].astype(np.uint64))
+            pnull.append(None if mask is None else np.unpackbits(np.asarray(mask, np.uint8), bitorder="little")[:n_rows][order])
+        counts = np.bincount(owner[order], minlength=n_ranks).tolist()
+        return cell[order], nul[order], pays, pnull, counts
+
+    def bytes_to_bitmap(self, flags):
+        return np.packbits(np.asarray(flags, np.uint8) != 0, bitorder="little")
+
+    def groupby_agg(self, keys, n_rows, vals, aggs):
+        from oracle import oracle as O
+        return O.groupby_agg(keys, n_rows, vals, aggs)
+
     def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
         """The fused C5 call, answered by the oracle (test infrastructure on both sides)."""
         from oracle import oracle as O

@@ -93,7 +93,7 @@ def _shard(n, rank, world):
     return cut[rank], cut[rank + 1]
 
 
-def _join_worker(rank, world, port, outdir):
+def _join_worker(rank, world, port, outdir, strategy="allgather"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -107,20 +107,20 @@ def _join_worker(rank, world, port, outdir):
     d = DistributedJoinGroupBy(NumpyEngine(), dist, "cpu")
     kc, kn, oa = d.join_groupby_sum((lkeys[l0:l1], pb(lk_null[l0:l1]), 0), (lval[l0:l1], None, 1), l1 - l0,
                                     (rkeys[r0:r1], pb(rk_null[r0:r1]), 0), (rgrp[r0:r1], pb(rg_null[r0:r1]), 0),
-                                    r1 - r0)
+                                    r1 - r0, strategy=strategy)
     np.savez(os.path.join(outdir, "j%d.npz" % rank), kc=kc, kn=kn, oa=oa)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_join_groupby_matches_oracle(world):
+@pytest.mark.parametrize("world,strategy", [(2, "allgather"), (3, "allgather"), (2, "shuffle"), (3, "shuffle")])
+def test_distributed_join_groupby_matches_oracle(world, strategy):
     import torch.multiprocessing as mp
     from oracle import oracle as O
     from tests.helpers import assert_groupby_equal
     port = _free_port()
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_join_worker, args=(world, port, outdir), nprocs=world, join=True)
+        mp.spawn(_join_worker, args=(world, port, outdir, strategy), nprocs=world, join=True)
         parts = [np.load(os.path.join(outdir, "j%d.npz" % r)) for r in range(world)]
     got = tuple(np.concatenate([p[name] for p in parts], axis=1) for name in ("kc", "kn", "oa"))
     lkeys, lk_null, lval, rkeys, rk_null, rgrp, rg_null = _join_data()
@@ -129,3 +129,44 @@ def test_distributed_join_groupby_matches_oracle(world):
                               (rkeys, pb(rk_null), O.I64), (rgrp, pb(rg_null), O.I64), len(rkeys))
     assert got[0].shape[1] == want[0].shape[1]
     assert_groupby_equal(got, want, [O.I64])
+
+
+# ---- non-mergeable aggregates (Std / Var / Median) across ranks: the row shuffle by key owner -----------
+AGGS_ANY = [(0, 7), (0, 5), (1, 6), (1, 7), (0, 0), (1, 4)]      # median, std, var, median, sum, count
+
+
+def _shuffle_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from pandrs_amd.dist import DistributedGroupBy
+    from tests.cpu_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys, km, v0, v1, m1 = _data(n=40_000, g=900)
+    v1 = np.round(v1 * 100).astype(np.int64)
+    n = len(keys)
+    lo, hi = (n // world // 8 * 8) * rank, n if rank == world - 1 else (n // world // 8 * 8) * (rank + 1)
+    bits = lambda m: np.packbits(np.unpackbits(m, bitorder="little")[:n][lo:hi], bitorder="little")
+    d = DistributedGroupBy(NumpyEngine(), dist, "cpu")
+    kc, kn, oa = d.groupby_agg([(keys[lo:hi], bits(km), 0)], hi - lo,
+                               [(v0[lo:hi], None, 1), (v1[lo:hi], bits(m1), 0)], AGGS_ANY)
+    np.savez(os.path.join(outdir, "s%d.npz" % rank), kc=kc, kn=kn, oa=oa)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shuffle_path_for_non_mergeable_aggregates(world):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from tests.helpers import assert_groupby_equal
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_shuffle_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, "s%d.npz" % r)) for r in range(world)]
+    got = tuple(np.concatenate([p[name] for p in parts], axis=1) for name in ("kc", "kn", "oa"))
+    keys, km, v0, v1, m1 = _data(n=40_000, g=900)
+    v1 = np.round(v1 * 100).astype(np.int64)
+    want = O.groupby_agg([(keys, km, O.I64)], len(keys), [(v0, None, O.F64), (v1, m1, O.I64)], AGGS_ANY)
+    assert got[0].shape[1] == want[0].shape[1]
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0, 3, 5])

@@ -76,3 +76,81 @@ def test_distributed_join_groupby_world1_rccl(ctx, pg):
     assert got[0].shape[1] == want[0].shape[1]
     assert_groupby_equal(got, want, [O.I64])
     assert set(d.last_wall_ms) == {"allgather_build", "local_join_groupby", "exchange_merge"}
+
+
+def test_shuffle_split_buckets_rows_by_owner(ctx):
+    """pandrs_hip_shuffle_split: every input row appears exactly once (null keys on the last rank or
+    dropped), rank-contiguous, all rows of one key on one rank, payload and null bytes travel with
+    their row; bytes_to_bitmap round-trips."""
+    from oracle import oracle_np as ONP
+    rng = np.random.default_rng(17)
+    n, ranks = 500_003, 5
+    k = (rng.integers(0, 20_000, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = O.pack_mask(rng.random(n) < 0.01)
+    p0 = np.arange(n, dtype=np.int64)                            # the original row index as payload
+    p1 = rng.normal(size=n)
+    m1 = O.pack_mask(rng.random(n) < 0.2)
+    p2 = rng.integers(0, 1000, n).astype(np.uint32)
+    for drop in (False, True):
+        cells, knull, pays, pnull, counts = ctx.shuffle_split((k, km, O.I64), [(p0, None, O.I64), (p1, m1, O.F64), (p2, None, O.U32CODE)],
+                                                              n, ranks, drop_null_keys=drop)
+        nul, cell = ONP.key_cells((k, km, O.I64), n)
+        rows = pays[0].view(np.int64)
+        assert sum(counts) == len(cells) == (n - int(nul.sum()) if drop else n)
+        np.testing.assert_array_equal(np.sort(rows), np.flatnonzero(nul == 0) if drop else np.arange(n))
+        np.testing.assert_array_equal(knull, nul[rows])
+        np.testing.assert_array_equal(cells[knull == 0], cell[rows][knull == 0])
+        np.testing.assert_array_equal(pays[1].view(np.float64), p1[rows])
+        np.testing.assert_array_equal(pays[2], p2[rows].astype(np.uint64))
+        np.testing.assert_array_equal(pnull[1], np.unpackbits(m1, bitorder="little")[:n][rows])
+        assert pnull[0] is None and pnull[2] is None
+        owner = np.repeat(np.arange(ranks), counts)
+        nn = knull == 0
+        first_owner = {}
+        ks, os_ = cells[nn], owner[nn]
+        o = np.argsort(ks, kind="stable")
+        same = ks[o][1:] == ks[o][:-1]
+        assert np.all(os_[o][1:][same] == os_[o][:-1][same]), "a key's rows must share one owner"
+        assert np.all(owner[~nn] == ranks - 1)
+        assert min(counts) > 0.5 * n / ranks                      # balanced
+    flags = (rng.random(1003) < 0.3).astype(np.uint8) * 7
+    np.testing.assert_array_equal(ctx.bytes_to_bitmap(flags), np.packbits(flags != 0, bitorder="little"))
+
+
+def test_distributed_non_mergeable_aggregates_world1_rccl(ctx, pg):
+    """Median / Std / Var across ranks go through the row shuffle; here with one rank over RCCL."""
+    from pandrs_amd.dist import DistributedGroupBy
+    rng = np.random.default_rng(8)
+    n, g = 1_000_000, 30_000
+    k = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = O.pack_mask(rng.random(n) < 0.001)
+    v0 = np.round(rng.normal(100, 10, n), 2)
+    v1 = rng.integers(-1000, 1000, n).astype(np.int64)
+    m1 = O.pack_mask(rng.random(n) < 0.1)
+    aggs = [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.STD), (1, O.VAR), (0, O.SUM), (1, O.COUNT)]
+    d = DistributedGroupBy(ctx, pg, "cuda:0")
+    kc, kn, oa = d.groupby_agg([(_dev(k), _dev(km), O.I64)], n, [(_dev(v0), None, O.F64), (_dev(v1), _dev(m1), O.I64)], aggs)
+    got = (kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy())
+    want = O.groupby_agg([(k, km, O.I64)], n, [(v0, None, O.F64), (v1, m1, O.I64)], aggs)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0, 1, 5])
+
+
+def test_distributed_join_shuffle_strategy_world1_rccl(ctx, pg):
+    from pandrs_amd.dist import DistributedJoinGroupBy
+    rng = np.random.default_rng(9)
+    nl, nr, g = 2_000_001, 200_003, 5_000
+    rk = (rng.permutation(4 * nr)[:nr].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rg = rng.integers(0, g, nr).astype(np.uint32)               # string-pool codes as the group column
+    rgm = O.pack_mask(rng.random(nr) < 0.001)
+    lk = np.where(rng.random(nl) < 0.9, rk[rng.integers(0, nr, nl)], rng.integers(1, 1 << 40, nl))
+    lkm = O.pack_mask(rng.random(nl) < 0.001)
+    lv = rng.normal(10, 3, nl)
+    lvm = O.pack_mask(rng.random(nl) < 0.01)
+    d = DistributedJoinGroupBy(ctx, pg, "cuda:0")
+    kc, kn, oa = d.join_groupby_sum((_dev(lk), _dev(lkm), O.I64), (_dev(lv), _dev(lvm), O.F64), nl,
+                                    (_dev(rk), None, O.I64), (_dev(rg.view(np.int32)), _dev(rgm), O.U32CODE), nr, strategy="shuffle")
+    got = (kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy())
+    want = O.join_groupby_sum((lk, lkm, O.I64), (lv, lvm, O.F64), nl, (rk, None, O.I64), (rg, rgm, O.U32CODE), nr)
+    assert got[0].shape[1] == want[0].shape[1]
+    assert_groupby_equal(got, want, [O.U32CODE])
+    assert "shuffle_rows" in d.last_wall_ms
