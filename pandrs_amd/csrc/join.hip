@@ -77,16 +77,10 @@ struct BuildArgs {
     uint32_t *flags;                            // [0] = a right partition did not fit LDS
 };
 
-// Build pass, one workgroup per right partition.  LDS: sk[R2] u64 | sp[R2] u32.
-// Sort (key, right row) so a key's matches are in ascending right-row order (join.rs:114,
-// :156-158), write the partition back sorted, publish every run {key -> start, count}.
-__global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t p = blockIdx.x, tid = threadIdx.x;
-    const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
-    const uint32_t nR = rend - rbeg;
-    if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
-    if (nR == 0) return;
+// Build pass, fallback body: bitonic sort of the whole partition by (key, right row) in LDS
+// (sk[R2] u64 | sp[R2] u32), written back sorted, every run {key -> start, count} published.
+__device__ __forceinline__ void build_partition_bitonic(const BuildArgs &a, unsigned char *smem, uint32_t rbeg, uint32_t nR) {
+    const uint32_t tid = threadIdx.x;
     uint32_t n2 = 64;
     while (n2 < nR) n2 <<= 1;
     uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
@@ -114,6 +108,106 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
             slot = (slot + 1) & a.table_mask;
         }
     }
+}
+
+// Build pass, one workgroup per right partition.  The join needs, per key, its right rows in
+// ascending order (join.rs:114, :156-158) — not an order between keys.  So instead of sorting the
+// partition: group the rows by key with an LDS hash table (count per key -> scan -> place), then
+// order the rows inside each key's run (a run is one row for a primary-key build side, the common
+// case, and a few rows otherwise).  ~4 LDS passes instead of the 91 stages of an 8192-element
+// bitonic sort.  A key with more than BH_MAXRUN rows sends the partition to the bitonic fallback.
+// LDS: sk[BH_SLOTS] u64 keys | pc[BH_SLOTS + 1] u32 (count | cursor << 16) | lrows[JN_RCAP] u32 | scan scratch
+constexpr uint32_t BH_SLOTS = 8192, BH_MAXRUN = 48;
+constexpr int BH_RPT = JN_RCAP / JN_THREADS;
+__global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
+    const uint32_t nR = rend - rbeg;
+    if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
+    if (nR == 0) return;
+    uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *pc = reinterpret_cast<uint32_t *>(sk + BH_SLOTS);
+    uint32_t *lrows = pc + BH_SLOTS + 8;
+    uint32_t *wt = lrows + JN_RCAP;                  // 17 words of scan scratch, [20] = fallback flag
+    for (uint32_t s = tid; s < BH_SLOTS; s += JN_THREADS) { sk[s] = EMPTY_KEY; pc[s] = 0; }
+    if (tid < 8) pc[BH_SLOTS + tid] = 0;
+    if (tid < 32) wt[tid] = 0;
+    __syncthreads();
+    // 1. count the rows of every distinct key; each thread remembers the slots of its rows
+    uint64_t k[BH_RPT];
+    uint32_t row[BH_RPT], slot[BH_RPT];
+#pragma unroll
+    for (int r = 0; r < BH_RPT; r++) {
+        const uint32_t i = r * JN_THREADS + tid;
+        if (i < nR) { k[r] = a.rkeys[rbeg + i]; row[r] = a.rrows[rbeg + i]; }
+    }
+#pragma unroll
+    for (int r = 0; r < BH_RPT; r++) {
+        const uint32_t i = r * JN_THREADS + tid;
+        if (i >= nR) continue;
+        uint32_t s = BH_SLOTS;                       // the sentinel-valued key counts in the extra entry
+        if (k[r] != EMPTY_KEY) {
+            s = hash32(k[r], 0x3243F6A8u) & (BH_SLOTS - 1);
+            for (;;) {
+                const uint64_t old = atomicCAS((unsigned long long *)&sk[s], EMPTY_KEY, k[r]);
+                if (old == EMPTY_KEY || old == k[r]) break;
+                s = (s + 1) & (BH_SLOTS - 1);
+            }
+        }
+        slot[r] = s;
+        if ((atomicAdd(&pc[s], 1u) & 0xFFFFu) + 1 > BH_MAXRUN) wt[20] = 1;
+    }
+    __syncthreads();
+    if (wt[20]) {                                    // a long run (hot build key): sort the partition instead
+        __syncthreads();
+        build_partition_bitonic(a, smem, rbeg, nR);
+        return;
+    }
+    // 2. exclusive scan of the counts = start of every key's run; cursor = start
+    {
+        uint32_t c[BH_RPT + 1], mine = 0;
+        const uint32_t s0 = tid * BH_RPT;
+#pragma unroll
+        for (int j = 0; j < BH_RPT; j++) { c[j] = pc[s0 + j]; mine += c[j]; }
+        c[BH_RPT] = tid == JN_THREADS - 1 ? pc[BH_SLOTS] : 0u;
+        mine += c[BH_RPT];
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<JN_THREADS>(mine, wt, &tot);
+#pragma unroll
+        for (int j = 0; j < BH_RPT; j++) { pc[s0 + j] = c[j] | (ex << 16); ex += c[j]; }
+        if (tid == JN_THREADS - 1) pc[BH_SLOTS] = c[BH_RPT] | (ex << 16);
+    }
+    __syncthreads();
+    // 3. place every row in its key's run (order inside a run arbitrary for now)
+#pragma unroll
+    for (int r = 0; r < BH_RPT; r++) {
+        const uint32_t i = r * JN_THREADS + tid;
+        if (i < nR) lrows[atomicAdd(&pc[slot[r]], 1u << 16) >> 16] = row[r];
+    }
+    __syncthreads();
+    // 4. per key: order its rows ascending (insertion sort of a short run), publish {key -> start, count}
+    for (uint32_t s = tid; s <= BH_SLOTS; s += JN_THREADS) {
+        const uint32_t v = pc[s], m = v & 0xFFFFu;
+        if (m == 0) continue;
+        const uint32_t start = (v >> 16) - m;
+        for (uint32_t x = 1; x < m; x++) {
+            const uint32_t rv = lrows[start + x];
+            uint32_t y = x;
+            while (y > 0 && lrows[start + y - 1] > rv) { lrows[start + y] = lrows[start + y - 1]; y--; }
+            lrows[start + y] = rv;
+        }
+        if (s == BH_SLOTS) { a.table[a.table_mask + 1].start = rbeg + start; a.table[a.table_mask + 1].count = m; continue; }
+        const uint64_t key = sk[s];
+        uint32_t g = hash32(key, 0x7F4A7C15u) & a.table_mask;
+        for (;;) {
+            uint64_t old = atomicCAS((unsigned long long *)&a.table[g].key, EMPTY_KEY, key);
+            if (old == EMPTY_KEY) { a.table[g].start = rbeg + start; a.table[g].count = m; break; }
+            g = (g + 1) & a.table_mask;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nR; i += JN_THREADS) a.rrows[rbeg + i] = lrows[i];
 }
 
 // General build path (a partition larger than the LDS sort buffers: very many build rows, or one
@@ -355,7 +449,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             BuildArgs ba{};
             ba.rkeys = prk; ba.rrows = prr; ba.roff = rpart.offsets; ba.rNB = rpart.NB;
             ba.table = table; ba.table_mask = cap_tab - 1; ba.flags = flags;
-            const size_t lds = (size_t)JN_RCAP * 12 + 64;
+            const size_t lds = (size_t)BH_SLOTS * 12 + JN_RCAP * 4 + 256;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_build_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (!generic) {
