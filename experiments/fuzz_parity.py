@@ -80,10 +80,12 @@ for case in range(n_cases):
             how = int(rng.integers(0, 4))
             jg = int(rng.random() < 0.25)
             ctx.set_option("join_generic", jg)
+            ctx.set_option("join_one_pass", int(rng.random() < 0.25))
             try:
                 gl, gr = ctx.join_indices(lk, nl, rk, nr, how)
             finally:
                 ctx.set_option("join_generic", 0)
+                ctx.set_option("join_one_pass", 0)
             wl, wr = O.join_indices(lk, nl, rk, nr, how)
             np.testing.assert_array_equal(gl, wl); np.testing.assert_array_equal(gr, wr)
             desc = "join nl=%d nr=%d kd=%d space=%d how=%d generic=%d -> %d rows" % (nl, nr, kd, space, how, jg, len(gl))

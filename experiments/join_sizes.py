@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pandrs_amd as pa
 ctx = pa.Context(0); d = "cuda:0"
+if os.environ.get("ONE_PASS"): ctx.set_option("join_one_pass", 1)
 import sys as _s
 CASES = [(5_000_000, 50_000_000), (30_000_000, 60_000_000), (1_000_000, 100_000_000)]
 if len(_s.argv) > 1 and _s.argv[1] == 'big':      # beyond one LDS partition per build bucket: general segmented sort

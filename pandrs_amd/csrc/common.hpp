@@ -146,6 +146,7 @@ struct Options {
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
+    int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
 };
 

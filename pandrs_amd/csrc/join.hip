@@ -32,6 +32,7 @@ constexpr int JN_THREADS = 1024;
 constexpr int JN_RCAP = 8192;           // right rows per partition that fit the LDS sort buffers
 constexpr uint32_t JN_SEED = 0x51ED270Bu;
 constexpr uint32_t NO_MATCH = 0xFFFFFFFFu;
+constexpr uint32_t JN_DIRECT = 0x80000000u;   // JoinEntry.count flag: a single-row run, `start` IS the right row (no gather)
 
 // ---- LDS bitonic sort of (key, payload) pairs, ascending by key then payload ----------------------
 template <typename PT>
@@ -66,7 +67,7 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t *sk, uint32_t
 // {key cell, first position of the key's run in the sorted right arrays, run length}.
 struct __attribute__((aligned(16))) JoinEntry {
     uint64_t key;
-    uint32_t start, count;
+    uint32_t start, count;      // count & JN_DIRECT: run of one row, start = that row itself
 };
 
 struct BuildArgs {
@@ -97,14 +98,15 @@ __device__ __forceinline__ void build_partition_bitonic(const BuildArgs &a, unsi
         if (i > 0 && sk[i - 1] == k) continue;          // not the start of a run
         uint32_t m = 1;
         while (i + m < nR && sk[i + m] == k) m++;
+        const uint32_t e_start = m == 1 ? sp[i] : rbeg + i, e_count = m == 1 ? (1u | JN_DIRECT) : m;
         if (k == EMPTY_KEY) {                            // the sentinel-valued key has a dedicated entry
-            a.table[a.table_mask + 1].start = rbeg + i; a.table[a.table_mask + 1].count = m;
+            a.table[a.table_mask + 1].start = e_start; a.table[a.table_mask + 1].count = e_count;
             continue;
         }
         uint32_t slot = hash32(k, 0x7F4A7C15u) & a.table_mask;
         for (;;) {                                       // distinct keys only: claim the first empty entry
             uint64_t old = atomicCAS((unsigned long long *)&a.table[slot].key, EMPTY_KEY, k);
-            if (old == EMPTY_KEY) { a.table[slot].start = rbeg + i; a.table[slot].count = m; break; }
+            if (old == EMPTY_KEY) { a.table[slot].start = e_start; a.table[slot].count = e_count; break; }
             slot = (slot + 1) & a.table_mask;
         }
     }
@@ -197,12 +199,13 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
             while (y > 0 && lrows[start + y - 1] > rv) { lrows[start + y] = lrows[start + y - 1]; y--; }
             lrows[start + y] = rv;
         }
-        if (s == BH_SLOTS) { a.table[a.table_mask + 1].start = rbeg + start; a.table[a.table_mask + 1].count = m; continue; }
+        const uint32_t e_start = m == 1 ? lrows[start] : rbeg + start, e_count = m == 1 ? (1u | JN_DIRECT) : m;
+        if (s == BH_SLOTS) { a.table[a.table_mask + 1].start = e_start; a.table[a.table_mask + 1].count = e_count; continue; }
         const uint64_t key = sk[s];
         uint32_t g = hash32(key, 0x7F4A7C15u) & a.table_mask;
         for (;;) {
             uint64_t old = atomicCAS((unsigned long long *)&a.table[g].key, EMPTY_KEY, key);
-            if (old == EMPTY_KEY) { a.table[g].start = rbeg + start; a.table[g].count = m; break; }
+            if (old == EMPTY_KEY) { a.table[g].start = e_start; a.table[g].count = e_count; break; }
             g = (g + 1) & a.table_mask;
         }
     }
@@ -214,17 +217,18 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
 // key with thousands of duplicates): the partitions were sorted by segmented_sort_u32; the sorted
 // non-null rows [0, *n_bound) form one array in which equal keys are adjacent (a key lives in
 // exactly one partition), so runs are published without looking at partition boundaries.
-__global__ void publish_runs_kernel(const uint64_t *rkeys, const uint32_t *n_bound, JoinEntry *table, uint32_t table_mask) {
+__global__ void publish_runs_kernel(const uint64_t *rkeys, const uint32_t *rrows, const uint32_t *n_bound, JoinEntry *table, uint32_t table_mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = *n_bound;
     if (i >= n) return;
     const uint64_t k = rkeys[i];
     if (i > 0 && rkeys[i - 1] == k) return;
     const uint32_t m = sorted_run_length(rkeys, i, n);
-    if (k == EMPTY_KEY) { table[table_mask + 1].start = i; table[table_mask + 1].count = m; return; }
+    const uint32_t e_start = m == 1 ? rrows[i] : i, e_count = m == 1 ? (1u | JN_DIRECT) : m;
+    if (k == EMPTY_KEY) { table[table_mask + 1].start = e_start; table[table_mask + 1].count = e_count; return; }
     uint32_t slot = hash32(k, 0x7F4A7C15u) & table_mask;
     for (;;) {
         uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
-        if (old == EMPTY_KEY) { table[slot].start = i; table[slot].count = m; break; }
+        if (old == EMPTY_KEY) { table[slot].start = e_start; table[slot].count = e_count; break; }
         slot = (slot + 1) & table_mask;
     }
 }
@@ -274,7 +278,146 @@ __global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, i
             }
         }
         match[l] = out;
-        cnt[l] = out.y;             // dense per-row output counts for the scan
+        cnt[l] = out.y & ~JN_DIRECT;    // dense per-row output counts for the scan
+    }
+}
+
+// ---- single-pass probe (opt-in, option join_one_pass): lookup + scan + emit in ONE kernel -----------
+// The three-kernel probe above writes and re-reads 16 B of intermediates per left row (match, count,
+// offset).  Here a tile of 2048 consecutive left rows looks its keys up, and the output position of
+// the tile comes from a decoupled look-back over the tiles before it (each tile publishes first its
+// own total, then its inclusive prefix, in one 64-bit word: flag << 62 | value), so the index pairs
+// are written in the reference's order straight away.  Tiles take their number from an atomic ticket,
+// which guarantees that every predecessor a tile waits for is already running.  The wait is bounded:
+// on a timeout the kernel raises err[0] and the host falls back to the three-kernel probe.
+constexpr int OP_THREADS = 256, OP_RPT = 8, OP_TILE = OP_THREADS * OP_RPT;
+constexpr unsigned long long OP_VALUE = (1ull << 62) - 1;
+struct OnePassArgs {
+    KeyDesc lkey; int64_t n_left;
+    const JoinEntry *table; uint32_t table_mask;
+    const uint32_t *rrows_sorted;
+    int keep_left, flag_right;
+    uint8_t *hit;
+    unsigned long long *status;     // [n_tiles], zeroed
+    uint32_t *ticket;               // zeroed; err = ticket + 1
+    uint64_t cap;                   // capacity of out_left / out_right (rows); the totals keep counting past it
+    int64_t *out_left, *out_right;
+};
+__global__ __launch_bounds__(OP_THREADS) void join_probe_onepass_kernel(OnePassArgs a) {
+    constexpr int NW = OP_THREADS / 64;
+    __shared__ uint32_t wsum[OP_RPT][NW];              // matches of (row slice r, wave w)
+    __shared__ uint32_t s_tile;
+    __shared__ unsigned long long s_excl;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    // row slice r of the tile = rows tile * OP_TILE + r * OP_THREADS + tid: coalesced key loads and,
+    // for a unique-key build side, coalesced output stores (consecutive lanes, consecutive rows)
+    const int64_t base = (int64_t)tile * OP_TILE + tid;
+    uint64_t k[OP_RPT];
+    uint32_t slot[OP_RPT];
+    bool nul[OP_RPT];
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++) {
+        const int64_t l = min(base + (int64_t)r * OP_THREADS, a.n_left - 1);
+        nul[r] = key_is_null(a.lkey, l) || base + (int64_t)r * OP_THREADS >= a.n_left;
+        k[r] = key_cell(a.lkey, l);
+        slot[r] = k[r] == EMPTY_KEY ? a.table_mask + 1 : (hash32(k[r], 0x7F4A7C15u) & a.table_mask);
+    }
+    JoinEntry e[OP_RPT];
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++) e[r] = a.table[slot[r]];
+    uint32_t start[OP_RPT], cnt[OP_RPT], inc[OP_RPT];
+    bool direct[OP_RPT];
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++) {
+        start[r] = NO_MATCH; cnt[r] = 0; direct[r] = false;
+        if (!nul[r]) {                                  // null left keys are dropped even for left/outer (join.rs:152)
+            bool found;
+            if (k[r] == EMPTY_KEY) {
+                found = e[r].count != 0;
+            } else {
+                while (e[r].key != k[r] && e[r].key != EMPTY_KEY) {
+                    slot[r] = (slot[r] + 1) & a.table_mask;
+                    e[r] = a.table[slot[r]];
+                }
+                found = e[r].key == k[r];
+            }
+            if (found) {
+                start[r] = e[r].start; cnt[r] = e[r].count & ~JN_DIRECT; direct[r] = (e[r].count & JN_DIRECT) != 0;
+                if (a.flag_right) a.hit[slot[r]] = 1;
+            } else if (a.keep_left) {
+                cnt[r] = 1;
+            }
+        }
+        uint32_t v = cnt[r];                            // inclusive scan over the wave's lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += t;
+        }
+        inc[r] = v;
+        if (lane == 63) wsum[r][wave] = v;
+    }
+    __syncthreads();
+    uint32_t tot = 0, before[OP_RPT];                   // matches of the tile; matches before (r, wave)
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++) {
+        before[r] = tot;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t x = wsum[r][w];
+            if (w < (int)wave) before[r] += x;
+            tot += x;
+        }
+    }
+    if (tid < 64) {                                     // wave 0: publish, then look back
+        unsigned long long excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&a.status[0], (2ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&a.status[tile], (1ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t j0 = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t j = j0 - lane;
+                unsigned long long v = 2ull << 62;      // before tile 0: inclusive prefix 0
+                if (j >= 0) {
+                    uint32_t spins = 0;
+                    v = __hip_atomic_load(&a.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 62) == 0) {
+                        if (++spins > (1u << 22)) { a.ticket[1] = 1; v = 2ull << 62; break; }   // never hang the GPU
+                        __builtin_amdgcn_s_sleep(2);
+                        v = __hip_atomic_load(&a.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const unsigned long long incl = __ballot((v >> 62) == 2);
+                const int first = incl ? __builtin_ctzll(incl) : 64;
+                unsigned long long add = (int)lane <= first ? (v & OP_VALUE) : 0ull;
+                for (int o = 32; o >= 1; o >>= 1) add += __shfl_xor(add, o, 64);
+                excl += add;
+                if (incl) break;
+                j0 -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&a.status[tile], (2ull << 62) | ((excl + tot) & OP_VALUE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const uint64_t tile_pos = s_excl;
+    uint32_t first_row[OP_RPT];
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++)                    // the gathers of all slices in flight together
+        first_row[r] = direct[r] ? start[r] : ((cnt[r] != 0 && start[r] != NO_MATCH) ? a.rrows_sorted[start[r]] : 0u);
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++) {
+        if (cnt[r] == 0) continue;
+        const int64_t l = base + (int64_t)r * OP_THREADS;
+        const uint64_t pos = tile_pos + before[r] + inc[r] - cnt[r];
+        if (pos + cnt[r] > a.cap) continue;
+        if (start[r] == NO_MATCH) { a.out_left[pos] = l; a.out_right[pos] = -1; continue; }
+        a.out_left[pos] = l; a.out_right[pos] = first_row[r];
+        for (uint32_t q = 1; q < cnt[r]; q++) { a.out_left[pos + q] = l; a.out_right[pos + q] = a.rrows_sorted[start[r] + q]; }
     }
 }
 
@@ -284,6 +427,7 @@ __global__ void mark_matched_kernel(const JoinEntry *table, const uint8_t *hit, 
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_entries || !hit[s]) return;
     const JoinEntry e = table[s];
+    if (e.count & JN_DIRECT) { rmatched[e.start] = 1; return; }
     for (uint32_t j = 0; j < e.count; j++) rmatched[rrows_sorted[e.start + j]] = 1;
 }
 
@@ -305,14 +449,14 @@ __global__ __launch_bounds__(EM_THREADS) void join_emit_kernel(const uint2 *matc
     }
 #pragma unroll
     for (int r = 0; r < EM_RPT; r++)
-        first[r] = (mt[r].y != 0 && mt[r].x != NO_MATCH) ? rrows_sorted[mt[r].x] : 0u;
+        first[r] = (mt[r].y & JN_DIRECT) ? mt[r].x : ((mt[r].y != 0 && mt[r].x != NO_MATCH) ? rrows_sorted[mt[r].x] : 0u);
 #pragma unroll
     for (int r = 0; r < EM_RPT; r++) {
         const int64_t l = base + (int64_t)r * EM_THREADS;
         if (l >= n_left || mt[r].y == 0) continue;
         if (mt[r].x == NO_MATCH) { out_left[o[r]] = l; out_right[o[r]] = -1; continue; }
         out_left[o[r]] = l; out_right[o[r]] = first[r];
-        for (uint32_t q = 1; q < mt[r].y; q++) { out_left[(size_t)o[r] + q] = l; out_right[(size_t)o[r] + q] = rrows_sorted[mt[r].x + q]; }
+        for (uint32_t q = 1; q < (mt[r].y & ~JN_DIRECT); q++) { out_left[(size_t)o[r] + q] = l; out_right[(size_t)o[r] + q] = rrows_sorted[mt[r].x + q]; }
     }
 }
 
@@ -405,7 +549,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
               + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded(size_t(nl + 2) * 4)
               + 2 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
               + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16)
-              + segsort_workspace_bytes(nr, P_MAX + 1, 4);
+              + segsort_workspace_bytes(nr, P_MAX + 1, 4) + Arena::padded((size_t(nl) / OP_TILE + 2) * 8) + 4096;
     ST_TRY(c->work.ensure(ws, c->stream));
 
     int64_t P = c->opt.partitions > 0 ? c->opt.partitions
@@ -416,6 +560,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
     int64_t M1 = 0, M2 = 0;
     // the LDS build cannot work when even the maximum fan-out leaves partitions above its capacity
     bool generic = c->opt.join_generic != 0 || (double)nr / (double)P > JN_RCAP * 0.95;
+    bool onepass_failed = false;
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.retries = attempt; c->timings.table_slots = JN_RCAP;
@@ -460,9 +605,79 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
                 ST_TRY(segmented_sort_u32(c, prk, prr, rpart.offsets, rpart.NB, (uint32_t)P, nr));
                 if (nr > 0)
                     hipLaunchKernelGGL(publish_runs_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
-                                       prk, rpart.offsets + (size_t)P * rpart.NB, table, cap_tab - 1);
+                                       prk, prr, rpart.offsets + (size_t)P * rpart.NB, table, cap_tab - 1);
             }
             HIP_TRY(hipGetLastError());
+        }
+        // ---- probe, single pass (opt-in: both probes are bound by the random table reads, ~40 G/s from
+        // MALL, and measure within a few percent of each other); the result buffers are sized for a
+        // unique-key build side up front and re-sized once if duplicate keys produce more rows
+        if (c->opt.join_one_pass && !onepass_failed && nl > 0) {
+            const uint32_t n_tiles = (uint32_t)((nl + OP_TILE - 1) / OP_TILE);
+            unsigned long long *status = c->work.take<unsigned long long>((size_t)n_tiles + 1);
+            uint32_t *ticket = c->work.take<uint32_t>(16);
+            if (!status || !ticket) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
+            uint64_t cap_out = (uint64_t)nl + (keep_right ? (uint64_t)nr : 0ull) + 16;
+            uint64_t total = 0;
+            bool bail = false;
+            for (int pass = 0;; pass++) {
+                ST_TRY(c->result.ensure(2 * Arena::padded(size_t(cap_out + 1) * 8) + 4096, c->stream));
+                c->jn.left_idx = c->result.take<int64_t>(cap_out + 1);
+                c->jn.right_idx = c->result.take<int64_t>(cap_out + 1);
+                if (!c->jn.left_idx || !c->jn.right_idx) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
+                HIP_TRY(hipMemsetAsync(status, 0, ((size_t)n_tiles + 1) * 8, c->stream));
+                HIP_TRY(hipMemsetAsync(ticket, 0, 64, c->stream));
+                {
+                    PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+                    OnePassArgs oa{};
+                    oa.lkey = lkey; oa.n_left = nl; oa.table = table; oa.table_mask = cap_tab - 1; oa.rrows_sorted = prr;
+                    oa.keep_left = keep_left ? 1 : 0; oa.flag_right = keep_right ? 1 : 0; oa.hit = hit;
+                    oa.status = status; oa.ticket = ticket; oa.cap = cap_out - (keep_right ? (uint64_t)nr : 0ull);
+                    oa.out_left = c->jn.left_idx; oa.out_right = c->jn.right_idx;
+                    hipLaunchKernelGGL(join_probe_onepass_kernel, dim3(n_tiles), dim3(OP_THREADS), 0, c->stream, oa);
+                    HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(h + 1, ticket + 1, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(h + 2, status + (n_tiles - 1), 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (h[0] || h[1]) { bail = true; break; }
+                total = ((uint64_t)h[2] | ((uint64_t)h[3] << 32)) & OP_VALUE;
+                if (total + (uint64_t)nr >= (1ull << 32) - 16384)
+                    return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: the output exceeds the 2^32-row per-call limit");
+                if (total + (keep_right ? (uint64_t)nr : 0ull) <= cap_out || pass > 0) break;
+                cap_out = total + (keep_right ? (uint64_t)nr : 0ull) + 16;     // duplicate build keys: exact size, probe again
+                if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(cap_tab) + 16, c->stream));
+            }
+            if (bail) {
+                if (h[0]) {     // a build partition overflowed (see below)
+                    if (attempt == 0 && P < P_MAX) P = std::min<int64_t>(P * 4, P_MAX);
+                    else generic = true;
+                } else {
+                    onepass_failed = true;      // look-back timed out: use the three-kernel probe
+                }
+                continue;
+            }
+            M1 = (int64_t)total;
+            if (keep_right && nr > 0) {
+                hipLaunchKernelGGL(mark_matched_kernel, dim3((cap_tab + 2 + 255) / 256), dim3(256), 0, c->stream,
+                                   table, hit, cap_tab + 2, prr, rmatched);
+                uint32_t *pred = c->work.take<uint32_t>(nr + 2);
+                uint32_t *roff2 = c->work.take<uint32_t>(nr + 2);
+                uint32_t *seg2 = c->work.take<uint32_t>(scan_seg_count((size_t)nr + 1));
+                if (!pred || !roff2 || !seg2) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
+                HIP_TRY(hipMemsetAsync(pred + nr, 0, 8, c->stream));
+                hipLaunchKernelGGL(unmatched_pred_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, rmatched, nr, pred);
+                ST_TRY(exclusive_scan_u32(c, pred, (size_t)nr + 1, roff2, seg2));
+                hipLaunchKernelGGL(append_unmatched_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
+                                   rmatched, roff2, nr, M1, c->jn.left_idx, c->jn.right_idx);
+                HIP_TRY(hipMemcpyAsync(h, roff2 + nr, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                M2 = h[0];
+            }
+            c->jn.n_rows = M1 + M2;
+            c->jn.valid = true;
+            break;
         }
         // ---- probe in original left order, scan of the per-row output counts
         {
