@@ -70,17 +70,44 @@ struct __attribute__((aligned(16))) JoinEntry {
     uint32_t start, count;      // count & JN_DIRECT: run of one row, start = that row itself
 };
 
+// The table is cut into one REGION per build partition (a key's partition is a function of the key,
+// so a lookup knows its region).  A build workgroup owns its region: it assembles the region's
+// open-addressing layout in LDS and writes it out with plain coalesced stores — no global atomics
+// (device-scope CAS on random addresses retires at only ~10 G/s on this chip, which used to BE the
+// build time).  regions == 1 is the plain global table filled with atomics (general build path).
+// The entry behind the last region serves the key ~0.
+constexpr uint32_t BH_SLOTS = 8192;             // entries per region = slots of the build kernel's LDS table
+constexpr uint32_t BH_SEED = 0x3243F6A8u;
+struct TableRef {
+    JoinEntry *t;
+    uint32_t regions, rmask;        // rmask = region capacity - 1
+    __device__ __forceinline__ uint32_t sentinel() const { return regions * (rmask + 1); }
+    __device__ __forceinline__ uint32_t base_of(uint64_t k) const {
+        return regions > 1 ? part_of(hash32(k, JN_SEED), regions) * (rmask + 1) : 0u;
+    }
+    __device__ __forceinline__ uint32_t home_of(uint64_t k) const { return hash32(k, BH_SEED) & rmask; }
+    // claims the first free entry of the key's probe sequence (distinct keys only)
+    __device__ __forceinline__ void insert(uint32_t base, uint64_t k, uint32_t start, uint32_t count) const {
+        uint32_t o = home_of(k);
+        for (uint32_t probes = 0; probes <= rmask; probes++) {       // bounded: a full region drops the entry instead of spinning
+            uint64_t old = atomicCAS((unsigned long long *)&t[base + o].key, EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { t[base + o].start = start; t[base + o].count = count; return; }
+            o = (o + 1) & rmask;
+        }
+    }
+};
+
 struct BuildArgs {
     uint64_t *rkeys; uint32_t *rrows;           // partitioned right side, sorted in place per partition
     const uint32_t *roff;                       // partition offsets (PartInfo.offsets)
     uint32_t rNB;
-    JoinEntry *table; uint32_t table_mask;      // capacity = table_mask + 1; entry [capacity] serves the key ~0
+    TableRef tab;
     uint32_t *flags;                            // [0] = a right partition did not fit LDS
 };
 
 // Build pass, fallback body: bitonic sort of the whole partition by (key, right row) in LDS
 // (sk[R2] u64 | sp[R2] u32), written back sorted, every run {key -> start, count} published.
-__device__ __forceinline__ void build_partition_bitonic(const BuildArgs &a, unsigned char *smem, uint32_t rbeg, uint32_t nR) {
+__device__ __forceinline__ void build_partition_bitonic(const BuildArgs &a, unsigned char *smem, uint32_t rbeg, uint32_t nR, uint32_t tbase) {
     const uint32_t tid = threadIdx.x;
     uint32_t n2 = 64;
     while (n2 < nR) n2 <<= 1;
@@ -100,15 +127,10 @@ __device__ __forceinline__ void build_partition_bitonic(const BuildArgs &a, unsi
         while (i + m < nR && sk[i + m] == k) m++;
         const uint32_t e_start = m == 1 ? sp[i] : rbeg + i, e_count = m == 1 ? (1u | JN_DIRECT) : m;
         if (k == EMPTY_KEY) {                            // the sentinel-valued key has a dedicated entry
-            a.table[a.table_mask + 1].start = e_start; a.table[a.table_mask + 1].count = e_count;
+            a.tab.t[a.tab.sentinel()].start = e_start; a.tab.t[a.tab.sentinel()].count = e_count;
             continue;
         }
-        uint32_t slot = hash32(k, 0x7F4A7C15u) & a.table_mask;
-        for (;;) {                                       // distinct keys only: claim the first empty entry
-            uint64_t old = atomicCAS((unsigned long long *)&a.table[slot].key, EMPTY_KEY, k);
-            if (old == EMPTY_KEY) { a.table[slot].start = e_start; a.table[slot].count = e_count; break; }
-            slot = (slot + 1) & a.table_mask;
-        }
+        a.tab.insert(tbase, k, e_start, e_count);
     }
 }
 
@@ -119,15 +141,21 @@ __device__ __forceinline__ void build_partition_bitonic(const BuildArgs &a, unsi
 // case, and a few rows otherwise).  ~4 LDS passes instead of the 91 stages of an 8192-element
 // bitonic sort.  A key with more than BH_MAXRUN rows sends the partition to the bitonic fallback.
 // LDS: sk[BH_SLOTS] u64 keys | pc[BH_SLOTS + 1] u32 (count | cursor << 16) | lrows[JN_RCAP] u32 | scan scratch
-constexpr uint32_t BH_SLOTS = 8192, BH_MAXRUN = 48;
+constexpr uint32_t BH_MAXRUN = 48;
 constexpr int BH_RPT = JN_RCAP / JN_THREADS;
 __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
     const uint32_t nR = rend - rbeg;
-    if (nR > JN_RCAP) { if (tid == 0) a.flags[0] = 1; return; }
-    if (nR == 0) return;
+    const uint32_t tbase = p * BH_SLOTS;
+    if (nR == 0 || nR > BH_SLOTS / 8 * 7) {
+        // nothing to build, or too much for a region that must keep free entries (the host retries): the
+        // region is written EMPTY either way — the probe that is already queued must find its way out
+        for (uint32_t s = tid; s < BH_SLOTS; s += JN_THREADS) a.tab.t[tbase + s] = JoinEntry{EMPTY_KEY, 0u, 0u};
+        if (nR != 0 && tid == 0) a.flags[0] = 1;
+        return;
+    }
     uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
     uint32_t *pc = reinterpret_cast<uint32_t *>(sk + BH_SLOTS);
     uint32_t *lrows = pc + BH_SLOTS + 8;
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
         if (i >= nR) continue;
         uint32_t s = BH_SLOTS;                       // the sentinel-valued key counts in the extra entry
         if (k[r] != EMPTY_KEY) {
-            s = hash32(k[r], 0x3243F6A8u) & (BH_SLOTS - 1);
+            s = hash32(k[r], BH_SEED) & (BH_SLOTS - 1);
             for (;;) {
                 const uint64_t old = atomicCAS((unsigned long long *)&sk[s], EMPTY_KEY, k[r]);
                 if (old == EMPTY_KEY || old == k[r]) break;
@@ -161,9 +189,12 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
         if ((atomicAdd(&pc[s], 1u) & 0xFFFFu) + 1 > BH_MAXRUN) wt[20] = 1;
     }
     __syncthreads();
-    if (wt[20]) {                                    // a long run (hot build key): sort the partition instead
+    if (wt[20]) {                                    // a long run (hot build key): sort the partition instead,
+        for (uint32_t s = tid; s < BH_SLOTS; s += JN_THREADS)      // publish into the (emptied) region with atomics
+            a.tab.t[tbase + s] = JoinEntry{EMPTY_KEY, 0u, 0u};
+        __threadfence();
         __syncthreads();
-        build_partition_bitonic(a, smem, rbeg, nR);
+        build_partition_bitonic(a, smem, rbeg, nR, tbase);
         return;
     }
     // 2. exclusive scan of the counts = start of every key's run; cursor = start
@@ -188,10 +219,11 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
         if (i < nR) lrows[atomicAdd(&pc[slot[r]], 1u << 16) >> 16] = row[r];
     }
     __syncthreads();
-    // 4. per key: order its rows ascending (insertion sort of a short run), publish {key -> start, count}
+    // 4. per key: order its rows ascending (insertion sort of a short run); the LDS table IS the region's
+    //    open-addressing layout (same hash, same probe order): write it out, entry by entry, coalesced
     for (uint32_t s = tid; s <= BH_SLOTS; s += JN_THREADS) {
         const uint32_t v = pc[s], m = v & 0xFFFFu;
-        if (m == 0) continue;
+        if (m == 0) { if (s < BH_SLOTS) a.tab.t[tbase + s] = JoinEntry{EMPTY_KEY, 0u, 0u}; continue; }
         const uint32_t start = (v >> 16) - m;
         for (uint32_t x = 1; x < m; x++) {
             const uint32_t rv = lrows[start + x];
@@ -200,14 +232,8 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
             lrows[start + y] = rv;
         }
         const uint32_t e_start = m == 1 ? lrows[start] : rbeg + start, e_count = m == 1 ? (1u | JN_DIRECT) : m;
-        if (s == BH_SLOTS) { a.table[a.table_mask + 1].start = e_start; a.table[a.table_mask + 1].count = e_count; continue; }
-        const uint64_t key = sk[s];
-        uint32_t g = hash32(key, 0x7F4A7C15u) & a.table_mask;
-        for (;;) {
-            uint64_t old = atomicCAS((unsigned long long *)&a.table[g].key, EMPTY_KEY, key);
-            if (old == EMPTY_KEY) { a.table[g].start = e_start; a.table[g].count = e_count; break; }
-            g = (g + 1) & a.table_mask;
-        }
+        if (s == BH_SLOTS) { a.tab.t[a.tab.sentinel()].start = e_start; a.tab.t[a.tab.sentinel()].count = e_count; continue; }
+        a.tab.t[tbase + s] = JoinEntry{sk[s], e_start, e_count};
     }
     __syncthreads();
     for (uint32_t i = tid; i < nR; i += JN_THREADS) a.rrows[rbeg + i] = lrows[i];
@@ -217,39 +243,36 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
 // key with thousands of duplicates): the partitions were sorted by segmented_sort_u32; the sorted
 // non-null rows [0, *n_bound) form one array in which equal keys are adjacent (a key lives in
 // exactly one partition), so runs are published without looking at partition boundaries.
-__global__ void publish_runs_kernel(const uint64_t *rkeys, const uint32_t *rrows, const uint32_t *n_bound, JoinEntry *table, uint32_t table_mask) {
+__global__ void publish_runs_kernel(const uint64_t *rkeys, const uint32_t *rrows, const uint32_t *n_bound, TableRef tab) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = *n_bound;
     if (i >= n) return;
     const uint64_t k = rkeys[i];
     if (i > 0 && rkeys[i - 1] == k) return;
     const uint32_t m = sorted_run_length(rkeys, i, n);
     const uint32_t e_start = m == 1 ? rrows[i] : i, e_count = m == 1 ? (1u | JN_DIRECT) : m;
-    if (k == EMPTY_KEY) { table[table_mask + 1].start = e_start; table[table_mask + 1].count = e_count; return; }
-    uint32_t slot = hash32(k, 0x7F4A7C15u) & table_mask;
-    for (;;) {
-        uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
-        if (old == EMPTY_KEY) { table[slot].start = e_start; table[slot].count = e_count; break; }
-        slot = (slot + 1) & table_mask;
-    }
+    if (k == EMPTY_KEY) { tab.t[tab.sentinel()].start = e_start; tab.t[tab.sentinel()].count = e_count; return; }
+    tab.insert(tab.base_of(k), k, e_start, e_count);
 }
 
 // Probe pass over the left rows in ORIGINAL order.  LK_RPT rows per thread: all key loads, then all
 // first-probe table reads (16-byte entries, cache resident for typical builds) are in flight together;
 // only rows whose first entry is neither their key nor empty walk on.
 constexpr int LK_THREADS = 256, LK_RPT = 8;
-__global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, int64_t n_left, const JoinEntry *table,
-                                                                 uint32_t table_mask, int keep_left, int flag_right,
+__global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, int64_t n_left, TableRef tab,
+                                                                 int keep_left, int flag_right,
                                                                  uint2 *match, uint32_t *cnt, uint8_t *hit) {
     const int64_t base = (int64_t)blockIdx.x * (LK_THREADS * LK_RPT) + threadIdx.x;
+    const JoinEntry *table = tab.t;
     uint64_t k[LK_RPT];
-    uint32_t slot[LK_RPT];
+    uint32_t slot[LK_RPT], tb[LK_RPT];
     bool nul[LK_RPT];
 #pragma unroll
     for (int r = 0; r < LK_RPT; r++) {
         const int64_t l = min(base + (int64_t)r * LK_THREADS, n_left - 1);
         nul[r] = key_is_null(lkey, l);
         k[r] = key_cell(lkey, l);
-        slot[r] = k[r] == EMPTY_KEY ? table_mask + 1 : (hash32(k[r], 0x7F4A7C15u) & table_mask);
+        tb[r] = tab.base_of(k[r]);
+        slot[r] = k[r] == EMPTY_KEY ? tab.sentinel() : tb[r] + tab.home_of(k[r]);
     }
     JoinEntry e[LK_RPT];
 #pragma unroll
@@ -264,8 +287,8 @@ __global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, i
             if (k[r] == EMPTY_KEY) {
                 found = e[r].count != 0;                // the sentinel-valued key's dedicated entry
             } else {
-                while (e[r].key != k[r] && e[r].key != EMPTY_KEY) {
-                    slot[r] = (slot[r] + 1) & table_mask;
+                for (uint32_t probes = 0; e[r].key != k[r] && e[r].key != EMPTY_KEY && probes < tab.rmask; probes++) {
+                    slot[r] = tb[r] + ((slot[r] - tb[r] + 1) & tab.rmask);      // bounded: never spin on a full region
                     e[r] = table[slot[r]];
                 }
                 found = e[r].key == k[r];
@@ -294,7 +317,7 @@ constexpr int OP_THREADS = 256, OP_RPT = 8, OP_TILE = OP_THREADS * OP_RPT;
 constexpr unsigned long long OP_VALUE = (1ull << 62) - 1;
 struct OnePassArgs {
     KeyDesc lkey; int64_t n_left;
-    const JoinEntry *table; uint32_t table_mask;
+    TableRef tab;
     const uint32_t *rrows_sorted;
     int keep_left, flag_right;
     uint8_t *hit;
@@ -316,18 +339,19 @@ __global__ __launch_bounds__(OP_THREADS) void join_probe_onepass_kernel(OnePassA
     // for a unique-key build side, coalesced output stores (consecutive lanes, consecutive rows)
     const int64_t base = (int64_t)tile * OP_TILE + tid;
     uint64_t k[OP_RPT];
-    uint32_t slot[OP_RPT];
+    uint32_t slot[OP_RPT], tb[OP_RPT];
     bool nul[OP_RPT];
 #pragma unroll
     for (int r = 0; r < OP_RPT; r++) {
         const int64_t l = min(base + (int64_t)r * OP_THREADS, a.n_left - 1);
         nul[r] = key_is_null(a.lkey, l) || base + (int64_t)r * OP_THREADS >= a.n_left;
         k[r] = key_cell(a.lkey, l);
-        slot[r] = k[r] == EMPTY_KEY ? a.table_mask + 1 : (hash32(k[r], 0x7F4A7C15u) & a.table_mask);
+        tb[r] = a.tab.base_of(k[r]);
+        slot[r] = k[r] == EMPTY_KEY ? a.tab.sentinel() : tb[r] + a.tab.home_of(k[r]);
     }
     JoinEntry e[OP_RPT];
 #pragma unroll
-    for (int r = 0; r < OP_RPT; r++) e[r] = a.table[slot[r]];
+    for (int r = 0; r < OP_RPT; r++) e[r] = a.tab.t[slot[r]];
     uint32_t start[OP_RPT], cnt[OP_RPT], inc[OP_RPT];
     bool direct[OP_RPT];
 #pragma unroll
@@ -338,9 +362,9 @@ __global__ __launch_bounds__(OP_THREADS) void join_probe_onepass_kernel(OnePassA
             if (k[r] == EMPTY_KEY) {
                 found = e[r].count != 0;
             } else {
-                while (e[r].key != k[r] && e[r].key != EMPTY_KEY) {
-                    slot[r] = (slot[r] + 1) & a.table_mask;
-                    e[r] = a.table[slot[r]];
+                for (uint32_t probes = 0; e[r].key != k[r] && e[r].key != EMPTY_KEY && probes < a.tab.rmask; probes++) {
+                    slot[r] = tb[r] + ((slot[r] - tb[r] + 1) & a.tab.rmask);
+                    e[r] = a.tab.t[slot[r]];
                 }
                 found = e[r].key == k[r];
             }
@@ -542,8 +566,16 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
     c->jn = JoinResult{};
     c->gb.valid = false;                        // the result arena is shared
     // workspace: one partition pass over the build side + the table + per-row arrays
-    uint32_t cap_tab = 64;
-    while ((double)cap_tab < 1.3 * (double)nr) cap_tab <<= 1;      // load <= 0.77; 16 B per entry (5 M build rows: 134 MB, cache resident)
+    // table capacity: the larger of the global layout (general build path: load <= 0.77) and the regional one
+    // (BH_SLOTS entries per build partition; up to P_MAX partitions after a retry); 16 B per entry
+    uint32_t cap_glob = 64;
+    while ((double)cap_glob < 1.3 * (double)nr) cap_glob <<= 1;
+    auto partitions_for = [&](int64_t P0) { return std::min<int64_t>(P0 * 4, P_MAX); };
+    int64_t P = c->opt.partitions > 0 ? c->opt.partitions
+                                     : std::max<int64_t>(1, (int64_t)std::ceil((double)nr / (JN_RCAP * 0.6)));
+    P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, nr / 8192)), P_MAX);
+    P = std::max<int64_t>(P, 1);
+    const uint32_t cap_tab = (uint32_t)std::max<uint64_t>(cap_glob, (uint64_t)partitions_for(P) * BH_SLOTS);
     size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nr + 1) * 8) + Arena::padded(size_t(nr + 1) * 4)
               + Arena::padded(size_t(cap_tab + 2) * 16) + Arena::padded(size_t(cap_tab) + 16)
               + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded(size_t(nl + 2) * 4)
@@ -552,10 +584,6 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
               + segsort_workspace_bytes(nr, P_MAX + 1, 4) + Arena::padded((size_t(nl) / OP_TILE + 2) * 8) + 4096;
     ST_TRY(c->work.ensure(ws, c->stream));
 
-    int64_t P = c->opt.partitions > 0 ? c->opt.partitions
-                                     : std::max<int64_t>(1, (int64_t)std::ceil((double)nr / (JN_RCAP * 0.6)));
-    P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, nr / 8192)), P_MAX);
-    P = std::max<int64_t>(P, 1);
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     int64_t M1 = 0, M2 = 0;
     // the LDS build cannot work when even the maximum fan-out leaves partitions above its capacity
@@ -579,9 +607,13 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
         HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
         HIP_TRY(hipMemsetAsync(cnt, 0, size_t(nl + 2) * 4, c->stream));
         HIP_TRY(hipMemsetAsync(rmatched, 0, size_t(nr) + 8, c->stream));
-        HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(cap_tab + 2) * 16, c->stream));      // keys = EMPTY
-        HIP_TRY(hipMemsetAsync(&table[cap_tab], 0, 32, c->stream));                     // entry [capacity] (the key ~0's own): count 0
-        if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(cap_tab) + 16, c->stream));
+        TableRef tab{table, 1u, cap_glob - 1};
+        if (!generic) { tab.regions = (uint32_t)P; tab.rmask = BH_SLOTS - 1; }          // regions are written whole by their build workgroups
+        const uint32_t n_entries = tab.regions * (tab.rmask + 1);
+        if ((uint64_t)tab.regions * (tab.rmask + 1) > cap_tab) return fail(PANDRS_HIP_ERR_COMPUTATION, "join: table geometry exceeds its allocation");
+        if (generic) HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(n_entries) * 16, c->stream));   // keys = EMPTY, filled with atomics
+        HIP_TRY(hipMemsetAsync(&table[n_entries], 0, 32, c->stream));                   // the key ~0's own entry: count 0
+        if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(n_entries) + 16, c->stream));
 
         // ---- build side: radix partition (null keys -> their own partition, never built), sort, publish
         PartInfo rpart{};
@@ -593,7 +625,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             PhaseTimer pt(c, PANDRS_HIP_PHASE_BUILD);
             BuildArgs ba{};
             ba.rkeys = prk; ba.rrows = prr; ba.roff = rpart.offsets; ba.rNB = rpart.NB;
-            ba.table = table; ba.table_mask = cap_tab - 1; ba.flags = flags;
+            ba.tab = tab; ba.flags = flags;
             const size_t lds = (size_t)BH_SLOTS * 12 + JN_RCAP * 4 + 256;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(join_build_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -605,7 +637,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
                 ST_TRY(segmented_sort_u32(c, prk, prr, rpart.offsets, rpart.NB, (uint32_t)P, nr));
                 if (nr > 0)
                     hipLaunchKernelGGL(publish_runs_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
-                                       prk, prr, rpart.offsets + (size_t)P * rpart.NB, table, cap_tab - 1);
+                                       prk, prr, rpart.offsets + (size_t)P * rpart.NB, tab);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -630,7 +662,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
                 {
                     PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
                     OnePassArgs oa{};
-                    oa.lkey = lkey; oa.n_left = nl; oa.table = table; oa.table_mask = cap_tab - 1; oa.rrows_sorted = prr;
+                    oa.lkey = lkey; oa.n_left = nl; oa.tab = tab; oa.rrows_sorted = prr;
                     oa.keep_left = keep_left ? 1 : 0; oa.flag_right = keep_right ? 1 : 0; oa.hit = hit;
                     oa.status = status; oa.ticket = ticket; oa.cap = cap_out - (keep_right ? (uint64_t)nr : 0ull);
                     oa.out_left = c->jn.left_idx; oa.out_right = c->jn.right_idx;
@@ -647,7 +679,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
                     return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: the output exceeds the 2^32-row per-call limit");
                 if (total + (keep_right ? (uint64_t)nr : 0ull) <= cap_out || pass > 0) break;
                 cap_out = total + (keep_right ? (uint64_t)nr : 0ull) + 16;     // duplicate build keys: exact size, probe again
-                if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(cap_tab) + 16, c->stream));
+                if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(n_entries) + 16, c->stream));
             }
             if (bail) {
                 if (h[0]) {     // a build partition overflowed (see below)
@@ -660,8 +692,8 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             }
             M1 = (int64_t)total;
             if (keep_right && nr > 0) {
-                hipLaunchKernelGGL(mark_matched_kernel, dim3((cap_tab + 2 + 255) / 256), dim3(256), 0, c->stream,
-                                   table, hit, cap_tab + 2, prr, rmatched);
+                hipLaunchKernelGGL(mark_matched_kernel, dim3((n_entries + 2 + 255) / 256), dim3(256), 0, c->stream,
+                                   table, hit, n_entries + 2, prr, rmatched);
                 uint32_t *pred = c->work.take<uint32_t>(nr + 2);
                 uint32_t *roff2 = c->work.take<uint32_t>(nr + 2);
                 uint32_t *seg2 = c->work.take<uint32_t>(scan_seg_count((size_t)nr + 1));
@@ -684,7 +716,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
             if (nl > 0) {
                 hipLaunchKernelGGL(join_lookup_kernel, dim3((unsigned)((nl + LK_THREADS * LK_RPT - 1) / (LK_THREADS * LK_RPT))), dim3(LK_THREADS), 0, c->stream,
-                                   lkey, nl, table, cap_tab - 1, keep_left ? 1 : 0, keep_right ? 1 : 0, match, cnt, hit);
+                                   lkey, nl, tab, keep_left ? 1 : 0, keep_right ? 1 : 0, match, cnt, hit);
             }
             HIP_TRY(hipGetLastError());
             ST_TRY(exclusive_scan_u32(c, cnt, (size_t)nl + 1, off, seg));    // off[nl] = rows from the probe
@@ -708,8 +740,8 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
         // ---- right / outer: unmatched right rows, ascending
         uint32_t *roff2 = nullptr;
         if (keep_right && nr > 0) {
-            hipLaunchKernelGGL(mark_matched_kernel, dim3((cap_tab + 2 + 255) / 256), dim3(256), 0, c->stream,
-                               table, hit, cap_tab + 2, prr, rmatched);
+            hipLaunchKernelGGL(mark_matched_kernel, dim3((n_entries + 2 + 255) / 256), dim3(256), 0, c->stream,
+                               table, hit, n_entries + 2, prr, rmatched);
             uint32_t *pred = c->work.take<uint32_t>(nr + 2);
             roff2 = c->work.take<uint32_t>(nr + 2);
             uint32_t *seg2 = c->work.take<uint32_t>(scan_seg_count((size_t)nr + 1));
