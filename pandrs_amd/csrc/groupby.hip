@@ -891,7 +891,7 @@ static int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_
     double d = std::max<uint32_t>(h[0], 1), s = (double)n_sample;
     double est;
     if (n_sample == n_rows) est = d;
-    else if (d >= s * 0.98) est = (double)n_rows;                 // (nearly) all distinct in sample
+    else if (s - d < 64.0) est = (double)n_rows;                  // too few repeats in the sample to measure: (nearly) all distinct
     else {
         // uniform-occupancy model d = G (1 - exp(-s/G)); Newton on G
         double G = d;
