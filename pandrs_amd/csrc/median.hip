@@ -90,7 +90,7 @@ __global__ void median_runs_kernel(const uint64_t *keys, const uint64_t *vals, c
     if (null_grp) { table[table_mask + 2].median = med; return; }
     if (k == EMPTY_KEY) { table[table_mask + 1].median = med; return; }
     uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
-    for (;;) {
+    for (uint32_t probes = 0; probes <= table_mask; probes++) {      // bounded: never spin on a full table
         uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
         if (old == EMPTY_KEY) { table[slot].median = med; break; }
         slot = (slot + 1) & table_mask;
@@ -107,7 +107,7 @@ __global__ void median_lookup_kernel(const uint64_t *gkeys, const uint8_t *gnull
     else if (k == EMPTY_KEY) med = table[table_mask + 1].median;
     else {
         uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
-        for (;;) {
+        for (uint32_t probes = 0; probes <= table_mask; probes++) {
             const MedianEntry e = table[slot];
             if (e.key == k) { med = e.median; break; }
             if (e.key == EMPTY_KEY) break;

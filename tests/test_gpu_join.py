@@ -264,3 +264,42 @@ def test_fused_join_general_fallback(ctx):
 
 def sparse(ids):
     return (np.asarray(ids).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+
+
+def test_join_full_size_properties():
+    """BASELINE config 5's shape at a size the oracle cannot reach (100 M probe x 10 M unique build rows):
+    size-independent properties.  Every probe row matches exactly the build row it was drawn from, in
+    left order; a 10 % miss variant drops exactly the misses; the fused join -> groupby(g).sum(v) conserves
+    the total of v over the matched rows and the per-group sums agree with a scatter-add of the same pairs."""
+    import torch
+    import pandrs_amd as pa
+    d = "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(47)
+    nb, npb, g = 10_000_000, 100_000_000, 100_000
+    rk = torch.randperm(nb * 2, device=d, generator=gen)[:nb].to(torch.int64) * -7046029254386353131
+    rg = torch.randint(0, g, (nb,), device=d, generator=gen, dtype=torch.int64)
+    pick = torch.randint(0, nb, (npb,), device=d, generator=gen)
+    lk = rk[pick]
+    lv = torch.randn(npb, device=d, generator=gen, dtype=torch.float64) * 10 + 100
+    c = pa.Context(0)
+    try:
+        li, ri = c.join_indices((lk, None, pa.I64), npb, (rk, None, pa.I64), nb, pa.INNER)
+        assert li.numel() == npb and bool((li == torch.arange(npb, device=d)).all()) and bool((ri == pick).all())
+        miss = torch.rand(npb, device=d, generator=gen) < 0.1
+        lk2 = torch.where(miss, lk ^ 1, lk)                     # odd multiplier => rk are distinct mod 2 patterns; most flips miss
+        li2, ri2 = c.join_indices((lk2, None, pa.I64), npb, (rk, None, pa.I64), nb, pa.LEFT)
+        assert li2.numel() == npb and bool((li2 == torch.arange(npb, device=d)).all())
+        hit = ri2 >= 0
+        assert bool((rk[ri2[hit]] == lk2[hit]).all())
+        assert int((~hit).sum()) > 0.05 * npb
+        del li, ri, li2, ri2, lk2, miss, hit
+        kc, kn, oa = c.join_groupby_sum((lk, None, pa.I64), (lv, None, pa.F64), npb, (rk, None, pa.I64), (rg, None, pa.I64), nb)
+        assert int(kn.sum()) == 0 and kc.shape[1] == torch.unique(rg[pick]).numel()
+        want = torch.zeros(g, dtype=torch.float64, device=d).index_add_(0, rg[pick], lv)
+        got = torch.zeros(g, dtype=torch.float64, device=d)
+        got[kc[0]] = oa[0]
+        assert float((got - want).abs().max()) <= 1e-9 * float(want.abs().max())
+        assert abs(float(oa[0].sum()) - float(lv.sum())) <= 1e-9 * abs(float(lv.sum()))
+    finally:
+        c.close()
