@@ -818,20 +818,52 @@ __global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
     uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
     uint64_t *sg = sk + FJ_SLOTS;
     uint32_t *fill = reinterpret_cast<uint32_t *>(sg + FJ_SLOTS);
-    uint32_t *wt = fill + FJ_BUCKETS;                                    // 17 words of scan scratch
-    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(wt + 18);
+    uint32_t *wt = fill + FJ_BUCKETS;                                    // [0] pairs of the current iteration
+    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(wt + 2);
+    uint32_t *wsum = wt + 4;                                             // FJ_RPT x 16 wave totals
     for (uint32_t i = tid; i < FJ_BUCKETS; i += JN_THREADS) fill[i] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < nR; i += JN_THREADS) {
         const uint64_t k = a.rkeys[rbeg + i], g = a.rpay[rbeg + i];
-        uint32_t b = hash32(k, 0x7F4A7C15u) & (FJ_BUCKETS - 1);
-        for (;;) {
-            const uint32_t c = atomicAdd(&fill[b], 1u);
-            if (c < 4) { sk[b * 4 + c] = k; sg[b * 4 + c] = g; break; }
-            b = (b + 1) & (FJ_BUCKETS - 1);
+        // two-choice placement: the emptier of the key's two buckets, then the other one, and only when
+        // both are full the buckets after the second (rare even at 90 % load)
+        const uint32_t b1 = hash32(k, 0x7F4A7C15u) & (FJ_BUCKETS - 1), b2 = hash32(k, 0x165667B1u) & (FJ_BUCKETS - 1);
+        const bool second_first = fill[b2] < fill[b1];
+        uint32_t b = second_first ? b2 : b1;
+        uint32_t c = atomicAdd(&fill[b], 1u);
+        if (c >= 4) { b = second_first ? b1 : b2; c = atomicAdd(&fill[b], 1u); }
+        if (c >= 4) {
+            b = b2;
+            do { b = (b + 1) & (FJ_BUCKETS - 1); c = atomicAdd(&fill[b], 1u); } while (c >= 4);
         }
+        sk[b * 4 + c] = k; sg[b * 4 + c] = g;
     }
     __syncthreads();
+    // every slot holding `key`, in a fixed order: the key's two buckets, then — only if both ever turned
+    // a row away (fill > 4) — the buckets behind the second, up to the first one that never did
+    auto visit_bucket = [&](uint32_t b, uint64_t key, auto &&fn) -> uint32_t {
+        const uint32_t c = fill[b];
+        const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(&sk[b * 4]);
+        const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(&sk[b * 4 + 2]);
+        if (c > 0 && lo.x == key) fn(b * 4);
+        if (c > 1 && lo.y == key) fn(b * 4 + 1);
+        if (c > 2 && hi.x == key) fn(b * 4 + 2);
+        if (c > 3 && hi.y == key) fn(b * 4 + 3);
+        return c;
+    };
+    auto visit_matches = [&](uint64_t key, auto &&fn) {
+        const uint32_t b1 = hash32(key, 0x7F4A7C15u) & (FJ_BUCKETS - 1), b2 = hash32(key, 0x165667B1u) & (FJ_BUCKETS - 1);
+        const uint32_t c1 = visit_bucket(b1, key, fn);
+        uint32_t c2 = c1;
+        if (b2 != b1) c2 = visit_bucket(b2, key, fn);
+        if (c1 > 4 && c2 > 4) {
+            uint32_t b = b2, c;
+            do {
+                b = (b + 1) & (FJ_BUCKETS - 1);
+                c = (b == b1) ? 5u : visit_bucket(b, key, fn);     // b1 was visited already; it is over-full, walk on
+            } while (c > 4);
+        }
+    };
     const uint32_t n_iter = (lend - lbeg + JN_THREADS * FJ_RPT - 1) / (JN_THREADS * FJ_RPT);
     for (uint32_t it = 0; it < n_iter; it++) {
         const uint32_t i0 = lbeg + it * (JN_THREADS * FJ_RPT) + tid;
@@ -842,49 +874,60 @@ __global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
             k[r] = __builtin_nontemporal_load(&a.lkeys[i]);
             v[r] = __builtin_nontemporal_load(&a.lpay[i]);
         }
-        uint32_t m[FJ_RPT], first[FJ_RPT], mine = 0;
+        uint32_t m[FJ_RPT], first[FJ_RPT];
 #pragma unroll
         for (int r = 0; r < FJ_RPT; r++) {
             m[r] = 0; first[r] = 0;
             if (i0 + (uint32_t)r * JN_THREADS >= lend) continue;
-            uint32_t b = hash32(k[r], 0x7F4A7C15u) & (FJ_BUCKETS - 1);
-            for (;;) {
-                const uint32_t c = fill[b];
-                const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(&sk[b * 4]);
-                const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(&sk[b * 4 + 2]);
-                const uint32_t hit = (uint32_t)(c > 0 && lo.x == k[r]) | ((uint32_t)(c > 1 && lo.y == k[r]) << 1) |
-                                     ((uint32_t)(c > 2 && hi.x == k[r]) << 2) | ((uint32_t)(c > 3 && hi.y == k[r]) << 3);
-                if (hit) {
-                    if (m[r] == 0) first[r] = b * 4 + (uint32_t)__builtin_ctz(hit);
-                    m[r] += (uint32_t)__builtin_popcount(hit);
-                }
-                if (c <= 4) break;
-                b = (b + 1) & (FJ_BUCKETS - 1);
-            }
-            mine += m[r];
+            visit_matches(k[r], [&](uint32_t slot) { if (m[r] == 0) first[r] = slot; m[r]++; });
         }
-        // compaction of the workgroup's pairs: ONE global atomic per workgroup and FJ_RPT x 1024 rows
-        // (same-address atomics retire at well under 100 M/s on this chip: never one per wave)
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan<JN_THREADS>(mine, wt, &tot);
-        if (tot == 0) continue;                         // uniform
-        if (tid == 0) *s_base = atomicAdd(a.cursor, (unsigned long long)tot);
+        // compaction of the workgroup's pairs, row-slice major: the pairs of slice r (rows i0 + r * 1024 + tid)
+        // come before those of slice r + 1, and inside a slice in thread order — consecutive lanes write
+        // consecutive pairs (coalesced stores; thread-major order would scatter every lane's 8 pairs 64 B
+        // apart).  ONE global atomic per workgroup and FJ_RPT x 1024 rows (same-address atomics retire at
+        // well under 100 M/s on this chip: never one per wave).
+        constexpr int NW = JN_THREADS / 64;
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        uint32_t inc[FJ_RPT];
+#pragma unroll
+        for (int r = 0; r < FJ_RPT; r++) {
+            uint32_t x = m[r];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(x, d, 64);
+                if (lane >= (uint32_t)d) x += t;
+            }
+            inc[r] = x;
+            if (lane == 63) wsum[r * NW + wave] = x;
+        }
         __syncthreads();
+        if (tid < 64) {                                 // exclusive scan of the FJ_RPT x NW (= 128) wave totals, 2 per lane
+            const uint32_t a0 = wsum[2 * lane], a1 = wsum[2 * lane + 1];
+            uint32_t x = a0 + a1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(x, d, 64);
+                if (lane >= (uint32_t)d) x += t;
+            }
+            const uint32_t tot = __shfl(x, 63, 64);
+            wsum[2 * lane] = x - a0 - a1; wsum[2 * lane + 1] = x - a1;
+            if (lane == 0) { wt[0] = tot; *s_base = tot ? atomicAdd(a.cursor, (unsigned long long)tot) : 0ull; }
+        }
+        __syncthreads();
+        const uint32_t tot = wt[0];
         const unsigned long long base = *s_base;
-        if (base + tot > a.cap) continue;               // uniform; host grows the buffer and runs the pass again
-        uint64_t pos = base + ex;
+        uint32_t before[FJ_RPT];
+#pragma unroll
+        for (int r = 0; r < FJ_RPT; r++) before[r] = wsum[r * NW + wave];
+        __syncthreads();                                // wsum / wt / s_base are rewritten by the next iteration
+        if (tot == 0 || base + tot > a.cap) continue;   // uniform; on overflow the host grows the buffer and runs the pass again
 #pragma unroll
         for (int r = 0; r < FJ_RPT; r++) {
             if (m[r] == 0) continue;
-            uint32_t slot = first[r];
-            a.out_g[pos] = sg[slot]; a.out_v[pos] = v[r]; pos++;
-            for (uint32_t q = 1; q < m[r]; q++) {       // further rows of a duplicated build key, in slot order
-                for (;;) {
-                    slot = (slot + 1) & (FJ_SLOTS - 1);
-                    if ((slot & 3) < min(fill[slot >> 2], 4u) && sk[slot] == k[r]) break;
-                }
-                a.out_g[pos] = sg[slot]; a.out_v[pos] = v[r]; pos++;
-            }
+            uint64_t pos = base + before[r] + inc[r] - m[r];
+            if (m[r] == 1) { a.out_g[pos] = sg[first[r]]; a.out_v[pos] = v[r]; continue; }
+            const uint64_t vr = v[r];                   // a duplicated build key: visit its slots again
+            visit_matches(k[r], [&](uint32_t slot) { a.out_g[pos] = sg[slot]; a.out_v[pos] = vr; pos++; });
         }
     }
 }
@@ -1015,7 +1058,7 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         fa.roff = rpart.offsets; fa.loff = lpart.offsets; fa.rNB = rpart.NB; fa.lNB = lpart.NB; fa.P = (uint32_t)P;
         fa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); fa.cap = cap_pairs;
         fa.out_g = out_g; fa.out_v = out_v; fa.flags = flags;
-        const size_t lds = (size_t)FJ_SLOTS * 16 + FJ_BUCKETS * 4 + 128;
+        const size_t lds = (size_t)FJ_SLOTS * 16 + FJ_BUCKETS * 4 + 16 + FJ_RPT * 16 * 4 + 64;
         uint64_t total = 0;
         for (;;) {
             {
