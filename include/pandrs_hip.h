@@ -324,6 +324,13 @@ int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space,
                                  const pandrs_hip_column *col, int64_t n,
                                  double out[4], int64_t *out_count);
 
+/* (sum, sum of squares, count) of the non-null values as f64 — the accumulator triple of
+ * parallel_std_f64 / parallel_var_f64 (src/optimized/jit/parallel.rs:190-250), from which the caller
+ * derives the reference's POPULATION variance  max(sum_sq / n - mean^2, 0)  (:222-233; n <= 1 => 0). */
+int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                  const pandrs_hip_column *col, int64_t n,
+                                  double *out_sum, double *out_sum_sq, int64_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

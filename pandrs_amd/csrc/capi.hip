@@ -306,4 +306,14 @@ int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space, const p
     return pandrs::reduce_entry(ctx, mem_space, col, n, out, out_count);
 }
 
+int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
+                                  double *out_sum, double *out_sum_sq, int64_t *out_count) {
+    if (!out_sum || !out_sum_sq || !out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce_moments: bad arguments");
+    double o[4];
+    int32_t st = pandrs::reduce_entry(ctx, mem_space, col, n, o, out_count, out_sum_sq);
+    if (st) return st;
+    *out_sum = o[0];
+    return 0;
+}
+
 }  // extern "C"

@@ -239,7 +239,7 @@ int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void 
                      const uint8_t *mask, const int64_t *idx, int64_t n, uint64_t fill_bits,
                      void *out);
 int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
-                     double out[4], int64_t *out_count);
+                     double out[4], int64_t *out_count, double *out_sumsq = nullptr);
 
 inline size_t dtype_bytes(int dtype, int64_t n) {
     switch (dtype) {

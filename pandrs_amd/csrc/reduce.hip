@@ -14,7 +14,7 @@ constexpr int RD_THREADS = 256;
 constexpr int RD_BLOCKS = 2048;
 
 struct RedPartial {
-    double fsum;
+    double fsum, fsq;   // sum and sum of squares (as f64)
     uint64_t isum;
     uint64_t mn, mx;   // order-preserving encodings
     uint64_t cnt;
@@ -23,7 +23,7 @@ struct RedPartial {
 template <bool IS_F64>
 __global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data, const uint8_t *null_bits,
                                                             int64_t n, RedPartial *partials) {
-    double fs = 0.0;
+    double fs = 0.0, fq = 0.0;
     uint64_t is = 0, cnt = 0;
     uint64_t mn = IS_F64 ? enc_f64(__longlong_as_double(0x7FF0000000000000ll)) : enc_i64(INT64_MAX);
     uint64_t mx = IS_F64 ? enc_f64(__longlong_as_double((long long)0xFFF0000000000000ull)) : enc_i64(INT64_MIN);
@@ -33,10 +33,11 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data
         cnt++;
         if (IS_F64) {
             double d = __longlong_as_double((long long)b);
-            fs += d;
+            fs += d; fq += d * d;
             if (d == d) { uint64_t e = enc_f64(d); mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
         } else {
             is += b;
+            const double d = (double)(int64_t)b; fq += d * d;
             uint64_t e = enc_i64((int64_t)b);
             mn = e < mn ? e : mn; mx = e > mx ? e : mx;
         }
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data
     // wave reduce
     for (int d = 32; d >= 1; d >>= 1) {
         fs += __shfl_down(fs, d, 64);
+        fq += __shfl_down(fq, d, 64);
         is += __shfl_down(is, d, 64);
         cnt += __shfl_down(cnt, d, 64);
         uint64_t a = __shfl_down(mn, d, 64), b2 = __shfl_down(mx, d, 64);
@@ -51,12 +53,12 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data
     }
     __shared__ RedPartial sh[RD_THREADS / 64];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) sh[w] = RedPartial{fs, is, mn, mx, cnt};
+    if (lane == 0) sh[w] = RedPartial{fs, fq, is, mn, mx, cnt};
     __syncthreads();
     if (threadIdx.x == 0) {
         RedPartial r = sh[0];
         for (int j = 1; j < RD_THREADS / 64; j++) {
-            r.fsum += sh[j].fsum; r.isum += sh[j].isum; r.cnt += sh[j].cnt;
+            r.fsum += sh[j].fsum; r.fsq += sh[j].fsq; r.isum += sh[j].isum; r.cnt += sh[j].cnt;
             r.mn = sh[j].mn < r.mn ? sh[j].mn : r.mn; r.mx = sh[j].mx > r.mx ? sh[j].mx : r.mx;
         }
         partials[blockIdx.x] = r;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data
 }
 
 int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
-                     double out[4], int64_t *out_count) {
+                     double out[4], int64_t *out_count, double *out_sumsq) {
     if (!c || !col || !out || !out_count || n < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce: bad arguments");
     if (col->dtype != PANDRS_HIP_I64 && col->dtype != PANDRS_HIP_F64)
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "reduce: dtype %d is not numeric", col->dtype);
@@ -100,10 +102,10 @@ int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_colu
     c->timings.algorithmic_bytes = n * 8 + (col->null_mask ? n / 8 : 0);
     ST_TRY(timings_end(c));
     // host combine of <= 1024 partials, in block order (deterministic)
-    double fs = 0.0; uint64_t is = 0, cnt = 0;
+    double fs = 0.0, fq = 0.0; uint64_t is = 0, cnt = 0;
     uint64_t mn = ~0ull, mx = 0;
     for (int b = 0; b < blocks; b++) {
-        fs += h[b].fsum; is += h[b].isum; cnt += h[b].cnt;
+        fs += h[b].fsum; fq += h[b].fsq; is += h[b].isum; cnt += h[b].cnt;
         mn = h[b].mn < mn ? h[b].mn : mn; mx = h[b].mx > mx ? h[b].mx : mx;
     }
     auto dec_f = [](uint64_t e) { uint64_t b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e; double d; std::memcpy(&d, &b, 8); return d; };
@@ -115,6 +117,7 @@ int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_colu
         out[2] = (double)(int64_t)(mn ^ 0x8000000000000000ull); out[3] = (double)(int64_t)(mx ^ 0x8000000000000000ull);
     }
     *out_count = (int64_t)cnt;
+    if (out_sumsq) *out_sumsq = fq;
     return 0;
 }
 

@@ -373,6 +373,24 @@ class Context:
         self._last = (1, 1, sp, ng.value)
         return self.groupby_fetch()
 
+    def column_std(self, col, n, population=True):
+        """parallel_std_f64_value / parallel_var (jit/parallel.rs:222-250): sqrt(max(sum_sq / n - mean^2, 0)),
+        n <= 1 => 0.0.  -> (std, variance)."""
+        keep = []
+        cc, sp = self._cols([col], keep)
+        s, q, cnt = C.c_double(0), C.c_double(0), C.c_int64(0)
+        st = self.lib.pandrs_hip_reduce_moments(self.h, sp, cc, int(n), C.byref(s), C.byref(q), C.byref(cnt))
+        if st:
+            _raise(st)
+        m = cnt.value
+        if m <= 1:
+            return 0.0, 0.0
+        mean = s.value / m
+        var = max(q.value / m - mean * mean, 0.0)
+        if not population:
+            var *= m / (m - 1.0)
+        return var ** 0.5, var
+
     def reduce_column(self, col, n):
         keep = []
         cc, sp = self._cols([col], keep)

@@ -583,3 +583,19 @@ def test_multi_key_wider_than_64_bits_is_dictionary_encoded(ctx):
     check_group_indices(ctx, [k0, k1], n)
     f = (rng.choice(np.array([0.0, -0.0, np.nan, 1e300, -1e300, 5e-324]), n), None, O.F64)   # full-range f64 key
     check(ctx, [f, k1], n, [v], [(0, O.MAX), (0, O.COUNT)], [O.F64, O.I64], exact=[0, 1])
+
+
+def test_column_population_std_like_parallel_std(ctx):
+    """jit/parallel.rs:374-380: std of [1,2,3,4,5] = 1.4142135623730951 (population); :354-372 sum 1..1000 / mean."""
+    std, var = ctx.column_std((np.array([1.0, 2.0, 3.0, 4.0, 5.0]), None, O.F64), 5)
+    assert abs(std - 1.4142135623730951) < 1e-10 and abs(var - 2.0) < 1e-10
+    assert ctx.column_std((np.array([7.0]), None, O.F64), 1) == (0.0, 0.0)
+    rng = np.random.default_rng(1)
+    n = 2_000_003
+    x = rng.normal(3, 2, n)
+    m = rng.random(n) < 0.1
+    std, _ = ctx.column_std((x, O.pack_mask(m), O.F64), n)
+    assert std == pytest.approx(np.std(x[~m]), rel=1e-9)
+    xi = rng.integers(-1000, 1000, n).astype(np.int64)
+    std, _ = ctx.column_std((xi, None, O.I64), n)
+    assert std == pytest.approx(np.std(xi.astype(np.float64)), rel=1e-9)
