@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pandrs_amd as pa
 from oracle import oracle as O
+from oracle import oracle_np as ONP
 from tests.helpers import assert_groupby_equal
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -69,6 +70,19 @@ for case in range(n_cases):
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN) or (vals[c][2] == O.I64 and op == O.SUM)]
             assert_groupby_equal(got, want, kdts, int_exact_rows=exact, rtol=1e-9)
+            if rng.random() < 0.3:      # group_by's own result on the same keys: a complete characterisation
+                cells, nulls, off, rows = ctx.groupby_indices(keys, n)
+                gcount = cells.shape[1]
+                assert off[0] == 0 and off[-1] == n and (gcount == 0 or np.all(np.diff(off) > 0))
+                np.testing.assert_array_equal(np.sort(rows), np.arange(n))
+                gid = np.repeat(np.arange(gcount), np.diff(off))
+                inner = np.ones(n, bool); inner[off[:-1]] = False
+                assert np.all(np.diff(rows)[inner[1:]] > 0)
+                for kk, col in enumerate(keys):
+                    nul, cell = ONP.key_cells(col, n)
+                    np.testing.assert_array_equal(nulls[kk][gid], nul[rows])
+                    np.testing.assert_array_equal(np.where(nulls[kk][gid] == 1, 0, cells[kk][gid]), cell[rows])
+                assert gcount == want[0].shape[1]
             desc = "groupby n=%d kd=%d g=%d %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, nk, aggs, opts)
         else:                       # ---------------- join
             nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000]))
