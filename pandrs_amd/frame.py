@@ -516,6 +516,29 @@ class GroupBy:
 
     par_filter = filter
 
+    def transform(self, transform_fn):
+        """operations.rs:132-276: transform_fn(group sub-frame) -> frame, for every group; the results are
+        concatenated column by column after the first result's schema (columns matched by POSITION, a
+        column of another type contributes nothing, like the reference's `if let Some(Column::X(..))`)."""
+        outs = [transform_fn(self.df.filter_by_indices(rows)) for rows in self.groups.values()]
+        result = OptimizedDataFrame()
+        if not outs:
+            return result
+        template = outs[0]
+        for ci, tcol in enumerate(template.columns):
+            values = []
+            for df in outs:
+                if ci < len(df.columns) and type(df.columns[ci]) is type(tcol):
+                    col = df.columns[ci]
+                    values.extend(col.get(i) for i in range(col.len()))
+            nulls = [v is None for v in values]
+            fill = {Int64Column: 0, Float64Column: 0.0, StringColumn: "", BooleanColumn: False}[type(tcol)]
+            data = [fill if v is None else v for v in values]
+            result.add_column(template.column_names[ci], type(tcol)(data, nulls if any(nulls) else None))
+        return result
+
+    par_transform = transform
+
     def aggregate(self, aggregations):
         """aggregations: iterable of (column, AggregateOp, alias)  (aggregation.rs:763-871)."""
         aggregations = [(c, AggregateOp(int(op)), alias) for c, op, alias in aggregations]

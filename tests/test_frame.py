@@ -261,3 +261,14 @@ def test_groups_median_custom_filter_par_groupby():
     assert parts["x_1"].column_names == ["k1", "k2", "v"] and parts["y_NA"].column("k2").data.tolist() == [0]
     with pytest.raises(ColumnNotFound):
         df2.par_groupby(["nope"])
+    # transform (operations.rs:132-276): per-group frames concatenated after the first result's schema
+    def demean(g):
+        out = OptimizedDataFrame()
+        vals = g.column("values").data.astype(np.float64)
+        out.add_column("keys", g.column("keys"))
+        out.add_column("centered", Float64Column(vals - vals.mean()))
+        return out
+    t = gb.transform(demean)
+    assert t.column_names == ["keys", "centered"] and t.row_count() == 5
+    got = sorted(zip(t.column("keys").to_list(), t.column("centered").data.tolist()))
+    assert got == [("A", -10.0), ("A", 10.0), ("B", -10.0), ("B", 10.0), ("C", 0.0)]
