@@ -265,6 +265,12 @@ int32_t pandrs_hip_shuffle_split(pandrs_hip_ctx *ctx, int32_t mem_space, const p
                                  const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows,
                                  int32_t n_ranks, int32_t drop_null_keys, int64_t *out_counts,
                                  int64_t *out_n_rows);
+/* One 64-bit hash cell per row of a COMPOSITE key (n_keys columns, nulls included): equal key tuples
+ * get equal cells on every rank, so the cells can serve as the shuffle key (dtype CELL64) of a
+ * multi-key groupby while the key columns themselves travel as payload.  Collisions only co-locate
+ * different tuples on one rank; the receiving groupby still separates them. */
+int32_t pandrs_hip_key_hash_cells(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
+                                  int32_t n_keys, int64_t n_rows, uint64_t *out_cells);
 /* out_cells / out_key_null: out_n_rows entries; out_payload[c] (8 bytes per row) / out_payload_null[c]
  * (1 byte per row; ignored for payloads without a mask).  Any pointer may be NULL to skip it. */
 int32_t pandrs_hip_shuffle_fetch(pandrs_hip_ctx *ctx, int32_t mem_space, uint64_t *out_cells,

@@ -250,6 +250,11 @@ int32_t pandrs_hip_shuffle_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t 
     return PANDRS_HIP_OK;
 }
 
+int32_t pandrs_hip_key_hash_cells(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
+                                  int32_t n_keys, int64_t n_rows, uint64_t *out_cells) {
+    return pandrs::key_hash_cells_entry(ctx, mem_space, keys, n_keys, n_rows, out_cells);
+}
+
 int32_t pandrs_hip_bytes_to_bitmap(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *bytes, int64_t n,
                                    uint8_t *out_bitmap) {
     return pandrs::bytes_to_bitmap_entry(ctx, mem_space, bytes, n, out_bitmap);

@@ -221,6 +221,8 @@ int32_t groupby_indices_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs
 int32_t shuffle_split_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *key,
                             const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows, int32_t n_ranks,
                             int32_t drop_null_keys, int64_t *out_counts, int64_t *out_n_rows);
+int32_t key_hash_cells_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
+                             int64_t n_rows, uint64_t *out_cells);
 int32_t bytes_to_bitmap_entry(pandrs_hip_ctx *c, int32_t mem_space, const uint8_t *bytes, int64_t n, uint8_t *out);
 int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dtype,
                             const uint64_t *records,

@@ -1987,6 +1987,53 @@ __global__ void bytes_to_bitmap_kernel(const uint8_t *bytes, int64_t n, uint8_t 
     out[b] = (uint8_t)v;
 }
 
+struct HashKeys { KeyDesc key[MAX_KEYS]; int n_keys; };
+__global__ void key_hash_cells_kernel(HashKeys hk, int64_t n, uint64_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < hk.n_keys; k++) {
+        const bool nul = key_is_null(hk.key[k], i);
+        uint64_t x = nul ? 0xD1B54A32D192ED03ull : key_cell(hk.key[k], i);
+        x ^= h + (nul ? 1 : 0);
+        x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+        h = x;
+    }
+    out[i] = h;
+}
+
+int32_t key_hash_cells_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
+                             int64_t n_rows, uint64_t *out_cells) {
+    if (!c || !keys || n_keys < 1 || n_keys > MAX_KEYS || n_rows < 0 || (n_rows && !out_cells))
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key_hash_cells: bad arguments");
+    ST_TRY(check_cols(keys, n_keys, "key", true));
+    if (n_rows == 0) return 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    Stager stg{c, mem_space};
+    uint64_t *dst = out_cells;
+    if (mem_space == PANDRS_HIP_MEM_HOST) {
+        size_t need = size_t(n_rows) * 8 + 4096;
+        for (int k = 0; k < n_keys; k++) need += dtype_bytes(keys[k].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
+        ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
+        dst = c->staging.take<uint64_t>(n_rows);
+        if (!dst) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+    }
+    HashKeys hk{};
+    hk.n_keys = n_keys;
+    for (int k = 0; k < n_keys; k++) {
+        if (!keys[k].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "key column %d has no data", k);
+        hk.key[k] = KeyDesc{stg.in(keys[k].data, dtype_bytes(keys[k].dtype, n_rows)),
+                            (const uint8_t *)stg.in(keys[k].null_mask, (n_rows + 7) / 8), nullptr, keys[k].dtype};
+    }
+    if (stg.status) return stg.status;
+    hipLaunchKernelGGL(key_hash_cells_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, hk, n_rows, dst);
+    HIP_TRY(hipGetLastError());
+    if (mem_space == PANDRS_HIP_MEM_HOST) HIP_TRY(hipMemcpyAsync(out_cells, dst, size_t(n_rows) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int32_t bytes_to_bitmap_entry(pandrs_hip_ctx *c, int32_t mem_space, const uint8_t *bytes, int64_t n, uint8_t *out) {
     if (!c || n < 0 || (n && (!bytes || !out))) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bytes_to_bitmap: bad arguments");
     if (n == 0) return 0;

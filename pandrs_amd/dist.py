@@ -81,35 +81,51 @@ class DistributedGroupBy:
             out.append(r.numpy().view(c.dtype) if was_numpy else r)
         return out
 
+    def _received_column(self, data, null_bytes, dtype):
+        """A payload column after the exchange -> (data, bitmap, dtype) for the ordinary entry points:
+        f64 / i64 travel as raw 8-byte words, u32 codes zero-extended (key dtype CELL64 = 4)."""
+        torch_like = hasattr(data, "is_cuda")
+        if dtype == 1:
+            data = data.view(self._torch().float64) if torch_like else data.view("float64")
+        elif dtype == 0 and not torch_like:
+            data = data.view("int64")
+        mask = None if null_bytes is None else self.engine.bytes_to_bitmap(null_bytes)
+        return (data, mask, 4 if dtype == 2 else dtype)
+
     def groupby_by_shuffle(self, keys, n_rows, vals, aggs):
-        """The general path (any aggregate except First/Last, which need the global row order): every
-        row goes to the owner of its key — pandrs_hip_shuffle_split, one all-to-all per column — and
-        the owner runs the ordinary groupby on the rows it received (key dtype CELL64)."""
+        """The general path (any aggregate except First/Last, which need the global row order; any number
+        of key columns): every row goes to the owner of its key — pandrs_hip_shuffle_split, one
+        all-to-all per column — and the owner runs the ordinary groupby on the rows it received.
+        A composite key is shuffled on a hash cell of the whole tuple (pandrs_hip_key_hash_cells) with
+        the key columns travelling as payload, so each rank packs complete tuples only."""
         eng = self.engine
-        if len(keys) != 1:
-            raise NotImplementedError("multi-key groupby is not sharded yet (per-shard key packing differs)")
         if any(op in (8, 9) for _, op in aggs):
             raise NotImplementedError("First/Last need the global row order and are not sharded")
-        cells, knull, pays, pnull, counts = eng.shuffle_split(keys[0], vals, n_rows, self.world, drop_null_keys=False)
-        got = self.exchange_columns([cells, knull] + pays + pnull, counts)
-        rc, rn = got[0], got[1]
-        rp, rpn = got[2:2 + len(vals)], got[2 + len(vals):]
-        n_recv = int(rc.shape[0])
-        kmask = eng.bytes_to_bitmap(rn) if keys[0][1] is not None else None
-        vals2 = []
-        for i, v in enumerate(vals):
-            data = rp[i]
-            if v[2] == 1:       # f64 payload travels as raw 8-byte words
-                data = data.view(self._torch().float64) if hasattr(data, "is_cuda") else data.view("float64")
-            elif not hasattr(data, "is_cuda"):
-                data = data.view("int64")
-            vals2.append((data, None if rpn[i] is None else eng.bytes_to_bitmap(rpn[i]), v[2]))
-        return eng.groupby_agg([(rc, kmask, 4)], n_recv, vals2, aggs)
+        if any(k[2] == 3 for k in keys) and len(keys) > 1:
+            raise NotImplementedError("bit-packed key columns cannot travel as shuffle payload")
+        if len(keys) == 1:
+            cells, knull, pays, pnull, counts = eng.shuffle_split(keys[0], vals, n_rows, self.world, drop_null_keys=False)
+            got = self.exchange_columns([cells, knull] + pays + pnull, counts)
+            rc, rn = got[0], got[1]
+            rp, rpn = got[2:2 + len(vals)], got[2 + len(vals):]
+            kmask = eng.bytes_to_bitmap(rn) if keys[0][1] is not None else None
+            keys2 = [(rc, kmask, 4)]
+        else:
+            hcell = eng.key_hash_cells(keys, n_rows)
+            payload = list(keys) + list(vals)
+            cells, _, pays, pnull, counts = eng.shuffle_split((hcell, None, 4), payload, n_rows, self.world, drop_null_keys=False)
+            got = self.exchange_columns(pays + pnull, counts)
+            rp_all, rpn_all = got[:len(payload)], got[len(payload):]
+            keys2 = [self._received_column(rp_all[i], rpn_all[i], k[2]) for i, k in enumerate(keys)]
+            rp, rpn = rp_all[len(keys):], rpn_all[len(keys):]
+        n_recv = int(rp[0].shape[0]) if vals else int(keys2[0][0].shape[0])
+        vals2 = [self._received_column(rp[i], rpn[i], v[2]) for i, v in enumerate(vals)]
+        return eng.groupby_agg(keys2, n_recv, vals2, aggs)
 
     def groupby_agg(self, keys, n_rows, vals, aggs, fetch=True):
         """Same arguments as Context.groupby_agg; every rank passes its own row range.
         Returns this rank's share of the groups (keys owned by this rank)."""
-        if any(op not in self.MERGEABLE_OPS for _, op in aggs):
+        if len(keys) > 1 or any(op not in self.MERGEABLE_OPS for _, op in aggs):
             return self.groupby_by_shuffle(keys, n_rows, vals, aggs)
         torch = self._torch()
         eng = self.engine

@@ -249,6 +249,20 @@ class Context:
             _raise(st)
         return cells, knull, pays, pnull, [int(x) for x in counts]
 
+    def key_hash_cells(self, keys, n_rows):
+        """One 64-bit hash cell per row of a composite key (the shuffle key of a multi-key groupby)."""
+        keep = []
+        kc, sp = self._cols(keys, keep)
+        if sp == L.MEM_DEVICE:
+            import torch
+            out = torch.empty(int(n_rows), dtype=torch.int64, device="cuda:%d" % self.device)
+        else:
+            out = np.empty(int(n_rows), np.uint64)
+        st = self.lib.pandrs_hip_key_hash_cells(self.h, sp, kc, len(keys), int(n_rows), _ptr(out))
+        if st:
+            _raise(st)
+        return out
+
     def bytes_to_bitmap(self, flags):
         """One byte per row (non-zero = set) -> LSB-first bitmap, same kind (numpy / torch) as the input."""
         n = int(flags.shape[0])

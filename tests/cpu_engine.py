@@ -84,7 +84,12 @@ class NumpyEngine:
     # ---- the shuffle path: rows to the owner of their key, then ordinary calls on the received rows
     def shuffle_split(self, key, payload, n_rows, n_ranks, drop_null_keys=False):
         from oracle import oracle_np as ONP
-        nul, cell = ONP.key_cells(key, n_rows)
+        if key[2] == 4:
+            data, mask, _ = key
+            cell = np.asarray(data)[:n_rows].view(np.uint64).copy()
+            nul = np.zeros(n_rows, np.uint8) if mask is None else np.unpackbits(np.asarray(mask, np.uint8), bitorder="little")[:n_rows]
+        else:
+            nul, cell = ONP.key_cells(key, n_rows)
         owner = ((cell * np.uint64(0xD6E8FEB86659FD93)) >> np.uint64(33)) % np.uint64(n_ranks)
         owner = np.where(nul.astype(bool), n_ranks - 1, owner).astype(np.int64)
         keep = np.ones(n_rows, bool) if not drop_null_keys else ~nul.astype(bool)
@@ -97,6 +102,16 @@ class NumpyEngine:
             pnull.append(None if mask is None else np.unpackbits(np.asarray(mask, np.uint8), bitorder="little")[:n_rows][order])
         counts = np.bincount(owner[order], minlength=n_ranks).tolist()
         return cell[order], nul[order], pays, pnull, counts
+
+    def key_hash_cells(self, keys, n_rows):
+        from oracle import oracle_np as ONP
+        h = np.full(n_rows, 0x9E3779B97F4A7C15, np.uint64)
+        for col in keys:
+            nul, cell = ONP.key_cells(col, n_rows)
+            x = (cell ^ h) + nul.astype(np.uint64) * np.uint64(0x1234567)
+            x ^= x >> np.uint64(33); x *= np.uint64(0xFF51AFD7ED558CCD); x ^= x >> np.uint64(29)
+            h = x
+        return h
 
     def bytes_to_bitmap(self, flags):
         return np.packbits(np.asarray(flags, np.uint8) != 0, bitorder="little")

@@ -170,3 +170,50 @@ def test_shuffle_path_for_non_mergeable_aggregates(world):
     want = O.groupby_agg([(keys, km, O.I64)], len(keys), [(v0, None, O.F64), (v1, m1, O.I64)], AGGS_ANY)
     assert got[0].shape[1] == want[0].shape[1]
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0, 3, 5])
+
+
+# ---- multi-key groupby across ranks: shuffle on a hash cell of the whole tuple ---------------------------
+def _mk_data(n=30_000):
+    rng = np.random.default_rng(5)
+    k0 = (rng.integers(0, 40, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    m0 = np.packbits(rng.random(n) < 0.02, bitorder="little")
+    k1 = rng.integers(0, 7, n).astype(np.uint32)
+    k2 = rng.choice(np.array([0.5, -0.0, 0.0, np.nan, 3.25]), n)
+    v = rng.normal(0, 1, n)
+    return k0, m0, k1, k2, v
+
+
+def _mk_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from pandrs_amd.dist import DistributedGroupBy
+    from tests.cpu_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k0, m0, k1, k2, v = _mk_data()
+    n = len(k0)
+    lo, hi = (n // world // 8 * 8) * rank, n if rank == world - 1 else (n // world // 8 * 8) * (rank + 1)
+    bits = lambda m: np.packbits(np.unpackbits(m, bitorder="little")[:n][lo:hi], bitorder="little")
+    d = DistributedGroupBy(NumpyEngine(), dist, "cpu")
+    kc, kn, oa = d.groupby_agg([(k0[lo:hi], bits(m0), 0), (k1[lo:hi], None, 2), (k2[lo:hi], None, 1)], hi - lo,
+                               [(v[lo:hi], None, 1)], [(0, 0), (0, 4), (0, 7)])
+    np.savez(os.path.join(outdir, "m%d.npz" % rank), kc=kc, kn=kn, oa=oa)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_key_groupby_across_ranks(world):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from tests.helpers import assert_groupby_equal
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_mk_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, "m%d.npz" % r)) for r in range(world)]
+    got = tuple(np.concatenate([p[name] for p in parts], axis=1) for name in ("kc", "kn", "oa"))
+    k0, m0, k1, k2, v = _mk_data()
+    want = O.groupby_agg([(k0, m0, O.I64), (k1, None, O.U32CODE), (k2, None, O.F64)], len(k0), [(v, None, O.F64)],
+                         [(0, O.SUM), (0, O.COUNT), (0, O.MEDIAN)])
+    assert got[0].shape[1] == want[0].shape[1]
+    assert_groupby_equal(got, want, [O.I64, O.U32CODE, O.F64], int_exact_rows=[1, 2])
