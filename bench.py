@@ -88,6 +88,19 @@ def cpu_baseline_typed(n_sample, n_groups, n_cols):
             "sample": "%d rows, %d-group key space, %d f64 cols, count/sum/min/max per column, %.2f s" % (n_sample, n_groups, n_cols, dt)}
 
 
+_REAL_STDOUT = None
+
+
+def emit(record):
+    """The one JSON line, on the process's real stdout."""
+    sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+    print(json.dumps(record), flush=True)
+    if _REAL_STDOUT is not None:
+        os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +115,14 @@ def main():
                     help="groupby = BASELINE config 2 (the headline line); join = config 5 shape "
                          "(probe --rows per GPU, build rows/10 per GPU, inner join -> groupby(g).sum(v))")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints a version banner
+    # on its first collective) write to file descriptor 1 behind Python's back, so fd 1 points at stderr
+    # until the record is printed
+    sys.stdout.flush()
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import pandrs_amd as pa
@@ -193,7 +214,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
             out["cpu_baseline_typed"] = cpu_baseline_typed(min(n, 8 * args.cpu_sample), g, ncol)
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -267,7 +288,7 @@ def bench_join(args, torch, pa, dist, rank, local_rank, world, device):
                             "phase_ms": {p: v / k for p, v in sorted(phases.items())}}}
         if djg is not None:
             res["roofline"]["wall_ms_last_step"] = djg.last_wall_ms
-        print(json.dumps(res))
+        emit(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
