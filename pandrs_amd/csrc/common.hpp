@@ -146,6 +146,7 @@ struct Options {
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
+    int64_t no_runs = 0;             // 1 = never use the run-folding aggregate kernels
     int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
 };
@@ -171,6 +172,7 @@ struct pandrs_hip_ctx {
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
     hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
     void *pinned = nullptr;      // small pinned host block for readbacks
+    bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)
     bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
     int quiet = 0;               // > 0: nested engine runs (slice / direct merges) do not record phase events
     int lds_bytes = 0;           // usable LDS per workgroup

@@ -31,10 +31,29 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = s < n_sample && s * stride < n_rows;
     uint64_t k = 0;
+    // second signal, for CLUSTERED inputs (e.g. rows sorted by key), where a strided sample shows no
+    // repeats at all: the share of adjacent row pairs whose keys differ.  #groups <= #runs = boundaries + 1
+    // whatever the order, so it bounds the estimate from above.  distinct[1] = boundaries, [2] = pairs.
+    bool pair = false, differs = false;
     if (live) {
         int64_t i = s * stride;
-        live = !key_is_null(key, i);
-        if (live) { k = key_cell(key, i); live = k != EMPTY_KEY; }
+        const bool nul = key_is_null(key, i);
+        k = key_cell(key, i);
+        if (i + 1 < n_rows) {
+            const bool nul2 = key_is_null(key, i + 1);
+            pair = true;
+            differs = nul != nul2 || (!nul && k != key_cell(key, i + 1));
+        }
+        live = !nul && k != EMPTY_KEY;
+    }
+    {   // one atomic pair per workgroup (same-address global atomics serialise)
+        __shared__ uint32_t sb[2];
+        if (threadIdx.x < 2) sb[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned long long mp = __ballot(pair), md = __ballot(differs);
+        if ((threadIdx.x & 63) == 0) { if (mp) atomicAdd(&sb[0], (uint32_t)__popcll(mp)); if (md) atomicAdd(&sb[1], (uint32_t)__popcll(md)); }
+        __syncthreads();
+        if (threadIdx.x == 0 && sb[0]) { atomicAdd(&distinct[2], sb[0]); if (sb[1]) atomicAdd(&distinct[1], sb[1]); }
     }
     // a dominant key would make every lane CAS the same address: peel the wave's two most common
     // leading keys first (one lane inserts for all lanes that hold the same key)
@@ -529,7 +548,12 @@ __device__ __forceinline__ double finalize(const FinDev &f, const uint64_t *st, 
 //         >= 0 = all sources share (kind, ops, validity): bit0 has validity bytes,
 //                bits1-3 ops present (add, min, max), bit4 kind (0 f64, 1 i64); raw rows, one round.
 //         The uniform profiles remove ~300 scalar branches per row pair from the hot loop.
-template <int NSRC, int PROFILE>
+//         RUNS (uniform profiles only): the rows arrive CLUSTERED by key (input sorted or grouped by key —
+//         the radix partition keeps neighbouring rows together), so with the usual row-per-lane layout
+//         the lanes of a wave hold the same few keys and their LDS atomics serialise on the same
+//         addresses.  Here every thread takes AG_RUN CONSECUTIVE rows, folds equal neighbours in
+//         registers and touches the table once per run.
+template <int NSRC, int PROFILE, bool RUNS = false>
 __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = NSRC > 0 ? NSRC : MAX_SRC;
@@ -580,6 +604,110 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         }
         __syncthreads();
 
+        if constexpr (RUNS) {
+            constexpr int AG_RUN = 4;
+            auto find_slot = [&](uint64_t k) -> uint32_t {
+                if (k == EMPTY_KEY) { misc[21] = 1; return T; }
+                const uint32_t NBK = T >> 2;
+                uint32_t bk = slot_of(hash32(k, a.seed), NBK), probe = 0;
+                while (probe < NBK) {
+                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
+                    const ulonglong2 lo = bp[0], hi = bp[1];
+                    const uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
+                    int hit = -1, emp = -1;
+#pragma unroll
+                    for (int q = 3; q >= 0; q--) {
+                        if (c4[q] == k) hit = q;
+                        if (c4[q] == EMPTY_KEY) emp = q;
+                    }
+                    if (hit >= 0) return 4 * bk + hit;
+                    if (emp >= 0) {
+                        const uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + emp], EMPTY_KEY, k);
+                        if (old == EMPTY_KEY || old == k) return 4 * bk + emp;
+                        continue;
+                    }
+                    bk = bk + 1 == NBK ? 0 : bk + 1;
+                    probe++;
+                }
+                misc[20] = 1;                       // table full: host retries with more partitions
+                return T + 2;
+            };
+            for (uint32_t base = beg + tid * AG_RUN; base < end; base += AG_THREADS * AG_RUN) {
+                uint64_t rk[AG_RUN], rv[AG_RUN][NS];
+                bool rok[AG_RUN][NS];
+#pragma unroll
+                for (int j = 0; j < AG_RUN; j++) {
+                    const uint32_t i = min(base + j, end - 1);
+                    rk[j] = __builtin_nontemporal_load(a.pkeys + i);
+#pragma unroll
+                    for (int c = 0; c < NS; c++) {
+                        if (c < nsrc) {
+                            const SrcDev &sd = a.src[s0 + c];
+                            rv[j][c] = __builtin_nontemporal_load(sd.vals + i);
+                            rok[j][c] = f_valid(sd) ? sd.valid[i] != 0 : true;
+                        }
+                    }
+                }
+                const int n_here = (int)min((uint32_t)AG_RUN, end - base);
+                uint64_t cur = rk[0], r_gs = 0, r_sum[NS], r_min[NS], r_max[NS];
+                uint32_t r_nn[NS];
+#pragma unroll
+                for (int c = 0; c < NS; c++) { r_sum[c] = 0; r_nn[c] = 0; r_min[c] = ~0ull; r_max[c] = 0ull; }
+#pragma unroll
+                for (int j = 0; j <= AG_RUN; j++) {
+                    const bool more = j < n_here;
+                    if (j > 0 && (!more || rk[j < AG_RUN ? j : 0] != cur)) {
+                        // ---- the run ends: one table update for all its rows ----
+                        const uint32_t slot = find_slot(cur);
+                        if (slot <= T) {
+                            if (round == 0) atomicAdd((unsigned long long *)&gsz[slot], r_gs);
+#pragma unroll
+                            for (int c = 0; c < NS; c++) {
+                                if (c < nsrc) {
+                                    const SrcDev &sd = a.src[s0 + c];
+                                    if (r_nn[c]) {
+                                        if (f_nn(sd)) atomicAdd((unsigned long long *)&st[(size_t)sd.st_nn * T1 + slot], (unsigned long long)r_nn[c]);
+                                        if (f_add(sd)) {
+                                            if (f_kind(sd) == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)sd.st_add * T1 + slot]), __longlong_as_double((long long)r_sum[c]));
+                                            else atomicAdd((unsigned long long *)&st[(size_t)sd.st_add * T1 + slot], r_sum[c]);
+                                        }
+                                    }
+                                    if (f_min(sd) && r_min[c] < st[(size_t)sd.st_min * T1 + slot])
+                                        atomicMin((unsigned long long *)&st[(size_t)sd.st_min * T1 + slot], r_min[c]);
+                                    if (f_max(sd) && r_max[c] > st[(size_t)sd.st_max * T1 + slot])
+                                        atomicMax((unsigned long long *)&st[(size_t)sd.st_max * T1 + slot], r_max[c]);
+                                }
+                            }
+                        }
+                        r_gs = 0;
+#pragma unroll
+                        for (int c = 0; c < NS; c++) { r_sum[c] = 0; r_nn[c] = 0; r_min[c] = ~0ull; r_max[c] = 0ull; }
+                    }
+                    if (!more || j == AG_RUN) break;
+                    cur = rk[j];
+                    r_gs += 1;
+#pragma unroll
+                    for (int c = 0; c < NS; c++) {
+                        if (c < nsrc && rok[j][c]) {
+                            const SrcDev &sd = a.src[s0 + c];
+                            const uint64_t x = rv[j][c];
+                            bool cmp = true;
+                            uint64_t e;
+                            if (f_kind(sd) == 0) {
+                                const double dd = __longlong_as_double((long long)x);
+                                cmp = dd == dd; e = enc_f64(dd);
+                                r_sum[c] = r_nn[c] ? (uint64_t)__double_as_longlong(__longlong_as_double((long long)r_sum[c]) + dd) : x;
+                            } else {
+                                e = enc_i64((int64_t)x);
+                                r_sum[c] += x;
+                            }
+                            r_nn[c]++;
+                            if (cmp) { if (e < r_min[c]) r_min[c] = e; if (e > r_max[c]) r_max[c] = e; }
+                        }
+                    }
+                }
+            }
+        } else {
         // Software pipeline: two rows per thread are processed while the NEXT two rows' global loads
         // are already in flight (indices are clamped to the partition's last row, so the prefetch
         // loads are unconditional; a clamped row is simply never processed).
@@ -697,6 +825,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
                 }
             }
         }
+        }   // !RUNS
         __syncthreads();
         if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
         const bool sentinel = misc[21] != 0, nullseen = misc[23] != 0;
@@ -881,12 +1010,12 @@ static int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_
     uint32_t *distinct = c->work.take<uint32_t>(64);
     if (!table || !distinct) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (estimate)");
     HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(slots) * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(distinct, 0, 4, c->stream));
+    HIP_TRY(hipMemsetAsync(distinct, 0, 16, c->stream));
     hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, c->stream,
                        key, n_rows, stride, n_sample, table, slots - 1, distinct);
     HIP_TRY(hipGetLastError());
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-    HIP_TRY(hipMemcpyAsync(h, distinct, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h, distinct, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double d = std::max<uint32_t>(h[0], 1), s = (double)n_sample;
     double est;
@@ -905,6 +1034,15 @@ static int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_
         }
         est = std::min<double>(std::max(G, d), (double)n_rows);
     }
+    c->clustered_rows = false;
+    if (h[2] >= 1024) {
+        c->clustered_rows = (double)h[1] < 0.5 * (double)h[2] && !c->opt.no_runs;    // most neighbours share their key
+        // runs of equal keys: an upper bound on the group count in any row order (exact for sorted
+        // input); + 3 sigma of the sampled share so that noise cannot push it below the truth
+        const double pairs = (double)h[2], b = (double)h[1];
+        const double share = std::min(1.0, (b + 3.0 * std::sqrt(b + 1.0)) / pairs);
+        est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
+    }
     *out_est = (int64_t)est;
     return 0;
 }
@@ -918,6 +1056,11 @@ static int32_t set_max_lds(K kernel, int bytes) {
 
 template <int NSRC, int PROFILE>
 static void launch_aggregate_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds) {
+    if (PROFILE >= 0 && c->clustered_rows && !a.direct) {       // rows clustered by key: fold runs inside the wave first
+        (void)set_max_lds(aggregate_kernel<NSRC, PROFILE, (PROFILE >= 0)>, (int)lds);
+        hipLaunchKernelGGL((aggregate_kernel<NSRC, PROFILE, (PROFILE >= 0)>), dim3(a.launch_grid), dim3(AG_THREADS), lds, c->stream, a);
+        return;
+    }
     (void)set_max_lds(aggregate_kernel<NSRC, PROFILE>, (int)lds);
     hipLaunchKernelGGL((aggregate_kernel<NSRC, PROFILE>), dim3(a.launch_grid), dim3(AG_THREADS), lds, c->stream, a);
 }
@@ -1118,6 +1261,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     ST_TRY(c->work.ensure(ws, c->stream));
     int64_t est = c->opt.groups_hint;
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
+    else c->clustered_rows = false;          // no sample taken: nothing known about the row order
     c->timings.estimated_groups = est;
 
     // ---- low-cardinality direct path: when every group fits one LDS table with room to spare,

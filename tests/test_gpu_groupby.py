@@ -599,3 +599,31 @@ def test_column_population_std_like_parallel_std(ctx):
     xi = rng.integers(-1000, 1000, n).astype(np.int64)
     std, _ = ctx.column_std((xi, None, O.I64), n)
     assert std == pytest.approx(np.std(xi.astype(np.float64)), rel=1e-9)
+
+
+@pytest.mark.parametrize("layout", ["sorted", "runs", "sorted_masked_i64"])
+def test_clustered_rows_fold_runs_inside_the_wave(ctx, layout):
+    """Rows sorted / grouped by key: the estimator's adjacency signal switches the aggregate to the
+    run-folding kernels (segmented scan over the lanes, one table update per run)."""
+    rng = np.random.default_rng({"sorted": 1, "runs": 2, "sorted_masked_i64": 3}[layout])
+    n, g = 3_000_000, 40_000
+    ids = rng.integers(0, g, n)
+    if layout == "runs":
+        ids = np.repeat(rng.integers(0, g, n // 50 + 1), rng.integers(1, 100, n // 50 + 1))[:n]
+        n = len(ids)
+    else:
+        ids = np.sort(ids)
+    k = (sparse_keys_from(ids), O.pack_mask(rng.random(n) < 0.001), O.I64)
+    if layout == "sorted_masked_i64":
+        v = [(rng.integers(-10**9, 10**9, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.2), O.I64)]
+        aggs, exact = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT)], [0, 2, 3, 4]
+    else:
+        pool = np.concatenate([rng.normal(size=1000), [np.nan, np.inf, -np.inf, -0.0]])
+        v = [(pool[rng.integers(0, len(pool), n)], None, O.F64), (rng.normal(5, 1, n), None, O.F64)]
+        aggs, exact = [(c, op) for c in range(2) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)], [2, 3, 6, 7, 8]
+    check(ctx, k, n, v, aggs, [O.I64], exact=exact)
+    ctx.set_option("no_runs", 1)
+    try:
+        check(ctx, k, n, v, aggs, [O.I64], exact=exact)
+    finally:
+        ctx.set_option("no_runs", 0)
