@@ -47,7 +47,14 @@ for case in range(n_cases):
             g = int(rng.choice([1, 3, 50, 2000, 60_000, 900_000]))
             skew = rng.choice(["uniform", "hot", "8020"])
             nk = 1 if rng.random() < 0.8 else 2
-            keys = [(rand_key(rng, n, kd, g, skew), mask(rng, n, rng.choice([0, 0, 0.01, 0.3])), kd)]
+            kdata = rand_key(rng, n, kd, g, skew)
+            layout = rng.choice(["any", "any", "any", "sorted", "runs"])
+            if kd != O.BOOLBITS and n > 1:
+                if layout == "sorted":
+                    kdata = np.sort(kdata) if kd != O.F64 else kdata[np.argsort(kdata.view(np.uint64), kind="stable")]
+                elif layout == "runs":
+                    kdata = np.repeat(kdata[: n // 20 + 1], 20)[:n]
+            keys = [(kdata, mask(rng, n, rng.choice([0, 0, 0.01, 0.3])), kd)]
             kdts = [kd]
             if nk == 2:
                 keys.append((rng.integers(0, 5, n).astype(np.uint32), mask(rng, n, rng.choice([0, 0.05])), O.U32CODE)); kdts.append(O.U32CODE)
@@ -83,7 +90,7 @@ for case in range(n_cases):
                     np.testing.assert_array_equal(nulls[kk][gid], nul[rows])
                     np.testing.assert_array_equal(np.where(nulls[kk][gid] == 1, 0, cells[kk][gid]), cell[rows])
                 assert gcount == want[0].shape[1]
-            desc = "groupby n=%d kd=%d g=%d %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, nk, aggs, opts)
+            desc = "groupby n=%d kd=%d g=%d %s %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, layout, nk, aggs, opts)
         else:                       # ---------------- join
             nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000]))
             kd = int(rng.choice([O.I64, O.I64, O.U32CODE, O.F64]))
