@@ -109,6 +109,10 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
                         int phase_scatter);
 int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out, uint32_t *seg);
 size_t scan_seg_count(size_t n);     // entries the `seg` scratch of exclusive_scan_u32 needs
+// sampled cardinality estimate (also sets c->clustered_rows); synchronises the stream
+int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est);
+// partition starts (offsets[p * NB]) of the first n partitions, gathered into a dense device array
+void gather_part_offsets(pandrs_hip_ctx *c, const uint32_t *offsets, uint32_t NB, uint32_t n, uint32_t *out);
 
 int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int n_vals,
                    const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl);

@@ -1,0 +1,543 @@
+// partition.hip — the radix partitioner shared by groupby, join, median and the shuffle (gfx950, wave64):
+// cardinality estimate, histogram, 3-kernel exclusive scan, LDS-staged scatter with XCD-shared write
+// cursors.  Split out of groupby.hip; the aggregate engine lives there.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace pandrs {
+
+template <typename K>
+static int32_t set_max_lds(K kernel, int bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ estimate
+__global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
+                                uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = s < n_sample && s * stride < n_rows;
+    uint64_t k = 0;
+    // second signal, for CLUSTERED inputs (e.g. rows sorted by key), where a strided sample shows no
+    // repeats at all: the share of adjacent row pairs whose keys differ.  #groups <= #runs = boundaries + 1
+    // whatever the order, so it bounds the estimate from above.  distinct[1] = boundaries, [2] = pairs.
+    bool pair = false, differs = false;
+    if (live) {
+        int64_t i = s * stride;
+        const bool nul = key_is_null(key, i);
+        k = key_cell(key, i);
+        if (i + 1 < n_rows) {
+            const bool nul2 = key_is_null(key, i + 1);
+            pair = true;
+            differs = nul != nul2 || (!nul && k != key_cell(key, i + 1));
+        }
+        live = !nul && k != EMPTY_KEY;
+    }
+    {   // one atomic pair per workgroup (same-address global atomics serialise)
+        __shared__ uint32_t sb[2];
+        if (threadIdx.x < 2) sb[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned long long mp = __ballot(pair), md = __ballot(differs);
+        if ((threadIdx.x & 63) == 0) { if (mp) atomicAdd(&sb[0], (uint32_t)__popcll(mp)); if (md) atomicAdd(&sb[1], (uint32_t)__popcll(md)); }
+        __syncthreads();
+        if (threadIdx.x == 0 && sb[0]) { atomicAdd(&distinct[2], sb[0]); if (sb[1]) atomicAdd(&distinct[1], sb[1]); }
+    }
+    // a dominant key would make every lane CAS the same address: peel the wave's two most common
+    // leading keys first (one lane inserts for all lanes that hold the same key)
+    bool peeled = false;       // this lane is (or was represented by) a leader already
+    for (int round = 0; round < 2; round++) {
+        unsigned long long m = __ballot(live && !peeled);
+        if (!m) break;
+        int leader = __ffsll((long long)m) - 1;
+        uint64_t lk = __shfl(k, leader, 64);
+        if (live && !peeled && k == lk) {
+            peeled = true;
+            if ((int)(threadIdx.x & 63) != leader) live = false;           // the leader inserts on their behalf
+        }
+    }
+    if (!live) return;
+    uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+    for (uint32_t probe = 0; probe <= table_mask; probe++) {
+        uint64_t cur = table[slot];
+        if (cur == k) return;
+        if (cur == EMPTY_KEY) {
+            uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { atomicAdd(distinct, 1u); return; }
+            if (old == k) return;
+        }
+        slot = (slot + 1) & table_mask;
+    }
+}
+
+// ------------------------------------------------------------------------------------ histogram
+// ------------------------------------------------------------------------------------ scan
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_IPT = 4;
+constexpr int SCAN_SEG = SCAN_THREADS * SCAN_IPT;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_partial_kernel(const uint32_t *in, size_t n,
+                                                                    uint32_t *seg_sum) {
+    __shared__ uint32_t wt[17];
+    size_t base = (size_t)blockIdx.x * SCAN_SEG + (size_t)threadIdx.x * SCAN_IPT;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) if (base + j < n) s += in[base + j];
+    uint32_t total;
+    block_exclusive_scan<SCAN_THREADS>(s, wt, &total);
+    if (threadIdx.x == 0) seg_sum[blockIdx.x] = total;
+}
+// single workgroup: exclusive scan of up to SCAN_SEG segment sums, in place
+__global__ __launch_bounds__(SCAN_THREADS) void scan_top_kernel(uint32_t *seg_sum, uint32_t n_seg) {
+    __shared__ uint32_t wt[17];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_seg; base += SCAN_THREADS) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_seg ? seg_sum[i] : 0u, total;
+        uint32_t ex = block_exclusive_scan<SCAN_THREADS>(v, wt, &total);
+        uint32_t c = carry;
+        if (i < n_seg) seg_sum[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+}
+// out[i] = exclusive prefix; out[n] = grand total (written by the last segment)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t *in, size_t n,
+                                                                  const uint32_t *seg_base,
+                                                                  uint32_t *out) {
+    __shared__ uint32_t wt[17];
+    size_t base = (size_t)blockIdx.x * SCAN_SEG + (size_t)threadIdx.x * SCAN_IPT;
+    uint32_t v[SCAN_IPT], s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) { v[j] = base + j < n ? in[base + j] : 0u; s += v[j]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan<SCAN_THREADS>(s, wt, &total) + seg_base[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+        if (base + j == n - 1) out[n] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------------ scatter
+__device__ __forceinline__ uint64_t move_load(const MoveDesc &m, int64_t i) {
+    switch (m.kind) {
+    case 0: return reinterpret_cast<const uint64_t *>(m.src)[i];
+    case 1: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 0ull : 1ull;
+    case 2: return reinterpret_cast<const uint8_t *>(m.src)[i];
+    case 6: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 1ull : 0ull;   // null bitmap -> null byte
+    case 3: case 5: return (uint64_t)i;                                // row index
+    default: return reinterpret_cast<const uint32_t *>(m.src)[i];      // 4: u32 source
+    }
+}
+__device__ __forceinline__ void move_store(const MoveDesc &m, uint32_t dst, uint64_t v) {
+    switch (m.kind) {
+    case 0: case 4: case 5: reinterpret_cast<uint64_t *>(m.dst)[dst] = v; break;
+    case 3: reinterpret_cast<uint32_t *>(m.dst)[dst] = (uint32_t)v; break;
+    default: reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
+    }
+}
+
+// Row r of a thread's tile slice is tile-local index r*THREADS + tid, clamped to the tile's last
+// row so every load below is unconditional (eight back-to-back coalesced loads, no per-row
+// branches).  Bases are wave-uniform (column + tbase), indices 32-bit: saddr + voffset addressing.
+template <int THREADS>
+__device__ __forceinline__ uint32_t tile_idx(uint32_t tid, int r, uint32_t tile_last) {
+    return min((uint32_t)(r * THREADS) + tid, tile_last);
+}
+
+template <int THREADS>
+__device__ __forceinline__ void load_column8(const void *col, int64_t tbase, uint32_t tid, uint32_t tile_last,
+                                             uint64_t (&out)[SC_RPT]) {
+    // streamed once: non-temporal, so the input does not evict the partially written output lines
+    // that the XCD's L2 is completing (shared-cursor write frontier)
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(col) + tbase;
+#pragma unroll
+    for (int r = 0; r < SC_RPT; r++) out[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
+}
+
+// key cells + null flags (bit r of *nulls) for the thread's SC_RPT rows; the dtype switch is
+// wave-uniform and sits outside the unrolled loads.  tbase is a multiple of 8 (tile aligned), so
+// bitmaps are addressed from a byte base.
+template <int THREADS>
+__device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, uint32_t tid, uint32_t tile_last,
+                                               uint64_t (&kc)[SC_RPT], uint32_t *nulls) {
+    switch (k.dtype) {
+    case PANDRS_HIP_U32CODE: {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(k.data) + tbase;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
+        break;
+    }
+    case PANDRS_HIP_BOOLBITS: {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(k.data) + (tbase >> 3);
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = tile_idx<THREADS>(tid, r, tile_last);
+            kc[r] = (src[j >> 3] >> (j & 7)) & 1;
+        }
+        break;
+    }
+    default: {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(k.data) + tbase;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
+        if (k.dtype == PANDRS_HIP_F64) {
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if ((kc[r] & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) kc[r] = CANON_NAN;
+        }
+    }
+    }
+    uint32_t nm = 0;
+    if (k.null_bits) {
+        const uint8_t *src = k.null_bits + (tbase >> 3);
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = tile_idx<THREADS>(tid, r, tile_last);
+            nm |= ((src[j >> 3] >> (j & 7)) & 1u) << r;
+        }
+    } else if (k.null_bytes) {
+        const uint8_t *src = k.null_bytes + tbase;
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) nm |= (src[tile_idx<THREADS>(tid, r, tile_last)] ? 1u : 0u) << r;
+    }
+    *nulls = nm;
+}
+
+// LDS: cursor[P+1] | cnt[P+1] | delta[P+1] | wave_tot[32] | pid[TILE] (u16) | stage[TILE] (u64)
+// THREADS = 1024: one 8192-row tile per CU (longest per-partition runs);
+// THREADS = 512 : 4096-row tiles, two workgroups per CU (loads of one overlap LDS work of the other).
+// Workgroup b owns rows [b*chunk, (b+1)*chunk).  hist is partition-major: hist[p*NB + q(b)] with
+// q(b) = (b % 8) * (NB/8) + b / 8, so the workgroups of one group g = b % 8 (the set that shares an
+// XCD under round-robin dispatch; a label, never a correctness assumption) own ONE contiguous
+// region of every partition.  NB is a multiple of 8.
+__device__ __forceinline__ uint32_t group_slot(uint32_t b, uint32_t NB) { return (b & 7) * (NB >> 3) + (b >> 3); }
+
+__global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
+                                                               int64_t chunk, uint32_t P,
+                                                               uint32_t seed, uint32_t *hist) {
+    extern __shared__ uint32_t cnt[];  // P + 1
+    const uint32_t NB = gridDim.x, b = blockIdx.x, qb = group_slot(b, NB), tid = threadIdx.x;
+    for (uint32_t p = tid; p <= P; p += HI_THREADS) cnt[p] = 0;
+    __syncthreads();
+    const int64_t beg = (int64_t)b * chunk, end = min(beg + chunk, n_rows);
+    // same tiling as the scatter: SC_RPT batched, branch-free key loads per thread and step
+    constexpr int TILE = HI_THREADS * SC_RPT;
+    for (int64_t tbase = beg; tbase < end; tbase += TILE) {
+        const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
+        uint64_t kc[SC_RPT];
+        uint32_t nulls;
+        load_key_cells<HI_THREADS>(key, tbase, tid, tile_n - 1, kc, &nulls);
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            if ((uint32_t)(r * HI_THREADS) + tid < tile_n) {
+                uint32_t p = ((nulls >> r) & 1) ? P : part_of(hash32(kc[r], seed), P);
+                atomicAdd(&cnt[p], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p <= P; p += HI_THREADS) hist[(size_t)p * NB + qb] = cnt[p];
+}
+
+// group cursors: gcur[p*8 + g] = first row of group g's region inside partition p
+__global__ void init_group_cursors_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1, uint32_t *gcur) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P1 * 8) gcur[i] = offsets[(size_t)(i >> 3) * NB + (i & 7) * (NB >> 3)];
+}
+
+// One tile of the scatter.  FULL = the tile has all TILE rows (every tile but the input's last):
+// no per-row predicates anywhere on that path.
+template <int THREADS, bool STAGED, bool FULL>
+__device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase, uint32_t tile_n,
+                                             uint32_t *cursor, uint32_t *cnt, uint32_t *delta,
+                                             uint32_t *wave_tot, uint16_t *pid, uint64_t *stage) {
+    constexpr uint32_t SPM = (1u << 13) - 1;
+    const uint32_t P1 = a.P + 1, tid = threadIdx.x;
+    const uint32_t ipt = (P1 + THREADS - 1) / THREADS;   // partition counters each thread scans
+    const uint32_t tile_last = tile_n - 1;
+    auto live = [&](int r) { return FULL || (uint32_t)(r * THREADS) + tid < tile_n; };
+
+    for (uint32_t p = tid; p < P1; p += THREADS) cnt[p] = 0;
+    block_sync_lds();
+    // per row: key cell + packed (partition << 13 | position)
+    uint64_t kc[SC_RPT];
+    uint32_t ps[SC_RPT], nulls;
+    load_key_cells<THREADS>(a.key, tbase, tid, tile_last, kc, &nulls);
+#pragma unroll
+    for (int r = 0; r < SC_RPT; r++) {
+        bool nul = (nulls >> r) & 1;
+        if (nul) kc[r] = 0ull;
+        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
+        ps[r] = p << 13;
+        if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
+    }
+    block_sync_lds();
+    // exclusive scan of cnt[] -> delta[] (tile-local partition starts)
+    {
+        uint32_t first = tid * ipt, s = 0;
+        for (uint32_t q = 0; q < ipt; q++) if (first + q < P1) s += cnt[first + q];
+        uint32_t ex = block_exclusive_scan<THREADS>(s, wave_tot, nullptr);
+        for (uint32_t q = 0; q < ipt; q++)
+            if (first + q < P1) { delta[first + q] = ex; ex += cnt[first + q]; }
+    }
+    block_sync_lds();
+#pragma unroll
+    for (int r = 0; r < SC_RPT; r++) ps[r] += delta[ps[r] >> 13];
+    block_sync_lds();
+    // delta[p] := global cursor - tile-local start, so dst = delta[p] + sorted position.
+    // Shared cursors: the 32 CUs of an XCD append to the SAME region of each partition, so a
+    // partition's 128-B lines are completed inside that XCD's 4 MiB L2 (frontier = P x columns x
+    // a few lines) instead of leaving it half-written from P x 32 private regions.
+    if (a.gcur) {
+        const uint32_t g = blockIdx.x & 7;
+        for (uint32_t p = tid; p < P1; p += THREADS) {
+            uint32_t n = cnt[p];
+            uint32_t c = n ? atomicAdd(&a.gcur[p * 8 + g], n) : 0u;
+            delta[p] = c - delta[p];
+        }
+    } else {
+        for (uint32_t p = tid; p < P1; p += THREADS) {
+            uint32_t c = cursor[p];
+            delta[p] = c - delta[p];
+            cursor[p] = c + cnt[p];
+        }
+    }
+    block_sync_lds();
+
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++)
+            if (live(r)) { stage[ps[r] & SPM] = kc[r]; pid[ps[r] & SPM] = (uint16_t)(ps[r] >> 13); }
+        // from here kc[] is dead: the first value column's loads go out before the barrier.
+        // mv[0 .. n_move8) are 8-byte columns (software-pipelined), the rest byte-wide.
+        uint64_t vnext[SC_RPT];
+        if (a.n_move8 > 0) load_column8<THREADS>(a.mv[0].src, tbase, tid, tile_last, vnext);
+        block_sync_lds();
+        uint32_t dst[SC_RPT];
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++) {
+            uint32_t j = r * THREADS + tid;
+            if (live(r)) { dst[r] = delta[pid[j]] + j; a.pkeys[dst[r]] = stage[j]; }
+        }
+        for (int m = 0; m < a.n_move8; m++) {
+            uint64_t *out = reinterpret_cast<uint64_t *>(a.mv[m].dst);
+            uint64_t v[SC_RPT];
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) v[r] = vnext[r];
+            // next column's loads fly under this column's staging
+            if (m + 1 < a.n_move8) load_column8<THREADS>(a.mv[m + 1].src, tbase, tid, tile_last, vnext);
+            block_sync_lds();   // previous column's linear reads done
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) if (live(r)) stage[ps[r] & SPM] = v[r];
+            block_sync_lds();
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) {
+                uint32_t j = r * THREADS + tid;
+                if (live(r)) out[dst[r]] = stage[j];
+            }
+        }
+        for (int m = a.n_move8; m < a.n_move; m++) {      // validity bytes / byte columns
+            const MoveDesc mv = a.mv[m];
+            block_sync_lds();
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if (live(r)) stage[ps[r] & SPM] = move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last));
+            block_sync_lds();
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++) {
+                uint32_t j = r * THREADS + tid;
+                if (live(r)) move_store(mv, dst[r], stage[j]);
+            }
+        }
+        block_sync_lds();
+    } else {
+        uint32_t dst[SC_RPT];
+#pragma unroll
+        for (int r = 0; r < SC_RPT; r++)
+            if (live(r)) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); a.pkeys[dst[r]] = kc[r]; }
+        for (int m = 0; m < a.n_move; m++) {
+            const MoveDesc mv = a.mv[m];
+#pragma unroll
+            for (int r = 0; r < SC_RPT; r++)
+                if (live(r)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
+        }
+        block_sync_lds();
+    }
+}
+
+template <int THREADS, bool STAGED>
+__global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
+    constexpr int TILE = THREADS * SC_RPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t P1 = a.P + 1;
+    // LDS: [cursor[P1] only with private cursors] | cnt[P1] | delta[P1] | wave_tot[32] | pid[TILE] | stage[TILE]
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cnt = a.gcur ? cursor : cursor + P1;
+    uint32_t *delta = cnt + P1;
+    uint32_t *wave_tot = delta + P1;
+    uint16_t *pid = reinterpret_cast<uint16_t *>(wave_tot + 32);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(
+        (reinterpret_cast<uintptr_t>(pid + TILE) + 15) & ~uintptr_t(15));
+
+    const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+    if (!a.gcur) for (uint32_t p = tid; p < P1; p += THREADS) cursor[p] = a.offsets[(size_t)p * NB + group_slot(b, NB)];
+    const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
+    for (int64_t tbase = beg; tbase < end; tbase += TILE) {
+        const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
+        if (tile_n == TILE)
+            scatter_tile<THREADS, STAGED, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+        else
+            scatter_tile<THREADS, STAGED, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+    }
+}
+
+size_t scan_seg_count(size_t n) { return (n + SCAN_SEG - 1) / SCAN_SEG + 16; }
+
+int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out,
+                                  uint32_t *seg) {
+    uint32_t n_seg = (uint32_t)((n + SCAN_SEG - 1) / SCAN_SEG);
+    hipLaunchKernelGGL(scan_partial_kernel, dim3(n_seg), dim3(SCAN_THREADS), 0, c->stream, in, n, seg);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, c->stream, seg, n_seg);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(n_seg), dim3(SCAN_THREADS), 0, c->stream, in, n, seg, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est) {
+    PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
+    const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
+    const int64_t stride = n_rows / n_sample;
+    uint32_t slots = 1;
+    while (slots < 2 * n_sample) slots <<= 1;
+    uint64_t *table = c->work.take<uint64_t>(slots);
+    uint32_t *distinct = c->work.take<uint32_t>(64);
+    if (!table || !distinct) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (estimate)");
+    HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(slots) * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(distinct, 0, 16, c->stream));
+    hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, c->stream,
+                       key, n_rows, stride, n_sample, table, slots - 1, distinct);
+    HIP_TRY(hipGetLastError());
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    HIP_TRY(hipMemcpyAsync(h, distinct, 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double d = std::max<uint32_t>(h[0], 1), s = (double)n_sample;
+    double est;
+    if (n_sample == n_rows) est = d;
+    else if (s - d < 64.0) est = (double)n_rows;                  // too few repeats in the sample to measure: (nearly) all distinct
+    else {
+        // uniform-occupancy model d = G (1 - exp(-s/G)); Newton on G
+        double G = d;
+        for (int it = 0; it < 50; it++) {
+            double e = std::exp(-s / G), f = G * (1 - e) - d, fp = 1 - e - (s / G) * e;
+            if (std::fabs(fp) < 1e-12) break;
+            double Gn = G - f / fp;
+            if (!(Gn > 0)) break;
+            if (std::fabs(Gn - G) < 1e-6 * G) { G = Gn; break; }
+            G = Gn;
+        }
+        est = std::min<double>(std::max(G, d), (double)n_rows);
+    }
+    c->clustered_rows = false;
+    if (h[2] >= 1024) {
+        c->clustered_rows = (double)h[1] < 0.5 * (double)h[2] && !c->opt.no_runs;    // most neighbours share their key
+        // runs of equal keys: an upper bound on the group count in any row order (exact for sorted
+        // input); + 3 sigma of the sampled share so that noise cannot push it below the truth
+        const double pairs = (double)h[2], b = (double)h[1];
+        const double share = std::min(1.0, (b + 3.0 * std::sqrt(b + 1.0)) / pairs);
+        est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
+    }
+    *out_est = (int64_t)est;
+    return 0;
+}
+
+template <int THREADS>
+static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t NB, bool staged) {
+    constexpr int TILE = THREADS * SC_RPT;
+    size_t lds = (size_t)(sa.P + 1) * (sa.gcur ? 8 : 12) + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
+    if (lds > 160 * 1024) return fail(PANDRS_HIP_ERR_COMPUTATION, "radix fan-out %u does not fit the scatter's LDS", sa.P);
+    if (staged) {
+        ST_TRY(set_max_lds(scatter_kernel<THREADS, true>, (int)lds));
+        hipLaunchKernelGGL((scatter_kernel<THREADS, true>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
+    } else {
+        ST_TRY(set_max_lds(scatter_kernel<THREADS, false>, (int)lds));
+        hipLaunchKernelGGL((scatter_kernel<THREADS, false>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1) {
+    const size_t NBmax = 1024 + 8;
+    return Arena::padded(size_t(1 << 19) * 8) + 4096
+         + 2 * Arena::padded((size_t(P_MAX + 1) * NBmax + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64)
+         + Arena::padded(size_t(P_MAX + 1) * 32)
+         + (size_t)n_cols8 * Arena::padded(size_t(n_rows) * 8) + (size_t)n_cols1 * Arena::padded(size_t(n_rows)) + (4 << 20);
+}
+
+int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
+                        int phase_scatter) {
+    const int64_t N = sa.n_rows;
+    const int SCT = c->opt.scatter_threads == 512 ? 512 : 1024;
+    const int SC_TILE = SCT * SC_RPT;
+    const uint32_t P1 = sa.P + 1;
+    int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
+    uint32_t NB = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), 1024);
+    int64_t chunk = ((n_tiles + NB - 1) / NB) * SC_TILE;
+    if (chunk == 0) chunk = SC_TILE;
+    NB = (uint32_t)std::max<int64_t>((N + chunk - 1) / chunk, 1);
+    NB = (NB + 7) & ~7u;                      // 8 groups of NB/8 workgroups (empty ones exit)
+    size_t M = (size_t)P1 * NB;
+    uint32_t *hist = c->work.take<uint32_t>(M + 8);
+    uint32_t *offsets = c->work.take<uint32_t>(M + 8);
+    uint32_t *seg = c->work.take<uint32_t>(scan_seg_count(M));
+    uint32_t *gcur = c->work.take<uint32_t>((size_t)P1 * 8);
+    if (!hist || !offsets || !seg || !gcur) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (partition)");
+    {
+        PhaseTimer pt(c, phase_hist);
+        hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(HI_THREADS), P1 * 4, c->stream,
+                           sa.key, N, chunk, sa.P, sa.seed, hist);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        PhaseTimer pt(c, phase_scan);
+        ST_TRY(exclusive_scan_u32(c, hist, M, offsets, seg));
+        if (c->opt.shared_cursors)
+            hipLaunchKernelGGL(init_group_cursors_kernel, dim3((P1 * 8 + 255) / 256), dim3(256), 0, c->stream,
+                               offsets, NB, P1, gcur);
+    }
+    sa.offsets = offsets; sa.chunk = chunk;
+    sa.gcur = c->opt.shared_cursors ? gcur : nullptr;
+    // 8-byte columns first (the staged kernel pipelines those)
+    std::stable_sort(sa.mv, sa.mv + sa.n_move, [](const MoveDesc &x, const MoveDesc &y) { return (x.kind != 0) < (y.kind != 0); });
+    sa.n_move8 = 0;
+    while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
+    {
+        PhaseTimer pt(c, phase_scatter);
+        if (SCT == 512) ST_TRY(launch_scatter<512>(c, sa, NB, c->opt.scatter_staged != 0));
+        else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
+    }
+    out->P = sa.P; out->NB = NB; out->offsets = offsets;
+    return 0;
+}
+
+__global__ void gather_part_offsets_kernel(const uint32_t *offsets, uint32_t NB, uint32_t n, uint32_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = offsets[(size_t)i * NB];
+}
+
+
+// partition starts (offsets[p * NB]) of the first n partitions, gathered into a dense array
+void gather_part_offsets(pandrs_hip_ctx *c, const uint32_t *offsets, uint32_t NB, uint32_t n, uint32_t *out) {
+    hipLaunchKernelGGL(gather_part_offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, offsets, NB, n, out);
+}
+
+
+}  // namespace pandrs
