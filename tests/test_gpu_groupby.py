@@ -627,3 +627,21 @@ def test_clustered_rows_fold_runs_inside_the_wave(ctx, layout):
         check(ctx, k, n, v, aggs, [O.I64], exact=exact)
     finally:
         ctx.set_option("no_runs", 0)
+
+
+@pytest.mark.parametrize("ncols,ops", [(12, (O.SUM, O.MEAN, O.MIN, O.MAX)), (16, (O.SUM, O.MAX)), (7, (O.STD, O.MIN, O.MEDIAN))])
+def test_many_value_columns_take_several_rounds(ctx, ncols, ops):
+    """Wide aggregations: the states of all columns do not fit one LDS table, so the aggregate processes
+    the columns in rounds (key table kept, state arrays reused); mixed dtypes and masks across columns."""
+    rng = np.random.default_rng(ncols)
+    n, g = 700_000, 30_000
+    k = (sparse_keys_from(rng.integers(0, g, n)), O.pack_mask(rng.random(n) < 0.001), O.I64)
+    vals = []
+    for c in range(ncols):
+        if c % 3 == 2:
+            vals.append((rng.integers(-10**6, 10**6, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.1) if c % 2 else None, O.I64))
+        else:
+            vals.append((rng.normal(c, 1 + c, n), O.pack_mask(rng.random(n) < 0.05) if c % 4 == 0 else None, O.F64))
+    aggs = [(c, op) for c in range(ncols) for op in ops]
+    exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.MEDIAN) or (op == O.SUM and vals[c][2] == O.I64)]
+    check(ctx, k, n, vals, aggs, [O.I64], exact=exact)
