@@ -37,12 +37,13 @@ def rand_key(rng, n, dtype, g, skew):
 def mask(rng, n, p):
     return O.pack_mask(rng.random(n) < p) if p > 0 else None
 
+SCALE = int(os.environ.get("FUZZ_SCALE", "1"))
 fails = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     try:
         if rng.random() < float(os.environ.get("FUZZ_GROUPBY_FRAC", "0.7")):      # ---------------- groupby
-            n = int(rng.choice([1, 7, 1000, 70_000, 300_000, 1_200_000, 5_000_000]))
+            n = int(rng.choice([1, 7, 1000, 70_000, 300_000, 1_200_000, 5_000_000])) * (SCALE if rng.random() < 0.5 else 1)
             kd = int(rng.choice([O.I64, O.I64, O.F64, O.U32CODE, O.BOOLBITS]))
             g = int(rng.choice([1, 3, 50, 2000, 60_000, 900_000]))
             skew = rng.choice(["uniform", "hot", "8020"])
@@ -92,7 +93,7 @@ for case in range(n_cases):
                 assert gcount == want[0].shape[1]
             desc = "groupby n=%d kd=%d g=%d %s %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, layout, nk, aggs, opts)
         else:                       # ---------------- join
-            nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000]))
+            nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])) * (SCALE if rng.random() < 0.5 else 1); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000])) * (SCALE if rng.random() < 0.5 else 1)
             kd = int(rng.choice([O.I64, O.I64, O.U32CODE, O.F64]))
             space = int(rng.choice([3, 500, 100_000, 5_000_000]))
             if nl * nr / max(space, 1) > 3e7: space = 100_000     # keep the output (and the oracle's run time) bounded
