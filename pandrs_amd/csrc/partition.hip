@@ -237,9 +237,19 @@ __global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int6
         load_key_cells<HI_THREADS>(key, tbase, tid, tile_n - 1, kc, &nulls);
 #pragma unroll
         for (int r = 0; r < SC_RPT; r++) {
-            if ((uint32_t)(r * HI_THREADS) + tid < tile_n) {
-                uint32_t p = ((nulls >> r) & 1) ? P : part_of(hash32(kc[r], seed), P);
-                atomicAdd(&cnt[p], 1u);
+            const bool act = (uint32_t)(r * HI_THREADS) + tid < tile_n;
+            const uint32_t p = ((nulls >> r) & 1) ? P : part_of(hash32(kc[r], seed), P);
+            // consecutive lanes hold consecutive rows: a run of equal partition ids (rows clustered by
+            // key) is counted by its first lane in ONE atomic instead of serialising on one LDS address
+            const uint32_t lane = tid & 63;
+            const uint32_t pp = __shfl_up(p, 1, 64);
+            const unsigned long long am = __ballot(act);
+            const bool head = act && (lane == 0 || pp != p || !((am >> (lane - 1)) & 1ull));
+            const unsigned long long hm = __ballot(head);
+            if (head) {
+                const unsigned long long above = lane == 63 ? 0ull : ((hm | ~am) >> (lane + 1));   // next head or first inactive lane
+                const uint32_t run = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+                atomicAdd(&cnt[p], run);
             }
         }
     }
