@@ -160,7 +160,14 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *ctx);
 int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *ctx);
 /* Pre-size the workspace arena (bytes) so the first timed call does not pay hipMalloc. */
 int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *ctx, int64_t workspace_bytes);
-/* Tuning knobs: "groups_hint" (0 = estimate), "scatter_staged" (0/1), "partitions" (0 = auto). */
+/* Tuning / testing knobs (all default to 0 = automatic unless noted):
+ *   "groups_hint"   expected number of groups (skips the sampled estimate)
+ *   "partitions"    force the radix fan-out; "p_max" lower the fan-out cap (forces the two-level path)
+ *   "load_pct"      LDS table load factor in percent (default 70); "p_target", "src_per_round" rounds heuristic
+ *   "scatter_staged" (default 1), "scatter_threads" (1024 / 512), "shared_cursors" (default 1)
+ *   "no_direct", "no_slice", "slice_rows", "no_runs", "generic_aggregate"  switch individual code paths off / on
+ *   "join_generic"  always build the join with the general segmented sort; "join_one_pass" single-pass probe
+ * Unknown names are rejected with PANDRS_HIP_ERR_INVALID_ARGUMENT. */
 int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *ctx, const char *name, int64_t value);
 int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
 
@@ -175,7 +182,9 @@ int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
  *     0.0 != -0.0 (string equality of val.to_string()).
  *   - every aggregate is an f64; I64 Sum wraps in i64 then casts; Mean of nothing = 0.0;
  *     Min/Max whose sentinel is unchanged = 0.0; Count = group size INCLUDING nulls;
- *     Std/Var = two-pass, Bessel; First/Last = value at first/last row, null => 0.0.
+ *     Std/Var = two-pass, Bessel; First/Last = value at first/last row, null => 0.0;
+ *     Median = middle of the sorted non-null values, even counts average the two middles
+ *     (Int64: added in i64 first), no non-null value => 0.0 (aggregation.rs:585-604, :703-722).
  *   - group order in the output is unspecified (reference: HashMap order).
  *   - value dtypes: I64 / F64 for numeric ops; Count accepts any dtype; anything else =>
  *     PANDRS_HIP_ERR_OPERATION_FAILED (aggregation.rs:748).
