@@ -214,6 +214,39 @@ class Context:
             _raise(st)
         return cells, nulls, off, rows
 
+    def groupby_agg_chunked(self, keys, n_rows, vals, aggs, chunk_rows):
+        """Groupby over more rows than one call takes (the per-call limit is 2^32 rows: 32-bit row
+        offsets) or than the workspace should hold at once: the rows are processed in chunks of
+        `chunk_rows` (a multiple of 8, so that null bitmaps split on byte boundaries), every chunk
+        leaves mergeable partial states, and one merge finishes.  Single key column and the mergeable
+        aggregates (Sum / Mean / Min / Max / Count), like the multi-GPU path it reuses."""
+        if chunk_rows <= 0 or chunk_rows % 8:
+            raise ValueError("chunk_rows must be a positive multiple of 8")
+        if len(keys) != 1:
+            raise NotImplementedError("chunked groupby takes one key column")
+        def cut(col, lo, hi):
+            data, mask, dt = col
+            if dt == L.BOOLBITS:
+                data = data[lo // 8:(hi + 7) // 8]
+            else:
+                data = data[lo:hi]
+            return (data, None if mask is None else mask[lo // 8:(hi + 7) // 8], dt)
+        recs = []
+        for lo in range(0, int(n_rows), int(chunk_rows)):
+            hi = min(lo + int(chunk_rows), int(n_rows))
+            self.groupby_partials([cut(keys[0], lo, hi)], hi - lo, [cut(v, lo, hi) for v in vals], aggs)
+            rec, _ = self.partials_split(1)
+            recs.append(rec)
+        if not recs:
+            return self.groupby_agg(keys, 0, vals, aggs)
+        if _is_torch(recs[0]):
+            import torch
+            allrec = torch.cat(recs, dim=0)
+        else:
+            allrec = np.concatenate(recs, axis=0)
+        self.groupby_merge(keys[0][2], allrec, [v[2] for v in vals], [v[1] is not None for v in vals], aggs)
+        return self.groupby_fetch()
+
     # -- row shuffle by key owner (multi-GPU) ------------------------------------------------------------
     def shuffle_split(self, key, payload, n_rows, n_ranks, drop_null_keys=False):
         """Buckets this shard's rows by the owner rank of their key, rank-contiguous.

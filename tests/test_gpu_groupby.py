@@ -645,3 +645,19 @@ def test_many_value_columns_take_several_rounds(ctx, ncols, ops):
     aggs = [(c, op) for c in range(ncols) for op in ops]
     exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.MEDIAN) or (op == O.SUM and vals[c][2] == O.I64)]
     check(ctx, k, n, vals, aggs, [O.I64], exact=exact)
+
+
+def test_chunked_groupby_beyond_one_call(ctx):
+    """Rows processed in chunks (the way a caller goes past the 2^32-row per-call limit or bounds the
+    workspace): partial states per chunk + one merge == one call over everything."""
+    rng = np.random.default_rng(64)
+    n, g = 1_000_003, 20_000
+    k = (sparse_keys_from(rng.integers(0, g, n)), O.pack_mask(rng.random(n) < 0.001), O.I64)
+    v0 = (rng.normal(0, 5, n), O.pack_mask(rng.random(n) < 0.1), O.F64)
+    v1 = (rng.integers(-100, 100, n).astype(np.int64), None, O.I64)
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (1, O.SUM), (1, O.MAX), (1, O.COUNT)]
+    got = ctx.groupby_agg_chunked([k], n, [v0, v1], aggs, chunk_rows=131_072)
+    want = O.groupby_agg([k], n, [v0, v1], aggs)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5])
+    with pytest.raises(ValueError):
+        ctx.groupby_agg_chunked([k], n, [v0], [(0, O.SUM)], chunk_rows=1001)
