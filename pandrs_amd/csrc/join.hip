@@ -8,10 +8,12 @@
 //   1. the BUILD (right) side is radix-partitioned on hash(key cell) with the groupby engine's
 //      histogram / scan / LDS-staged scatter, carrying the original row index; null keys go to a
 //      partition of their own and are never built (join.rs:112);
-//   2. build pass, one workgroup per partition: bitonic sort in LDS by (key, right row) — so a
-//      key's matches are in ascending right-row order, the reference's per-key Vec<usize> order
-//      (join.rs:114, :156-158) — written back sorted; every run {key -> start, count} is published
-//      in a global open-addressing table of 16-byte entries (cache-resident for typical builds);
+//   2. build pass, one workgroup per partition: the rows are grouped by key with an LDS hash table
+//      (count per key -> scan -> place) and every key's short run is put in ascending right-row
+//      order, the reference's per-key Vec<usize> order (join.rs:114, :156-158); that LDS table is the
+//      partition's region of the global table of 16-byte {key, start, count} entries and is stored
+//      whole, without global atomics.  Partitions with a long run fall back to an LDS bitonic sort,
+//      partitions beyond LDS to the general segmented sort (segsort.hip);
 //   3. probe pass over the LEFT rows in their ORIGINAL order (never partitioned): one table lookup
 //      per row -> {first match, output rows}; null left keys emit nothing (join.rs:152);
 //   4. exclusive scan of the per-left-row counts = output offsets in reference order
@@ -52,15 +54,6 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t *sk, PT *sp, uint32_t 
             __syncthreads();
         }
     }
-}
-
-__device__ __forceinline__ uint32_t lds_lower_bound(const uint64_t *sk, uint32_t n, uint64_t key) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (sk[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
 }
 
 // Global open-addressing table over the build side's DISTINCT keys: 16-byte entries
