@@ -159,7 +159,8 @@ struct pandrs_hip_ctx {
     std::mutex mu;
     // one arena per lifetime class: buffers that must survive a nested engine run never share an
     // arena with what that run allocates (work: per-run scratch; temp: direct-path records;
-    // side: slice records; super: two-level columns; packed: multi-key cells; pairs: fused-join pairs)
+    // side: slice records; super: two-level columns; packed: multi-key cells and dictionaries;
+    // pairs: fused-join pairs; groups: retained group index (CSR); shuf: retained shuffle buckets)
     pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups, shuf;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
