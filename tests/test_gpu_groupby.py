@@ -661,3 +661,29 @@ def test_chunked_groupby_beyond_one_call(ctx):
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5])
     with pytest.raises(ValueError):
         ctx.groupby_agg_chunked([k], n, [v0], [(0, O.SUM)], chunk_rows=1001)
+
+
+def test_device_resident_inputs_for_the_newer_entry_points(ctx):
+    """Median, group indices and multi-key dictionary encoding with DEVICE pointers (torch tensors):
+    same results as with host pointers."""
+    import torch
+    rng = np.random.default_rng(808)
+    n = 400_000
+    k0 = sparse_keys_from(rng.integers(0, 3000, n))
+    m0 = O.pack_mask(rng.random(n) < 0.01)
+    k1 = rng.integers(-2**62, 2**62, n)
+    v = rng.normal(0, 1, n)
+    vm = O.pack_mask(rng.random(n) < 0.1)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    aggs = [(0, O.MEDIAN), (0, O.SUM), (0, O.COUNT)]
+    got = ctx.groupby_agg([(dev(k0), dev(m0), O.I64)], n, [(dev(v), dev(vm), O.F64)], aggs)
+    got = tuple(x.cpu().numpy() for x in got)
+    want = O.groupby_agg([(k0, m0, O.I64)], n, [(v, vm, O.F64)], aggs)
+    assert_groupby_equal((got[0].view(np.uint64), got[1], got[2]), want, [O.I64], int_exact_rows=[0, 2])
+    cells, nulls, off, rows = ctx.groupby_indices([(dev(k0), dev(m0), O.I64), (dev(k1), None, O.I64)], n)
+    h = ctx.groupby_indices([(k0, m0, O.I64), (k1, None, O.I64)], n)
+    assert cells.shape == h[0].shape and int(off[-1]) == n
+    a = np.lexsort((cells.cpu().numpy()[1], cells.cpu().numpy()[0], nulls.cpu().numpy()[0]))
+    b = np.lexsort((h[0].view(np.int64)[1], h[0].view(np.int64)[0], h[1][0]))
+    np.testing.assert_array_equal(cells.cpu().numpy()[:, a], h[0].view(np.int64)[:, b])
+    np.testing.assert_array_equal(np.diff(off.cpu().numpy())[a], np.diff(h[2])[b])
