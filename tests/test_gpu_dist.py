@@ -183,3 +183,74 @@ def test_distributed_multi_key_world1_rccl(ctx, pg):
     first = np.zeros(inv.max() + 1, np.uint64)
     first[inv] = h
     np.testing.assert_array_equal(first[inv], h)
+
+
+# ---- two REAL ranks on the one GPU: the HIP engine on both sides, gloo as the transport ---------------
+def _two_rank_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import pandrs_amd
+    from pandrs_amd.dist import DistributedGroupBy, DistributedJoinGroupBy
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = pandrs_amd.Context(0)
+    rng = np.random.default_rng(2024)
+    n, g = 600_000, 40_000
+    k = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = rng.random(n) < 0.002
+    v0 = np.round(rng.normal(100, 10, n), 1)
+    v1 = rng.integers(-1000, 1000, n).astype(np.int64)
+    m1 = rng.random(n) < 0.1
+    lo, hi = (n // world // 8 * 8) * rank, n if rank == world - 1 else (n // world // 8 * 8) * (rank + 1)
+    pb = lambda m: np.packbits(m, bitorder="little")
+    d = DistributedGroupBy(c, dist, "cpu")
+    out = {}
+    for name, aggs in (("merge", [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 4)]), ("shuffle", [(0, 7), (1, 7), (0, 5), (1, 0)])):
+        kc, kn, oa = d.groupby_agg([(k[lo:hi], pb(km[lo:hi]), 0)], hi - lo, [(v0[lo:hi], None, 1), (v1[lo:hi], pb(m1[lo:hi]), 0)], aggs)
+        out[name + "_kc"], out[name + "_kn"], out[name + "_oa"] = np.asarray(kc).view(np.uint64), np.asarray(kn), np.asarray(oa)
+    nr = 50_000
+    rk = (rng.permutation(4 * nr)[:nr].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rg = rng.integers(0, 900, nr).astype(np.int64)
+    lk = np.where(rng.random(n) < 0.9, rk[rng.integers(0, nr, n)], rng.integers(1, 1 << 40, n))
+    r0, r1 = nr * rank // world, nr * (rank + 1) // world
+    for strategy in ("allgather", "shuffle"):
+        j = DistributedJoinGroupBy(c, dist, "cpu")
+        kc, kn, oa = j.join_groupby_sum((lk[lo:hi], None, 0), (v0[lo:hi], None, 1), hi - lo, (rk[r0:r1], None, 0), (rg[r0:r1], None, 0), r1 - r0, strategy=strategy)
+        out["join_" + strategy + "_kc"], out["join_" + strategy + "_kn"], out["join_" + strategy + "_oa"] = np.asarray(kc).view(np.uint64), np.asarray(kn), np.asarray(oa)
+    np.savez(os.path.join(outdir, "t%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    c.close()
+
+
+def test_two_real_ranks_share_the_gpu_over_gloo(tmp_path):
+    """Two processes, each with its own HIP context on cuda:0 and its own row range (host columns), exchange
+    over gloo: partial-state merge, row shuffle (Median / Std) and both distributed join strategies with the
+    REAL engine on both sides of a real exchange.  (RCCL needs one GPU per rank; the driver has those.)"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(os.path.join(tmp_path, "t%d.npz" % r)) for r in range(2)]
+    cat = lambda name: tuple(np.concatenate([p[name + s_] for p in parts], axis=1) for s_ in ("_kc", "_kn", "_oa"))
+    rng = np.random.default_rng(2024)
+    n, g = 600_000, 40_000
+    k = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = rng.random(n) < 0.002
+    v0 = np.round(rng.normal(100, 10, n), 1)
+    v1 = rng.integers(-1000, 1000, n).astype(np.int64)
+    m1 = rng.random(n) < 0.1
+    keys, vals = [(k, O.pack_mask(km), O.I64)], [(v0, None, O.F64), (v1, O.pack_mask(m1), O.I64)]
+    aggs = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 4)]
+    assert_groupby_equal(cat("merge"), O.groupby_agg(keys, n, vals, aggs), [O.I64], int_exact_rows=[2, 3, 4, 5])
+    aggs = [(0, 7), (1, 7), (0, 5), (1, 0)]
+    assert_groupby_equal(cat("shuffle"), O.groupby_agg(keys, n, vals, aggs), [O.I64], int_exact_rows=[0, 1, 3])
+    nr = 50_000
+    rk = (rng.permutation(4 * nr)[:nr].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rg = rng.integers(0, 900, nr).astype(np.int64)
+    lk = np.where(rng.random(n) < 0.9, rk[rng.integers(0, nr, n)], rng.integers(1, 1 << 40, n))
+    want = O.join_groupby_sum((lk, None, O.I64), (v0, None, O.F64), n, (rk, None, O.I64), (rg, None, O.I64), nr)
+    for strategy in ("allgather", "shuffle"):
+        got = cat("join_" + strategy)
+        assert got[0].shape[1] == want[0].shape[1], strategy
+        assert_groupby_equal(got, want, [O.I64])
