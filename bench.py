@@ -207,6 +207,12 @@ def main():
                          "note": "whole groupby pipeline (estimate+histogram+scan+scatter+aggregate) "
                                  "timed with hipEvents on the library stream; B = N(K+8C)+G(K+8A)"},
         }
+        if "scatter" in phases and phases["scatter"] > 0:
+            # the task's literal reading (dominant kernel only) beside the whole-pipeline figure above
+            dom = max((p for p in phases if not p.startswith("merge_") and p != "exchange_wall"), key=lambda p: phases[p])
+            out["roofline"]["dominant_kernel"] = {"phase": dom, "ms": phases[dom], "achieved": bytes_alg / (phases[dom] * 1e-3) / 1e9,
+                                                  "frac": bytes_alg / (phases[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                  "note": "algorithmic bytes of the whole call / this kernel's hipEvent time"}
         if world > 1 or force_dist:
             out["roofline"]["wall_ms_last_step"] = dgb.last_timings.get("wall_ms")
             out["roofline"]["note"] = ("local partial aggregation + split + all-to-all + merge; device_ms = hipEvent time of the "
