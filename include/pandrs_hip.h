@@ -315,6 +315,11 @@ int32_t pandrs_hip_gather_f64(pandrs_hip_ctx *ctx, int32_t mem_space, const doub
 int32_t pandrs_hip_gather_u32(pandrs_hip_ctx *ctx, int32_t mem_space, const uint32_t *src,
                               const uint8_t *src_null_mask, const int64_t *idx, int64_t n,
                               uint32_t fill, uint32_t *out);
+/* The same gather with the source length in the signature, for either memory space (host columns are
+ * staged): src->dtype selects the element — out holds 8 bytes per row for I64 / F64 (fill_bits = the
+ * fill value's bit pattern), 4 for U32CODE, and one 0/1 byte per row for BOOLBITS. */
+int32_t pandrs_hip_gather_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *src,
+                                 int64_t n_src, const int64_t *idx, int64_t n, uint64_t fill_bits, void *out);
 /* bit-packed source (BooleanColumn), byte-per-row output */
 int32_t pandrs_hip_gather_bool(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *src_bits,
                                const uint8_t *src_null_mask, const int64_t *idx, int64_t n,

@@ -1,0 +1,503 @@
+// pandrs_hip.hpp — C++17 host-side mirror of the reference's API for the accelerated path, over the
+// C ABI of include/pandrs_hip.h (header only; link libpandrs_hip.so).
+//
+// The reference is a Rust crate and this image has no Rust toolchain, so this header plays the part of
+// the crate-side shim in a compiled language: same type and method names, argument meaning and error
+// behaviour as
+//   OptimizedDataFrame        src/optimized/split_dataframe/core.rs, group/grouping.rs:22-115,
+//                             join.rs:32-73, aggregate.rs:21-217
+//   Column / *Column          src/column/{int64,float64,string,boolean}_column.rs, core/column.rs:163-177
+//   GroupBy, AggregateOp      group/types.rs:11-55, group/aggregation.rs:763-871, group/operations.rs:438-547
+//   LazyFrame                 src/optimized/lazy.rs:98-170, :186-425
+//   JoinType                  join.rs:11-20
+//   Error                     src/core/error.rs:6 (Result<T, Error> becomes: returns T, throws Error)
+// Everything numeric happens in the library (host pointers, PANDRS_HIP_MEM_HOST — the way the Rust shim
+// of INTEGRATION.md calls it); this header only stringifies keys, names columns and assembles frames,
+// exactly the host-side work the reference keeps.  tests/cpp/reference_like_tests.cpp replays the
+// reference's own tests through it.
+#pragma once
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "pandrs_hip.h"
+
+namespace pandrs {
+
+// ---- errors (src/core/error.rs) ---------------------------------------------------------------------
+struct Error : std::runtime_error {
+    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount };
+    Kind kind;
+    Error(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
+};
+
+namespace detail {
+// device failures map like src/gpu/mod.rs:206-210
+inline void check(int32_t st) {
+    if (st == PANDRS_HIP_OK) return;
+    const std::string msg = pandrs_hip_last_error();
+    switch (st) {
+    case PANDRS_HIP_ERR_INVALID_ARGUMENT: throw Error(Error::InvalidInput, msg);
+    case PANDRS_HIP_ERR_TYPE_MISMATCH: throw Error(Error::ColumnTypeMismatch, msg);
+    case PANDRS_HIP_ERR_OPERATION_FAILED: throw Error(Error::OperationFailed, msg);
+    default: throw Error(Error::Computation, msg);
+    }
+}
+// process-wide context, created on first use (cf. get_gpu_manager, src/gpu/mod.rs:249-282)
+inline pandrs_hip_ctx *context() {
+    static std::once_flag once;
+    static pandrs_hip_ctx *ctx = nullptr;
+    std::call_once(once, [] {
+        check(pandrs_hip_init(nullptr));
+        check(pandrs_hip_ctx_create(0, &ctx));
+    });
+    return ctx;
+}
+// create_bitmask (src/core/column.rs:163-177): LSB first, 1 = null; empty when nothing is null
+inline std::vector<uint8_t> create_bitmask(const std::vector<bool> &nulls) {
+    bool any = false;
+    for (bool b : nulls) any = any || b;
+    if (!any) return {};
+    std::vector<uint8_t> m((nulls.size() + 7) / 8, 0);
+    for (size_t i = 0; i < nulls.size(); i++)
+        if (nulls[i]) m[i >> 3] |= (uint8_t)(1u << (i & 7));
+    return m;
+}
+inline bool bit_at(const std::vector<uint8_t> &m, size_t i) { return !m.empty() && ((m[i >> 3] >> (i & 7)) & 1); }
+// f64::to_string(): shortest round-trip digits, never an exponent ("1", "0.1", "NaN", "inf", "-0")
+inline std::string rust_f64_to_string(double v) {
+    if (v != v) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
+}  // namespace detail
+
+// ---- GLOBAL_STRING_POOL (src/column/string_pool.rs:28-53): equal string <=> equal code ----------------
+class StringPool {
+public:
+    static StringPool &global() { static StringPool p; return p; }
+    uint32_t get_or_insert(const std::string &s) {
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = codes_.find(s);
+        if (it != codes_.end()) return it->second;
+        const uint32_t c = (uint32_t)strings_.size();
+        strings_.push_back(s);
+        codes_.emplace(s, c);
+        return c;
+    }
+    std::string get(uint32_t code) const {
+        std::lock_guard<std::mutex> lock(mu_);
+        return strings_.at(code);
+    }
+private:
+    mutable std::mutex mu_;
+    std::vector<std::string> strings_;
+    std::unordered_map<std::string, uint32_t> codes_;
+};
+
+// ---- columns ----------------------------------------------------------------------------------------------
+struct Int64Column {          // src/column/int64_column.rs:52-66
+    std::vector<int64_t> data;
+    std::vector<uint8_t> null_mask;
+    Int64Column() = default;
+    explicit Int64Column(std::vector<int64_t> d) : data(std::move(d)) {}
+    static Int64Column with_nulls(std::vector<int64_t> d, const std::vector<bool> &nulls) {
+        Int64Column c(std::move(d)); c.null_mask = detail::create_bitmask(nulls); return c;
+    }
+    size_t len() const { return data.size(); }
+};
+struct Float64Column {        // src/column/float64_column.rs:9-13
+    std::vector<double> data;
+    std::vector<uint8_t> null_mask;
+    Float64Column() = default;
+    explicit Float64Column(std::vector<double> d) : data(std::move(d)) {}
+    static Float64Column with_nulls(std::vector<double> d, const std::vector<bool> &nulls) {
+        Float64Column c(std::move(d)); c.null_mask = detail::create_bitmask(nulls); return c;
+    }
+    size_t len() const { return data.size(); }
+};
+struct StringColumn {         // src/column/string_column.rs:26-72 (GlobalPool mode): pool codes
+    std::vector<uint32_t> indices;
+    std::vector<uint8_t> null_mask;
+    StringColumn() = default;
+    explicit StringColumn(const std::vector<std::string> &values) {
+        indices.reserve(values.size());
+        for (auto &s : values) indices.push_back(StringPool::global().get_or_insert(s));
+    }
+    static StringColumn with_nulls(const std::vector<std::string> &values, const std::vector<bool> &nulls) {
+        StringColumn c(values); c.null_mask = detail::create_bitmask(nulls); return c;
+    }
+    size_t len() const { return indices.size(); }
+    std::string get(size_t i) const { return StringPool::global().get(indices[i]); }
+};
+struct BooleanColumn {        // src/column/boolean_column.rs:10-15: LSB-first packed bits
+    std::vector<uint8_t> bits;
+    size_t length = 0;
+    std::vector<uint8_t> null_mask;
+    BooleanColumn() = default;
+    explicit BooleanColumn(const std::vector<bool> &values) : bits((values.size() + 7) / 8, 0), length(values.size()) {
+        for (size_t i = 0; i < values.size(); i++)
+            if (values[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+    size_t len() const { return length; }
+    bool get(size_t i) const { return (bits[i >> 3] >> (i & 7)) & 1; }
+};
+using Column = std::variant<Int64Column, Float64Column, StringColumn, BooleanColumn>;
+
+namespace detail {
+inline size_t col_len(const Column &c) { return std::visit([](auto &x) { return x.len(); }, c); }
+inline int32_t col_dtype(const Column &c) { return (int32_t)c.index(); }   // variant order == pandrs_hip_dtype order
+inline pandrs_hip_column view(const Column &c) {
+    pandrs_hip_column v{};
+    v.dtype = col_dtype(c);
+    std::visit([&](auto &x) {
+        using T = std::decay_t<decltype(x)>;
+        if constexpr (std::is_same_v<T, StringColumn>) v.data = x.indices.data();
+        else if constexpr (std::is_same_v<T, BooleanColumn>) v.data = x.bits.data();
+        else v.data = x.data.data();
+        v.null_mask = x.null_mask.empty() ? nullptr : x.null_mask.data();
+    }, c);
+    return v;
+}
+// group-key cell -> the string the reference's result frame holds (grouping.rs:69-98)
+inline std::string key_string(int32_t dtype, uint64_t cell, bool is_null, const char *null_string = "NULL") {
+    if (is_null) return null_string;
+    switch (dtype) {
+    case PANDRS_HIP_I64: return std::to_string((int64_t)cell);
+    case PANDRS_HIP_F64: { double d; std::memcpy(&d, &cell, 8); return rust_f64_to_string(d); }
+    case PANDRS_HIP_U32CODE: return StringPool::global().get((uint32_t)cell);
+    default: return cell ? "true" : "false";
+    }
+}
+}  // namespace detail
+
+enum class AggregateOp { Sum = 0, Mean, Min, Max, Count, Std, Var, Median, First, Last, Custom };   // types.rs:11-34
+enum class JoinType { Inner = 0, Left, Right, Outer };                                              // join.rs:11-20
+
+class GroupBy;
+
+// ---- OptimizedDataFrame ------------------------------------------------------------------------------------
+class OptimizedDataFrame {
+public:
+    std::vector<Column> columns;
+    std::vector<std::string> column_names;
+    std::unordered_map<std::string, size_t> column_indices;
+
+    OptimizedDataFrame &add_column(const std::string &name, Column column) {
+        if (column_indices.count(name)) throw Error(Error::DuplicateColumnName, name);
+        if (!columns.empty() && detail::col_len(column) != row_count_)
+            throw Error(Error::InconsistentRowCount, "expected " + std::to_string(row_count_) + " rows, found " + std::to_string(detail::col_len(column)));
+        row_count_ = detail::col_len(column);
+        column_indices[name] = columns.size();
+        column_names.push_back(name);
+        columns.push_back(std::move(column));
+        return *this;
+    }
+    const Column &column(const std::string &name) const {
+        auto it = column_indices.find(name);
+        if (it == column_indices.end()) throw Error(Error::ColumnNotFound, name);
+        return columns[it->second];
+    }
+    bool contains_column(const std::string &name) const { return column_indices.count(name) != 0; }
+    size_t row_count() const { return row_count_; }
+    size_t column_count() const { return columns.size(); }
+
+    GroupBy group_by(const std::vector<std::string> &cols) const;                      // grouping.rs:22-28
+    std::map<std::string, OptimizedDataFrame> par_groupby(const std::vector<std::string> &cols) const;   // grouping.rs:124-331
+
+    OptimizedDataFrame inner_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Inner); }
+    OptimizedDataFrame left_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Left); }
+    OptimizedDataFrame right_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Right); }
+    OptimizedDataFrame outer_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Outer); }
+
+    // whole-column reductions (split_dataframe/aggregate.rs:21-217)
+    double sum(const std::string &name) const { return reduce(name)[0]; }
+    double mean(const std::string &name) const { return reduce(name)[1]; }
+    double min(const std::string &name) const { return reduce(name)[2]; }
+    double max(const std::string &name) const { return reduce(name)[3]; }
+
+    // data_ops.rs:124-209: row gather of every column; nulls become 0 / 0.0 / "" / false
+    OptimizedDataFrame filter_by_indices(const std::vector<int64_t> &indices) const {
+        std::vector<int64_t> idx;
+        for (int64_t i : indices) if (i >= 0 && (size_t)i < row_count_) idx.push_back(i);
+        OptimizedDataFrame out;
+        for (size_t c = 0; c < columns.size(); c++) out.add_column(column_names[c], gather(columns[c], idx));
+        return out;
+    }
+
+private:
+    size_t row_count_ = 0;
+
+    std::vector<double> reduce(const std::string &name) const {
+        const Column &c = column(name);
+        if (c.index() > 1) throw Error(Error::OperationFailed, "column '" + name + "' is not numeric");
+        pandrs_hip_column v = detail::view(c);
+        std::vector<double> out(4);
+        int64_t cnt = 0;
+        detail::check(pandrs_hip_reduce_column(detail::context(), PANDRS_HIP_MEM_HOST, &v, (int64_t)detail::col_len(c), out.data(), &cnt));
+        return out;
+    }
+    // join_impl's / filter_by_indices' per-column gather on the device (join.rs:296-357, :475-552)
+    static Column gather(const Column &src, const std::vector<int64_t> &idx) {
+        const int64_t n = (int64_t)idx.size(), n_src = (int64_t)detail::col_len(src);
+        pandrs_hip_column v = detail::view(src);
+        auto call = [&](uint64_t fill, void *out) {
+            detail::check(pandrs_hip_gather_column(detail::context(), PANDRS_HIP_MEM_HOST, &v, n_src, idx.data(), n, fill, out));
+        };
+        switch (src.index()) {
+        case 0: { Int64Column o; o.data.resize(n); call(0, o.data.data()); return o; }
+        case 1: { Float64Column o; o.data.resize(n); call(0, o.data.data()); return o; }
+        case 2: { StringColumn o; o.indices.resize(n); call(StringPool::global().get_or_insert(""), o.indices.data()); return o; }
+        default: {
+            std::vector<uint8_t> bytes(n);
+            call(0, bytes.data());
+            std::vector<bool> b(n);
+            for (int64_t i = 0; i < n; i++) b[i] = bytes[i] != 0;
+            return BooleanColumn(b);
+        }
+        }
+    }
+    // join.rs:76-555
+    OptimizedDataFrame join_impl(const OptimizedDataFrame &other, const std::string &left_on, const std::string &right_on, JoinType how) const {
+        if (!contains_column(left_on)) throw Error(Error::ColumnNotFound, left_on);              // :84-87
+        if (!other.contains_column(right_on)) throw Error(Error::ColumnNotFound, right_on);      // :89-92
+        const Column &lc = column(left_on), &rc = other.column(right_on);
+        pandrs_hip_column lv = detail::view(lc), rv = detail::view(rc);
+        int64_t n = 0;      // a key-type mismatch surfaces as ColumnTypeMismatch from the library (:98-104)
+        detail::check(pandrs_hip_join_indices(detail::context(), PANDRS_HIP_MEM_HOST, &lv, (int64_t)detail::col_len(lc), &rv,
+                                              (int64_t)detail::col_len(rc), (int32_t)how, &n));
+        std::vector<int64_t> li(n), ri(n);
+        detail::check(pandrs_hip_join_fetch(detail::context(), PANDRS_HIP_MEM_HOST, li.data(), ri.data()));
+        OptimizedDataFrame result;
+        if (n == 0) {       // empty result: NON-KEY columns only, suffix decided against the LEFT frame (:227-284)
+            for (auto &name : column_names) if (name != left_on) result.add_column(name, gather(column(name), {}));
+            for (auto &name : other.column_names)
+                if (name != right_on) result.add_column(contains_column(name) ? name + "_right" : name, gather(other.column(name), {}));
+            return result;
+        }
+        for (auto &name : column_names) if (name != left_on) result.add_column(name, gather(column(name), li));     // :290-361
+        {   // key column: the left value, else the right one (:364-472)
+            Column a = gather(lc, li), b = gather(rc, ri);
+            std::visit([&](auto &x) {
+                using T = std::decay_t<decltype(x)>;
+                auto &y = std::get<T>(b);
+                if constexpr (std::is_same_v<T, BooleanColumn>) {
+                    std::vector<bool> v(n);
+                    for (int64_t i = 0; i < n; i++) v[i] = li[i] >= 0 ? x.get(i) : y.get(i);
+                    x = BooleanColumn(v);
+                } else if constexpr (std::is_same_v<T, StringColumn>) {
+                    for (int64_t i = 0; i < n; i++) if (li[i] < 0) x.indices[i] = y.indices[i];
+                } else {
+                    for (int64_t i = 0; i < n; i++) if (li[i] < 0) x.data[i] = y.data[i];
+                }
+            }, a);
+            result.add_column(left_on, std::move(a));
+        }
+        for (auto &name : other.column_names)                                                                       // :475-552
+            if (name != right_on) result.add_column(result.contains_column(name) ? name + "_right" : name, gather(other.column(name), ri));
+        return result;
+    }
+    friend class GroupBy;
+};
+
+// ---- GroupBy (group/types.rs:46-55) ------------------------------------------------------------------------
+class GroupBy {
+public:
+    using Aggregation = std::tuple<std::string, AggregateOp, std::string>;      // (column, op, alias)
+    const OptimizedDataFrame &df;
+    std::vector<std::string> group_by_columns;
+
+    GroupBy(const OptimizedDataFrame &d, std::vector<std::string> cols) : df(d), group_by_columns(std::move(cols)) {}
+
+    // aggregation.rs:763-871: key column(s) as strings, then one Float64 column per alias in request order
+    OptimizedDataFrame aggregate(const std::vector<Aggregation> &aggregations) const {
+        for (auto &a : aggregations)
+            if (!df.contains_column(std::get<0>(a))) throw Error(Error::ColumnNotFound, std::get<0>(a));       // :770-774
+        std::vector<pandrs_hip_column> keys, vals;
+        std::vector<std::string> val_names;
+        for (auto &k : group_by_columns) keys.push_back(detail::view(df.column(k)));
+        std::vector<pandrs_hip_agg_spec> specs;
+        for (auto &a : aggregations) {
+            size_t vi = 0;
+            while (vi < val_names.size() && val_names[vi] != std::get<0>(a)) vi++;
+            if (vi == val_names.size()) { val_names.push_back(std::get<0>(a)); vals.push_back(detail::view(df.column(std::get<0>(a)))); }
+            specs.push_back(pandrs_hip_agg_spec{(int32_t)vi, (int32_t)std::get<1>(a)});
+        }
+        int64_t g = 0;
+        detail::check(pandrs_hip_groupby_agg(detail::context(), PANDRS_HIP_MEM_HOST, keys.data(), (int32_t)keys.size(), (int64_t)df.row_count(),
+                                             vals.data(), (int32_t)vals.size(), specs.data(), (int32_t)specs.size(), &g));
+        const size_t nk = keys.size(), na = specs.size();
+        std::vector<std::vector<uint64_t>> kc(nk, std::vector<uint64_t>(g));
+        std::vector<std::vector<uint8_t>> kn(nk, std::vector<uint8_t>(g));
+        std::vector<std::vector<double>> oa(na, std::vector<double>(g));
+        std::vector<uint64_t *> pk; std::vector<uint8_t *> pn; std::vector<double *> pa;
+        for (auto &v : kc) pk.push_back(v.data());
+        for (auto &v : kn) pn.push_back(v.data());
+        for (auto &v : oa) pa.push_back(v.data());
+        detail::check(pandrs_hip_groupby_fetch(detail::context(), PANDRS_HIP_MEM_HOST, pk.data(), pn.data(), pa.data()));
+        OptimizedDataFrame result;
+        for (size_t k = 0; k < nk; k++) {
+            std::vector<std::string> strs(g);
+            for (int64_t i = 0; i < g; i++) strs[i] = detail::key_string(keys[k].dtype, kc[k][i], kn[k][i] != 0);
+            result.add_column(group_by_columns[k], StringColumn(strs));                                           // :856-860
+        }
+        for (size_t a = 0; a < na; a++) result.add_column(std::get<2>(aggregations[a]), Float64Column(oa[a]));  // :863-867
+        return result;
+    }
+    // operations.rs:498-521: aliases "{col}_{op}"
+    OptimizedDataFrame agg(const std::vector<std::pair<std::string, AggregateOp>> &aggs) const {
+        std::vector<Aggregation> v;
+        for (auto &a : aggs) v.emplace_back(a.first, a.second, a.first + "_" + op_name(a.second));
+        return aggregate(v);
+    }
+    OptimizedDataFrame sum(const std::string &c) const { return agg({{c, AggregateOp::Sum}}); }
+    OptimizedDataFrame mean(const std::string &c) const { return agg({{c, AggregateOp::Mean}}); }
+    OptimizedDataFrame min(const std::string &c) const { return agg({{c, AggregateOp::Min}}); }
+    OptimizedDataFrame max(const std::string &c) const { return agg({{c, AggregateOp::Max}}); }
+    OptimizedDataFrame count(const std::string &c) const { return agg({{c, AggregateOp::Count}}); }
+    OptimizedDataFrame std(const std::string &c) const { return agg({{c, AggregateOp::Std}}); }
+    OptimizedDataFrame var(const std::string &c) const { return agg({{c, AggregateOp::Var}}); }
+    OptimizedDataFrame median(const std::string &c) const { return agg({{c, AggregateOp::Median}}); }
+    OptimizedDataFrame first(const std::string &c) const { return agg({{c, AggregateOp::First}}); }
+    OptimizedDataFrame last(const std::string &c) const { return agg({{c, AggregateOp::Last}}); }
+
+    // the pub field `groups` (types.rs:52): HashMap<Vec<String>, Vec<usize>>, every list ascending
+    std::map<std::vector<std::string>, std::vector<size_t>> groups(const char *null_string = "NULL") const {
+        std::vector<pandrs_hip_column> keys;
+        for (auto &k : group_by_columns) keys.push_back(detail::view(df.column(k)));
+        int64_t g = 0;
+        const int64_t n = (int64_t)df.row_count();
+        detail::check(pandrs_hip_groupby_indices(detail::context(), PANDRS_HIP_MEM_HOST, keys.data(), (int32_t)keys.size(), n, &g));
+        const size_t nk = keys.size();
+        std::vector<std::vector<uint64_t>> kc(nk, std::vector<uint64_t>(g));
+        std::vector<std::vector<uint8_t>> kn(nk, std::vector<uint8_t>(g));
+        std::vector<uint64_t *> pk; std::vector<uint8_t *> pn;
+        for (auto &v : kc) pk.push_back(v.data());
+        for (auto &v : kn) pn.push_back(v.data());
+        std::vector<int64_t> off(g + 1), rows(n);
+        detail::check(pandrs_hip_groupby_indices_fetch(detail::context(), PANDRS_HIP_MEM_HOST, pk.data(), pn.data(), off.data(), rows.data()));
+        std::map<std::vector<std::string>, std::vector<size_t>> out;
+        for (int64_t i = 0; i < g; i++) {
+            std::vector<std::string> key;
+            for (size_t k = 0; k < nk; k++) key.push_back(detail::key_string(keys[k].dtype, kc[k][i], kn[k][i] != 0, null_string));
+            auto &v = out[key];
+            v.insert(v.end(), rows.begin() + off[i], rows.begin() + off[i + 1]);
+        }
+        return out;
+    }
+    // CustomAggregation / aggregate_custom (types.rs:58-67, aggregation.rs:391-497): host closure over the
+    // group's non-null values (Int64 cast to f64); the groups come from the device
+    OptimizedDataFrame custom(const std::string &column, const std::string &result_name, const std::function<double(const std::vector<double> &)> &fn) const {
+        if (!df.contains_column(column)) throw Error(Error::ColumnNotFound, column);
+        const Column &c = df.column(column);
+        if (c.index() > 1) throw Error(Error::OperationFailed, "column '" + column + "' is not numeric");
+        auto gs = groups();
+        OptimizedDataFrame result;
+        for (size_t k = 0; k < group_by_columns.size(); k++) {
+            std::vector<std::string> strs;
+            for (auto &kv : gs) strs.push_back(kv.first[k]);
+            result.add_column(group_by_columns[k], StringColumn(strs));
+        }
+        std::vector<double> vals;
+        for (auto &kv : gs) {
+            std::vector<double> v;
+            for (size_t r : kv.second) {
+                if (c.index() == 0) { auto &x = std::get<Int64Column>(c); if (!detail::bit_at(x.null_mask, r)) v.push_back((double)x.data[r]); }
+                else { auto &x = std::get<Float64Column>(c); if (!detail::bit_at(x.null_mask, r)) v.push_back(x.data[r]); }
+            }
+            vals.push_back(fn(v));
+        }
+        result.add_column(result_name, Float64Column(vals));
+        return result;
+    }
+
+    static std::string op_name(AggregateOp op) {
+        static const char *names[] = {"sum", "mean", "min", "max", "count", "std", "var", "median", "first", "last", "custom"};
+        return names[(int)op];
+    }
+};
+
+inline GroupBy OptimizedDataFrame::group_by(const std::vector<std::string> &cols) const {
+    for (auto &c : cols) if (!contains_column(c)) throw Error(Error::ColumnNotFound, c);       // grouping.rs:53-57
+    return GroupBy(*this, cols);
+}
+inline std::map<std::string, OptimizedDataFrame> OptimizedDataFrame::par_groupby(const std::vector<std::string> &cols) const {
+    for (auto &c : cols) if (!contains_column(c)) throw Error(Error::ColumnNotFound, c);
+    std::map<std::string, std::vector<int64_t>> merged;           // parts joined with "_" (:186), a null part is "NA" (:158)
+    for (auto &kv : GroupBy(*this, cols).groups("NA")) {
+        std::string name;
+        for (size_t i = 0; i < kv.first.size(); i++) name += (i ? "_" : "") + kv.first[i];
+        auto &v = merged[name];
+        v.insert(v.end(), kv.second.begin(), kv.second.end());
+    }
+    std::map<std::string, OptimizedDataFrame> out;
+    for (auto &kv : merged) {
+        std::vector<int64_t> rows = kv.second;
+        std::sort(rows.begin(), rows.end());
+        out.emplace(kv.first, filter_by_indices(rows));
+    }
+    return out;
+}
+
+// ---- LazyFrame (lazy.rs:98-170): the two operations on the accelerated path ---------------------------------
+class LazyFrame {
+public:
+    explicit LazyFrame(OptimizedDataFrame df) : source_(std::move(df)) {}
+    LazyFrame &aggregate(std::vector<std::string> group_by, std::vector<GroupBy::Aggregation> aggregations) {
+        ops_.push_back(Op{true, std::move(group_by), std::move(aggregations), nullptr, "", "", JoinType::Inner});
+        return *this;
+    }
+    LazyFrame &join(const OptimizedDataFrame &right, const std::string &left_on, const std::string &right_on, JoinType how) {
+        ops_.push_back(Op{false, {}, {}, std::make_shared<OptimizedDataFrame>(right), left_on, right_on, how});
+        return *this;
+    }
+    OptimizedDataFrame execute() const {
+        OptimizedDataFrame df = source_;
+        for (auto &op : ops_) {
+            if (op.is_aggregate) {
+                for (auto &a : op.aggregations) {                   // lazy.rs:377-382: only these five ops
+                    const AggregateOp o = std::get<1>(a);
+                    if (o != AggregateOp::Sum && o != AggregateOp::Mean && o != AggregateOp::Min && o != AggregateOp::Max && o != AggregateOp::Count)
+                        throw Error(Error::OperationFailed, "Aggregation operation " + GroupBy::op_name(o) + " is not supported in LazyFrame");
+                }
+                df = df.group_by(op.group_by).aggregate(op.aggregations);
+            } else {
+                switch (op.how) {                                   // lazy.rs:405-425
+                case JoinType::Inner: df = df.inner_join(*op.right, op.left_on, op.right_on); break;
+                case JoinType::Left: df = df.left_join(*op.right, op.left_on, op.right_on); break;
+                case JoinType::Right: df = df.right_join(*op.right, op.left_on, op.right_on); break;
+                default: df = df.outer_join(*op.right, op.left_on, op.right_on);
+                }
+            }
+        }
+        return df;
+    }
+private:
+    struct Op {
+        bool is_aggregate;
+        std::vector<std::string> group_by;
+        std::vector<GroupBy::Aggregation> aggregations;
+        std::shared_ptr<OptimizedDataFrame> right;
+        std::string left_on, right_on;
+        JoinType how;
+    };
+    OptimizedDataFrame source_;
+    std::vector<Op> ops_;
+};
+
+}  // namespace pandrs

@@ -312,6 +312,11 @@ int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space, const p
     return pandrs::reduce_entry(ctx, mem_space, col, n, out, out_count);
 }
 
+int32_t pandrs_hip_gather_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *src, int64_t n_src,
+                                 const int64_t *idx, int64_t n, uint64_t fill_bits, void *out) {
+    return pandrs::gather_column_entry(ctx, mem_space, src, n_src, idx, n, fill_bits, out);
+}
+
 int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
                                   double *out_sum, double *out_sum_sq, int64_t *out_count) {
     if (!out_sum || !out_sum_sq || !out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce_moments: bad arguments");

@@ -242,7 +242,9 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
                                int64_t nr, int64_t *out_n_groups);
 int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void *src,
                      const uint8_t *mask, const int64_t *idx, int64_t n, uint64_t fill_bits,
-                     void *out);
+                     void *out, int64_t n_src = -1);
+int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *src, int64_t n_src,
+                            const int64_t *idx, int64_t n, uint64_t fill_bits, void *out);
 int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
                      double out[4], int64_t *out_count, double *out_sumsq = nullptr);
 

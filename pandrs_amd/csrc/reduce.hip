@@ -125,18 +125,18 @@ int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_colu
 // kind 0: 8-byte elements, 1: 4-byte, 2: bit-packed source -> byte per row
 template <int KIND>
 __global__ void gather_kernel(const void *src, const uint8_t *null_bits, const int64_t *idx, int64_t n,
-                              uint64_t fill, void *out) {
+                              uint64_t fill, void *out, int64_t n_src) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t j = idx[i];
-    bool take = j >= 0 && !(null_bits && bit_at(null_bits, j));
+    bool take = j >= 0 && (n_src < 0 || j < n_src) && !(null_bits && bit_at(null_bits, j));   // n_src < 0: length not known to the ABI
     if (KIND == 0) reinterpret_cast<uint64_t *>(out)[i] = take ? reinterpret_cast<const uint64_t *>(src)[j] : fill;
     else if (KIND == 1) reinterpret_cast<uint32_t *>(out)[i] = take ? reinterpret_cast<const uint32_t *>(src)[j] : (uint32_t)fill;
     else reinterpret_cast<uint8_t *>(out)[i] = take ? (uint8_t)bit_at(reinterpret_cast<const uint8_t *>(src), j) : (uint8_t)fill;
 }
 
 int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void *src, const uint8_t *mask,
-                     const int64_t *idx, int64_t n, uint64_t fill_bits, void *out) {
+                     const int64_t *idx, int64_t n, uint64_t fill_bits, void *out, int64_t n_src) {
     if (!c || n < 0 || (n && (!idx || !out))) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "gather: bad arguments");
     if (n == 0) return 0;
     if (mem_space == PANDRS_HIP_MEM_HOST)
@@ -149,14 +149,65 @@ int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void 
     {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_GATHER);
         dim3 grid((unsigned)((n + 255) / 256)), block(256);
-        if (kind == 0) hipLaunchKernelGGL(gather_kernel<0>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out);
-        else if (kind == 1) hipLaunchKernelGGL(gather_kernel<1>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out);
-        else hipLaunchKernelGGL(gather_kernel<2>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out);
+        if (kind == 0) hipLaunchKernelGGL(gather_kernel<0>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src);
+        else if (kind == 1) hipLaunchKernelGGL(gather_kernel<1>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src);
+        else hipLaunchKernelGGL(gather_kernel<2>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src);
         HIP_TRY(hipGetLastError());
     }
     int64_t esz = kind == 0 ? 8 : (kind == 1 ? 4 : 1);
     c->timings.algorithmic_bytes = n * (8 + 2 * esz);
     ST_TRY(timings_end(c));
+    return 0;
+}
+
+// Column gather with the source length in the signature, so that host-resident columns can be staged:
+// the form a host-side shim uses (pandrs_hip_gather_column).
+int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *src, int64_t n_src,
+                            const int64_t *idx, int64_t n, uint64_t fill_bits, void *out) {
+    if (!c || !src || n_src < 0 || n < 0 || (n && (!idx || !out)))
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "gather_column: bad arguments");
+    if (src->dtype < PANDRS_HIP_I64 || src->dtype > PANDRS_HIP_BOOLBITS)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "gather_column: bad dtype %d", src->dtype);
+    const int kind = src->dtype == PANDRS_HIP_U32CODE ? 1 : (src->dtype == PANDRS_HIP_BOOLBITS ? 2 : 0);
+    if (n == 0) return 0;
+    if (mem_space == PANDRS_HIP_MEM_DEVICE)
+        return gather_entry(c, mem_space, kind, src->data, src->null_mask, idx, n, fill_bits, out, n_src);
+    const size_t esz = kind == 0 ? 8 : (kind == 1 ? 4 : 1);
+    const void *d_src = nullptr; const uint8_t *d_mask = nullptr; int64_t *d_idx = nullptr; void *d_out = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t sbytes = dtype_bytes(src->dtype, n_src), mbytes = (size_t)(n_src + 7) / 8;
+        ST_TRY(c->staging.ensure(sbytes + mbytes + size_t(n) * (8 + esz) + 4096, c->stream));
+        if (n_src > 0 && src->data) {
+            void *p = c->staging.take<uint8_t>(sbytes + 16);
+            if (!p) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+            HIP_TRY(hipMemcpyAsync(p, src->data, sbytes, hipMemcpyHostToDevice, c->stream));
+            d_src = p;
+            if (src->null_mask) {
+                uint8_t *m = c->staging.take<uint8_t>(mbytes + 16);
+                if (!m) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+                HIP_TRY(hipMemcpyAsync(m, src->null_mask, mbytes, hipMemcpyHostToDevice, c->stream));
+                d_mask = m;
+            }
+        }
+        d_idx = c->staging.take<int64_t>(n);
+        d_out = c->staging.take<uint8_t>(size_t(n) * esz + 16);
+        if (!d_idx || !d_out) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+        HIP_TRY(hipMemcpyAsync(d_idx, idx, size_t(n) * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (!d_src) {                                   // empty source: every row takes the fill value
+        for (int64_t i = 0; i < n; i++) {
+            if (kind == 0) reinterpret_cast<uint64_t *>(out)[i] = fill_bits;
+            else if (kind == 1) reinterpret_cast<uint32_t *>(out)[i] = (uint32_t)fill_bits;
+            else reinterpret_cast<uint8_t *>(out)[i] = (uint8_t)fill_bits;
+        }
+        return 0;
+    }
+    ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, d_src, d_mask, d_idx, n, fill_bits, d_out, n_src));
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipMemcpyAsync(out, d_out, size_t(n) * esz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
