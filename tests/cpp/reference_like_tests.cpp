@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pandrs_hip.hpp"
@@ -196,6 +197,23 @@ static void test_key_strings_and_errors() {
     CHECK(threw);
 }
 
+// tests/concurrency_test.rs:351-398: four threads group the same frame at once
+static void test_concurrent_callers_share_one_frame() {
+    OptimizedDataFrame df;
+    std::vector<std::string> keys; std::vector<int64_t> vals;
+    for (int i = 0; i < 40000; i++) { keys.push_back("g" + std::to_string(i % 4)); vals.push_back(i); }
+    df.add_column("k", StringColumn(keys));
+    df.add_column("v", Int64Column(vals));
+    std::vector<std::map<std::string, double>> got(4);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 4; t++) th.emplace_back([&, t] { got[t] = by_key(df.group_by({"k"}).sum("v"), "k", "v_sum"); });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < 4; t++) {
+        CHECK(got[t].size() == 4);
+        for (int g = 0; g < 4; g++) CHECK(got[t]["g" + std::to_string(g)] == 10000.0 * g + 4.0 * (9999.0 * 10000.0 / 2.0));
+    }
+}
+
 int main() {
     int32_t n_dev = 0;
     if (pandrs_hip_init(nullptr) != PANDRS_HIP_OK || pandrs_hip_device_count(&n_dev) != PANDRS_HIP_OK || n_dev == 0) {
@@ -212,6 +230,7 @@ int main() {
     RUN(test_string_key_merge_vectors);
     RUN(test_whole_column_reductions);
     RUN(test_key_strings_and_errors);
+    RUN(test_concurrent_callers_share_one_frame);
     std::printf("%d tests, %d failed checks\n", g_run, g_failed);
     return g_failed ? 2 : 0;
 }
