@@ -214,6 +214,62 @@ static void test_concurrent_callers_share_one_frame() {
     }
 }
 
+// Parity of the whole C++ path against the CPU oracle (oracle/pandrs_oracle.c, test infrastructure) on a
+// seeded random frame: nullable i64 key, nullable f64 and i64 values, every aggregate incl. Median.
+extern "C" {
+int oracle_groupby_agg(const pandrs_hip_column *keys, int n_keys, int64_t n_rows, const pandrs_hip_column *vals, int n_vals,
+                       const pandrs_hip_agg_spec *aggs, int n_aggs, int64_t *out_n_groups, uint64_t **out_keys,
+                       uint8_t **out_key_null, double **out_aggs);
+void oracle_free(void *p);
+}
+static void test_random_frame_matches_the_oracle() {
+    const size_t n = 300000;
+    uint64_t state = 0x243F6A8885A308D3ull;
+    auto next = [&] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
+    std::vector<int64_t> k(n), vi(n);
+    std::vector<double> vf(n);
+    std::vector<bool> kn(n), fn(n), in(n);
+    for (size_t i = 0; i < n; i++) {
+        k[i] = (int64_t)((next() % 5000) * 0x9E3779B97F4A7C15ull);
+        vf[i] = (double)(int64_t)(next() % 200001 - 100000) / 64.0;
+        vi[i] = (int64_t)(next() % 2001) - 1000;
+        kn[i] = next() % 1000 == 0; fn[i] = next() % 10 == 0; in[i] = next() % 7 == 0;
+    }
+    OptimizedDataFrame df;
+    df.add_column("k", Int64Column::with_nulls(k, kn));
+    df.add_column("f", Float64Column::with_nulls(vf, fn));
+    df.add_column("i", Int64Column::with_nulls(vi, in));
+    const std::vector<std::pair<std::string, AggregateOp>> req = {
+        {"f", AggregateOp::Sum}, {"f", AggregateOp::Mean}, {"f", AggregateOp::Min}, {"f", AggregateOp::Max}, {"f", AggregateOp::Count},
+        {"f", AggregateOp::Std}, {"f", AggregateOp::Median}, {"f", AggregateOp::First}, {"i", AggregateOp::Sum}, {"i", AggregateOp::Var},
+        {"i", AggregateOp::Median}, {"i", AggregateOp::Last}};
+    auto r = df.group_by({"k"}).agg(req);
+    pandrs_hip_column keys[1] = {detail::view(df.column("k"))};
+    pandrs_hip_column vals[2] = {detail::view(df.column("f")), detail::view(df.column("i"))};
+    std::vector<pandrs_hip_agg_spec> specs;
+    for (auto &a : req) specs.push_back({a.first == "f" ? 0 : 1, (int32_t)a.second});
+    int64_t g = 0; uint64_t *ok = nullptr; uint8_t *on = nullptr; double *oa = nullptr;
+    CHECK(oracle_groupby_agg(keys, 1, (int64_t)n, vals, 2, specs.data(), (int)specs.size(), &g, &ok, &on, &oa) == 0);
+    CHECK((size_t)g == r.row_count() && r.column_count() == 1 + req.size());
+    std::map<std::string, size_t> row_of;
+    auto &kc = std::get<StringColumn>(r.column("k"));
+    for (size_t j = 0; j < r.row_count(); j++) row_of[kc.get(j)] = j;
+    int bad = 0;
+    for (int64_t j = 0; j < g; j++) {
+        auto it = row_of.find(on[j] ? "NULL" : std::to_string((int64_t)ok[j]));
+        if (it == row_of.end()) { bad++; continue; }
+        for (size_t a = 0; a < req.size(); a++) {
+            const double want = oa[a * (size_t)g + (size_t)j];
+            const double got = std::get<Float64Column>(r.columns[1 + a]).data[it->second];
+            const bool exact = req[a].second != AggregateOp::Sum && req[a].second != AggregateOp::Mean && req[a].second != AggregateOp::Std &&
+                               req[a].second != AggregateOp::Var;
+            if (exact ? got != want : std::fabs(got - want) > 1e-9 * std::max(1.0, std::fabs(want))) bad++;
+        }
+    }
+    CHECK(bad == 0);
+    oracle_free(ok); oracle_free(on); oracle_free(oa);
+}
+
 int main() {
     int32_t n_dev = 0;
     if (pandrs_hip_init(nullptr) != PANDRS_HIP_OK || pandrs_hip_device_count(&n_dev) != PANDRS_HIP_OK || n_dev == 0) {
@@ -231,6 +287,7 @@ int main() {
     RUN(test_whole_column_reductions);
     RUN(test_key_strings_and_errors);
     RUN(test_concurrent_callers_share_one_frame);
+    RUN(test_random_frame_matches_the_oracle);
     std::printf("%d tests, %d failed checks\n", g_run, g_failed);
     return g_failed ? 2 : 0;
 }

@@ -16,6 +16,7 @@ def _build(out):
     libdir = os.path.join(ROOT, "pandrs_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "reference_like_tests.cpp"), "-L" + libdir, "-lpandrs_hip",
+                           "-L" + os.path.join(ROOT, "oracle"), "-lpandrs_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", out])
 
 
@@ -35,4 +36,4 @@ def test_cpp_mirror_replays_the_reference_tests():
         _build(exe)
         r = subprocess.run([exe], capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert "11 tests, 0 failed checks" in r.stdout
+        assert "12 tests, 0 failed checks" in r.stdout
