@@ -426,6 +426,49 @@ public:
         return result;
     }
 
+    // operations.rs:51-74: keep the rows of the groups whose sub-frame passes filter_fn
+    OptimizedDataFrame filter(const std::function<bool(const OptimizedDataFrame &)> &filter_fn) const {
+        std::vector<int64_t> keep;
+        for (auto &kv : groups()) {
+            std::vector<int64_t> rows(kv.second.begin(), kv.second.end());
+            if (filter_fn(df.filter_by_indices(rows))) keep.insert(keep.end(), rows.begin(), rows.end());
+        }
+        return df.filter_by_indices(keep);
+    }
+    // operations.rs:132-276: transform_fn(group sub-frame) -> frame for every group, results concatenated
+    // column by column after the first result's schema (columns matched by position and type)
+    OptimizedDataFrame transform(const std::function<OptimizedDataFrame(const OptimizedDataFrame &)> &transform_fn) const {
+        std::vector<OptimizedDataFrame> outs;
+        for (auto &kv : groups()) outs.push_back(transform_fn(df.filter_by_indices(std::vector<int64_t>(kv.second.begin(), kv.second.end()))));
+        OptimizedDataFrame result;
+        if (outs.empty()) return result;
+        const OptimizedDataFrame &tmpl = outs[0];
+        for (size_t ci = 0; ci < tmpl.columns.size(); ci++) {
+            Column acc = tmpl.columns[ci];
+            std::visit([&](auto &a) {
+                using T = std::decay_t<decltype(a)>;
+                std::vector<bool> nulls;
+                auto push_nulls = [&](const T &x) { for (size_t i = 0; i < x.len(); i++) nulls.push_back(detail::bit_at(x.null_mask, i)); };
+                push_nulls(a);
+                for (size_t d = 1; d < outs.size(); d++) {
+                    if (ci >= outs[d].columns.size() || !std::holds_alternative<T>(outs[d].columns[ci])) continue;
+                    const T &x = std::get<T>(outs[d].columns[ci]);
+                    if constexpr (std::is_same_v<T, StringColumn>) a.indices.insert(a.indices.end(), x.indices.begin(), x.indices.end());
+                    else if constexpr (std::is_same_v<T, BooleanColumn>) {
+                        std::vector<bool> v(a.length + x.length);
+                        for (size_t i = 0; i < a.length; i++) v[i] = a.get(i);
+                        for (size_t i = 0; i < x.length; i++) v[a.length + i] = x.get(i);
+                        a = BooleanColumn(v);
+                    } else a.data.insert(a.data.end(), x.data.begin(), x.data.end());
+                    push_nulls(x);
+                }
+                a.null_mask = detail::create_bitmask(nulls);
+            }, acc);
+            result.add_column(tmpl.column_names[ci], std::move(acc));
+        }
+        return result;
+    }
+
     static std::string op_name(AggregateOp op) {
         static const char *names[] = {"sum", "mean", "min", "max", "count", "std", "var", "median", "first", "last", "custom"};
         return names[(int)op];

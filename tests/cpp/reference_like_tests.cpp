@@ -99,6 +99,18 @@ static void test_groupby_example_and_shortcuts() {
     CHECK(by_key(gb.first("values"), "category", "values_first")["B"] == 20.0 && by_key(gb.last("values"), "category", "values_last")["A"] == 15.0);
     auto groups = gb.groups();
     CHECK((groups[{"A"}] == std::vector<size_t>{0, 2, 5}) && (groups[{"B"}] == std::vector<size_t>{1, 4}) && (groups[{"C"}] == std::vector<size_t>{3}));
+    auto big = gb.filter([](const OptimizedDataFrame &g) { return g.row_count() >= 2; });                 // operations.rs:51-74
+    CHECK(big.row_count() == 5 && std::get<StringColumn>(big.column("category")).len() == 5);
+    auto centered = gb.transform([](const OptimizedDataFrame &g) {                                        // operations.rs:132-276
+        auto &v = std::get<Int64Column>(g.column("values")).data;
+        double m = 0; for (auto x : v) m += (double)x; m /= (double)v.size();
+        std::vector<double> c; for (auto x : v) c.push_back((double)x - m);
+        OptimizedDataFrame out; out.add_column("category", g.column("category")); out.add_column("centered", Float64Column(c));
+        return out;
+    });
+    CHECK(centered.row_count() == 6 && centered.column_count() == 2);
+    double abs_sum = 0; for (double x : std::get<Float64Column>(centered.column("centered")).data) abs_sum += x;
+    CHECK(std::fabs(abs_sum) < 1e-9);
     auto range = gb.custom("values", "range", [](const std::vector<double> &v) { return *std::max_element(v.begin(), v.end()) - *std::min_element(v.begin(), v.end()); });
     CHECK(by_key(range, "category", "range")["A"] == 5.0 && by_key(range, "category", "range")["C"] == 0.0);
 }
