@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--workload", choices=["groupby", "join"], default="groupby",
                     help="groupby = BASELINE config 2 (the headline line); join = config 5 shape "
                          "(probe --rows per GPU, build rows/10 per GPU, inner join -> groupby(g).sum(v))")
+    ap.add_argument("--join-strategy", choices=["auto", "allgather", "shuffle"], default="auto",
+                    help="N > 1, --workload join: replicate the build side, or shuffle both sides to the owner of their key")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints a version banner
@@ -245,7 +247,7 @@ def bench_join(args, torch, pa, dist, rank, local_rank, world, device):
     if world > 1 or (os.environ.get("PANDRS_BENCH_FORCE_DIST") == "1" and dist is not None):
         from pandrs_amd.dist import DistributedJoinGroupBy
         djg = DistributedJoinGroupBy(ctx, dist, device)
-        step = lambda: djg.join_groupby_sum(*cols)
+        step = lambda: djg.join_groupby_sum(*cols, strategy=args.join_strategy)
     else:
         djg = None
         step = lambda: ctx.join_groupby_sum(*cols)
@@ -286,7 +288,9 @@ def bench_join(args, torch, pa, dist, rank, local_rank, world, device):
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE config 5 shape: %d probe rows/GPU x %d build rows/GPU, "
                                       "inner join -> groupby(g in [0,100000)).sum(v)" % (nl, nr),
-                          "parallelism": "all-gather build side + local fused join + 1 all-to-all of partial sums"
+                          "parallelism": ("%s + local fused join + 1 all-to-all of partial sums" %
+                                          {"allgather": "all-gather of the build side", "shuffle": "row shuffle of both sides by key owner",
+                                           "auto": "all-gather of the build side or row shuffle by key owner (by size and world)"}[args.join_strategy])
                           if world > 1 else "1 GPU"},
                "roofline": {"bound": "hbm", "achieved": bytes_alg / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": bytes_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,

@@ -265,10 +265,17 @@ class DistributedJoinGroupBy:
     def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right, strategy="allgather"):
         """Columns are (data, mask, dtype) like Context.join_groupby_sum; every rank passes its own
         row ranges of both sides.  -> this rank's share of (g cells, g null flags, sums).
-        strategy "allgather": the build side is replicated, the probe side stays put (small builds);
+        strategy "auto" picks between the two; "allgather": the build side is replicated, the probe side stays put (small builds);
         "shuffle": both sides go to the owner of their join key (SURVEY.md 8e's radix all-to-all) —
         every GPU then builds only 1/world of the build side, at the price of moving the probe rows."""
         t0 = time.perf_counter()
+        if strategy == "auto":
+            # replicating the build side makes EVERY rank build all of it; shuffling moves the probe rows once.
+            # By the single-GPU numbers (DESIGN.md 8e) the shuffle wins from 4 ranks up once the build side is large.
+            torch = self.groupby._torch()
+            tot = torch.tensor([int(n_right)], dtype=torch.int64, device=self.device if str(self.device) != "cpu" else "cpu")
+            self.dist.all_reduce(tot)
+            strategy = "shuffle" if self.world >= 4 and int(tot.item()) >= 8_000_000 else "allgather"
         if strategy == "shuffle":
             lk2, lv2, nl2 = self._shuffled_side(lkey, lval, n_left)
             rk2, rg2, nr2 = self._shuffled_side(rkey, rgroup, n_right)

@@ -113,7 +113,7 @@ def _join_worker(rank, world, port, outdir, strategy="allgather"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,strategy", [(2, "allgather"), (3, "allgather"), (2, "shuffle"), (3, "shuffle")])
+@pytest.mark.parametrize("world,strategy", [(2, "allgather"), (3, "allgather"), (2, "shuffle"), (3, "shuffle"), (2, "auto")])
 def test_distributed_join_groupby_matches_oracle(world, strategy):
     import torch.multiprocessing as mp
     from oracle import oracle as O
