@@ -69,6 +69,24 @@ def cpu_baseline(n_sample, n_groups, n_cols, aggs):
                       % (n_sample, n_groups, n_cols, dt)}
 
 
+def cpu_baseline_parallel(n_sample, n_groups, n_cols, aggs):
+    """SURVEY.md 8(d)(i), second half: the faithful restatement in the reference's PARALLEL shape
+    (par_groupby chunk-map + serial merge, par_aggregate folds) on the box's host-core share."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    rng = np.random.default_rng(43)
+    ids = rng.integers(0, n_groups, n_sample).astype(np.uint64)
+    keys = (ids * np.uint64(0x9E3779B97F4A7C15) ^ np.uint64(0x5555AAAA5555AAAA)).view(np.int64)
+    vals = [(rng.normal(100, 10, n_sample), None, O.F64) for _ in range(n_cols)]
+    O.lib()
+    t0 = time.perf_counter()
+    O.groupby_agg([(keys, None, O.I64)], n_sample, vals, aggs, faithful=True, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "port",
+            "sample": "%d rows, same shape; par_groupby / par_aggregate shaped restatement (oracle_groupby_agg_ref_mt), %.1f s" % (n_sample, dt)}
+
+
 def cpu_baseline_typed(n_sample, n_groups, n_cols):
     """a FAIR typed CPU baseline beside the faithful one — i64 open-addressing
     hash, all host cores, count/sum/min/max per column (mean = sum / count) — so the GPU/CPU ratio is
@@ -221,6 +239,7 @@ def main():
                                        "local and merge pipelines + wall time of the exchange; B = N(K+8C)+G(K+8A) per GPU")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
+            out["cpu_baseline_parallel"] = cpu_baseline_parallel(min(n, 2 * args.cpu_sample), g, ncol, aggs)
             out["cpu_baseline_typed"] = cpu_baseline_typed(min(n, 8 * args.cpu_sample), g, ncol)
         emit(out)
     if dist is not None:

@@ -97,12 +97,14 @@ def _take(ptr, shape, np_dtype):
     return out
 
 
-def groupby_agg(keys, n_rows, vals, aggs, faithful=False, pools=None):
+def groupby_agg(keys, n_rows, vals, aggs, faithful=False, pools=None, threads=1):
     """-> (key_cells[n_keys, G] u64, key_null[n_keys, G] u8, aggs[n_aggs, G] f64).
 
     faithful=False: typed restatement, output sorted by key (nulls last).
     faithful=True : string-keyed HashMap shape of the reference (lazy.rs:186-404); output in
                     table order.  `pools[k]` = list of bytes/str for U32CODE key column k.
+                    threads > 1: the reference's parallel shape (par_groupby's chunk-map + serial merge,
+                    grouping.rs:203-280, then par_aggregate's parallel folds).
     """
     keep = []
     kc, vc, ag = _cols(keys, keep), _cols(vals, keep), _aggs(aggs)
@@ -123,9 +125,14 @@ def groupby_agg(keys, n_rows, vals, aggs, faithful=False, pools=None):
                 keep.append(a)
                 arrs.append(C.cast(a, C.c_void_p))
             pool_arr = (C.c_void_p * len(arrs))(*[a if a is not None else None for a in arrs])
-        rc = L.oracle_groupby_agg_ref(kc, C.c_int(len(keys)), pool_arr, C.c_int64(n_rows),
-                                      vc, C.c_int(len(vals)), ag, C.c_int(len(aggs)),
-                                      C.byref(ng), C.byref(pk), C.byref(pn), C.byref(pa))
+        if threads > 1:
+            rc = L.oracle_groupby_agg_ref_mt(kc, C.c_int(len(keys)), pool_arr, C.c_int64(n_rows),
+                                             vc, C.c_int(len(vals)), ag, C.c_int(len(aggs)), C.c_int(int(threads)),
+                                             C.byref(ng), C.byref(pk), C.byref(pn), C.byref(pa))
+        else:
+            rc = L.oracle_groupby_agg_ref(kc, C.c_int(len(keys)), pool_arr, C.c_int64(n_rows),
+                                          vc, C.c_int(len(vals)), ag, C.c_int(len(aggs)),
+                                          C.byref(ng), C.byref(pk), C.byref(pn), C.byref(pa))
     else:
         rc = L.oracle_groupby_agg(kc, C.c_int(len(keys)), C.c_int64(n_rows),
                                   vc, C.c_int(len(vals)), ag, C.c_int(len(aggs)),

@@ -348,21 +348,18 @@ static int format_key_part(char *buf, size_t cap, const ocol *c, int64_t i,
     return 0;
 }
 
-int oracle_groupby_agg_ref(const ocol *keys, int n_keys, const char *const *const *pools,
-                           int64_t n_rows, const ocol *vals, int n_vals,
-                           const oagg *aggs, int n_aggs,
-                           int64_t *out_n_groups, uint64_t **out_keys, uint8_t **out_key_null,
-                           double **out_aggs) {
-    *out_n_groups = 0; *out_keys = NULL; *out_key_null = NULL; *out_aggs = NULL;
-    for (int a = 0; a < n_aggs; a++)
-        if (aggs[a].col < 0 || aggs[a].col >= n_vals) return PANDRS_HIP_ERR_INVALID_ARGUMENT;
-    stable t; t.n_groups = 0; t.cap_groups = 1024; t.n_slots = 2048;
-    t.groups = (sgroup *)malloc(sizeof(sgroup) * (size_t)t.cap_groups);
-    t.slots = (int64_t *)malloc(sizeof(int64_t) * (size_t)t.n_slots);
-    for (int64_t i = 0; i < t.n_slots; i++) t.slots[i] = -1;
+/* Phase 1 of the reference's grouping over the rows [row_lo, row_hi): one String per key part, a
+ * SipHash-1-3 of the Vec<String>, a HashMap probe and a Vec::push per row (lazy.rs:195-236,
+ * grouping.rs:62-104).  Returns the largest group or -1 on error. */
+static int64_t build_string_groups(const ocol *keys, int n_keys, const char *const *const *pools,
+                                   int64_t row_lo, int64_t row_hi, stable *t) {
+    t->n_groups = 0; t->cap_groups = 1024; t->n_slots = 2048;
+    t->groups = (sgroup *)malloc(sizeof(sgroup) * (size_t)t->cap_groups);
+    t->slots = (int64_t *)malloc(sizeof(int64_t) * (size_t)t->n_slots);
+    for (int64_t i = 0; i < t->n_slots; i++) t->slots[i] = -1;
     char buf[1024];
     int64_t max_group = 0;
-    for (int64_t row = 0; row < n_rows; row++) {
+    for (int64_t row = row_lo; row < row_hi; row++) {
         /* Vec<String>: each part followed by 0xFF as <str as Hash>::hash writes it; a length
          * prefix as <[T] as Hash> does (lazy.rs:195-236). */
         size_t len = 0;
@@ -372,30 +369,30 @@ int oracle_groupby_agg_ref(const ocol *keys, int n_keys, const char *const *cons
             int w = format_key_part(part, 64, &keys[k], row, pools ? pools[k] : NULL);
             if (w >= 64) { free(part); part = (char *)malloc((size_t)w + 1);
                            format_key_part(part, (size_t)w + 1, &keys[k], row, pools ? pools[k] : NULL); }
-            if (len + (size_t)w + 1 > sizeof(buf)) { free(part); return PANDRS_HIP_ERR_INVALID_ARGUMENT; }
+            if (len + (size_t)w + 1 > sizeof(buf)) { free(part); return -1; }
             memcpy(buf + len, part, (size_t)w); len += (size_t)w; buf[len++] = (char)0xFF;
             free(part);
         }
         uint64_t h = siphash13((const uint8_t *)buf, len);
-        int64_t p = (int64_t)(h & (uint64_t)(t.n_slots - 1)), g = -1;
-        while (t.slots[p] >= 0) {
-            sgroup *c = &t.groups[t.slots[p]];
-            if (c->hash == h && c->key_len == len && memcmp(c->key, buf, len) == 0) { g = t.slots[p]; break; }
-            p = (p + 1) & (t.n_slots - 1);
+        int64_t p = (int64_t)(h & (uint64_t)(t->n_slots - 1)), g = -1;
+        while (t->slots[p] >= 0) {
+            sgroup *c = &t->groups[t->slots[p]];
+            if (c->hash == h && c->key_len == len && memcmp(c->key, buf, len) == 0) { g = t->slots[p]; break; }
+            p = (p + 1) & (t->n_slots - 1);
         }
         if (g < 0) {
-            if (t.n_groups == t.cap_groups) {
-                t.cap_groups *= 2;
-                t.groups = (sgroup *)realloc(t.groups, sizeof(sgroup) * (size_t)t.cap_groups);
+            if (t->n_groups == t->cap_groups) {
+                t->cap_groups *= 2;
+                t->groups = (sgroup *)realloc(t->groups, sizeof(sgroup) * (size_t)t->cap_groups);
             }
-            g = t.n_groups++;
-            sgroup *c = &t.groups[g];
+            g = t->n_groups++;
+            sgroup *c = &t->groups[g];
             c->key = (char *)malloc(len); memcpy(c->key, buf, len); c->key_len = (uint32_t)len;
             c->hash = h; c->rows = NULL; c->n = 0; c->cap = 0; c->first_row = row;
-            t.slots[p] = g;
-            if (t.n_groups * 2 > t.n_slots) stable_grow(&t);
+            t->slots[p] = g;
+            if (t->n_groups * 2 > t->n_slots) stable_grow(t);
         }
-        sgroup *c = &t.groups[g];
+        sgroup *c = &t->groups[g];
         if (c->n == c->cap) {                                 /* Vec::push growth */
             c->cap = c->cap ? c->cap * 2 : 4;
             c->rows = (int64_t *)realloc(c->rows, sizeof(int64_t) * (size_t)c->cap);
@@ -403,28 +400,131 @@ int oracle_groupby_agg_ref(const ocol *keys, int n_keys, const char *const *cons
         c->rows[c->n++] = row;
         if (c->n > max_group) max_group = c->n;
     }
-    int64_t g = t.n_groups; size_t gg = (size_t)(g ? g : 1);
+    return max_group;
+}
+
+/* Phase 2: per group, the reference's gather + fold for every requested aggregate
+ * (aggregation.rs:500-754); `parallel` folds the groups on all cores like par_aggregate (:22-182). */
+static int fold_string_groups(const stable *t, const ocol *keys, int n_keys, const ocol *vals,
+                              const oagg *aggs, int n_aggs, int64_t max_group, int n_threads,
+                              int64_t *out_n_groups, uint64_t **out_keys, uint8_t **out_key_null, double **out_aggs) {
+    int64_t g = t->n_groups; size_t gg = (size_t)(g ? g : 1);
     uint64_t *ok = (uint64_t *)calloc(gg * (size_t)(n_keys ? n_keys : 1), 8);
     uint8_t *on = (uint8_t *)calloc(gg * (size_t)(n_keys ? n_keys : 1), 1);
     double *oa = (double *)calloc(gg * (size_t)(n_aggs ? n_aggs : 1), 8);
-    double *scratch = (double *)malloc(8 * (size_t)(max_group ? max_group : 1));
     int rc = 0;
-    for (int64_t gi = 0; gi < g && !rc; gi++) {
-        sgroup *c = &t.groups[gi];
-        for (int k = 0; k < n_keys; k++) {
-            int nu = is_null(keys[k].null_mask, c->first_row);
-            on[(size_t)k * (size_t)g + (size_t)gi] = (uint8_t)nu;
-            ok[(size_t)k * (size_t)g + (size_t)gi] = nu ? 0 : key_cell(&keys[k], c->first_row);
+#pragma omp parallel num_threads(n_threads > 1 ? n_threads : 1)
+    {
+        double *scratch = (double *)malloc(8 * (size_t)(max_group ? max_group : 1));
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t gi = 0; gi < g; gi++) {
+            const sgroup *c = &t->groups[gi];
+            for (int k = 0; k < n_keys; k++) {
+                int nu = is_null(keys[k].null_mask, c->first_row);
+                on[(size_t)k * (size_t)g + (size_t)gi] = (uint8_t)nu;
+                ok[(size_t)k * (size_t)g + (size_t)gi] = nu ? 0 : key_cell(&keys[k], c->first_row);
+            }
+            for (int a = 0; a < n_aggs; a++) {
+                int r = fold_group(&vals[aggs[a].col], aggs[a].op, c->rows, c->n,
+                                   &oa[(size_t)a * (size_t)g + (size_t)gi], scratch);
+                if (r) {
+#pragma omp atomic write
+                    rc = r;
+                }
+            }
         }
-        for (int a = 0; a < n_aggs && !rc; a++)
-            rc = fold_group(&vals[aggs[a].col], aggs[a].op, c->rows, c->n,
-                            &oa[(size_t)a * (size_t)g + (size_t)gi], scratch);
+        free(scratch);
     }
-    for (int64_t gi = 0; gi < g; gi++) { free(t.groups[gi].key); free(t.groups[gi].rows); }
-    free(t.groups); free(t.slots); free(scratch);
     if (rc) { free(ok); free(on); free(oa); return rc; }
     *out_n_groups = g; *out_keys = ok; *out_key_null = on; *out_aggs = oa;
     return 0;
+}
+
+static void free_string_groups(stable *t) {
+    for (int64_t gi = 0; gi < t->n_groups; gi++) { free(t->groups[gi].key); free(t->groups[gi].rows); }
+    free(t->groups); free(t->slots);
+}
+
+int oracle_groupby_agg_ref(const ocol *keys, int n_keys, const char *const *const *pools,
+                           int64_t n_rows, const ocol *vals, int n_vals,
+                           const oagg *aggs, int n_aggs,
+                           int64_t *out_n_groups, uint64_t **out_keys, uint8_t **out_key_null,
+                           double **out_aggs) {
+    *out_n_groups = 0; *out_keys = NULL; *out_key_null = NULL; *out_aggs = NULL;
+    for (int a = 0; a < n_aggs; a++)
+        if (aggs[a].col < 0 || aggs[a].col >= n_vals) return PANDRS_HIP_ERR_INVALID_ARGUMENT;
+    stable t;
+    int64_t max_group = build_string_groups(keys, n_keys, pools, 0, n_rows, &t);
+    if (max_group < 0) { free_string_groups(&t); return PANDRS_HIP_ERR_INVALID_ARGUMENT; }
+    int rc = fold_string_groups(&t, keys, n_keys, vals, aggs, n_aggs, max_group, 1, out_n_groups, out_keys, out_key_null, out_aggs);
+    free_string_groups(&t);
+    return rc;
+}
+
+/* The reference's PARALLEL shape: par_groupby's chunk-map on all cores, then its
+ * serial merge of the chunk maps in chunk order (grouping.rs:203-280: the row lists stay ascending),
+ * then par_aggregate's parallel per-group folds (aggregation.rs:22-182, without its row race).
+ * Same results as oracle_groupby_agg_ref up to group order. */
+int oracle_groupby_agg_ref_mt(const ocol *keys, int n_keys, const char *const *const *pools,
+                              int64_t n_rows, const ocol *vals, int n_vals,
+                              const oagg *aggs, int n_aggs, int n_threads,
+                              int64_t *out_n_groups, uint64_t **out_keys, uint8_t **out_key_null,
+                              double **out_aggs) {
+    *out_n_groups = 0; *out_keys = NULL; *out_key_null = NULL; *out_aggs = NULL;
+    for (int a = 0; a < n_aggs; a++)
+        if (aggs[a].col < 0 || aggs[a].col >= n_vals) return PANDRS_HIP_ERR_INVALID_ARGUMENT;
+    if (n_threads < 1) n_threads = 1;
+    stable *parts = (stable *)calloc((size_t)n_threads, sizeof(stable));
+    int failed = 0;
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; t++) {
+        const int64_t lo = n_rows * t / n_threads, hi = n_rows * (t + 1) / n_threads;
+        if (build_string_groups(keys, n_keys, pools, lo, hi, &parts[t]) < 0) {
+#pragma omp atomic write
+            failed = 1;
+        }
+    }
+    /* serial merge into the first chunk's map, chunk by chunk */
+    stable *m = &parts[0];
+    int64_t max_group = 0;
+    for (int64_t gi = 0; gi < m->n_groups; gi++) if (m->groups[gi].n > max_group) max_group = m->groups[gi].n;
+    for (int t = 1; t < n_threads && !failed; t++) {
+        stable *s = &parts[t];
+        for (int64_t gi = 0; gi < s->n_groups; gi++) {
+            sgroup *src = &s->groups[gi];
+            int64_t p = (int64_t)(src->hash & (uint64_t)(m->n_slots - 1)), g = -1;
+            while (m->slots[p] >= 0) {
+                sgroup *c = &m->groups[m->slots[p]];
+                if (c->hash == src->hash && c->key_len == src->key_len && memcmp(c->key, src->key, src->key_len) == 0) { g = m->slots[p]; break; }
+                p = (p + 1) & (m->n_slots - 1);
+            }
+            if (g < 0) {                                     /* the whole group moves over */
+                if (m->n_groups == m->cap_groups) {
+                    m->cap_groups *= 2;
+                    m->groups = (sgroup *)realloc(m->groups, sizeof(sgroup) * (size_t)m->cap_groups);
+                }
+                g = m->n_groups++;
+                m->groups[g] = *src;
+                src->key = NULL; src->rows = NULL;
+                m->slots[p] = g;
+                if (m->n_groups * 2 > m->n_slots) stable_grow(m);
+            } else {                                         /* extend(): the later chunk's rows come after */
+                sgroup *c = &m->groups[g];
+                if (c->n + src->n > c->cap) {
+                    c->cap = (c->n + src->n) * 2;
+                    c->rows = (int64_t *)realloc(c->rows, sizeof(int64_t) * (size_t)c->cap);
+                }
+                memcpy(c->rows + c->n, src->rows, sizeof(int64_t) * (size_t)src->n);
+                c->n += src->n;
+            }
+            if (m->groups[g].n > max_group) max_group = m->groups[g].n;
+        }
+    }
+    int rc = failed ? PANDRS_HIP_ERR_INVALID_ARGUMENT
+                    : fold_string_groups(m, keys, n_keys, vals, aggs, n_aggs, max_group, n_threads, out_n_groups, out_keys, out_key_null, out_aggs);
+    for (int t = 0; t < n_threads; t++) free_string_groups(&parts[t]);
+    free(parts);
+    return rc;
 }
 
 /* ---------------------------------------------------------------- join

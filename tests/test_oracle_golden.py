@@ -274,3 +274,19 @@ def test_typed_multithreaded_baseline_agrees_with_oracle():
     o1, o2 = np.argsort(k), np.argsort(wk[0])
     np.testing.assert_array_equal(k[o1], wk[0][o2])
     np.testing.assert_allclose(st[o1], wa[:, o2].T, rtol=1e-12)
+
+
+def test_parallel_faithful_restatement_equals_the_serial_one():
+    """bench.py's third CPU figure: par_groupby / par_aggregate shaped restatement on all cores.  Same
+    groups, same row lists (ascending after the chunk merge), hence bit-identical aggregates."""
+    from tests.helpers import sort_groups
+    rng = np.random.default_rng(12)
+    n = 120_000
+    keys = [((rng.integers(0, 3000, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64), O.pack_mask(rng.random(n) < 0.01), O.I64),
+            (rng.integers(0, 4, n).astype(np.uint32), None, O.U32CODE)]
+    vals = [(rng.normal(0, 1, n), O.pack_mask(rng.random(n) < 0.1), O.F64), (rng.integers(-5, 5, n).astype(np.int64), None, O.I64)]
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (1, O.MAX), (1, O.COUNT), (0, O.MEDIAN), (1, O.FIRST), (0, O.LAST), (0, O.STD)]
+    a = sort_groups(*O.groupby_agg(keys, n, vals, aggs, faithful=True), [O.I64, O.U32CODE])
+    b = sort_groups(*O.groupby_agg(keys, n, vals, aggs, faithful=True, threads=5), [O.I64, O.U32CODE])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
