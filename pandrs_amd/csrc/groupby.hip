@@ -170,7 +170,11 @@ __device__ __forceinline__ double finalize(const FinDev &f, const uint64_t *st, 
 //         the lanes of a wave hold the same few keys and their LDS atomics serialise on the same
 //         addresses.  Here every thread takes AG_RUN CONSECUTIVE rows, folds equal neighbours in
 //         registers and touches the table once per run.
-template <int NSRC, int PROFILE, bool RUNS = false>
+//         MERGE (NSRC 0, PROFILE -1): the rows are partial records (merge of partials, multi-GPU exchange):
+//         every source feeds exactly ONE state and carries no validity, so the loop is one record per
+//         thread with a runtime loop over the states — no per-source register arrays (the generic loop
+//         keeps 2 x 16 values + flags live and spills at 12+ states).
+template <int NSRC, int PROFILE, bool RUNS = false, bool MERGE = false>
 __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = NSRC > 0 ? NSRC : MAX_SRC;
@@ -221,34 +225,58 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         }
         __syncthreads();
 
-        if constexpr (RUNS) {
-            constexpr int AG_RUN = 4;
-            auto find_slot = [&](uint64_t k) -> uint32_t {
-                if (k == EMPTY_KEY) { misc[21] = 1; return T; }
-                const uint32_t NBK = T >> 2;
-                uint32_t bk = slot_of(hash32(k, a.seed), NBK), probe = 0;
-                while (probe < NBK) {
-                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
-                    const ulonglong2 lo = bp[0], hi = bp[1];
-                    const uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
-                    int hit = -1, emp = -1;
+        auto find_slot = [&](uint64_t k) -> uint32_t {
+            if (k == EMPTY_KEY) { misc[21] = 1; return T; }
+            const uint32_t NBK = T >> 2;
+            uint32_t bk = slot_of(hash32(k, a.seed), NBK), probe = 0;
+            while (probe < NBK) {
+                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
+                const ulonglong2 lo = bp[0], hi = bp[1];
+                const uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
+                int hit = -1, emp = -1;
 #pragma unroll
-                    for (int q = 3; q >= 0; q--) {
-                        if (c4[q] == k) hit = q;
-                        if (c4[q] == EMPTY_KEY) emp = q;
-                    }
-                    if (hit >= 0) return 4 * bk + hit;
-                    if (emp >= 0) {
-                        const uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + emp], EMPTY_KEY, k);
-                        if (old == EMPTY_KEY || old == k) return 4 * bk + emp;
-                        continue;
-                    }
-                    bk = bk + 1 == NBK ? 0 : bk + 1;
-                    probe++;
+                for (int q = 3; q >= 0; q--) {
+                    if (c4[q] == k) hit = q;
+                    if (c4[q] == EMPTY_KEY) emp = q;
                 }
-                misc[20] = 1;                       // table full: host retries with more partitions
-                return T + 2;
-            };
+                if (hit >= 0) return 4 * bk + hit;
+                if (emp >= 0) {
+                    const uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + emp], EMPTY_KEY, k);
+                    if (old == EMPTY_KEY || old == k) return 4 * bk + emp;
+                    continue;
+                }
+                bk = bk + 1 == NBK ? 0 : bk + 1;
+                probe++;
+            }
+            misc[20] = 1;                       // table full: host retries with more partitions
+            return T + 2;
+        };
+        if constexpr (MERGE) {
+            for (uint32_t i = beg + tid; i < end; i += AG_THREADS) {
+                const uint32_t slot = find_slot(__builtin_nontemporal_load(a.pkeys + i));
+                if (slot > T) continue;
+                if (round == 0) atomicAdd((unsigned long long *)&gsz[slot], (unsigned long long)a.pgsize[i]);
+                for (int c = 0; c < nsrc; c++) {
+                    const SrcDev &sd = a.src[s0 + c];
+                    const uint64_t x = __builtin_nontemporal_load(sd.vals + i);
+                    if (sd.st_add >= 0) {
+                        if (sd.kind == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)sd.st_add * T1 + slot]), __longlong_as_double((long long)x));
+                        else atomicAdd((unsigned long long *)&st[(size_t)sd.st_add * T1 + slot], x);
+                    } else if (sd.st_nn >= 0) {
+                        atomicAdd((unsigned long long *)&st[(size_t)sd.st_nn * T1 + slot], x);
+                    } else {
+                        // partial extremes are never NaN (NaN operands were ignored when they were folded)
+                        const uint64_t e = sd.kind == 0 ? enc_f64(__longlong_as_double((long long)x)) : enc_i64((int64_t)x);
+                        if (sd.st_min >= 0) {
+                            if (e < st[(size_t)sd.st_min * T1 + slot]) atomicMin((unsigned long long *)&st[(size_t)sd.st_min * T1 + slot], e);
+                        } else if (sd.st_max >= 0) {
+                            if (e > st[(size_t)sd.st_max * T1 + slot]) atomicMax((unsigned long long *)&st[(size_t)sd.st_max * T1 + slot], e);
+                        }
+                    }
+                }
+            }
+        } else if constexpr (RUNS) {
+            constexpr int AG_RUN = 4;
             for (uint32_t base = beg + tid * AG_RUN; base < end; base += AG_THREADS * AG_RUN) {
                 uint64_t rk[AG_RUN], rv[AG_RUN][NS];
                 bool rok[AG_RUN][NS];
@@ -643,6 +671,12 @@ static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int max_src_pe
         case 4: done = launch_aggregate_profile<4>(c, a, profile, lds); break;
         }
         if (done) return;
+    }
+    if (a.pgsize && !a.direct && !a.second_pass && (max_src_per_round > 4 || c->opt.generic_aggregate < 0)) {
+        // partial records with many states: the lean one-record-per-thread loop
+        (void)set_max_lds(aggregate_kernel<0, -1, false, true>, (int)lds);
+        hipLaunchKernelGGL((aggregate_kernel<0, -1, false, true>), dim3(a.launch_grid), dim3(AG_THREADS), lds, c->stream, a);
+        return;
     }
     switch (max_src_per_round) {
     case 0:     // count-only: no value sources
