@@ -41,10 +41,19 @@ if "c3" in which:
     if "c3u" in which:      # same shape, uniform keys: how much of C3's aggregate time is hot-key LDS contention?
         k2 = torch.randint(0, g, (n,), device=d, generator=gen).to(torch.int32)
         run("C3-uniform 100M/u32 codes 10K groups uniform/9 aggs", n, lambda: ctx.groupby_compute([(k2, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
-        for P in (64, 128, 256, 1024):
+        for P in (16, 32, 64, 128, 256, 1024):
             ctx.set_option("partitions", P)
             run("C3 80-20 P=%d" % P, n, lambda: ctx.groupby_compute([(k, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
         ctx.set_option("partitions", 0)
+        # fewer, larger partitions cut into row slices (tasks ~ 512): less scatter fan-out, more distinct
+        # groups per LDS table (fewer same-address atomics), at the price of merging the slices' partials
+        for P in (8, 16, 32, 64, 128):
+            ctx.set_option("partitions", P); ctx.set_option("slice_rows", n // 512)
+            run("C3 80-20 P=%d sliced/512" % P, n, lambda: ctx.groupby_compute([(k, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
+        for P in (16, 32, 64):
+            ctx.set_option("partitions", P); ctx.set_option("slice_rows", n // 512)
+            run("C3-uniform P=%d sliced/512" % P, n, lambda: ctx.groupby_compute([(k2, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs))
+        ctx.set_option("partitions", 0); ctx.set_option("slice_rows", 0)
         del k2
     del k, v, hot
 if "c4" in which:

@@ -688,21 +688,43 @@ static void launch_aggregate(pandrs_hip_ctx *c, const AggArgs &a, int max_src_pe
     }
 }
 
-// copies r2's groups (keys row 0, null flags, aggregates or states) behind res's; `cap` = res's stride
+// copies r2's groups (keys row 0, null flags, aggregates or states) behind res's; `cap` = res's stride.
+// One launch for all columns (blockIdx.y = column; the last one is the null-flag byte column).
+struct AppendArgs {
+    uint64_t *dst[MAX_AGGS + 2];
+    const uint64_t *src[MAX_AGGS + 2];
+    uint8_t *dst_null;
+    const uint8_t *src_null;
+    uint32_t n, n_cols;
+};
+__global__ __launch_bounds__(256) void append_groups_kernel(AppendArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    if (blockIdx.y == a.n_cols) a.dst_null[i] = a.src_null[i];
+    else a.dst[blockIdx.y][i] = a.src[blockIdx.y][i];
+}
 static int32_t append_groups(pandrs_hip_ctx *c, GroupbyResult &res, size_t cap, const GroupbyResult &r2,
                              bool partials, const Plan &pl, int n_aggs) {
     const size_t g2 = (size_t)r2.n_groups, at = (size_t)res.n_groups;
     if (g2 == 0) return 0;
     if (at + g2 > cap) return fail(PANDRS_HIP_ERR_COMPUTATION, "nested result has more groups than reserved");
-    HIP_TRY(hipMemcpyAsync(res.keys + at, r2.keys, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(res.key_null + at, r2.key_null, g2, hipMemcpyDeviceToDevice, c->stream));
+    AppendArgs a{};
+    uint32_t nc = 0;
+    a.dst[nc] = res.keys + at; a.src[nc++] = r2.keys;
     if (partials) {
-        for (size_t k = 0; k < 1 + (size_t)pl.n_states; k++)
-            HIP_TRY(hipMemcpyAsync(res.states + k * cap + at, r2.states + k * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+        for (size_t k = 0; k < 1 + (size_t)pl.n_states; k++) {
+            a.dst[nc] = res.states + k * cap + at; a.src[nc++] = r2.states + k * (size_t)r2.cap;
+        }
     } else {
-        for (int f = 0; f < n_aggs; f++)
-            HIP_TRY(hipMemcpyAsync(res.aggs + (size_t)f * cap + at, r2.aggs + (size_t)f * (size_t)r2.cap, g2 * 8, hipMemcpyDeviceToDevice, c->stream));
+        for (int f = 0; f < n_aggs; f++) {
+            a.dst[nc] = reinterpret_cast<uint64_t *>(res.aggs + (size_t)f * cap + at);
+            a.src[nc++] = reinterpret_cast<const uint64_t *>(r2.aggs + (size_t)f * (size_t)r2.cap);
+        }
     }
+    a.dst_null = res.key_null + at; a.src_null = r2.key_null;
+    a.n = (uint32_t)g2; a.n_cols = nc;
+    hipLaunchKernelGGL(append_groups_kernel, dim3((unsigned)((g2 + 255) / 256), nc + 1), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
     res.n_groups += (int64_t)g2;
     return 0;
 }
@@ -877,7 +899,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : 3072;   // rounds only when one round would need more partitions than this
     int spr = n_src > 0 ? n_src : 1;           // sources per round
     int n_rounds = 1, round_states = 0, max_spr = 0;
-    int64_t T = 0, P = 0;
+    int64_t T = 0, P = 0, auto_slice_rows = 0;
     int8_t round_begin[MAX_ROUNDS + 1];
     for (;; spr = (spr + 1) / 2) {
         if (c->opt.src_per_round > 0 && !pl.needs_second_pass) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
@@ -902,7 +924,18 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     const size_t slot_bytes = 20 + 8 * (size_t)round_states;
     if (c->opt.partitions > 0) P = c->opt.partitions;
     else {
-        int64_t p_par = std::min<int64_t>(512, N / 16384);       // enough workgroups to fill 256 CUs
+        // enough workgroups to fill 256 CUs (a partial record carries every state: fewer per workgroup)
+        int64_t p_par = std::min<int64_t>(512, N / (merge ? 2048 : 16384));
+        // Mid cardinalities (too many groups for the direct path, far fewer than 512 tables hold): a few
+        // large partitions cut into ~512 row slices beat 512 small ones - the scatter fans out less and
+        // an LDS table with more distinct groups sees fewer same-address atomics (hot keys) - as long as
+        // the slices' partial records (slices per partition x groups) stay cheap to merge.
+        if (!merge && !c->opt.no_slice && c->opt.slice_rows <= 0 && pl.mergeable && n_rounds == 1 &&
+            N >= (int64_t(1) << 24) && P < p_par && pl.n_states >= 4) {   // (1-2 states: measured 5 % slower)
+            int64_t p_rec = 16;
+            while (p_rec * 262144 < p_par * est) p_rec *= 2;
+            if (std::max(P, p_rec) <= 64) { P = std::max(P, p_rec); auto_slice_rows = N / p_par; p_par = 1; }
+        }
         P = std::max<int64_t>(std::max<int64_t>(P, p_par), 1);
         if (P > 256) P = (P + 127) / 128 * 128;
     }
@@ -968,7 +1001,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
         const bool slicing = !c->opt.no_slice && pl.mergeable && n_rounds == 1;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
-                                                          : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
+                                 : auto_slice_rows > 0 ? auto_slice_rows
+                                                       : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
         const int64_t max_slices = slicing ? 2 * (N / slice_rows) + 2 : 0;       // slices of multi-slice partitions
         const size_t side_cap = (size_t)max_slices * (size_t)(T + 2);
         size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2)) + (slicing ? side_cap : 0);
@@ -1057,7 +1091,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 ms.merge_states = aa.side_states;
                 ms.merge_stride = side_cap;
                 Options saved = c->opt;
-                c->opt.no_slice = 1; c->opt.no_direct = 1; c->opt.groups_hint = 0; c->opt.partitions = 0;
+                c->opt.no_slice = 1; c->opt.no_direct = 1; c->opt.partitions = 0;
+                c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>(n_side, est), 1);   // an upper bound: no second estimate
                 pandrs_hip_timings tsave = c->timings;
                 c->quiet++;
                 int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot + 1);
