@@ -195,6 +195,26 @@ def test_hot_key_partitions_are_sliced(ctx):
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5, 6, 7])
 
 
+@pytest.mark.parametrize("skew", [False, True])
+def test_mid_cardinality_takes_few_sliced_partitions(ctx, skew):
+    """>= 16 M rows, >= 4 states, a few thousand groups: the engine picks 16-64 large partitions and
+    cuts them into ~512 row slices whose partial records are merged (DESIGN.md, 'Mid cardinalities');
+    C3's shape (u32 codes, 80/20 skew, nulls in one column) against the oracle."""
+    rng = np.random.default_rng(77 + skew)
+    n, g = 17_000_000, 6_000
+    ids = rng.integers(0, g, n)
+    if skew:
+        hot = rng.random(n) < 0.8
+        ids = np.where(hot, rng.integers(0, g // 5, n), ids)
+    keys = [(ids.astype(np.uint32), None, O.U32CODE)]
+    vals = [(rng.normal(100, 10, n), None, O.F64),
+            (rng.integers(-10**6, 10**6, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.1), O.I64)]
+    aggs = [(c, op) for c in range(2) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    check(ctx, keys, n, vals, aggs, [O.U32CODE], exact=[2, 3, 4, 6, 7, 8])
+    t = ctx.timings()
+    assert 16 <= t["n_partitions"] <= 64, t["n_partitions"]
+
+
 def test_two_level_for_huge_cardinality(ctx):
     """More groups than one radix level holds (forced here with a small partition cap): rows are
     split by an independent hash into super-partitions, the engine runs per super-partition and the
