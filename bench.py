@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--groups", type=int, default=1_000_000)
     ap.add_argument("--cols", type=int, default=4)
-    ap.add_argument("--cpu-sample", type=int, default=6_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["groupby", "join"], default="groupby",
                     help="groupby = BASELINE config 2 (the headline line); join = config 5 shape "
@@ -240,7 +240,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
             out["cpu_baseline_parallel"] = cpu_baseline_parallel(min(n, 2 * args.cpu_sample), g, ncol, aggs)
-            out["cpu_baseline_typed"] = cpu_baseline_typed(min(n, 8 * args.cpu_sample), g, ncol)
+            out["cpu_baseline_typed"] = cpu_baseline_typed(min(n, 3 * args.cpu_sample), g, ncol)
         emit(out)
     if dist is not None:
         dist.barrier()
