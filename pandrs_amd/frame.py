@@ -615,6 +615,68 @@ class GroupBy:
     def last(self, column):
         return self._short(column, AggregateOp.Last)
 
+    # ---- GroupByJitExt (src/optimized/jit/groupby.rs:68-290).  The reference wraps fixed closures in
+    # CustomAggregation and runs them through aggregate_custom over each group's non-null f64 values:
+    # Kahan sum / mean / std, plain min / max folds, and the chunked "parallel" variants.  The same
+    # quantities come out of the device aggregates; what differs from the AggregateOp path is only the
+    # value for a group WITHOUT non-null values (min / max folds stay at +-inf instead of 0.0) and the
+    # parallel std being the POPULATION std from E[x^2] - E[x]^2 (jit/parallel.rs:222-233).  Kahan and the
+    # device's sums agree to ~1e-13 relative on benign data; tests compare with the closures themselves.
+    def _jit(self, column, result_name, op, fix=None):
+        col = self.df.column(column) if column in self.df.column_indices else None
+        if col is None:
+            raise ColumnNotFound(column)
+        if col.dtype not in (L.I64, L.F64):
+            raise OperationFailed(L.ERR_OPERATION_FAILED, "column '%s' is not numeric" % column)
+        key_cols = [self.df.column(k) for k in self.group_by_columns]
+        n = self.df.row_count()
+        vals = [col.view()]
+        specs = [(0, int(op)), (0, int(AggregateOp.Count))]
+        if col.null_mask is not None:        # nulls per group: the sum of an indicator column
+            ind = np.unpackbits(col.null_mask, bitorder="little")[:n].astype(np.int64)
+            vals.append((ind, None, L.I64))
+            specs.append((1, int(AggregateOp.Sum)))
+        kc, kn, oa = get_context().groupby_agg([k.view() for k in key_cols], n, vals, specs)
+        nn = oa[1] - (oa[2] if len(specs) == 3 else 0.0)          # non-null values per group
+        out = fix(oa[0], nn) if fix else oa[0]
+        result = OptimizedDataFrame()
+        for i, (name, k) in enumerate(zip(self.group_by_columns, key_cols)):
+            result.add_column(name, StringColumn(_key_strings(k.dtype, kc[i], kn[i])))
+        result.add_column(result_name, Float64Column(np.asarray(out, np.float64)))
+        return result
+
+    def sum_jit(self, column, result_name):                # jit/groupby.rs:69-96
+        return self._jit(column, result_name, AggregateOp.Sum)
+
+    def mean_jit(self, column, result_name):               # :98-128, empty -> 0.0
+        return self._jit(column, result_name, AggregateOp.Mean)
+
+    def std_jit(self, column, result_name):                # :130-172, n <= 1 -> 0.0, n - 1 denominator
+        return self._jit(column, result_name, AggregateOp.Std)
+
+    def var_jit(self, column, result_name):
+        return self._jit(column, result_name, AggregateOp.Var)
+
+    def min_jit(self, column, result_name):                # :174-190, fold from +inf: empty stays +inf
+        return self._jit(column, result_name, AggregateOp.Min, lambda v, nn: np.where(nn == 0, np.inf, v))
+
+    def max_jit(self, column, result_name):                # :192-208
+        return self._jit(column, result_name, AggregateOp.Max, lambda v, nn: np.where(nn == 0, -np.inf, v))
+
+    def parallel_sum_jit(self, column, result_name, config=None):     # :210-228 (Kahan per chunk + Kahan combine)
+        return self._jit(column, result_name, AggregateOp.Sum)
+
+    def parallel_mean_jit(self, column, result_name, config=None):    # :230-247, count 0 -> 0.0
+        return self._jit(column, result_name, AggregateOp.Mean)
+
+    def parallel_std_jit(self, column, result_name, config=None):     # :249-266 -> parallel_std_f64_value
+        def population(v, nn):                                        # sample variance * (n - 1) / n, n <= 1 -> 0.0
+            return np.sqrt(np.where(nn > 1, v * (nn - 1) / np.maximum(nn, 1), 0.0))
+        return self._jit(column, result_name, AggregateOp.Var, population)
+
+    def aggregate_jit(self, column, func, result_name):               # :268-290: any closure -> host custom path
+        return self.aggregate_custom([(column, func, result_name)])
+
     # operations.rs:550-594: the par_* shortcuts share the exact path (see par_aggregate above)
     par_sum, par_mean, par_min, par_max, par_count = sum, mean, min, max, count
     par_std, par_var, par_median = std, var, median

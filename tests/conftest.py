@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # PyTorch (device memory + torch.distributed in these tests) is loaded BEFORE the first HIP call of
+    # libpandrs_hip.so, the order bench.py uses: its import maps several GB of code objects and, once
+    # on a fresh GPU box, stalled for minutes when it came in lazily after the runtime was already busy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

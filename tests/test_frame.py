@@ -1,6 +1,8 @@
 """Host mirror of the reference API (pandrs_amd/frame.py): these read like the reference's own
 tests (tests/optimized_groupby_test.rs, tests/optimized_join_test.rs, tests/optimized_lazy_test.rs,
 examples/optimized_groupby_example.rs) but assert exact values against the oracle / golden data."""
+import math
+
 import numpy as np
 import pytest
 
@@ -272,3 +274,60 @@ def test_groups_median_custom_filter_par_groupby():
     assert t.column_names == ["keys", "centered"] and t.row_count() == 5
     got = sorted(zip(t.column("keys").to_list(), t.column("centered").data.tolist()))
     assert got == [("A", -10.0), ("A", 10.0), ("B", -10.0), ("B", 10.0), ("C", 0.0)]
+
+
+# ------------------------------------------------------------------------------ JIT extension (G7)
+def test_ready_made_aggregations_known_answers():
+    """src/optimized/jit/groupby.rs:455-520: the reference's own known answers for its aggregation closures."""
+    from pandrs_amd import aggregations as A
+    assert abs(A.weighted_mean([1.0, 2.0, 3.0, 4.0, 5.0]) - 55.0 / 15.0) < 1e-10          # test_jit_aggregation
+    assert abs(A.geometric_mean([1.0, 2.0, 4.0, 8.0]) - 64.0 ** 0.25) < 1e-10              # test_geometric_mean
+    assert abs(A.harmonic_mean([1.0, 2.0, 4.0]) - 3.0 / 1.75) < 1e-10                      # test_harmonic_mean
+    assert A.value_range([1.0, 5.0, 3.0, 9.0, 2.0]) == 8.0                                 # test_range
+    assert abs(A.coefficient_of_variation([10.0, 12.0, 14.0, 16.0, 18.0]) - 0.22587697572631278) < 1e-10
+    # the closures' guards: empty input, no admissible value, single value, zero mean
+    for f in (A.weighted_mean, A.geometric_mean, A.harmonic_mean, A.value_range, A.coefficient_of_variation,
+              A.kahan_sum, A.kahan_mean, A.kahan_std, A.population_std):
+        assert f([]) == 0.0
+    assert A.geometric_mean([-1.0, 0.0]) == 0.0 and A.harmonic_mean([0.0, 0.0]) == 0.0
+    assert A.coefficient_of_variation([3.0]) == 0.0 and A.coefficient_of_variation([-1.0, 1.0]) == 0.0
+    tiny = [1.0] + [1e-16] * 10                              # each addend is below half an ulp of the running sum
+    assert sum(tiny) == 1.0 and A.kahan_sum(tiny) == math.fsum(tiny) > 1.0
+    assert abs(A.population_std([2.0, 4.0, 4.0, 4.0, 5.0, 5.0, 7.0, 9.0]) - 2.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_groupby_jit_extension_matches_its_closures():
+    """GroupByJitExt (jit/groupby.rs:68-290): sum/mean/std/min/max_jit and the parallel_* variants come from the
+    device aggregates; each must equal the reference's closure run over the group's non-null values."""
+    from pandrs_amd import aggregations as A
+    rng = np.random.default_rng(5)
+    n = 20_000
+    df = OptimizedDataFrame()
+    df.add_column("k", Int64Column(rng.integers(0, 300, n)))
+    vnull = rng.random(n) < 0.2
+    vnull[:] |= (df.column("k").data == 7)                  # group 7: no non-null value at all
+    df.add_column("v", Float64Column.with_nulls(rng.normal(100, 10, n), vnull))
+    df.add_column("i", Int64Column(rng.integers(-1000, 1000, n)))
+    gb = df.group_by(["k"])
+    fmin = lambda v: min(v) if v else float("inf")
+    fmax = lambda v: max(v) if v else float("-inf")
+    cases = [("sum_jit", A.kahan_sum), ("mean_jit", A.kahan_mean), ("std_jit", A.kahan_std), ("min_jit", fmin),
+             ("max_jit", fmax), ("parallel_sum_jit", A.kahan_sum), ("parallel_mean_jit", A.kahan_mean),
+             ("parallel_std_jit", A.population_std)]
+    for col in ("v", "i"):
+        for name, closure in cases:
+            got = getattr(gb, name)(col, "r")
+            want = gb.aggregate_jit(col, closure, "r")
+            g = dict(zip(got.column("k").to_list(), got.column("r").data.tolist()))
+            w = dict(zip(want.column("k").to_list(), want.column("r").data.tolist()))
+            assert g.keys() == w.keys() and len(g) == 300
+            for key in w:
+                assert g[key] == pytest.approx(w[key], rel=1e-9, abs=1e-9), (name, col, key)   # 1e-9: the f64 tolerance
+    assert gb.min_jit("v", "r").column("r").data[gb.min_jit("v", "r").column("k").to_list().index("7")] == float("inf")
+    # a ready-made closure through the custom path, against numpy on the same groups
+    cv = gb.aggregate_jit("i", A.coefficient_of_variation, "cv")
+    kcol = df.column("k").data
+    for key, val in zip(cv.column("k").to_list()[:20], cv.column("cv").data[:20]):
+        x = df.column("i").data[kcol == int(key)].astype(np.float64)
+        assert val == pytest.approx(x.std(ddof=1) / abs(x.mean()), rel=1e-9)
