@@ -76,7 +76,11 @@ typedef enum pandrs_hip_agg_op {
     PANDRS_HIP_AGG_MEDIAN = 7,
     PANDRS_HIP_AGG_FIRST = 8,
     PANDRS_HIP_AGG_LAST = 9,
-    PANDRS_HIP_AGG_CUSTOM = 10   /* always PANDRS_HIP_ERR_OPERATION_FAILED (aggregation.rs:744) */
+    PANDRS_HIP_AGG_CUSTOM = 10,  /* always PANDRS_HIP_ERR_OPERATION_FAILED (aggregation.rs:744) */
+    /* beyond AggregateOp: the legacy frame's AggFunc::Nunique (src/dataframe/groupby.rs:514-519, SURVEY.md
+     * 8f item 2) — the number of distinct non-null values of the group (sort + dedup: values equal under
+     * `==`, so -0.0 and 0.0 are one value and every NaN is its own), 0.0 for a group without values (:467). */
+    PANDRS_HIP_AGG_NUNIQUE = 11
 } pandrs_hip_agg_op;
 
 /* JoinType, src/optimized/split_dataframe/join.rs:11-20 */

@@ -186,7 +186,8 @@ inline std::string key_string(int32_t dtype, uint64_t cell, bool is_null, const 
 }
 }  // namespace detail
 
-enum class AggregateOp { Sum = 0, Mean, Min, Max, Count, Std, Var, Median, First, Last, Custom };   // types.rs:11-34
+enum class AggregateOp { Sum = 0, Mean, Min, Max, Count, Std, Var, Median, First, Last, Custom,   // types.rs:11-34
+                         Nunique };   // + the legacy AggFunc::Nunique (src/dataframe/groupby.rs:41)
 enum class JoinType { Inner = 0, Left, Right, Outer };                                              // join.rs:11-20
 
 class GroupBy;
@@ -375,6 +376,7 @@ public:
     OptimizedDataFrame median(const std::string &c) const { return agg({{c, AggregateOp::Median}}); }
     OptimizedDataFrame first(const std::string &c) const { return agg({{c, AggregateOp::First}}); }
     OptimizedDataFrame last(const std::string &c) const { return agg({{c, AggregateOp::Last}}); }
+    OptimizedDataFrame nunique(const std::string &c) const { return agg({{c, AggregateOp::Nunique}}); }   // legacy GroupBy::nunique (src/dataframe/groupby.rs:386-393)
 
     // the pub field `groups` (types.rs:52): HashMap<Vec<String>, Vec<usize>>, every list ascending
     std::map<std::vector<std::string>, std::vector<size_t>> groups(const char *null_string = "NULL") const {
@@ -470,7 +472,7 @@ public:
     }
 
     static std::string op_name(AggregateOp op) {
-        static const char *names[] = {"sum", "mean", "min", "max", "count", "std", "var", "median", "first", "last", "custom"};
+        static const char *names[] = {"sum", "mean", "min", "max", "count", "std", "var", "median", "first", "last", "custom", "nunique"};
         return names[(int)op];
     }
 };

@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 I64, F64, U32CODE, BOOLBITS, CELL64 = 0, 1, 2, 3, 4
-SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM = range(11)
+SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM, NUNIQUE = range(12)
 INNER, LEFT, RIGHT, OUTER = range(4)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

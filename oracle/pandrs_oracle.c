@@ -182,6 +182,13 @@ static int fold_group(const ocol *col, int op, const int64_t *rows, int64_t n, d
             *out = (n && !is_null(m, rows[0])) ? (double)d[rows[0]] : 0.0; return 0;
         case PANDRS_HIP_AGG_LAST:            /* :615-624 */
             *out = (n && !is_null(m, rows[n - 1])) ? (double)d[rows[n - 1]] : 0.0; return 0;
+        case PANDRS_HIP_AGG_NUNIQUE: {       /* legacy AggFunc::Nunique, src/dataframe/groupby.rs:514-519 (values as f64
+                                              * there; distinct i64 stay distinct here — exact for |x| < 2^53) */
+            int64_t *iv = (int64_t *)scratch; int64_t c = 0, u = 0;
+            for (int64_t i = 0; i < n; i++) if (!is_null(m, rows[i])) iv[c++] = d[rows[i]];
+            qsort(iv, (size_t)c, 8, cmp_i64);
+            for (int64_t i = 0; i < c; i++) if (i == 0 || iv[i] != iv[i - 1]) u++;
+            *out = (double)u; return 0; }    /* :467 — no values => 0.0 */
         }
     } else if (col->dtype == PANDRS_HIP_F64) {
         const double *d = (const double *)col->data; const uint8_t *m = col->null_mask;
@@ -219,6 +226,16 @@ static int fold_group(const ocol *col, int op, const int64_t *rows, int64_t n, d
             *out = (n && !is_null(m, rows[0])) ? d[rows[0]] : 0.0; return 0;
         case PANDRS_HIP_AGG_LAST:            /* :733-742 */
             *out = (n && !is_null(m, rows[n - 1])) ? d[rows[n - 1]] : 0.0; return 0;
+        case PANDRS_HIP_AGG_NUNIQUE: {       /* src/dataframe/groupby.rs:514-519: sort_by(partial_cmp), Vec::dedup (==), len.
+                                              * NaNs: the reference's sort leaves their place unspecified; here they are
+                                              * set aside first and every NaN counts as its own value (NaN != NaN). */
+            int64_t c = 0, nans = 0, u = 0;
+            for (int64_t i = 0; i < n; i++) if (!is_null(m, rows[i])) {
+                if (isnan(d[rows[i]])) nans++; else scratch[c++] = d[rows[i]];
+            }
+            qsort(scratch, (size_t)c, 8, cmp_f64_partial);
+            for (int64_t i = 0; i < c; i++) if (i == 0 || scratch[i] != scratch[i - 1]) u++;
+            *out = (double)(u + nans); return 0; }
         }
     }
     return PANDRS_HIP_ERR_OPERATION_FAILED;  /* :748 — String/Bool x numeric op */

@@ -4,9 +4,9 @@ C ABI in include/pandrs_hip.h; this package is the host-side mirror of the refer
 There is no CPU fallback: without the built library or a gfx950 device, calls fail loudly."""
 from . import _lib
 from ._lib import (I64, F64, U32CODE, BOOLBITS, CELL64, SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST,
-                   LAST, CUSTOM, INNER, LEFT, RIGHT, OUTER)
+                   LAST, CUSTOM, NUNIQUE, INNER, LEFT, RIGHT, OUTER)
 from .engine import Context, PandrsHipError, ColumnTypeMismatch, OperationFailed
 
 __all__ = ["Context", "PandrsHipError", "ColumnTypeMismatch", "OperationFailed", "_lib",
            "I64", "F64", "U32CODE", "BOOLBITS", "CELL64", "SUM", "MEAN", "MIN", "MAX", "COUNT", "STD", "VAR",
-           "MEDIAN", "FIRST", "LAST", "CUSTOM", "INNER", "LEFT", "RIGHT", "OUTER"]
+           "MEDIAN", "FIRST", "LAST", "CUSTOM", "NUNIQUE", "INNER", "LEFT", "RIGHT", "OUTER"]

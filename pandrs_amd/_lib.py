@@ -16,7 +16,7 @@ PHASE_NAMES = ["stage_in", "estimate", "histogram", "scan", "scatter", "aggregat
 
 # enums (include/pandrs_hip.h)
 I64, F64, U32CODE, BOOLBITS, CELL64 = 0, 1, 2, 3, 4
-SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM = range(11)
+SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM, NUNIQUE = range(12)
 INNER, LEFT, RIGHT, OUTER = range(4)
 MEM_HOST, MEM_DEVICE = 0, 1
 OK, ERR_INVALID_ARGUMENT, ERR_TYPE_MISMATCH, ERR_OPERATION_FAILED, ERR_COMPUTATION, \

@@ -131,7 +131,9 @@ size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_byte
 
 // median.hip: fills aggregate `fin_index` of c->gb with the groups' medians of one value column
 // (kind 0 = f64, 1 = i64); `key` is the key source the engine ran on.
+// Median and Nunique: no engine state, filled by median_pass (a per-group sort) after the engine run
+inline bool is_sorted_pass_op(int op) { return op == PANDRS_HIP_AGG_MEDIAN || op == PANDRS_HIP_AGG_NUNIQUE; }
 int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const void *vdata, const uint8_t *vnull,
-                    int kind, int fin_index);
+                    int kind, int fin_index, int mode = 0);   // mode 0: median, 1: number of distinct values
 
 }  // namespace pandrs

@@ -317,7 +317,7 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         for (int k = 0; k < n_keys; k++) need += dtype_bytes(keys[k].dtype, n_rows) + (n_rows + 7) / 8 + 1024;
         for (int s = 0; s < pl.n_src; s++) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
         for (int a = 0; a < n_aggs; a++)
-            if (aggs[a].op == PANDRS_HIP_AGG_MEDIAN) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
+            if (is_sorted_pass_op(aggs[a].op)) need += size_t(n_rows) * 8 + (n_rows + 7) / 8 + 1024;
         ST_TRY(c->staging.ensure(need + (1 << 16), c->stream));
     }
     rs.key = KeyDesc{stg.in(keys[0].data, dtype_bytes(keys[0].dtype, n_rows)),
@@ -333,12 +333,12 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     const void *med_data[MAX_AGGS]{};
     const uint8_t *med_null[MAX_AGGS]{};
     for (int a = 0; a < n_aggs && pl.has_median; a++) {
-        if (aggs[a].op != PANDRS_HIP_AGG_MEDIAN) continue;
+        if (!is_sorted_pass_op(aggs[a].op)) continue;
         const int col = aggs[a].col;
         for (int s = 0; s < pl.n_src; s++)
             if (pl.src_col[s] == col) { med_data[a] = rs.val_data[s]; med_null[a] = rs.val_null_bits[s]; }
         for (int b = 0; b < a && !med_data[a]; b++)
-            if (aggs[b].op == PANDRS_HIP_AGG_MEDIAN && aggs[b].col == col) { med_data[a] = med_data[b]; med_null[a] = med_null[b]; }
+            if (is_sorted_pass_op(aggs[b].op) && aggs[b].col == col) { med_data[a] = med_data[b]; med_null[a] = med_null[b]; }
         if (!med_data[a]) {
             if (n_rows > 0 && !vals[col].data) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "value column %d has no data", col);
             med_data[a] = stg.in(vals[col].data, size_t(n_rows) * 8);
@@ -350,8 +350,9 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
     if (n_keys > 1 && n_rows > 0) ST_TRY(pack_multi_key(c, stg, keys, n_keys, n_rows, rs.key, pd));
     ST_TRY(run_engine(c, rs, pl, /*merge=*/false, partials, n_aggs, keys[0].dtype, n_keys));
     for (int a = 0; a < n_aggs && pl.has_median; a++)       // Median: a per-group sort, one pass per column
-        if (aggs[a].op == PANDRS_HIP_AGG_MEDIAN)
-            ST_TRY(median_pass(c, rs.key, n_rows, med_data[a], med_null[a], pl.fin_kind[a], a));
+        if (is_sorted_pass_op(aggs[a].op))
+            ST_TRY(median_pass(c, rs.key, n_rows, med_data[a], med_null[a], pl.fin_kind[a], a,
+                               aggs[a].op == PANDRS_HIP_AGG_NUNIQUE ? 1 : 0));
     if (n_keys > 1 && c->gb.n_groups > 0) {
         hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((c->gb.n_groups + 255) / 256)), dim3(256), 0, c->stream,
                            pd, c->gb.n_groups, (size_t)c->gb.cap, c->gb.keys, c->gb.key_null);

@@ -581,7 +581,7 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
     for (int a = 0; a < n_aggs; a++) {
         int c = aggs[a].col, op = aggs[a].op;
         if (c < 0 || c >= n_vals) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "aggregate %d: column %d out of range", a, c);
-        if (op < 0 || op > PANDRS_HIP_AGG_CUSTOM) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad op %d", op);
+        if (op < 0 || op > PANDRS_HIP_AGG_NUNIQUE) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad op %d", op);
         pl.fin_op[a] = (int8_t)op; pl.fin_kind[a] = 0; pl.fin_src[a] = -1;
         if (op == PANDRS_HIP_AGG_COUNT) continue;   // any dtype (aggregation.rs:743)
         if (op == PANDRS_HIP_AGG_CUSTOM)
@@ -591,7 +591,7 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
         if (dt != PANDRS_HIP_I64 && dt != PANDRS_HIP_F64)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                         "Aggregation operation %d is not supported for column type %d", op, dt);
-        if (op == PANDRS_HIP_AGG_MEDIAN) {      // no engine state: filled by median_pass after the run
+        if (is_sorted_pass_op(op)) {            // Median / Nunique: no engine state, filled by median_pass after the run
             pl.fin_kind[a] = dt == PANDRS_HIP_F64 ? 0 : 1;
             pl.has_median = true;
             continue;

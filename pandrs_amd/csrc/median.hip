@@ -97,8 +97,54 @@ __global__ void median_runs_kernel(const uint64_t *keys, const uint64_t *vals, c
     }
 }
 
+// ---- Nunique (legacy AggFunc::Nunique, src/dataframe/groupby.rs:514-519): after the same sort a group's
+// distinct values are the positions whose value differs from the predecessor's (`==` on the decoded
+// values: -0.0 == 0.0, NaN != NaN, as Vec::dedup sees them).  Lanes of a wave that share a key form a
+// segment (the rows are sorted, so a key's lanes are contiguous); the segment's first lane adds the
+// segment's count of new values to the key's table entry — one global atomic per key and wave, not per
+// row, so one huge group costs n/64 same-address atomics instead of n.
+__global__ __launch_bounds__(256) void nunique_runs_kernel(const uint64_t *keys, const uint64_t *vals, const uint32_t *null_beg,
+                                                           uint32_t n, int kind, MedianEntry *table, uint32_t table_mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    const uint32_t nb = *null_beg;
+    const uint64_t k = valid ? keys[i] : 0ull;
+    const bool null_grp = valid && i >= nb;
+    const bool run_head = valid && (i == 0 || i == nb || keys[i - 1] != k);
+    bool newv = run_head;
+    if (valid && !run_head) {
+        const uint64_t a = vals[i - 1], b = vals[i];
+        newv = kind == 0 ? dec_f64(a) != dec_f64(b) : a != b;
+    }
+    const bool seg_head = valid && (lane == 0 || run_head);
+    const unsigned long long H = __ballot(seg_head), NV = __ballot(newv);
+    if (!seg_head) return;
+    const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1)) << (lane + 1);   // heads after this lane
+    const unsigned long long seg = (above ? ((1ull << __builtin_ctzll(above)) - 1) : ~0ull) & ~((1ull << lane) - 1);
+    const unsigned long long cnt = (unsigned long long)__builtin_popcountll(NV & seg);
+    if (cnt == 0) return;
+    unsigned long long *counter = nullptr;
+    if (null_grp) counter = reinterpret_cast<unsigned long long *>(&table[table_mask + 2].median);
+    else if (k == EMPTY_KEY) counter = reinterpret_cast<unsigned long long *>(&table[table_mask + 1].median);
+    else {
+        uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
+        for (uint32_t probes = 0; probes <= table_mask; probes++) {      // bounded: never spin on a full table
+            const uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
+            if (old == EMPTY_KEY || old == k) { counter = reinterpret_cast<unsigned long long *>(&table[slot].median); break; }
+            slot = (slot + 1) & table_mask;
+        }
+    }
+    if (counter) atomicAdd(counter, cnt);
+}
+
+__global__ void clear_table_values_kernel(MedianEntry *table, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) table[i].median = 0.0;        // all-zero bits: also the u64 counter 0
+}
+
+// mode 0: the entry holds the median; 1: a u64 count of distinct values in the same 8 bytes
 __global__ void median_lookup_kernel(const uint64_t *gkeys, const uint8_t *gnull, int64_t n_groups,
-                                     const MedianEntry *table, uint32_t table_mask, double *out) {
+                                     const MedianEntry *table, uint32_t table_mask, double *out, int mode) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_groups) return;
     const uint64_t k = gkeys[j];
@@ -114,14 +160,14 @@ __global__ void median_lookup_kernel(const uint64_t *gkeys, const uint8_t *gnull
             slot = (slot + 1) & table_mask;
         }
     }
-    out[j] = med;
+    out[j] = mode ? (double)(unsigned long long)__double_as_longlong(med) : med;
 }
 
 // Fills aggregate `fin_index` of the retained groupby result (c->gb) with the groups' medians of
 // one value column.  `key` is the engine's key source (original column or packed cells), `kind`
 // 0 = f64, 1 = i64.  Uses c->work from scratch (the engine is done with it).
 int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const void *vdata, const uint8_t *vnull,
-                    int kind, int fin_index) {
+                    int kind, int fin_index, int mode) {
     GroupbyResult &res = c->gb;
     const int64_t G = res.n_groups;
     if (G <= 0) return 0;
@@ -158,6 +204,10 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     if (!table) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
     HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(cap_tab) * 16, c->stream));
     HIP_TRY(hipMemsetAsync(&table[cap_tab], 0, 64, c->stream));    // [cap] the key ~0's entry, [cap+1] the NULL group's: 0.0 until a run fills them
+    if (mode == 1) {                                               // counters start at 0 (the memset left all-ones)
+        hipLaunchKernelGGL(clear_table_values_kernel, dim3((cap_tab + 255) / 256), dim3(256), 0, c->stream, table, cap_tab);
+        HIP_TRY(hipGetLastError());
+    }
     if (nv > 0) {
         uint64_t *pk = c->work.take<uint64_t>(nv + 1), *pv = c->work.take<uint64_t>(nv + 1);
         if (!pk || !pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
@@ -171,12 +221,16 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
         const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
         hipLaunchKernelGGL(fill_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end, 0ull);
         ST_TRY(segmented_sort_u64(c, pk, pv, part.offsets, part.NB, (uint32_t)P + 1, nv, kind == 0 ? 1 : 2));
-        hipLaunchKernelGGL(median_runs_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream,
-                           pk, pv, null_beg, (uint32_t)nv, kind, table, cap_tab - 1);
+        if (mode == 1)
+            hipLaunchKernelGGL(nunique_runs_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream,
+                               pk, pv, null_beg, (uint32_t)nv, kind, table, cap_tab - 1);
+        else
+            hipLaunchKernelGGL(median_runs_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream,
+                               pk, pv, null_beg, (uint32_t)nv, kind, table, cap_tab - 1);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(median_lookup_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,
-                       res.keys, res.key_null, G, table, cap_tab - 1, res.aggs + (size_t)fin_index * res.cap);
+                       res.keys, res.key_null, G, table, cap_tab - 1, res.aggs + (size_t)fin_index * res.cap, mode);
     HIP_TRY(hipGetLastError());
     return 0;
 }

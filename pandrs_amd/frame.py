@@ -38,6 +38,7 @@ class AggregateOp(IntEnum):          # types.rs:11-34, same order
     First = 8
     Last = 9
     Custom = 10
+    Nunique = 11                     # not in the reference's enum: the legacy AggFunc::Nunique (src/dataframe/groupby.rs:41)
 
 
 class JoinType(IntEnum):             # join.rs:11-20
@@ -62,7 +63,7 @@ class InconsistentRowCount(ValueError):
 _OP_NAME = {AggregateOp.Sum: "sum", AggregateOp.Mean: "mean", AggregateOp.Min: "min", AggregateOp.Max: "max",
             AggregateOp.Count: "count", AggregateOp.Std: "std", AggregateOp.Var: "var",
             AggregateOp.Median: "median", AggregateOp.First: "first", AggregateOp.Last: "last",
-            AggregateOp.Custom: "custom"}       # operations.rs:501-514
+            AggregateOp.Custom: "custom", AggregateOp.Nunique: "nunique"}       # operations.rs:501-514
 
 
 # ---------------------------------------------------------------------------------------------- columns
@@ -614,6 +615,9 @@ class GroupBy:
 
     def last(self, column):
         return self._short(column, AggregateOp.Last)
+
+    def nunique(self, column):       # legacy GroupBy::nunique, src/dataframe/groupby.rs:386-393, alias "{col}_nunique"
+        return self._short(column, AggregateOp.Nunique)
 
     # ---- GroupByJitExt (src/optimized/jit/groupby.rs:68-290).  The reference wraps fixed closures in
     # CustomAggregation and runs them through aggregate_custom over each group's non-null f64 values:

@@ -97,6 +97,7 @@ static void test_groupby_example_and_shortcuts() {
     CHECK(by_key(gb.median("values"), "category", "values_median")["A"] == 15.0);
     CHECK(by_key(gb.median("values"), "category", "values_median")["B"] == 22.5);
     CHECK(by_key(gb.first("values"), "category", "values_first")["B"] == 20.0 && by_key(gb.last("values"), "category", "values_last")["A"] == 15.0);
+    CHECK(by_key(gb.nunique("values"), "category", "values_nunique")["A"] == 2.0 && by_key(gb.nunique("values"), "category", "values_nunique")["C"] == 1.0);   // {10, 15, 15}
     auto groups = gb.groups();
     CHECK((groups[{"A"}] == std::vector<size_t>{0, 2, 5}) && (groups[{"B"}] == std::vector<size_t>{1, 4}) && (groups[{"C"}] == std::vector<size_t>{3}));
     auto big = gb.filter([](const OptimizedDataFrame &g) { return g.row_count() >= 2; });                 // operations.rs:51-74

@@ -304,6 +304,50 @@ def test_median_random(ctx, n, g, skew):
     check(ctx, k, n, [vf, vi], [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.MEAN), (1, O.MAX), (1, O.COUNT)], [O.I64], exact=[0, 1, 3, 4])
 
 
+@pytest.mark.parametrize("n,g,skew", [(300_000, 2_000, False), (2_500_000, 30_000, False), (2_000_000, 40, True)])
+def test_nunique_random(ctx, n, g, skew):
+    """PANDRS_HIP_AGG_NUNIQUE (legacy AggFunc::Nunique): distinct non-null values per group, exact; few distinct
+    values per group (so duplicates abound), nulls, NaNs, signed zeros, a hot key, beside other aggregates."""
+    rng = np.random.default_rng(n + g)
+    ids = rng.integers(0, g, n)
+    if skew:
+        ids[rng.random(n) < 0.7] = 3
+    keys = [(sparse_keys_from(ids), O.pack_mask(rng.random(n) < 0.02), O.I64)]
+    vf = rng.integers(-6, 6, n).astype(np.float64) / 2.0
+    vf[rng.random(n) < 0.01] = np.nan
+    vf[rng.random(n) < 0.05] = -0.0
+    vi = rng.integers(-2**62, 2**62, n)
+    small = rng.integers(0, 7, n).astype(np.int64) - 3
+    vals = [(vf, O.pack_mask(rng.random(n) < 0.1), O.F64), (np.where(rng.random(n) < 0.6, small, vi), None, O.I64)]
+    aggs = [(0, O.NUNIQUE), (1, O.NUNIQUE), (0, O.COUNT), (1, O.MIN), (1, O.MEDIAN)]    # (Median of a NaN-holding column is unspecified)
+    check(ctx, keys, n, vals, aggs, [O.I64], exact=[0, 1, 2, 3])
+
+
+def test_nunique_edge_cases_and_frame_shortcut(ctx):
+    key = (np.array([1, 1, 1, 1, 2, 2, 3, 3, 3], np.int64), None, O.I64)
+    vf = (np.array([2.5, 2.5, -0.0, 0.0, 7.0, 0.0, np.nan, np.nan, 1.0]), O.pack_mask([0, 0, 0, 0, 1, 1, 0, 0, 0]), O.F64)
+    kc, kn, oa = ctx.groupby_agg([key], 9, [vf], [(0, O.NUNIQUE)])
+    assert dict(zip(kc[0].view(np.int64).tolist(), oa[0].tolist())) == {1: 2.0, 2: 0.0, 3: 3.0}
+    # empty input, one group of one row
+    kc, kn, oa = ctx.groupby_agg([(np.zeros(0, np.int64), None, O.I64)], 0, [(np.zeros(0), None, O.F64)], [(0, O.NUNIQUE)])
+    assert oa.shape[1] == 0
+    kc, kn, oa = ctx.groupby_agg([(np.array([5], np.int64), None, O.I64)], 1, [(np.array([1.5]), None, O.F64)], [(0, O.NUNIQUE)])
+    assert oa[0].tolist() == [1.0]
+    # string column: OperationFailed like every numeric op (aggregation.rs:748)
+    import pandrs_amd as pa
+    with pytest.raises(pa.OperationFailed):
+        ctx.groupby_agg([key], 9, [(np.zeros(9, np.uint32), None, O.U32CODE)], [(0, O.NUNIQUE)])
+    # partial states of a sort-based aggregate are not mergeable
+    with pytest.raises(pa.OperationFailed):
+        ctx.groupby_partials([key], 9, [vf], [(0, O.NUNIQUE)])
+    from pandrs_amd.frame import OptimizedDataFrame, Int64Column, StringColumn
+    df = OptimizedDataFrame()
+    df.add_column("k", StringColumn(["a", "b", "a", "a", "b"]))
+    df.add_column("v", Int64Column([3, 3, 3, 4, 3]))
+    r = df.group_by(["k"]).nunique("v")                      # legacy GroupBy::nunique: alias "{col}_nunique"
+    assert dict(zip(r.column("k").to_list(), r.column("v_nunique").data.tolist())) == {"a": 2.0, "b": 1.0}
+
+
 def test_median_multi_key_and_string_codes(ctx):
     rng = np.random.default_rng(99)
     n = 300_000

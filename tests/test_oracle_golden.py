@@ -211,6 +211,21 @@ def test_source_derived_quirks():
     assert o4[0].tolist() == [2.0, 2.0, 1.0]
 
 
+def test_nunique_source_derived():
+    """AggFunc::Nunique of the legacy frame (src/dataframe/groupby.rs:455-467, :514-519): the group's
+    parseable values are sorted, `dedup`-ed (==) and counted; no value => 0.0.  No asserting test in the
+    reference — pinned by the cited lines (parity unpinned for this op)."""
+    key = (np.array([1, 1, 1, 1, 2, 2, 3, 3, 3], np.int64), None, O.I64)
+    vf = (np.array([2.5, 2.5, -0.0, 0.0, 7.0, 0.0, np.nan, np.nan, 1.0]), O.pack_mask([0, 0, 0, 0, 1, 1, 0, 0, 0]), O.F64)
+    vi = (np.array([4, -4, 4, 9, 1, 1, 5, 5, 5], np.int64), O.pack_mask([0, 0, 0, 1, 0, 0, 0, 0, 0]), O.I64)
+    for faithful in (False, True):
+        kc, kn, oa = O.groupby_agg([key], 9, [vf, vi], [(0, O.NUNIQUE), (1, O.NUNIQUE), (0, O.COUNT)], faithful=faithful)
+        got = {int(k): oa[:, j].tolist() for j, k in enumerate(kc[0].view(np.int64))}
+        assert got == {1: [2.0, 2.0, 4.0],      # {2.5, 0.0 (== -0.0)}; {4, -4} with the null row skipped
+                       2: [0.0, 1.0, 2.0],      # every value null => 0.0 (:467)
+                       3: [3.0, 1.0, 3.0]}      # NaN != NaN: dedup keeps both, plus 1.0
+
+
 def test_join_quirks_source_derived():
     # null keys never match; null LEFT keys vanish even from left/outer (join.rs:152);
     # null RIGHT keys are unmatched => appended by right/outer (join.rs:211-224);
