@@ -14,7 +14,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = pa.Context(0)
 OPS_MERGEABLE = [O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT]
-OPS_ALL = OPS_MERGEABLE + [O.STD, O.VAR, O.FIRST, O.LAST, O.MEDIAN, O.MEDIAN]
+OPS_ALL = OPS_MERGEABLE + [O.STD, O.VAR, O.FIRST, O.LAST, O.MEDIAN, O.MEDIAN, O.NUNIQUE, O.NUNIQUE]
 
 def rand_key(rng, n, dtype, g, skew):
     ids = rng.integers(0, g, n)
@@ -63,7 +63,10 @@ for case in range(n_cases):
             nv = int(rng.integers(1, 4))
             vals = []
             for _ in range(nv):
-                if rng.random() < 0.6: vals.append((rng.normal(50, 20, n), mask(rng, n, rng.choice([0, 0, 0.1])), O.F64))
+                r = rng.random()
+                if r < 0.15: vals.append((rng.integers(-4, 5, n).astype(np.float64) / 2.0, mask(rng, n, rng.choice([0, 0, 0.1])), O.F64))   # few distinct values, +-0.0
+                elif r < 0.25: vals.append((rng.integers(-3, 4, n).astype(np.int64), mask(rng, n, rng.choice([0, 0.2])), O.I64))
+                elif r < 0.65: vals.append((rng.normal(50, 20, n), mask(rng, n, rng.choice([0, 0, 0.1])), O.F64))
                 else: vals.append((rng.integers(-10**6, 10**6, n).astype(np.int64), mask(rng, n, rng.choice([0, 0.2])), O.I64))
             ops = OPS_ALL if rng.random() < 0.4 else OPS_MERGEABLE
             aggs = [(int(rng.integers(0, nv)), int(rng.choice(ops))) for _ in range(int(rng.integers(1, 9)))]
@@ -76,7 +79,7 @@ for case in range(n_cases):
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
-            exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN) or (vals[c][2] == O.I64 and op == O.SUM)]
+            exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
             assert_groupby_equal(got, want, kdts, int_exact_rows=exact, rtol=1e-9)
             if rng.random() < 0.3:      # group_by's own result on the same keys: a complete characterisation
                 cells, nulls, off, rows = ctx.groupby_indices(keys, n)
