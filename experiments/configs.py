@@ -56,6 +56,16 @@ if "c3" in which:
         ctx.set_option("partitions", 0); ctx.set_option("slice_rows", 0)
         del k2
     del k, v, hot
+if "sortops" in which:       # the sort-based aggregates: one (key, value) segmented sort per column
+    n, g = 100_000_000, 1_000_000
+    k = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64) * MIX
+    v = torch.randn(n, device=d, generator=gen, dtype=torch.float64)
+    w = torch.randint(0, 50, (n,), device=d, generator=gen, dtype=torch.int64)
+    run("100M/1M groups/median(f64)", n, lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.MEDIAN)]))
+    run("100M/1M groups/nunique(i64, 50 values)", n, lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(w, None, pa.I64)], [(0, pa.NUNIQUE)]))
+    run("100M/1M groups/std(f64)", n, lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.STD)]))
+    run("100M/1M groups/first+last(f64)", n, lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.FIRST), (0, pa.LAST)]))
+    del k, v, w
 if "c4" in which:
     n, g = 125_000_000, 10_000_000
     k = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64) * MIX; v = torch.randn(n, device=d, generator=gen, dtype=torch.float64)

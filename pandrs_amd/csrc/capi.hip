@@ -127,6 +127,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "join_one_pass")) c->opt.join_one_pass = value;
     else if (!std::strcmp(name, "load_pct")) c->opt.load_pct = value;
     else if (!std::strcmp(name, "generic_aggregate")) c->opt.generic_aggregate = value;
+    else if (!std::strcmp(name, "median_generic")) c->opt.median_generic = value;
     else if (!std::strcmp(name, "shared_cursors")) c->opt.shared_cursors = value;
     else if (!std::strcmp(name, "no_direct")) c->opt.no_direct = value;
     else if (!std::strcmp(name, "no_slice")) c->opt.no_slice = value;

@@ -144,6 +144,7 @@ struct Options {
     int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
+    int64_t median_generic = 0;      // 1 = Median / Nunique: skip the LDS group-sort fast path (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
     int64_t no_runs = 0;             // 1 = never use the run-folding aggregate kernels

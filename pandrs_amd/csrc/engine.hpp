@@ -125,8 +125,22 @@ size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
 // 2 = i64 rewritten to their order-preserving u64 encodings (and left encoded).
 int32_t segmented_sort_u32(pandrs_hip_ctx *c, uint64_t *keys, uint32_t *pay, const uint32_t *offsets, uint32_t NB,
                            uint32_t n_parts, int64_t n_rows);
+// `only` (optional, device, one byte per partition): sort just the partitions whose byte is non-zero.
+// `tiles` (optional) receives the device task list the sort ran on — one SortTask per SS_TILE-row tile of
+// every sorted partition, `counters[0]` of them, at most `max_tasks` — for kernels that walk the sorted rows.
+constexpr uint32_t SS_TILE = 8192;
+struct SortTask {
+    uint32_t pbeg, pend;    // the partition's row range
+    uint32_t tile;          // tile index inside the partition
+    uint32_t multi;         // the partition has more than one tile
+};
+struct SortTiles {
+    const SortTask *tasks = nullptr;
+    const uint32_t *counters = nullptr;
+    uint32_t max_tasks = 0;
+};
 int32_t segmented_sort_u64(pandrs_hip_ctx *c, uint64_t *keys, uint64_t *pay, const uint32_t *offsets, uint32_t NB,
-                           uint32_t n_parts, int64_t n_rows, int enc);
+                           uint32_t n_parts, int64_t n_rows, int enc, const uint8_t *only = nullptr, SortTiles *tiles = nullptr);
 size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_bytes);
 
 // median.hip: fills aggregate `fin_index` of c->gb with the groups' medians of one value column

@@ -9,9 +9,12 @@
 //   1. rows with a null value are dropped by a stream compaction (only when the column has a mask);
 //   2. (key cell, value) pairs are radix-partitioned on the key hash, null keys to their own
 //      partition (one group, grouping.rs:74);
-//   3. every partition is sorted by (key, order-preserving value code) — segsort.hip, any size;
-//   4. a run of equal keys is a group in ascending value order: its median goes into a global
-//      open-addressing table key -> median;
+//   3. FAST PATH (group_sort_kernel): a partition that fits LDS is grouped by key with an LDS hash table and
+//      every group's values are sorted on their own, one wave per batch of groups — the result goes
+//      straight into a global open-addressing table key -> median; partitions that do not fit are
+//      flagged and take the GENERAL PATH: sorted by (key, order-preserving value code) — segsort.hip, any
+//      size — where a run of equal keys is a group in ascending value order;
+//   4. either way the group's median (or distinct count) lands in the global table key -> value;
 //   5. the engine's groups look their median up (miss = no non-null value = 0.0).
 // f64 values are ordered by their IEEE total order (the reference's partial_cmp sort leaves the
 // position of NaNs unspecified; -0.0 sorts before +0.0, which compare equal anyway).
@@ -65,35 +68,38 @@ struct __attribute__((aligned(16))) MedianEntry {
     double median;
 };
 
-// keys / vals: the sorted partitions; rows [0, *null_beg) have non-null keys (equal keys adjacent,
-// a key lives in one partition), rows [*null_beg, n) are the NULL-key group (cells zeroed).
+// General path, after the segmented sort.  One workgroup per sorted tile (SortTask): equal keys are adjacent
+// inside the tile's partition [pbeg, pend); the NULL-key partition (pbeg == *null_beg, cells zeroed) is one group.
 // kind 0: vals are enc_f64 codes, 1: enc_i64 codes.
-__global__ void median_runs_kernel(const uint64_t *keys, const uint64_t *vals, const uint32_t *null_beg, uint32_t n, int kind,
-                                   MedianEntry *table, uint32_t table_mask) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t nb = *null_beg;
-    const bool null_grp = i >= nb;
-    const uint32_t seg_beg = null_grp ? nb : 0u, seg_end = null_grp ? n : nb;
-    const uint64_t k = keys[i];
-    if (i > seg_beg && keys[i - 1] == k) return;
-    const uint32_t m = sorted_run_length(keys, i, seg_end), mid = m >> 1;
-    double med;
-    if (kind == 0) {
-        const double hi = dec_f64(vals[i + mid]);
-        med = (m & 1) ? hi : (dec_f64(vals[i + mid - 1]) + hi) / 2.0;           // aggregation.rs:715-719
-    } else {
-        const int64_t hi = dec_i64(vals[i + mid]);
-        med = (m & 1) ? (double)hi                                               // aggregation.rs:597-601: the add is in i64
-                      : (double)(int64_t)((uint64_t)dec_i64(vals[i + mid - 1]) + (uint64_t)hi) / 2.0;
-    }
-    if (null_grp) { table[table_mask + 2].median = med; return; }
-    if (k == EMPTY_KEY) { table[table_mask + 1].median = med; return; }
-    uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
-    for (uint32_t probes = 0; probes <= table_mask; probes++) {      // bounded: never spin on a full table
-        uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
-        if (old == EMPTY_KEY) { table[slot].median = med; break; }
-        slot = (slot + 1) & table_mask;
+constexpr int MR_THREADS = 1024;
+__global__ __launch_bounds__(MR_THREADS) void median_runs_kernel(const SortTask *tasks, const uint32_t *counters,
+                                                                 const uint64_t *keys, const uint64_t *vals, const uint32_t *null_beg,
+                                                                 int kind, MedianEntry *table, uint32_t table_mask) {
+    if (blockIdx.x >= counters[0]) return;
+    const SortTask t = tasks[blockIdx.x];
+    const uint32_t tbeg = t.pbeg + t.tile * SS_TILE, tend = min(tbeg + SS_TILE, t.pend);
+    const bool null_grp = t.pbeg >= *null_beg;
+    for (uint32_t i = tbeg + threadIdx.x; i < tend; i += MR_THREADS) {
+        const uint64_t k = keys[i];
+        if (i > t.pbeg && keys[i - 1] == k) continue;
+        const uint32_t m = sorted_run_length(keys, i, t.pend), mid = m >> 1;
+        double med;
+        if (kind == 0) {
+            const double hi = dec_f64(vals[i + mid]);
+            med = (m & 1) ? hi : (dec_f64(vals[i + mid - 1]) + hi) / 2.0;           // aggregation.rs:715-719
+        } else {
+            const int64_t hi = dec_i64(vals[i + mid]);
+            med = (m & 1) ? (double)hi                                               // aggregation.rs:597-601: the add is in i64
+                          : (double)(int64_t)((uint64_t)dec_i64(vals[i + mid - 1]) + (uint64_t)hi) / 2.0;
+        }
+        if (null_grp) { table[table_mask + 2].median = med; continue; }
+        if (k == EMPTY_KEY) { table[table_mask + 1].median = med; continue; }
+        uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
+        for (uint32_t probes = 0; probes <= table_mask; probes++) {      // bounded: never spin on a full table
+            uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { table[slot].median = med; break; }
+            slot = (slot + 1) & table_mask;
+        }
     }
 }
 
@@ -103,38 +109,44 @@ __global__ void median_runs_kernel(const uint64_t *keys, const uint64_t *vals, c
 // segment (the rows are sorted, so a key's lanes are contiguous); the segment's first lane adds the
 // segment's count of new values to the key's table entry — one global atomic per key and wave, not per
 // row, so one huge group costs n/64 same-address atomics instead of n.
-__global__ __launch_bounds__(256) void nunique_runs_kernel(const uint64_t *keys, const uint64_t *vals, const uint32_t *null_beg,
-                                                           uint32_t n, int kind, MedianEntry *table, uint32_t table_mask) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    const bool valid = i < n;
-    const uint32_t nb = *null_beg;
-    const uint64_t k = valid ? keys[i] : 0ull;
-    const bool null_grp = valid && i >= nb;
-    const bool run_head = valid && (i == 0 || i == nb || keys[i - 1] != k);
-    bool newv = run_head;
-    if (valid && !run_head) {
-        const uint64_t a = vals[i - 1], b = vals[i];
-        newv = kind == 0 ? dec_f64(a) != dec_f64(b) : a != b;
-    }
-    const bool seg_head = valid && (lane == 0 || run_head);
-    const unsigned long long H = __ballot(seg_head), NV = __ballot(newv);
-    if (!seg_head) return;
-    const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1)) << (lane + 1);   // heads after this lane
-    const unsigned long long seg = (above ? ((1ull << __builtin_ctzll(above)) - 1) : ~0ull) & ~((1ull << lane) - 1);
-    const unsigned long long cnt = (unsigned long long)__builtin_popcountll(NV & seg);
-    if (cnt == 0) return;
-    unsigned long long *counter = nullptr;
-    if (null_grp) counter = reinterpret_cast<unsigned long long *>(&table[table_mask + 2].median);
-    else if (k == EMPTY_KEY) counter = reinterpret_cast<unsigned long long *>(&table[table_mask + 1].median);
-    else {
-        uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
-        for (uint32_t probes = 0; probes <= table_mask; probes++) {      // bounded: never spin on a full table
-            const uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
-            if (old == EMPTY_KEY || old == k) { counter = reinterpret_cast<unsigned long long *>(&table[slot].median); break; }
-            slot = (slot + 1) & table_mask;
+__global__ __launch_bounds__(MR_THREADS) void nunique_runs_kernel(const SortTask *tasks, const uint32_t *counters,
+                                                                  const uint64_t *keys, const uint64_t *vals, const uint32_t *null_beg,
+                                                                  int kind, MedianEntry *table, uint32_t table_mask) {
+    if (blockIdx.x >= counters[0]) return;
+    const SortTask t = tasks[blockIdx.x];
+    const uint32_t tbeg = t.pbeg + t.tile * SS_TILE, tend = min(tbeg + SS_TILE, t.pend);
+    const bool null_grp = t.pbeg >= *null_beg;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = tbeg; base < tend; base += MR_THREADS) {         // uniform trip count: the ballots need every lane
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < tend;
+        const uint64_t k = valid ? keys[i] : 0ull;
+        const bool run_head = valid && (i == t.pbeg || keys[i - 1] != k);
+        bool newv = run_head;
+        if (valid && !run_head) {
+            const uint64_t a = vals[i - 1], b = vals[i];
+            newv = kind == 0 ? dec_f64(a) != dec_f64(b) : a != b;
         }
+        const bool seg_head = valid && (lane == 0 || run_head);
+        const unsigned long long H = __ballot(seg_head), NV = __ballot(newv);
+        if (!seg_head) continue;
+        const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1)) << (lane + 1);   // heads after this lane
+        const unsigned long long seg = (above ? ((1ull << __builtin_ctzll(above)) - 1) : ~0ull) & ~((1ull << lane) - 1);
+        const unsigned long long cnt = (unsigned long long)__builtin_popcountll(NV & seg);
+        if (cnt == 0) continue;
+        unsigned long long *counter = nullptr;
+        if (null_grp) counter = reinterpret_cast<unsigned long long *>(&table[table_mask + 2].median);
+        else if (k == EMPTY_KEY) counter = reinterpret_cast<unsigned long long *>(&table[table_mask + 1].median);
+        else {
+            uint32_t slot = hash32(k, 0x2545F491u) & table_mask;
+            for (uint32_t probes = 0; probes <= table_mask; probes++) {      // bounded: never spin on a full table
+                const uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k);
+                if (old == EMPTY_KEY || old == k) { counter = reinterpret_cast<unsigned long long *>(&table[slot].median); break; }
+                slot = (slot + 1) & table_mask;
+            }
+        }
+        if (counter) atomicAdd(counter, cnt);
     }
-    if (counter) atomicAdd(counter, cnt);
 }
 
 __global__ void clear_table_values_kernel(MedianEntry *table, uint32_t n) {
@@ -161,6 +173,235 @@ __global__ void median_lookup_kernel(const uint64_t *gkeys, const uint8_t *gnull
         }
     }
     out[j] = mode ? (double)(unsigned long long)__double_as_longlong(med) : med;
+}
+
+// ---- fast path: one workgroup per partition, everything in LDS -----------------------------------
+// A partition of <= GS_CAP rows with <= GS_KEYS distinct keys never needs the general sort: its rows
+// are grouped by key with an LDS hash table (count per key -> scan -> place the value codes into the
+// key's run), every run is sorted on its own — runs are short (a group's share of the rows), so a
+// wave sorts a run with a bitonic network over LDS without block barriers; runs of >= GS_BIG values
+// are sorted by the whole workgroup — and the median / distinct count goes straight into the global
+// key table.  One read of the partitioned pairs, nothing written back.  The network is the
+// "always ascending" bitonic variant (first step of a merge mirrors the partner, i ^ (k - 1)), so an
+// arbitrary run length needs no padding: a compare-exchange whose upper index is past the end is a no-op.
+// Partitions that do not fit (a hot key, a huge NULL group, nearly unique keys) are flagged in
+// `only[]` and left to the general path below.
+constexpr int GS_THREADS = 1024;
+constexpr uint32_t GS_CAP = 15360, GS_SLOTS = 2048, GS_KEYS = 1536, GS_BIG = 1024;
+constexpr int GS_RPT = GS_CAP / GS_THREADS;
+constexpr size_t GS_LDS = size_t(GS_CAP) * 8 + size_t(GS_SLOTS + 2) * 8 + 2 * size_t(GS_SLOTS + 4) * 4 + 64 * 4 + 32 * 4 + 72 * 4 + (GS_SLOTS + 16) * 2;
+
+struct GroupSortArgs {
+    const uint64_t *pkeys, *pvals;   // partitioned key cells and raw 8-byte values
+    const uint32_t *offsets;
+    uint32_t NB, P;
+    int kind, mode;                  // kind 0 f64 / 1 i64; mode 0 median / 1 distinct count
+    MedianEntry *table;
+    uint32_t table_mask;
+    uint8_t *only;                   // [P + 1] out: 1 = this partition is left to the general path
+};
+
+// compare-exchange c of one step of the ascending bitonic network over v[0, m): distance 1 << lj; `mask` is
+// the partner distance as an xor mask — 2j - 1 for the first step of a merge (the mirrored partner), j after
+__device__ __forceinline__ void gs_cex(uint64_t *v, uint32_t m, uint32_t lj, uint32_t mask, uint32_t c) {
+    const uint32_t l = ((c >> lj) << (lj + 1)) | (c & ((1u << lj) - 1)), r = l ^ mask;
+    const uint64_t x = v[l], y = v[min(r, m - 1)];
+    if (r < m && x > y) { v[l] = y; v[r] = x; }
+}
+
+__device__ __forceinline__ void gs_publish(const GroupSortArgs &a, bool null_part, uint64_t key, double value) {
+    if (null_part) { a.table[a.table_mask + 2].median = value; return; }
+    if (key == EMPTY_KEY) { a.table[a.table_mask + 1].median = value; return; }
+    uint32_t slot = hash32(key, 0x2545F491u) & a.table_mask;
+    for (uint32_t probes = 0; probes <= a.table_mask; probes++) {        // bounded: never spin on a full table
+        const uint64_t old = atomicCAS((unsigned long long *)&a.table[slot].key, EMPTY_KEY, key);
+        if (old == EMPTY_KEY) { a.table[slot].median = value; return; }
+        slot = (slot + 1) & a.table_mask;
+    }
+}
+
+__global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t beg = a.offsets[(size_t)p * a.NB], end = a.offsets[(size_t)(p + 1) * a.NB], n = end - beg;
+    if (n == 0) return;
+    if (n > GS_CAP) { if (tid == 0) a.only[p] = 1; return; }
+    const bool null_part = p == a.P;
+    uint64_t *lv = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *hk = lv + GS_CAP;                                   // [GS_SLOTS + 1]: the last entry is the key ~0's
+    uint32_t *hc = reinterpret_cast<uint32_t *>(hk + GS_SLOTS + 2);   // rows per key
+    uint32_t *hs = hc + GS_SLOTS + 4;                             // run start, then (after placement) run end
+    uint32_t *big = hs + GS_SLOTS + 4;                            // slots of the runs sorted by the whole workgroup
+    uint32_t *wt = big + 64;                                      // scan scratch; [20] overflow, [21] distinct keys, [22] big runs
+    uint32_t *occ = wt + 32;                                      // one bit per slot: the slot holds a run
+    uint16_t *runs = reinterpret_cast<uint16_t *>(occ + 72);      // the occupied slots, any order: wt[23] of them; wt[24] = next to take
+    for (uint32_t s = tid; s < GS_SLOTS + 1; s += GS_THREADS) { hk[s] = EMPTY_KEY; hc[s] = 0; }
+    if (tid < 32) wt[tid] = 0;
+    if (tid < 72) occ[tid] = 0;
+    __syncthreads();
+    // 1. count the rows of every key; a thread keeps the slots of its rows.  All of the thread's key and
+    // value loads are issued up front (one HBM latency per partition, not one per row).
+    uint64_t kreg[GS_RPT], xreg[GS_RPT];
+#pragma unroll
+    for (int r = 0; r < GS_RPT; r++) {
+        const uint32_t i = min((uint32_t)(r * GS_THREADS) + tid, n - 1);
+        kreg[r] = a.pkeys[beg + i];
+        xreg[r] = a.pvals[beg + i];
+    }
+    uint32_t sl[GS_RPT];
+#pragma unroll
+    for (int r = 0; r < GS_RPT; r++) {
+        const uint32_t i = r * GS_THREADS + tid;
+        sl[r] = 0;
+        if (i >= n) continue;
+        uint32_t s = 0;
+        if (!null_part) {
+            const uint64_t k = kreg[r];
+            s = GS_SLOTS;
+            if (k != EMPTY_KEY) {
+                s = hash32(k, 0x68E31DA4u) & (GS_SLOTS - 1);
+                uint32_t probes = 0;
+                for (; probes < GS_SLOTS; probes++) {
+                    const uint64_t old = atomicCAS((unsigned long long *)&hk[s], EMPTY_KEY, k);
+                    if (old == EMPTY_KEY) { if (atomicAdd(&wt[21], 1u) >= GS_KEYS) wt[20] = 1; break; }
+                    if (old == k) break;
+                    s = (s + 1) & (GS_SLOTS - 1);
+                }
+                if (probes == GS_SLOTS) { wt[20] = 1; s = 0; }
+            }
+        }
+        sl[r] = s;
+        atomicAdd(&hc[s], 1u);
+    }
+    __syncthreads();
+    if (wt[20]) { if (tid == 0) a.only[p] = 1; return; }          // too many distinct keys for the table
+    // 2. exclusive scan of the counts = start of every run
+    {
+        const uint32_t c0 = hc[2 * tid], c1 = hc[2 * tid + 1];
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan<GS_THREADS>(c0 + c1, wt, &tot);
+        hs[2 * tid] = ex; hs[2 * tid + 1] = ex + c0;
+        if (tid == GS_THREADS - 1) hs[GS_SLOTS] = ex + c0 + c1;
+        if (c0) { atomicOr(&occ[(2 * tid) >> 5], 1u << ((2 * tid) & 31)); runs[atomicAdd(&wt[23], 1u)] = (uint16_t)(2 * tid); }
+        if (c1) { atomicOr(&occ[(2 * tid + 1) >> 5], 1u << ((2 * tid + 1) & 31)); runs[atomicAdd(&wt[23], 1u)] = (uint16_t)(2 * tid + 1); }
+        if (tid == 0 && hc[GS_SLOTS]) { atomicOr(&occ[GS_SLOTS >> 5], 1u << (GS_SLOTS & 31)); runs[atomicAdd(&wt[23], 1u)] = (uint16_t)GS_SLOTS; }
+        if (c0 >= GS_BIG) big[atomicAdd(&wt[22], 1u)] = 2 * tid;
+        if (c1 >= GS_BIG) big[atomicAdd(&wt[22], 1u)] = 2 * tid + 1;
+        if (tid == 0 && hc[GS_SLOTS] >= GS_BIG) big[atomicAdd(&wt[22], 1u)] = GS_SLOTS;
+    }
+    __syncthreads();
+    // 3. place the order-preserving value codes into their key's run
+#pragma unroll
+    for (int r = 0; r < GS_RPT; r++) {
+        const uint32_t i = r * GS_THREADS + tid;
+        if (i >= n) continue;
+        const uint64_t x = xreg[r];
+        const uint32_t pos = atomicAdd(&hs[sl[r]], 1u);
+        lv[pos] = a.kind == 0 ? enc_f64(__longlong_as_double((long long)x)) : enc_i64((int64_t)x);
+    }
+    __syncthreads();
+    // 4a. the few long runs: the whole workgroup sorts each
+    const uint32_t n_big = wt[22];
+    for (uint32_t b = 0; b < n_big; b++) {
+        const uint32_t s = big[b], m = hc[s];
+        uint64_t *v = lv + (hs[s] - m);
+        uint32_t lm = 1;
+        while ((1u << lm) < m) lm++;
+        for (uint32_t lk = 1; lk <= lm; lk++) {
+            for (int lj = (int)lk - 1; lj >= 0; lj--) {
+                const uint32_t mask = lj + 1 == (int)lk ? (2u << lj) - 1 : 1u << lj;
+                for (uint32_t c = tid; c < (1u << (lm - 1)); c += GS_THREADS) gs_cex(v, m, (uint32_t)lj, mask, c);
+                __syncthreads();
+            }
+        }
+    }
+    // 4b. the waves take batches of GS_ILP runs from the shared list (an LDS ticket, so long and short runs
+    // balance out) and sort the short ones — a bitonic network over LDS without workgroup barriers —
+    // GS_ILP runs side by side — one step of a run is two dependent LDS round trips and
+    // nothing else, so four independent runs in flight are what keeps the wave busy — and leaves each run's
+    // result in the slot's (count, cursor) words.  The global table is filled afterwards by all threads at
+    // once: a wave publishing run after run would wait for one device-scope atomic round trip per run.
+    constexpr int GS_ILP = 4;
+    const uint32_t n_runs = wt[23];
+    {
+        for (;;) {                                        // waves take batches of GS_ILP runs from the shared list
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(&wt[24], (uint32_t)GS_ILP);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            if (first >= n_runs) break;
+            const uint32_t my_slot = first + lane < n_runs && lane < GS_ILP ? (uint32_t)runs[first + lane] : 0u;
+            const uint32_t my_m = first + lane < n_runs && lane < GS_ILP ? hc[my_slot] : 0u;
+            const uint32_t my_end = my_m ? hs[my_slot] : 0u;
+            uint32_t rm[GS_ILP], rbase[GS_ILP], rslot[GS_ILP], lm = 0;
+#pragma unroll
+            for (int r = 0; r < GS_ILP; r++) {
+                rm[r] = (uint32_t)__builtin_amdgcn_readlane((int)my_m, r);
+                rbase[r] = rm[r] ? (uint32_t)__builtin_amdgcn_readlane((int)my_end, r) - rm[r] : 0u;
+                rslot[r] = (uint32_t)__builtin_amdgcn_readlane((int)my_slot, r);
+                if (rm[r] >= 2 && rm[r] < GS_BIG) { uint32_t l2 = 1; while ((1u << l2) < rm[r]) l2++; lm = max(lm, l2); }
+            }
+            for (uint32_t lk = 1; lk <= lm; lk++) {
+                for (int lj = (int)lk - 1; lj >= 0; lj--) {
+                    const uint32_t mask = lj + 1 == (int)lk ? (2u << lj) - 1 : 1u << lj;
+                    for (uint32_t c = lane; c < (1u << (lm - 1)); c += 64) {
+                        const uint32_t l = ((c >> lj) << (lj + 1)) | (c & ((1u << lj) - 1)), rr = l ^ mask;
+                        uint64_t x[GS_ILP], y[GS_ILP];
+                        bool live[GS_ILP];
+#pragma unroll
+                        for (int r = 0; r < GS_ILP; r++) {          // all loads first: independent, in flight together
+                            live[r] = rr < rm[r] && rm[r] < GS_BIG;  // (a run beyond its own size: the extra steps are no-ops)
+                            const uint32_t lc = live[r] ? l : 0u, rc = live[r] ? rr : 0u;
+                            x[r] = lv[rbase[r] + lc]; y[r] = lv[rbase[r] + rc];
+                        }
+#pragma unroll
+                        for (int r = 0; r < GS_ILP; r++)
+                            if (live[r] && x[r] > y[r]) { lv[rbase[r] + l] = y[r]; lv[rbase[r] + rr] = x[r]; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the wave's own LDS traffic, in order
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < GS_ILP; r++) {
+                const uint32_t m = rm[r];
+                if (m == 0) continue;
+                const uint64_t *v = lv + rbase[r];
+                double out;
+                if (a.mode == 0) {
+                    const uint32_t mid = m >> 1;
+                    if (a.kind == 0) {
+                        const double hi = dec_f64(v[mid]);
+                        out = (m & 1) ? hi : (dec_f64(v[mid - 1]) + hi) / 2.0;                      // aggregation.rs:715-719
+                    } else {
+                        const int64_t hi = dec_i64(v[mid]);
+                        out = (m & 1) ? (double)hi                                                  // aggregation.rs:597-601: the add is in i64
+                                      : (double)(int64_t)((uint64_t)dec_i64(v[mid - 1]) + (uint64_t)hi) / 2.0;
+                    }
+                } else {
+                    uint32_t cnt = 0;
+                    for (uint32_t j = lane; j < m; j += 64) {
+                        bool nv = j == 0;
+                        if (j > 0) { const uint64_t x = v[j - 1], y = v[j]; nv = a.kind == 0 ? dec_f64(x) != dec_f64(y) : x != y; }
+                        cnt += nv ? 1u : 0u;
+                    }
+                    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+                    out = __longlong_as_double((long long)(unsigned long long)cnt);     // a u64 count in the entry's 8 bytes
+                }
+                if (lane == 0) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(out);
+                    hc[rslot[r]] = (uint32_t)bits; hs[rslot[r]] = (uint32_t)(bits >> 32);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = tid; s < GS_SLOTS + 1; s += GS_THREADS) {
+        if (!((occ[s >> 5] >> (s & 31)) & 1u)) continue;
+        const double out = __longlong_as_double((long long)((unsigned long long)hc[s] | ((unsigned long long)hs[s] << 32)));
+        gs_publish(a, null_part, s == GS_SLOTS ? EMPTY_KEY : hk[s], out);
+    }
 }
 
 // Fills aggregate `fin_index` of the retained groupby result (c->gb) with the groups' medians of
@@ -211,22 +452,46 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     if (nv > 0) {
         uint64_t *pk = c->work.take<uint64_t>(nv + 1), *pv = c->work.take<uint64_t>(nv + 1);
         if (!pk || !pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
-        int64_t P = std::max<int64_t>(1, (int64_t)std::ceil((double)nv / 4900.0));
+        // Fast path first: partitions of ~9 K rows (they must fit GS_CAP with room for an uneven hash
+        // split) with at most GS_KEYS distinct keys each are finished in LDS by group_sort_kernel; what it
+        // flags in `only` (oversized partitions: a hot key, a large NULL group) goes through the general
+        // sort below.  With nearly unique keys (more than ~1 K groups per partition even at P_MAX) the
+        // fast path cannot apply anywhere and is skipped.
+        const bool fast = !c->opt.median_generic;
+        int64_t P = std::max<int64_t>(1, (int64_t)std::ceil((double)nv / (fast ? 9000.0 : 4900.0)));
+        if (fast) P = std::max<int64_t>(P, (int64_t)std::ceil((double)G / 1000.0));
         P = std::min<int64_t>(P, P_MAX);
+        const bool use_fast = fast && (double)G / (double)P <= 1200.0;
+        if (!use_fast) P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)nv / 4900.0)), P_MAX);
         PartInfo part{};
         ScatterArgs sa{};
         sa.key = kd; sa.pkeys = pk; sa.n_rows = nv; sa.P = (uint32_t)P; sa.seed = 0x3C6EF372u;
         sa.mv[sa.n_move++] = MoveDesc{vals, pv, 0, 0};
         ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER));
         const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
+        uint8_t *only = nullptr;
+        if (use_fast) {
+            only = c->work.take<uint8_t>((size_t)P + 16);
+            if (!only) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
+            HIP_TRY(hipMemsetAsync(only, 0, (size_t)P + 16, c->stream));
+            GroupSortArgs ga{};
+            ga.pkeys = pk; ga.pvals = pv; ga.offsets = part.offsets; ga.NB = part.NB; ga.P = (uint32_t)P;
+            ga.kind = kind; ga.mode = mode; ga.table = table; ga.table_mask = cap_tab - 1; ga.only = only;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS));
+            hipLaunchKernelGGL(group_sort_kernel, dim3((unsigned)P + 1), dim3(GS_THREADS), GS_LDS, c->stream, ga);
+            HIP_TRY(hipGetLastError());
+        }
+        // general path (every partition, or only the flagged ones): sort by (key, value code), walk the runs
         hipLaunchKernelGGL(fill_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end, 0ull);
-        ST_TRY(segmented_sort_u64(c, pk, pv, part.offsets, part.NB, (uint32_t)P + 1, nv, kind == 0 ? 1 : 2));
+        SortTiles tiles;
+        ST_TRY(segmented_sort_u64(c, pk, pv, part.offsets, part.NB, (uint32_t)P + 1, nv, kind == 0 ? 1 : 2, only, &tiles));
         if (mode == 1)
-            hipLaunchKernelGGL(nunique_runs_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream,
-                               pk, pv, null_beg, (uint32_t)nv, kind, table, cap_tab - 1);
+            hipLaunchKernelGGL(nunique_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
+                               tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
         else
-            hipLaunchKernelGGL(median_runs_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream,
-                               pk, pv, null_beg, (uint32_t)nv, kind, table, cap_tab - 1);
+            hipLaunchKernelGGL(median_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
+                               tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(median_lookup_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,

@@ -19,14 +19,7 @@
 namespace pandrs {
 
 constexpr int SS_THREADS = 1024;
-constexpr uint32_t SS_TILE = 8192;
 constexpr int SS_EPT = SS_TILE / SS_THREADS;     // outputs per thread in a merge pass
-
-struct SortTask {
-    uint32_t pbeg, pend;    // the partition's row range
-    uint32_t tile;          // tile index inside the partition
-    uint32_t multi;         // the partition has more than one tile
-};
 
 // composite order: key, then payload
 template <typename PT>
@@ -36,7 +29,7 @@ __device__ __forceinline__ bool pair_le(uint64_t ka, PT pa, uint64_t kb, PT pb) 
 
 // One workgroup: exclusive scan of the partitions' tile counts, one task per tile.
 // counters[0] = tasks written, counters[1] = most tiles in one partition.
-__global__ __launch_bounds__(SS_THREADS) void build_sort_tasks_kernel(const uint32_t *offsets, uint32_t NB, uint32_t n_parts,
+__global__ __launch_bounds__(SS_THREADS) void build_sort_tasks_kernel(const uint32_t *offsets, uint32_t NB, uint32_t n_parts, const uint8_t *only,
                                                                       SortTask *tasks, uint32_t max_tasks, uint32_t *counters) {
     __shared__ uint32_t wt[17];
     __shared__ uint32_t s_max;
@@ -46,7 +39,7 @@ __global__ __launch_bounds__(SS_THREADS) void build_sort_tasks_kernel(const uint
     for (uint32_t base = 0; base < n_parts; base += SS_THREADS) {
         const uint32_t p = base + threadIdx.x;
         uint32_t beg = 0, end = 0;
-        if (p < n_parts) { beg = offsets[(size_t)p * NB]; end = offsets[(size_t)(p + 1) * NB]; }
+        if (p < n_parts && (!only || only[p])) { beg = offsets[(size_t)p * NB]; end = offsets[(size_t)(p + 1) * NB]; }
         const uint32_t nt = (end - beg + SS_TILE - 1) / SS_TILE;
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan<SS_THREADS>(nt, wt, &tot);
@@ -175,13 +168,14 @@ size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_byte
 // Workspace comes from c->work (not reset here).  Synchronises the stream once.
 template <typename PT>
 static int32_t segsort_impl(pandrs_hip_ctx *c, uint64_t *keys, PT *pay, const uint32_t *offsets, uint32_t NB,
-                            uint32_t n_parts, int64_t n_rows, int enc) {
+                            uint32_t n_parts, int64_t n_rows, int enc, const uint8_t *only = nullptr, SortTiles *tiles = nullptr) {
     if (n_rows <= 0 || n_parts == 0) return 0;
     const uint32_t max_tasks = (uint32_t)((size_t)n_rows / SS_TILE + n_parts + 8);
     SortTask *tasks = c->work.take<SortTask>(max_tasks);
     uint32_t *counters = c->work.take<uint32_t>(64);
     if (!tasks || !counters) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (segmented sort)");
-    hipLaunchKernelGGL(build_sort_tasks_kernel, dim3(1), dim3(SS_THREADS), 0, c->stream, offsets, NB, n_parts, tasks, max_tasks, counters);
+    if (tiles) { tiles->tasks = tasks; tiles->counters = counters; tiles->max_tasks = max_tasks; }
+    hipLaunchKernelGGL(build_sort_tasks_kernel, dim3(1), dim3(SS_THREADS), 0, c->stream, offsets, NB, n_parts, only, tasks, max_tasks, counters);
     const size_t lds = (size_t)SS_TILE * (8 + sizeof(PT)) + 64;
     auto launch_chunk = [&](auto kernel) -> int32_t {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -218,8 +212,8 @@ int32_t segmented_sort_u32(pandrs_hip_ctx *c, uint64_t *keys, uint32_t *pay, con
     return segsort_impl<uint32_t>(c, keys, pay, offsets, NB, n_parts, n_rows, 0);
 }
 int32_t segmented_sort_u64(pandrs_hip_ctx *c, uint64_t *keys, uint64_t *pay, const uint32_t *offsets, uint32_t NB,
-                           uint32_t n_parts, int64_t n_rows, int enc) {
-    return segsort_impl<uint64_t>(c, keys, pay, offsets, NB, n_parts, n_rows, enc);
+                           uint32_t n_parts, int64_t n_rows, int enc, const uint8_t *only, SortTiles *tiles) {
+    return segsort_impl<uint64_t>(c, keys, pay, offsets, NB, n_parts, n_rows, enc, only, tiles);
 }
 
 }  // namespace pandrs

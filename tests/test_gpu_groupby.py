@@ -301,7 +301,12 @@ def test_median_random(ctx, n, g, skew):
     k = (sparse_keys_from(ids), O.pack_mask(rng.random(n) < 0.001), O.I64)
     vf = (np.round(rng.normal(0, 100, n), 1), None, O.F64)                   # rounded: many ties
     vi = (rng.integers(-10**6, 10**6, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.1), O.I64)
-    check(ctx, k, n, [vf, vi], [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.MEAN), (1, O.MAX), (1, O.COUNT)], [O.I64], exact=[0, 1, 3, 4])
+    for generic in (0, 1):       # 0: LDS group-sort fast path (+ general path for flagged partitions), 1: general path only
+        ctx.set_option("median_generic", generic)
+        try:
+            check(ctx, k, n, [vf, vi], [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.MEAN), (1, O.MAX), (1, O.COUNT)], [O.I64], exact=[0, 1, 3, 4])
+        finally:
+            ctx.set_option("median_generic", 0)
 
 
 @pytest.mark.parametrize("n,g,skew", [(300_000, 2_000, False), (2_500_000, 30_000, False), (2_000_000, 40, True)])
@@ -320,7 +325,33 @@ def test_nunique_random(ctx, n, g, skew):
     small = rng.integers(0, 7, n).astype(np.int64) - 3
     vals = [(vf, O.pack_mask(rng.random(n) < 0.1), O.F64), (np.where(rng.random(n) < 0.6, small, vi), None, O.I64)]
     aggs = [(0, O.NUNIQUE), (1, O.NUNIQUE), (0, O.COUNT), (1, O.MIN), (1, O.MEDIAN)]    # (Median of a NaN-holding column is unspecified)
-    check(ctx, keys, n, vals, aggs, [O.I64], exact=[0, 1, 2, 3])
+    for generic in (0, 1):
+        ctx.set_option("median_generic", generic)
+        try:
+            check(ctx, keys, n, vals, aggs, [O.I64], exact=[0, 1, 2, 3])
+        finally:
+            ctx.set_option("median_generic", 0)
+
+
+def test_sort_based_aggregates_fast_path_shapes(ctx):
+    """The LDS group-sort path of Median / Nunique at its edges: runs of every length around the wave /
+    workgroup hand-over (GS_BIG = 512), a partition-filling group, more distinct keys per partition than the
+    LDS table takes (=> general path), the key ~0 and a NULL-key group that fills several partitions' worth."""
+    rng = np.random.default_rng(4242)
+    sizes = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 257, 511, 512, 513, 1000, 1023, 1025, 2047, 4097, 9000, 15360, 15361, 40_000]
+    ids = np.repeat(np.arange(len(sizes)), sizes)
+    n = len(ids)
+    perm = rng.permutation(n)
+    k = sparse_keys_from(ids)[perm]
+    k[ids[perm] == 5] = -1                                     # one group keyed by the table sentinel ~0
+    vals = [(np.round(rng.normal(0, 50, n), 0) + 0.0, None, O.F64), (rng.integers(-40, 40, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.3), O.I64)]
+    aggs = [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.NUNIQUE), (1, O.NUNIQUE), (0, O.COUNT)]
+    check(ctx, [(k, O.pack_mask(rng.random(n) < 0.2), O.I64)], n, vals, aggs, [O.I64], exact=[0, 1, 2, 3, 4])
+    # nearly unique keys: ~2 rows per group, far more groups per partition than the LDS table holds
+    n2 = 600_000
+    k2 = sparse_keys_from(rng.integers(0, n2 // 2, n2))
+    v2 = [(rng.integers(0, 3, n2).astype(np.float64), None, O.F64)]
+    check(ctx, [(k2, None, O.I64)], n2, v2, [(0, O.MEDIAN), (0, O.NUNIQUE)], [O.I64], exact=[0, 1])
 
 
 def test_nunique_edge_cases_and_frame_shortcut(ctx):
