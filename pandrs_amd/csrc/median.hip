@@ -486,7 +486,8 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
         hipLaunchKernelGGL(fill_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end, 0ull);
         SortTiles tiles;
         ST_TRY(segmented_sort_u64(c, pk, pv, part.offsets, part.NB, (uint32_t)P + 1, nv, kind == 0 ? 1 : 2, only, &tiles));
-        if (mode == 1)
+        if (tiles.max_tasks == 0) { /* every partition was finished by the fast path */ }
+        else if (mode == 1)
             hipLaunchKernelGGL(nunique_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
                                tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
         else

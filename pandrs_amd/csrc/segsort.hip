@@ -165,7 +165,7 @@ size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_byte
 }
 
 // Sorts partitions [0, n_parts) of (keys, pay), described by `offsets` (PartInfo layout), in place.
-// Workspace comes from c->work (not reset here).  Synchronises the stream once.
+// Workspace comes from c->work (not reset here).  Synchronises the stream once (after the task list is built).
 template <typename PT>
 static int32_t segsort_impl(pandrs_hip_ctx *c, uint64_t *keys, PT *pay, const uint32_t *offsets, uint32_t NB,
                             uint32_t n_parts, int64_t n_rows, int enc, const uint8_t *only = nullptr, SortTiles *tiles = nullptr) {
@@ -177,19 +177,23 @@ static int32_t segsort_impl(pandrs_hip_ctx *c, uint64_t *keys, PT *pay, const ui
     if (tiles) { tiles->tasks = tasks; tiles->counters = counters; tiles->max_tasks = max_tasks; }
     hipLaunchKernelGGL(build_sort_tasks_kernel, dim3(1), dim3(SS_THREADS), 0, c->stream, offsets, NB, n_parts, only, tasks, max_tasks, counters);
     const size_t lds = (size_t)SS_TILE * (8 + sizeof(PT)) + 64;
+    // the task count first (the one host sync of this function): grids are sized exactly, and a call with
+    // nothing to sort (every partition filtered out) launches nothing more
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n_tasks = h[0], max_tiles = h[1];
+    if (tiles) tiles->max_tasks = n_tasks;
+    if (n_tasks == 0) return 0;
     auto launch_chunk = [&](auto kernel) -> int32_t {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kernel, dim3(max_tasks), dim3(SS_THREADS), lds, c->stream, tasks, counters, keys, pay);
+        hipLaunchKernelGGL(kernel, dim3(n_tasks), dim3(SS_THREADS), lds, c->stream, tasks, counters, keys, pay);
         return 0;
     };
     if (enc == 1) ST_TRY(launch_chunk(chunk_sort_kernel<PT, 1>));
     else if (enc == 2) ST_TRY(launch_chunk(chunk_sort_kernel<PT, 2>));
     else ST_TRY(launch_chunk(chunk_sort_kernel<PT, 0>));
     HIP_TRY(hipGetLastError());
-    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-    HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint32_t n_tasks = h[0], max_tiles = h[1];
     if (max_tiles <= 1) return 0;
     uint64_t *tk = c->work.take<uint64_t>(n_rows + 1);
     PT *tp = c->work.take<PT>(n_rows + 1);
