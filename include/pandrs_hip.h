@@ -171,6 +171,7 @@ int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *ctx, int64_t workspace_bytes);
  *   "scatter_staged" (default 1), "scatter_threads" (1024 / 512), "shared_cursors" (default 1)
  *   "no_direct", "no_slice", "slice_rows", "no_runs", "generic_aggregate"  switch individual code paths off / on
  *   "join_generic"  always build the join with the general segmented sort; "join_one_pass" single-pass probe
+ *   "median_generic" Median / Nunique: always the general segmented-sort pass, never the LDS group-sort path
  * Unknown names are rejected with PANDRS_HIP_ERR_INVALID_ARGUMENT. */
 int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *ctx, const char *name, int64_t value);
 int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
