@@ -124,7 +124,7 @@ size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
 // in place, whatever the partition sizes.  `enc`: 0 = payload compared as is, 1 = f64 bits and
 // 2 = i64 rewritten to their order-preserving u64 encodings (and left encoded).
 int32_t segmented_sort_u32(pandrs_hip_ctx *c, uint64_t *keys, uint32_t *pay, const uint32_t *offsets, uint32_t NB,
-                           uint32_t n_parts, int64_t n_rows);
+                           uint32_t n_parts, int64_t n_rows, const uint8_t *only = nullptr);
 // `only` (optional, device, one byte per partition): sort just the partitions whose byte is non-zero.
 // `tiles` (optional) receives the device task list the sort ran on — one SortTask per SS_TILE-row tile of
 // every sorted partition, `counters[0]` of them, at most `max_tasks` — for kernels that walk the sorted rows.
@@ -145,6 +145,9 @@ size_t segsort_workspace_bytes(int64_t n_rows, uint32_t n_parts, size_t pay_byte
 
 // median.hip: fills aggregate `fin_index` of c->gb with the groups' medians of one value column
 // (kind 0 = f64, 1 = i64); `key` is the key source the engine ran on.
+// median.hip, LDS group-sort path for (key cell, row) partitions: see group_sort_kernel<uint32_t, true>
+int32_t group_order_partitions(pandrs_hip_ctx *c, uint64_t *pk, uint32_t *prow, const uint32_t *offsets, uint32_t NB,
+                               uint32_t P, uint8_t *only);
 // Median and Nunique: no engine state, filled by median_pass (a per-group sort) after the engine run
 inline bool is_sorted_pass_op(int op) { return op == PANDRS_HIP_AGG_MEDIAN || op == PANDRS_HIP_AGG_NUNIQUE; }
 int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const void *vdata, const uint8_t *vnull,

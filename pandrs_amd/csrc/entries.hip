@@ -79,13 +79,25 @@ struct SortedGroups {
 };
 static int32_t build_sorted_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, SortedGroups *o) {
     const size_t ws = engine_workspace_bytes(n_rows, 1, 0) + 3 * Arena::padded(size_t(n_rows + 2) * 4)
-                    + Arena::padded(scan_seg_count((size_t)n_rows + 1) * 4) + segsort_workspace_bytes(n_rows, P_MAX + 2, 4) + (1 << 20);
+                    + Arena::padded(scan_seg_count((size_t)n_rows + 1) * 4) + segsort_workspace_bytes(n_rows, P_MAX + 2, 4) + (size_t(9) << 20);
     ST_TRY(c->work.ensure(ws, c->stream));
     o->pk = c->work.take<uint64_t>(n_rows + 1);
     o->prow = c->work.take<uint32_t>(n_rows + 2); o->flag = c->work.take<uint32_t>(n_rows + 2); o->gid = c->work.take<uint32_t>(n_rows + 2);
     uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)n_rows + 1));
     if (!o->pk || !o->prow || !o->flag || !o->gid || !seg) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (group index)");
-    int64_t P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)n_rows / 4900.0)), P_MAX);
+    // partitions of ~9 K rows: most are grouped and ordered in LDS (group_sort_kernel), the general sort takes the rest
+    // (not with nearly unique keys — more than ~1 K groups per partition overflow the LDS table everywhere: a sampled
+    // estimate decides for large inputs, small ones just try)
+    bool fast = !c->opt.median_generic;
+    if (fast && n_rows >= (int64_t(1) << 21)) {
+        int64_t est = 0;
+        ST_TRY(estimate_groups(c, key, n_rows, &est));
+        const int64_t p_fast = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)n_rows / 9000.0)), P_MAX);
+        fast = (double)est / (double)p_fast <= 1200.0;
+    }
+    int64_t P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)n_rows / (fast ? 9000.0 : 4900.0))), P_MAX);
+    uint8_t *only = fast ? c->work.take<uint8_t>((size_t)P + 16) : nullptr;
+    if (fast && !only) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (group index)");
     PartInfo part{};
     ScatterArgs sa{};
     sa.key = key; sa.pkeys = o->pk; sa.n_rows = n_rows; sa.P = (uint32_t)P; sa.seed = 0x6A09E667u;
@@ -94,8 +106,9 @@ static int32_t build_sorted_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_
     o->null_beg = part.offsets + (size_t)P * part.NB;
     const uint32_t *null_end = part.offsets + (size_t)(P + 1) * part.NB;
     PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+    if (fast) ST_TRY(group_order_partitions(c, o->pk, o->prow, part.offsets, part.NB, (uint32_t)P, only));
     hipLaunchKernelGGL(zero_range_kernel, dim3(256), dim3(256), 0, c->stream, o->pk, o->null_beg, null_end);
-    ST_TRY(segmented_sort_u32(c, o->pk, o->prow, part.offsets, part.NB, (uint32_t)P + 1, n_rows));
+    ST_TRY(segmented_sort_u32(c, o->pk, o->prow, part.offsets, part.NB, (uint32_t)P + 1, n_rows, only));
     hipLaunchKernelGGL(run_start_flags_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
                        o->pk, o->null_beg, (uint32_t)n_rows, o->flag);
     HIP_TRY(hipMemsetAsync(o->flag + n_rows, 0, 8, c->stream));

@@ -189,10 +189,17 @@ __global__ void median_lookup_kernel(const uint64_t *gkeys, const uint8_t *gnull
 constexpr int GS_THREADS = 1024;
 constexpr uint32_t GS_CAP = 15360, GS_SLOTS = 2048, GS_KEYS = 1536, GS_BIG = 1024;
 constexpr int GS_RPT = GS_CAP / GS_THREADS;
-constexpr size_t GS_LDS = size_t(GS_CAP) * 8 + size_t(GS_SLOTS + 2) * 8 + 2 * size_t(GS_SLOTS + 4) * 4 + 64 * 4 + 32 * 4 + 72 * 4 + (GS_SLOTS + 16) * 2;
+constexpr uint32_t GS_PROBES = 192;
+constexpr size_t gs_lds_bytes(size_t value_bytes) {
+    return size_t(GS_CAP) * value_bytes + size_t(GS_SLOTS + 2) * 8 + 2 * size_t(GS_SLOTS + 4) * 4 + 64 * 4 + 32 * 4 + 72 * 4 + (GS_SLOTS + 16) * 2;
+}
+constexpr size_t GS_LDS = gs_lds_bytes(8);
 
 struct GroupSortArgs {
-    const uint64_t *pkeys, *pvals;   // partitioned key cells and raw 8-byte values
+    const uint64_t *pkeys;           // partitioned key cells
+    const void *pvals;               // partitioned payload: raw 8-byte values (reduce modes) or u32 row indices (REORDER)
+    uint64_t *out_keys;              // REORDER: the partition rewritten in place, grouped by key (equal keys
+    uint32_t *out_rows;              //          adjacent, any order between keys), rows ascending inside a key
     const uint32_t *offsets;
     uint32_t NB, P;
     int kind, mode;                  // kind 0 f64 / 1 i64; mode 0 median / 1 distinct count
@@ -203,9 +210,10 @@ struct GroupSortArgs {
 
 // compare-exchange c of one step of the ascending bitonic network over v[0, m): distance 1 << lj; `mask` is
 // the partner distance as an xor mask — 2j - 1 for the first step of a merge (the mirrored partner), j after
-__device__ __forceinline__ void gs_cex(uint64_t *v, uint32_t m, uint32_t lj, uint32_t mask, uint32_t c) {
+template <typename VT>
+__device__ __forceinline__ void gs_cex(VT *v, uint32_t m, uint32_t lj, uint32_t mask, uint32_t c) {
     const uint32_t l = ((c >> lj) << (lj + 1)) | (c & ((1u << lj) - 1)), r = l ^ mask;
-    const uint64_t x = v[l], y = v[min(r, m - 1)];
+    const VT x = v[l], y = v[min(r, m - 1)];
     if (r < m && x > y) { v[l] = y; v[r] = x; }
 }
 
@@ -220,6 +228,10 @@ __device__ __forceinline__ void gs_publish(const GroupSortArgs &a, bool null_par
     }
 }
 
+// VT = uint64_t, REORDER = false: Median / Nunique as described above.  VT = uint32_t, REORDER = true: the payload
+// is the row index; the sorted runs are written back over the partition (key cell of the run, ascending rows) —
+// group_by's own result (entries.hip, build_sorted_groups) without the general sort.
+template <typename VT, bool REORDER>
 __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
     if (n == 0) return;
     if (n > GS_CAP) { if (tid == 0) a.only[p] = 1; return; }
     const bool null_part = p == a.P;
-    uint64_t *lv = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *hk = lv + GS_CAP;                                   // [GS_SLOTS + 1]: the last entry is the key ~0's
+    VT *lv = reinterpret_cast<VT *>(smem);
+    uint64_t *hk = reinterpret_cast<uint64_t *>(lv + GS_CAP);     // [GS_SLOTS + 1]: the last entry is the key ~0's
     uint32_t *hc = reinterpret_cast<uint32_t *>(hk + GS_SLOTS + 2);   // rows per key
     uint32_t *hs = hc + GS_SLOTS + 4;                             // run start, then (after placement) run end
     uint32_t *big = hs + GS_SLOTS + 4;                            // slots of the runs sorted by the whole workgroup
@@ -241,12 +253,13 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
     __syncthreads();
     // 1. count the rows of every key; a thread keeps the slots of its rows.  All of the thread's key and
     // value loads are issued up front (one HBM latency per partition, not one per row).
-    uint64_t kreg[GS_RPT], xreg[GS_RPT];
+    uint64_t kreg[GS_RPT];
+    VT xreg[GS_RPT];
 #pragma unroll
     for (int r = 0; r < GS_RPT; r++) {
         const uint32_t i = min((uint32_t)(r * GS_THREADS) + tid, n - 1);
         kreg[r] = a.pkeys[beg + i];
-        xreg[r] = a.pvals[beg + i];
+        xreg[r] = reinterpret_cast<const VT *>(a.pvals)[beg + i];
     }
     uint32_t sl[GS_RPT];
 #pragma unroll
@@ -255,19 +268,22 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
         sl[r] = 0;
         if (i >= n) continue;
         uint32_t s = 0;
-        if (!null_part) {
+        if (!null_part && !wt[20]) {
             const uint64_t k = kreg[r];
             s = GS_SLOTS;
             if (k != EMPTY_KEY) {
                 s = hash32(k, 0x68E31DA4u) & (GS_SLOTS - 1);
+                // (probe chains are short at <= 75 % load; a long one means the partition has too many keys: give
+                // up at once — and stop every other thread's search — instead of walking a full table per row)
                 uint32_t probes = 0;
-                for (; probes < GS_SLOTS; probes++) {
+                for (; probes < GS_PROBES; probes++) {
                     const uint64_t old = atomicCAS((unsigned long long *)&hk[s], EMPTY_KEY, k);
                     if (old == EMPTY_KEY) { if (atomicAdd(&wt[21], 1u) >= GS_KEYS) wt[20] = 1; break; }
                     if (old == k) break;
+                    if ((probes & 7) == 7 && wt[20]) { probes = GS_PROBES; break; }
                     s = (s + 1) & (GS_SLOTS - 1);
                 }
-                if (probes == GS_SLOTS) { wt[20] = 1; s = 0; }
+                if (probes >= GS_PROBES) { wt[20] = 1; s = 0; }
             }
         }
         sl[r] = s;
@@ -295,16 +311,17 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
     for (int r = 0; r < GS_RPT; r++) {
         const uint32_t i = r * GS_THREADS + tid;
         if (i >= n) continue;
-        const uint64_t x = xreg[r];
+        const VT x = xreg[r];
         const uint32_t pos = atomicAdd(&hs[sl[r]], 1u);
-        lv[pos] = a.kind == 0 ? enc_f64(__longlong_as_double((long long)x)) : enc_i64((int64_t)x);
+        if constexpr (REORDER) lv[pos] = x;
+        else lv[pos] = a.kind == 0 ? enc_f64(__longlong_as_double((long long)x)) : enc_i64((int64_t)x);
     }
     __syncthreads();
     // 4a. the few long runs: the whole workgroup sorts each
     const uint32_t n_big = wt[22];
     for (uint32_t b = 0; b < n_big; b++) {
         const uint32_t s = big[b], m = hc[s];
-        uint64_t *v = lv + (hs[s] - m);
+        VT *v = lv + (hs[s] - m);
         uint32_t lm = 1;
         while ((1u << lm) < m) lm++;
         for (uint32_t lk = 1; lk <= lm; lk++) {
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
                     const uint32_t mask = lj + 1 == (int)lk ? (2u << lj) - 1 : 1u << lj;
                     for (uint32_t c = lane; c < (1u << (lm - 1)); c += 64) {
                         const uint32_t l = ((c >> lj) << (lj + 1)) | (c & ((1u << lj) - 1)), rr = l ^ mask;
-                        uint64_t x[GS_ILP], y[GS_ILP];
+                        VT x[GS_ILP], y[GS_ILP];
                         bool live[GS_ILP];
 #pragma unroll
                         for (int r = 0; r < GS_ILP; r++) {          // all loads first: independent, in flight together
@@ -365,7 +382,15 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
             for (int r = 0; r < GS_ILP; r++) {
                 const uint32_t m = rm[r];
                 if (m == 0) continue;
-                const uint64_t *v = lv + rbase[r];
+                const VT *v = lv + rbase[r];
+                if constexpr (REORDER) {
+                    const uint64_t key = null_part ? 0ull : (rslot[r] == GS_SLOTS ? EMPTY_KEY : hk[rslot[r]]);
+                    for (uint32_t j = lane; j < m; j += 64) {
+                        a.out_keys[beg + rbase[r] + j] = key;
+                        a.out_rows[beg + rbase[r] + j] = (uint32_t)v[j];
+                    }
+                    continue;
+                }
                 double out;
                 if (a.mode == 0) {
                     const uint32_t mid = m >> 1;
@@ -396,6 +421,7 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (REORDER) return;
     __syncthreads();
     for (uint32_t s = tid; s < GS_SLOTS + 1; s += GS_THREADS) {
         if (!((occ[s >> 5] >> (s & 31)) & 1u)) continue;
@@ -477,9 +503,9 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
             GroupSortArgs ga{};
             ga.pkeys = pk; ga.pvals = pv; ga.offsets = part.offsets; ga.NB = part.NB; ga.P = (uint32_t)P;
             ga.kind = kind; ga.mode = mode; ga.table = table; ga.table_mask = cap_tab - 1; ga.only = only;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel<uint64_t, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS));
-            hipLaunchKernelGGL(group_sort_kernel, dim3((unsigned)P + 1), dim3(GS_THREADS), GS_LDS, c->stream, ga);
+            hipLaunchKernelGGL((group_sort_kernel<uint64_t, false>), dim3((unsigned)P + 1), dim3(GS_THREADS), GS_LDS, c->stream, ga);
             HIP_TRY(hipGetLastError());
         }
         // general path (every partition, or only the flagged ones): sort by (key, value code), walk the runs
@@ -497,6 +523,22 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     }
     hipLaunchKernelGGL(median_lookup_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,
                        res.keys, res.key_null, G, table, cap_tab - 1, res.aggs + (size_t)fin_index * res.cap, mode);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// group_by's own result (entries.hip): rewrites every partition that fits LDS in place, grouped by key with the
+// rows of a key ascending; `only[p]` (zeroed here) is set for the partitions left to the general sort.
+int32_t group_order_partitions(pandrs_hip_ctx *c, uint64_t *pk, uint32_t *prow, const uint32_t *offsets, uint32_t NB,
+                               uint32_t P, uint8_t *only) {
+    HIP_TRY(hipMemsetAsync(only, 0, (size_t)P + 16, c->stream));
+    GroupSortArgs ga{};
+    ga.pkeys = pk; ga.pvals = prow; ga.out_keys = pk; ga.out_rows = prow;
+    ga.offsets = offsets; ga.NB = NB; ga.P = P; ga.only = only;
+    const size_t lds = gs_lds_bytes(4);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel<uint32_t, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((group_sort_kernel<uint32_t, true>), dim3(P + 1), dim3(GS_THREADS), lds, c->stream, ga);
     HIP_TRY(hipGetLastError());
     return 0;
 }

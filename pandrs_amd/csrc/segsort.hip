@@ -212,8 +212,8 @@ static int32_t segsort_impl(pandrs_hip_ctx *c, uint64_t *keys, PT *pay, const ui
 }
 
 int32_t segmented_sort_u32(pandrs_hip_ctx *c, uint64_t *keys, uint32_t *pay, const uint32_t *offsets, uint32_t NB,
-                           uint32_t n_parts, int64_t n_rows) {
-    return segsort_impl<uint32_t>(c, keys, pay, offsets, NB, n_parts, n_rows, 0);
+                           uint32_t n_parts, int64_t n_rows, const uint8_t *only) {
+    return segsort_impl<uint32_t>(c, keys, pay, offsets, NB, n_parts, n_rows, 0, only);
 }
 int32_t segmented_sort_u64(pandrs_hip_ctx *c, uint64_t *keys, uint64_t *pay, const uint32_t *offsets, uint32_t NB,
                            uint32_t n_parts, int64_t n_rows, int enc, const uint8_t *only, SortTiles *tiles) {
