@@ -76,17 +76,28 @@ __global__ __launch_bounds__(SS_THREADS) void chunk_sort_kernel(const SortTask *
         sk[i] = k; sp[i] = p;
     }
     __syncthreads();
-    for (uint32_t k = 2; k <= n2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < n2; i += SS_THREADS) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const uint64_t ka = sk[i], kb = sk[x];
-                    const PT pa = sp[i], pb = sp[x];
-                    const bool gt = !pair_le<PT>(ka, pa, kb, pb);
-                    const bool up = (i & k) == 0;
-                    if (gt == up) { sk[i] = kb; sk[x] = ka; sp[i] = pb; sp[x] = pa; }
-                }
+    // every thread owns SS_CPT compare-exchanges per step (indexed by CE, so no thread idles on the upper half of
+    // a pair) and issues all of their LDS reads before the first compare: the step is LDS-latency bound otherwise
+    constexpr int SS_CPT = SS_TILE / 2 / SS_THREADS;
+    for (uint32_t k = 2, lk = 1; k <= n2; k <<= 1, lk++) {
+        for (int lj = (int)lk - 1; lj >= 0; lj--) {
+            const uint32_t j = 1u << lj;
+            uint32_t l[SS_CPT];
+            uint64_t ka[SS_CPT], kb[SS_CPT];
+            PT pa[SS_CPT], pb[SS_CPT];
+#pragma unroll
+            for (int q = 0; q < SS_CPT; q++) {
+                const uint32_t c = min((uint32_t)(q * SS_THREADS) + threadIdx.x, (n2 >> 1) - 1);
+                l[q] = ((c >> lj) << (lj + 1)) | (c & (j - 1));
+                ka[q] = sk[l[q]]; kb[q] = sk[l[q] + j];
+                pa[q] = sp[l[q]]; pb[q] = sp[l[q] + j];
+            }
+#pragma unroll
+            for (int q = 0; q < SS_CPT; q++) {
+                if ((uint32_t)(q * SS_THREADS) + threadIdx.x >= (n2 >> 1)) continue;
+                const bool gt = !pair_le<PT>(ka[q], pa[q], kb[q], pb[q]);
+                const bool up = (l[q] & k) == 0;
+                if (gt == up) { sk[l[q]] = kb[q]; sk[l[q] + j] = ka[q]; sp[l[q]] = pb[q]; sp[l[q] + j] = pa[q]; }
             }
             __syncthreads();
         }
