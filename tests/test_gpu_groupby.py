@@ -215,6 +215,23 @@ def test_mid_cardinality_takes_few_sliced_partitions(ctx, skew):
     assert 16 <= t["n_partitions"] <= 64, t["n_partitions"]
 
 
+def test_mid_cardinality_sliced_partitions_with_null_keys_and_a_hot_key(ctx):
+    """The same rule on sparse i64 keys with 3 % NULL keys (their own partition), the table-sentinel key, one key on
+    30 % of the rows (its partition is sliced again by the hot-key rule) and wrapping i64 sums."""
+    rng = np.random.default_rng(1234)
+    n, g = 16_800_000, 20_000
+    ids = rng.integers(0, g, n)
+    ids[rng.random(n) < 0.3] = 11
+    k = sparse_keys_from(ids)
+    k[ids == 12] = -1
+    keys = [(k, O.pack_mask(rng.random(n) < 0.03), O.I64)]
+    vals = [(rng.integers(-2**62, 2**62, n).astype(np.int64), None, O.I64),
+            (rng.normal(0, 1e6, n), O.pack_mask(rng.random(n) < 0.5), O.F64)]
+    aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (1, O.SUM), (1, O.MEAN), (1, O.MIN), (1, O.MAX), (1, O.COUNT)]
+    check(ctx, keys, n, vals, aggs, [O.I64], exact=[0, 1, 2, 5, 6, 7])
+    assert 16 <= ctx.timings()["n_partitions"] <= 64
+
+
 def test_two_level_for_huge_cardinality(ctx):
     """More groups than one radix level holds (forced here with a small partition cap): rows are
     split by an independent hash into super-partitions, the engine runs per super-partition and the
