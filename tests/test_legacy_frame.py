@@ -1,0 +1,154 @@
+"""The legacy string-typed frame's groupby through the engine (pandrs_amd/legacy.py):
+the reference's known answers for this API plus a literal restatement of src/dataframe/groupby.rs:188-212 and
+:444-530 (string keys, per-group re-parse of the cells) as the checker."""
+import math
+
+import numpy as np
+import pytest
+
+from pandrs_amd.legacy import AggFunc, ColumnAggBuilder, DataFrame, InvalidValue, NamedAgg, parse_f64_cells
+from pandrs_amd.frame import ColumnNotFound, rust_f64_to_string
+
+
+def legacy_restatement(df, by, column, func, custom=None):
+    """{key tuple: f64} exactly as DataFrameGroupBy::new + calculate_aggregation compute it (host loops)."""
+    groups = {}
+    cols = [df.get_column_string_values(c) for c in by]
+    for i in range(df.row_count()):
+        groups.setdefault(tuple(c[i] for c in cols), []).append(i)           # :199-211
+    cells = df.get_column_string_values(column)
+    vals, ok = parse_f64_cells(cells)
+    out = {}
+    for key, idx in groups.items():
+        gv = [float(vals[i]) for i in idx if ok[i]]                           # :452-463
+        if not gv:
+            out[key] = 0.0                                                   # :465-467
+            continue
+        n = len(gv)
+        if func == AggFunc.Sum:
+            s = 0.0
+            for x in gv:
+                s += x
+            r = s
+        elif func == AggFunc.Mean:
+            s = 0.0
+            for x in gv:
+                s += x
+            r = s / n
+        elif func == AggFunc.Min:
+            r = math.inf
+            for x in gv:
+                r = x if (x < r or math.isnan(r)) and not math.isnan(x) else r       # f64::min ignores NaN
+        elif func == AggFunc.Max:
+            r = -math.inf
+            for x in gv:
+                r = x if (x > r or math.isnan(r)) and not math.isnan(x) else r
+        elif func == AggFunc.Count:
+            r = float(n)
+        elif func in (AggFunc.Std, AggFunc.Var):
+            if n <= 1:
+                r = 0.0
+            else:
+                mean = sum(gv) / n
+                var = sum((x - mean) ** 2 for x in gv) / (n - 1)
+                r = math.sqrt(var) if func == AggFunc.Std else var
+        elif func == AggFunc.Median:
+            sv = sorted(gv)
+            r = (sv[n // 2 - 1] + sv[n // 2]) / 2.0 if n % 2 == 0 else sv[n // 2]
+        elif func == AggFunc.First:
+            r = gv[0]
+        elif func == AggFunc.Last:
+            r = gv[-1]
+        elif func == AggFunc.Nunique:
+            r = float(len(set(gv)))
+        else:
+            r = float(custom(gv))
+        out[key] = r
+    return out
+
+
+def test_rust_float_grammar_and_type_inference():
+    vals, ok = parse_f64_cells(["1", "-2.5", "+3e2", ".5", "7.", "inf", "-Infinity", "NaN", "", " 1", "1_0", "0x10", "abc", "1e", "e5"])
+    assert ok.tolist() == [True] * 8 + [False] * 7
+    assert vals[:7].tolist() == [1.0, -2.5, 300.0, 0.5, 7.0, math.inf, -math.inf] and math.isnan(vals[7])
+    df = DataFrame()
+    df.add_column("i", ["1", "", "-3"])              # src/optimized/convert.rs:31-45: all i64 (empty => 0)
+    df.add_column("f", ["1.5", "", "2"])             # :48-61
+    df.add_column("b", ["TRUE", "0", ""])            # :64-83
+    df.add_column("s", ["x", "1", "true"])           # :86
+    df.add_column("n", [1.5, 2, True])               # numbers are stringified the way Rust prints them
+    assert df.get_column_string_values("n") == ["1.5", "2", "true"]
+    o = df.to_optimized()
+    assert [type(c).__name__ for c in o.columns] == ["Int64Column", "Float64Column", "BooleanColumn", "StringColumn", "StringColumn"]
+    assert o.column("i").data.tolist() == [1, 0, -3] and o.column("f").data.tolist() == [1.5, 0.0, 2.0]
+    assert [o.column("b").get(i) for i in range(3)] == [True, False, False]
+    with pytest.raises(ColumnNotFound):
+        df.groupby(["nope"])                          # groupby.rs:185-190
+    assert AggFunc.Nunique.as_str() == "nunique" and [a.alias for a in ColumnAggBuilder("v").agg(AggFunc.Sum, "t").agg(AggFunc.Max, "m").build()] == ["t", "m"]
+
+
+@pytest.mark.gpu
+def test_reference_known_answers_through_the_legacy_api(golden):
+    for case in golden["groupby"]:
+        if "key_strings" not in case or "value_nulls" in case:
+            continue
+        df = DataFrame()
+        df.add_column("k", case["key_strings"])
+        df.add_column("v", case.get("values_i64", case.get("values_f64")))
+        gb = df.groupby(["k"])
+        funcs = sorted({f for e in case["expect"].values() for f in e})
+        res = gb.agg([NamedAgg("v", AggFunc[f.capitalize()], "v_" + f) for f in funcs])
+        keys = res.get_column_string_values("k")
+        for f in funcs:
+            got = dict(zip(keys, (float(x) for x in res.get_column_string_values("v_" + f))))
+            for k, e in case["expect"].items():
+                if f in e:
+                    assert got[k] == pytest.approx(e[f], rel=1e-12), (case["cite"], k, f)
+
+
+@pytest.mark.gpu
+def test_every_aggfunc_against_the_literal_restatement():
+    rng = np.random.default_rng(31)
+    n = 30_000
+    k1 = rng.choice(["north", "south", "east", "west", ""], n).tolist()
+    k2 = rng.integers(0, 40, n).tolist()
+    cells = [rust_f64_to_string(float(x)) for x in np.round(rng.normal(50, 20, n), 1)]
+    for i in rng.choice(n, n // 10, replace=False):
+        cells[i] = rng.choice(["", "n/a", "1_000", " 7", "NaN"])                 # unparseable cells (and NaN, which parses)
+    for i in range(n):
+        if k2[i] == 7:
+            cells[i] = "missing"                                              # groups without a single parseable cell
+    df = DataFrame()
+    df.add_column("region", k1)
+    df.add_column("shop", k2)
+    df.add_column("amount", cells)
+    gb = df.groupby(["region", "shop"])
+    assert gb.ngroups() == len({(a, str(b)) for a, b in zip(k1, k2)})
+    sizes = gb.size()
+    assert sum(int(s) for s in sizes.get_column_string_values("size")) == n and "_" in sizes.get_column_string_values("group")[0]
+    funcs = [f for f in AggFunc if f not in (AggFunc.Custom, AggFunc.Median, AggFunc.Min, AggFunc.Max)]   # (NaN cells: see below)
+    res = gb.agg([NamedAgg("amount", f, f.as_str()) for f in funcs] + [NamedAgg.custom("amount", "span", lambda v: max(v) - min(v))])
+    assert res.column_names == ["region", "shop"] + [f.as_str() for f in funcs] + ["span"]
+    keys = list(zip(res.get_column_string_values("region"), res.get_column_string_values("shop")))
+    for f in funcs:
+        want = legacy_restatement(df, ["region", "shop"], "amount", f)
+        got = dict(zip(keys, (float(x) for x in res.get_column_string_values(f.as_str()))))
+        assert got.keys() == want.keys()
+        for key in want:
+            w, g = want[key], got[key]
+            assert (math.isnan(w) and math.isnan(g)) or g == pytest.approx(w, rel=1e-9, abs=1e-9), (f, key, g, w)
+    # Min / Max / Median on a NaN-free column (the reference's sort leaves NaN positions unspecified; its folds skip them)
+    clean = DataFrame()
+    clean.add_column("region", k1)
+    clean.add_column("amount", [c if c != "NaN" else "" for c in cells])
+    gb2 = clean.groupby_single("region")
+    for f in (AggFunc.Min, AggFunc.Max, AggFunc.Median, AggFunc.First, AggFunc.Last, AggFunc.Nunique):
+        r = getattr(gb2, f.as_str())("amount") if hasattr(gb2, f.as_str()) else gb2.agg([NamedAgg("amount", f, "amount_" + f.as_str())])
+        got = dict(zip(r.get_column_string_values("region"), (float(x) for x in r.get_column_string_values("amount_" + f.as_str()))))
+        want = legacy_restatement(clean, ["region"], "amount", f)
+        assert got == {k[0]: pytest.approx(v, rel=1e-12) for k, v in want.items()}, f
+    # closures and sub-frames
+    big = gb2.filter(lambda g: g.row_count() > n // 6)
+    assert big.row_count() == sum(c for c in (k1.count(r) for r in set(k1)) if c > n // 6)
+    with pytest.raises(InvalidValue):
+        gb2.agg([])
