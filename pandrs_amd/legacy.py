@@ -1,4 +1,4 @@
-"""The legacy string-typed frame's groupby on the device.
+"""The legacy string-typed frame's groupby and merge on the device.
 
 `src/dataframe/groupby.rs` groups a `DataFrame` of stringified cells on `Vec<String>` keys (:188-212) and, for
 every aggregate of every group, re-parses the group's cells with `parse::<f64>()` (:444-463): cells that do
@@ -328,3 +328,70 @@ class DataFrameGroupBy:
             for name in parts[0].column_names:
                 out.add_column(name, [c for p in parts for c in p.get_column_string_values(name)])
         return out
+
+
+# ------------------------------------------------------------------------------------------------- merge
+class JoinType(IntEnum):             # src/dataframe/pandas_compat/merge.rs:11-20 (same order as the engine's)
+    Inner = 0
+    Left = 1
+    Right = 2
+    Outer = 3
+
+
+def _numeric_column(df, name):
+    """get_column_numeric_values (src/dataframe/base.rs:542-…): the column as f64, or None unless EVERY cell parses."""
+    vals, ok = parse_f64_cells(df.get_column_string_values(name))
+    return vals if ok.all() else None
+
+
+def merge(left, right, on, how, suffixes=("_x", "_y")):
+    """pandas_compat::merge (src/dataframe/pandas_compat/merge.rs:34-265) with the match pairs from
+    pandrs_hip_join_indices: the build side is the right frame, left rows in order, a left row's matches in right
+    order, unmatched left rows for Left / Outer, unmatched right rows appended for Right / Outer (:70-118) — the
+    order contract of the optimized join, and these frames hold no nulls.  Numeric join columns compare by
+    `f64::to_bits` (:56-59): the bit patterns are joined as i64 cells, so -0.0 != 0.0 and NaN payloads count;
+    anything else compares as strings (pool codes).  A missing side is NaN in numeric columns and "" in string
+    columns (:150, :172); overlapping non-key columns get the suffixes, left then right (:128-133, :236-262)."""
+    for side, df in (("left", left), ("right", right)):
+        if not df.contains_column(on):
+            raise InvalidValue("Join column '%s' not found in %s DataFrame" % (on, side))
+    ln, rn = _numeric_column(left, on), _numeric_column(right, on)
+    if ln is not None and rn is not None:
+        lk, rk = (ln.view(np.int64), None, L.I64), (rn.view(np.int64), None, L.I64)
+    else:                                            # the reference's join strings: the bits as decimal text, or the cell
+        def join_strings(df, num):
+            return [str(int(b)) for b in num.view(np.uint64)] if num is not None else df.get_column_string_values(on)
+
+        def codes(strs):
+            return (np.fromiter((GLOBAL_STRING_POOL.get_or_insert(s) for s in strs), dtype=np.uint32, count=len(strs)), None, L.U32CODE)
+        lk, rk = codes(join_strings(left, ln)), codes(join_strings(right, rn))
+    li, ri = get_context().join_indices(lk, left.row_count(), rk, right.row_count(), int(how))
+    li, ri = np.asarray(li), np.asarray(ri)
+
+    def take(df, name, idx, other=None, other_idx=None):
+        num = _numeric_column(df, name)
+        miss = idx < 0
+        if num is not None:
+            out = np.where(miss, np.nan, num[np.where(miss, 0, idx)]) if len(num) else np.full(len(idx), np.nan)
+            if other is not None:                     # the join key: the right value where the left row is missing
+                onum = _numeric_column(other, name)
+                if onum is not None and len(onum):
+                    out = np.where(miss & (other_idx >= 0), onum[np.where(other_idx < 0, 0, other_idx)], out)
+            return [rust_f64_to_string(float(x)) for x in out]
+        cells = df.get_column_string_values(name)
+        out = ["" if i < 0 else cells[i] for i in idx.tolist()]
+        if other is not None:
+            ocells = other.get_column_string_values(name)
+            out = [ocells[j] if (i < 0 <= j) else c for c, i, j in zip(out, idx.tolist(), other_idx.tolist())]
+        return out
+
+    overlapping = [c for c in right.column_names if c != on and c in left.column_names]
+    result = DataFrame()
+    for name in left.column_names:
+        new = name + suffixes[0] if name in overlapping else name
+        result.add_column(new, take(left, name, li, right, ri) if name == on else take(left, name, li))
+    for name in right.column_names:
+        if name == on:
+            continue
+        result.add_column(name + suffixes[1] if name in overlapping else name, take(right, name, ri))
+    return result
