@@ -11,6 +11,7 @@ n, g = int(os.environ.get("ROWS", 100_000_000)), int(os.environ.get("GROUPS", 1_
 k = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64) * -7046029254386353131
 v = torch.randn(n, device=d, generator=gen, dtype=torch.float64)
 op = pa.NUNIQUE if os.environ.get("OP") == "nunique" else pa.MEDIAN
+ctx.set_option("median_generic", int(os.environ.get("GENERIC", "0")))
 for i in range(3):
     ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, op)])
     t = ctx.timings()

@@ -371,6 +371,29 @@ def test_sort_based_aggregates_fast_path_shapes(ctx):
     check(ctx, [(k2, None, O.I64)], n2, v2, [(0, O.MEDIAN), (0, O.NUNIQUE)], [O.I64], exact=[0, 1])
 
 
+@pytest.mark.parametrize("g", [1, 7, 60])
+def test_median_of_few_huge_groups_takes_the_selection_path(ctx, g):
+    """Low-cardinality keys: a group is far larger than an LDS partition and sits alone in its hash partition —
+    single_key_median_kernel (radix select, no sort); with 60 keys some partitions hold two keys and stay on the
+    general path.  Constant and two-valued columns (every lane in one histogram bin), a masked i64 column, a
+    large NULL-key group, odd and even group sizes."""
+    rng = np.random.default_rng(900 + g)
+    n = 2_500_001
+    ids = rng.integers(0, g, n)
+    keys = [(sparse_keys_from(ids), O.pack_mask(rng.random(n) < 0.15), O.I64)]
+    vals = [(np.round(rng.normal(0, 1000, n), 2) + 0.0, None, O.F64),
+            (rng.integers(-2**62, 2**62, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.3), O.I64),
+            (np.full(n, 42.5), None, O.F64),
+            ((rng.random(n) < 0.5).astype(np.int64) * 7, None, O.I64)]
+    aggs = [(0, O.MEDIAN), (1, O.MEDIAN), (2, O.MEDIAN), (3, O.MEDIAN), (0, O.COUNT), (0, O.NUNIQUE)]
+    for generic in (0, 1):
+        ctx.set_option("median_generic", generic)
+        try:
+            check(ctx, keys, n, vals, aggs, [O.I64], exact=[0, 1, 2, 3, 4, 5])
+        finally:
+            ctx.set_option("median_generic", 0)
+
+
 def test_nunique_edge_cases_and_frame_shortcut(ctx):
     key = (np.array([1, 1, 1, 1, 2, 2, 3, 3, 3], np.int64), None, O.I64)
     vf = (np.array([2.5, 2.5, -0.0, 0.0, 7.0, 0.0, np.nan, np.nan, 1.0]), O.pack_mask([0, 0, 0, 0, 1, 1, 0, 0, 0]), O.F64)
