@@ -8,7 +8,7 @@ d = "cuda:0"
 ctx = pa.Context(0)
 gen = torch.Generator(device=d); gen.manual_seed(7)
 n = int(os.environ.get("ROWS", 100_000_000))
-for g in (1, 3, 50, 1000):
+for g in (1, 3, 50, 400, 1000, 3000):
     ids = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64)
     k = ids * -7046029254386353131
     v = torch.randn(n, device=d, generator=gen, dtype=torch.float64)

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(GS_THREADS) void group_sort_kernel(GroupSortArgs a)
 // whose lanes all hit one bin (constant or clustered columns) adds its population count once — 64 same-address
 // LDS atomics would serialise.  The partition's flag is cleared; partitions with several keys keep it.
 constexpr int SK_THREADS = 1024, SK_BINS = 2048;
-constexpr uint32_t SK_MAX_ROWS = 1u << 20;
+constexpr uint32_t SK_MAX_ROWS = 1u << 16;
 __global__ __launch_bounds__(SK_THREADS) void single_key_median_kernel(GroupSortArgs a) {
     __shared__ uint32_t hist[SK_BINS];
     __shared__ uint32_t wt[20];
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(SK_THREADS) void single_key_median_kernel(GroupSort
     const uint32_t p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     if (!a.only[p]) return;
     const uint32_t beg = a.offsets[(size_t)p * a.NB], end = a.offsets[(size_t)(p + 1) * a.NB], n = end - beg;
-    // one workgroup streams the partition 7-13 times: worth it up to ~1 M rows (100 M rows in ONE group measured
-    // 707 ms this way against 31 ms for the sort); larger partitions stay with the general path
+    // one workgroup streams the partition 7-13 times: only for partitions a single tile of the chip-wide selection
+    // below would cover anyway (100 M rows in ONE group measured 707 ms this way, 3.6 ms spread over the chip)
     if (n == 0 || n > SK_MAX_ROWS) return;
     const bool null_part = p == a.P;
     const uint64_t k0 = a.pkeys[beg];
@@ -514,6 +514,174 @@ __global__ __launch_bounds__(SK_THREADS) void single_key_median_kernel(GroupSort
     }
 }
 
+// ---- the same selection for single-key partitions of MORE than SK_MAX_ROWS rows, spread over the chip ---------
+// (one group holding a large share of 100 M rows: one workgroup would stream it for 700 ms).  The flagged big
+// partitions are cut into tiles of SEL_TILE rows; per pass every tile's workgroup histograms its rows that still
+// match the partition's prefix (LDS, then its non-empty bins into the partition's global histogram), and one
+// workgroup per partition picks the bin holding the wanted rank.  Six (histogram, pick) launches find the upper
+// middle; the lower middle of an even count is the same code when an equal element ranks below it (the final
+// rank inside the code's run is >= 1), otherwise the largest code below — one more pass (atomicMax).  No host
+// round trip: every kernel is launched for the worst-case grid and exits on the device-side counts.
+constexpr uint32_t SEL_TILE = 1u << 16;
+struct SelTask { uint32_t pbeg, pend, tile, idx; };
+struct SelState {
+    unsigned long long prefix, hi, key;
+    uint32_t rank, n, active, multi, part, need_lo, pad0, pad1;
+};
+struct SelArgs {
+    const uint64_t *pkeys, *pvals;
+    const uint32_t *offsets;
+    uint32_t NB, P;
+    int kind, pass;
+    MedianEntry *table;
+    uint32_t table_mask;
+    uint8_t *only;
+    SelTask *tasks;
+    uint32_t *counters;                 // [0] tasks, [1] big partitions
+    SelState *st;
+    uint32_t *hist;                     // [max_big][SK_BINS], zero between passes
+    unsigned long long *maxbelow;       // [max_big]
+    uint32_t max_tasks, max_big;
+};
+__device__ __forceinline__ uint64_t sel_code(const SelArgs &a, uint32_t row) {
+    const uint64_t x = a.pvals[row];
+    return a.kind == 0 ? enc_f64(__longlong_as_double((long long)x)) : enc_i64((int64_t)x);
+}
+// one workgroup: the big flagged partitions get a dense index, a state and their tile tasks
+__global__ __launch_bounds__(SK_THREADS) void sel_init_kernel(SelArgs a) {
+    __shared__ uint32_t wt[17];
+    uint32_t task_carry = 0, big_carry = 0;
+    for (uint32_t base = 0; base < a.P + 1; base += SK_THREADS) {
+        const uint32_t p = base + threadIdx.x;
+        uint32_t beg = 0, end = 0;
+        bool big = false;
+        if (p <= a.P && a.only[p]) {
+            beg = a.offsets[(size_t)p * a.NB]; end = a.offsets[(size_t)(p + 1) * a.NB];
+            big = end - beg > SK_MAX_ROWS;
+        }
+        const uint32_t nt = big ? (end - beg + SEL_TILE - 1) / SEL_TILE : 0u;
+        uint32_t tot_t, tot_b;
+        const uint32_t ex_t = block_exclusive_scan<SK_THREADS>(nt, wt, &tot_t);
+        __syncthreads();
+        const uint32_t ex_b = block_exclusive_scan<SK_THREADS>(big ? 1u : 0u, wt, &tot_b);
+        __syncthreads();
+        const uint32_t idx = big_carry + ex_b;
+        if (big && idx < a.max_big) {
+            SelState s{};
+            s.n = end - beg; s.rank = s.n >> 1; s.active = 1; s.part = p; s.key = a.pkeys[beg];
+            a.st[idx] = s;
+            for (uint32_t t = 0; t < nt; t++)
+                if (task_carry + ex_t + t < a.max_tasks) a.tasks[task_carry + ex_t + t] = SelTask{beg, end, t, idx};
+        }
+        task_carry += tot_t; big_carry += tot_b;
+    }
+    if (threadIdx.x == 0) { a.counters[0] = min(task_carry, a.max_tasks); a.counters[1] = min(big_carry, a.max_big); }
+}
+// a tile whose keys are not all the partition's first key marks the partition (the NULL group is one group anyway)
+__global__ __launch_bounds__(SK_THREADS) void sel_multi_kernel(SelArgs a) {
+    if (blockIdx.x >= a.counters[0]) return;
+    const SelTask t = a.tasks[blockIdx.x];
+    if (a.st[t.idx].part == a.P) return;
+    const uint64_t k0 = a.st[t.idx].key;
+    const uint32_t b = t.pbeg + t.tile * SEL_TILE, e = min(b + SEL_TILE, t.pend);
+    int diff = 0;
+    for (uint32_t i = b + threadIdx.x; i < e; i += SK_THREADS) diff |= a.pkeys[i] != k0 ? 1 : 0;
+    if (__syncthreads_or(diff) && threadIdx.x == 0) a.st[t.idx].multi = 1;
+}
+__global__ __launch_bounds__(SK_THREADS) void sel_hist_kernel(SelArgs a) {
+    __shared__ uint32_t hist[SK_BINS];
+    if (blockIdx.x >= a.counters[0]) return;
+    const SelTask t = a.tasks[blockIdx.x];
+    const SelState S = a.st[t.idx];
+    if (S.multi || !S.active) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const int bits = a.pass < 5 ? 11 : 9, shift = 64 - 11 * a.pass - bits;
+    for (uint32_t bb = tid; bb < SK_BINS; bb += SK_THREADS) hist[bb] = 0;
+    __syncthreads();
+    const uint32_t b = t.pbeg + t.tile * SEL_TILE, e = min(b + SEL_TILE, t.pend);
+    for (uint32_t i0 = b; i0 < e; i0 += SK_THREADS) {                // uniform trip count: the ballots need every lane
+        const uint32_t i = i0 + tid;
+        bool in = i < e;
+        uint32_t bin = 0;
+        if (in) {
+            const uint64_t c = sel_code(a, i);
+            in = a.pass == 0 || (c >> (shift + bits)) == (S.prefix >> (shift + bits));
+            bin = (uint32_t)(c >> shift) & ((1u << bits) - 1);
+        }
+        const unsigned long long act = __ballot(in);
+        if (!act) continue;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(act));
+        if (__ballot(in && bin == first) == act) {
+            if (lane == (uint32_t)__builtin_ctzll(act)) atomicAdd(&hist[first], (uint32_t)__builtin_popcountll(act));
+        } else if (in) atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    uint32_t *g = a.hist + (size_t)t.idx * SK_BINS;
+    for (uint32_t bb = tid; bb < SK_BINS; bb += SK_THREADS)
+        if (hist[bb]) atomicAdd(&g[bb], hist[bb]);
+}
+__global__ __launch_bounds__(SK_THREADS) void sel_pick_kernel(SelArgs a) {
+    __shared__ uint32_t wt[17];
+    __shared__ uint32_t s_bin, s_less;
+    const uint32_t idx = blockIdx.x, tid = threadIdx.x;
+    if (idx >= a.counters[1]) return;
+    SelState S = a.st[idx];
+    if (S.multi || !S.active) return;
+    const int bits = a.pass < 5 ? 11 : 9, shift = 64 - 11 * a.pass - bits;
+    uint32_t *g = a.hist + (size_t)idx * SK_BINS;
+    const uint32_t c0 = g[2 * tid], c1 = g[2 * tid + 1];
+    g[2 * tid] = 0; g[2 * tid + 1] = 0;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<SK_THREADS>(c0 + c1, wt, &tot);
+    if (S.rank >= ex && S.rank < ex + c0) { s_bin = 2 * tid; s_less = ex; }
+    else if (S.rank >= ex + c0 && S.rank < ex + c0 + c1) { s_bin = 2 * tid + 1; s_less = ex + c0; }
+    __syncthreads();
+    if (tid == 0) {
+        S.prefix |= (unsigned long long)s_bin << shift;
+        S.rank -= s_less;
+        if (a.pass == 5) {
+            S.hi = S.prefix;
+            S.active = 0;
+            S.need_lo = (!(S.n & 1) && S.rank == 0) ? 1u : 0u;       // even count and no equal element ranks below the upper middle
+        }
+        a.st[idx] = S;
+    }
+}
+__global__ __launch_bounds__(SK_THREADS) void sel_maxbelow_kernel(SelArgs a) {
+    if (blockIdx.x >= a.counters[0]) return;
+    const SelTask t = a.tasks[blockIdx.x];
+    const SelState S = a.st[t.idx];
+    if (S.multi || !S.need_lo) return;
+    const uint32_t b = t.pbeg + t.tile * SEL_TILE, e = min(b + SEL_TILE, t.pend);
+    unsigned long long m = 0;
+    for (uint32_t i = b + threadIdx.x; i < e; i += SK_THREADS) {
+        const unsigned long long c = sel_code(a, i);
+        if (c < S.hi && c > m) m = c;
+    }
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned long long q = __shfl_xor(m, o, 64); m = q > m ? q : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&a.maxbelow[t.idx], m);
+}
+__global__ void sel_finish_kernel(SelArgs a) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.counters[1]) return;
+    const SelState S = a.st[idx];
+    if (S.multi) return;                                              // several keys: stays flagged for the general path
+    const unsigned long long lo_c = S.need_lo ? a.maxbelow[idx] : S.hi;
+    double med;
+    if (a.kind == 0) {
+        const double hi = dec_f64(S.hi);
+        med = (S.n & 1) ? hi : (dec_f64(lo_c) + hi) / 2.0;                                 // aggregation.rs:715-719
+    } else {
+        const int64_t hi = dec_i64(S.hi);
+        med = (S.n & 1) ? (double)hi                                                       // aggregation.rs:597-601: the add is in i64
+                        : (double)(int64_t)((uint64_t)dec_i64(lo_c) + (uint64_t)hi) / 2.0;
+    }
+    GroupSortArgs ga{};
+    ga.table = a.table; ga.table_mask = a.table_mask;
+    gs_publish(ga, S.part == a.P, S.key, med);
+    a.only[S.part] = 0;
+}
+
 // Fills aggregate `fin_index` of the retained groupby result (c->gb) with the groups' medians of
 // one value column.  `key` is the engine's key source (original column or packed cells), `kind`
 // 0 = f64, 1 = i64.  Uses c->work from scratch (the engine is done with it).
@@ -530,7 +698,8 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     uint32_t cap_tab = 64;
     while ((double)cap_tab < 1.5 * (double)G) cap_tab <<= 1;
     const size_t ws = engine_workspace_bytes(n_rows, 4, 1) + segsort_workspace_bytes(n_rows, P_MAX + 2, 8)
-                    + Arena::padded(size_t(cap_tab + 4) * 16) + (1 << 20);
+                    + Arena::padded(size_t(cap_tab + 4) * 16) + (1 << 20)
+                    + (size_t(n_rows) / SEL_TILE + size_t(n_rows) / SK_MAX_ROWS + 8) * (sizeof(SelTask) + sizeof(SelState) + SK_BINS * 4 + 16) + 8192;
     ST_TRY(c->work.ensure(ws, c->stream));
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     KeyDesc kd = key;
@@ -590,8 +759,35 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel<uint64_t, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS));
             hipLaunchKernelGGL((group_sort_kernel<uint64_t, false>), dim3((unsigned)P + 1), dim3(GS_THREADS), GS_LDS, c->stream, ga);
-            if (mode == 0)      // Median of a flagged partition that holds one key: selection, no sort
+            if (mode == 0) {    // Median of a flagged partition that holds one key: selection, no sort
                 hipLaunchKernelGGL(single_key_median_kernel, dim3((unsigned)P + 1), dim3(SK_THREADS), 0, c->stream, ga);
+                if ((uint64_t)nv > SK_MAX_ROWS) {       // ... and of the ones too large for one workgroup
+                    SelArgs sa2{};
+                    sa2.pkeys = pk; sa2.pvals = pv; sa2.offsets = part.offsets; sa2.NB = part.NB; sa2.P = (uint32_t)P;
+                    sa2.kind = kind; sa2.table = table; sa2.table_mask = cap_tab - 1; sa2.only = only;
+                    sa2.max_big = (uint32_t)((uint64_t)nv / SK_MAX_ROWS + 2);
+                    sa2.max_tasks = (uint32_t)((uint64_t)nv / SEL_TILE + sa2.max_big + 2);
+                    sa2.tasks = c->work.take<SelTask>(sa2.max_tasks);
+                    sa2.counters = c->work.take<uint32_t>(64);
+                    sa2.st = c->work.take<SelState>(sa2.max_big);
+                    sa2.hist = c->work.take<uint32_t>((size_t)sa2.max_big * SK_BINS);
+                    sa2.maxbelow = c->work.take<unsigned long long>(sa2.max_big);
+                    if (!sa2.tasks || !sa2.counters || !sa2.st || !sa2.hist || !sa2.maxbelow)
+                        return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median selection)");
+                    HIP_TRY(hipMemsetAsync(sa2.counters, 0, 256, c->stream));
+                    HIP_TRY(hipMemsetAsync(sa2.hist, 0, (size_t)sa2.max_big * SK_BINS * 4, c->stream));
+                    HIP_TRY(hipMemsetAsync(sa2.maxbelow, 0, (size_t)sa2.max_big * 8, c->stream));
+                    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(SK_THREADS), 0, c->stream, sa2);
+                    hipLaunchKernelGGL(sel_multi_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+                    for (int pass = 0; pass < 6; pass++) {
+                        sa2.pass = pass;
+                        hipLaunchKernelGGL(sel_hist_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+                        hipLaunchKernelGGL(sel_pick_kernel, dim3(sa2.max_big), dim3(SK_THREADS), 0, c->stream, sa2);
+                    }
+                    hipLaunchKernelGGL(sel_maxbelow_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+                    hipLaunchKernelGGL(sel_finish_kernel, dim3((sa2.max_big + 255) / 256), dim3(256), 0, c->stream, sa2);
+                }
+            }
             HIP_TRY(hipGetLastError());
         }
         // general path (every partition, or only the flagged ones): sort by (key, value code), walk the runs
