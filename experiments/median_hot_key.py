@@ -8,7 +8,7 @@ d = "cuda:0"
 ctx = pa.Context(0)
 gen = torch.Generator(device=d); gen.manual_seed(3)
 n, g = 100_000_000, 1_000_000
-for share in (0.0, 0.1, 0.5, 0.9):
+for share in [float(x) for x in os.environ.get("SHARES", "0.0,0.1,0.5,0.9").split(",")]:
     ids = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64)
     ids[torch.rand(n, device=d, generator=gen) < share] = 4242
     k = ids * -7046029254386353131

@@ -682,6 +682,126 @@ __global__ void sel_finish_kernel(SelArgs a) {
     a.only[S.part] = 0;
 }
 
+// Everything after the null compaction, for one set of (key cell, value) pairs; `depth` 1 = the rows of one
+// hot partition of the level above, partitioned again with another hash `seed`.
+constexpr uint32_t HOT_MIN_ROWS = 1u << 22, HOT_MAX = 8;     // (a nested level costs ~0.3 ms of launches and syncs: only where the sort would cost more)
+// the flagged non-NULL partitions of more than HOT_MIN_ROWS rows: out[0] = how many, then (partition, beg, end) triples
+__global__ __launch_bounds__(SK_THREADS) void list_hot_partitions_kernel(const uint8_t *only, const uint32_t *offsets, uint32_t NB,
+                                                                         uint32_t P, uint32_t *out) {
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += SK_THREADS) {
+        if (!only[p]) continue;
+        const uint32_t beg = offsets[(size_t)p * NB], end = offsets[(size_t)(p + 1) * NB];
+        if (end - beg <= HOT_MIN_ROWS) continue;
+        const uint32_t i = atomicAdd(&s_n, 1u);
+        if (i < HOT_MAX) { out[1 + 3 * i] = p; out[2 + 3 * i] = beg; out[3 + 3 * i] = end; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = s_n;
+}
+static int32_t median_pairs(pandrs_hip_ctx *c, const KeyDesc &kd, const uint64_t *vals, int64_t nv, int64_t G, int kind, int mode,
+                            MedianEntry *table, uint32_t cap_tab, uint32_t seed, int depth) {
+    uint64_t *pk = c->work.take<uint64_t>(nv + 1), *pv = c->work.take<uint64_t>(nv + 1);
+    if (!pk || !pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
+    // Fast path first: partitions of ~9 K rows (they must fit GS_CAP with room for an uneven hash
+    // split) with at most GS_KEYS distinct keys each are finished in LDS by group_sort_kernel; what it
+    // flags in `only` (oversized partitions: a hot key, a large NULL group) goes through the general
+    // sort below.  With nearly unique keys (more than ~1 K groups per partition even at P_MAX) the
+    // fast path cannot apply anywhere and is skipped.
+    const bool fast = !c->opt.median_generic;
+    int64_t P = std::max<int64_t>(1, (int64_t)std::ceil((double)nv / (fast ? 9000.0 : 4900.0)));
+    if (fast) P = std::max<int64_t>(P, (int64_t)std::ceil((double)G / 1000.0));
+    if (fast && depth > 0) P = P_MAX;        // the finest split: the hot key should end up ALONE in its sub-partition (selection path)
+    P = std::min<int64_t>(P, P_MAX);
+    const bool use_fast = fast && (depth > 0 || (double)G / (double)P <= 1200.0);
+    if (!use_fast) P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)nv / 4900.0)), P_MAX);
+    PartInfo part{};
+    ScatterArgs sa{};
+    sa.key = kd; sa.pkeys = pk; sa.n_rows = nv; sa.P = (uint32_t)P; sa.seed = seed;
+    sa.mv[sa.n_move++] = MoveDesc{vals, pv, 0, 0};
+    ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER));
+    const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
+    uint8_t *only = nullptr;
+    if (use_fast) {
+        only = c->work.take<uint8_t>((size_t)P + 16);
+        if (!only) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
+        HIP_TRY(hipMemsetAsync(only, 0, (size_t)P + 16, c->stream));
+        GroupSortArgs ga{};
+        ga.pkeys = pk; ga.pvals = pv; ga.offsets = part.offsets; ga.NB = part.NB; ga.P = (uint32_t)P;
+        ga.kind = kind; ga.mode = mode; ga.table = table; ga.table_mask = cap_tab - 1; ga.only = only;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel<uint64_t, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS));
+        hipLaunchKernelGGL((group_sort_kernel<uint64_t, false>), dim3((unsigned)P + 1), dim3(GS_THREADS), GS_LDS, c->stream, ga);
+        if (mode == 0) {    // Median of a flagged partition that holds one key: selection, no sort
+            hipLaunchKernelGGL(single_key_median_kernel, dim3((unsigned)P + 1), dim3(SK_THREADS), 0, c->stream, ga);
+            if ((uint64_t)nv > SK_MAX_ROWS) {       // ... and of the ones too large for one workgroup
+                SelArgs sa2{};
+                sa2.pkeys = pk; sa2.pvals = pv; sa2.offsets = part.offsets; sa2.NB = part.NB; sa2.P = (uint32_t)P;
+                sa2.kind = kind; sa2.table = table; sa2.table_mask = cap_tab - 1; sa2.only = only;
+                sa2.max_big = (uint32_t)((uint64_t)nv / SK_MAX_ROWS + 2);
+                sa2.max_tasks = (uint32_t)((uint64_t)nv / SEL_TILE + sa2.max_big + 2);
+                sa2.tasks = c->work.take<SelTask>(sa2.max_tasks);
+                sa2.counters = c->work.take<uint32_t>(64);
+                sa2.st = c->work.take<SelState>(sa2.max_big);
+                sa2.hist = c->work.take<uint32_t>((size_t)sa2.max_big * SK_BINS);
+                sa2.maxbelow = c->work.take<unsigned long long>(sa2.max_big);
+                if (!sa2.tasks || !sa2.counters || !sa2.st || !sa2.hist || !sa2.maxbelow)
+                    return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median selection)");
+                HIP_TRY(hipMemsetAsync(sa2.counters, 0, 256, c->stream));
+                HIP_TRY(hipMemsetAsync(sa2.hist, 0, (size_t)sa2.max_big * SK_BINS * 4, c->stream));
+                HIP_TRY(hipMemsetAsync(sa2.maxbelow, 0, (size_t)sa2.max_big * 8, c->stream));
+                hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(SK_THREADS), 0, c->stream, sa2);
+                hipLaunchKernelGGL(sel_multi_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+                for (int pass = 0; pass < 6; pass++) {
+                    sa2.pass = pass;
+                    hipLaunchKernelGGL(sel_hist_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+                    hipLaunchKernelGGL(sel_pick_kernel, dim3(sa2.max_big), dim3(SK_THREADS), 0, c->stream, sa2);
+                }
+                hipLaunchKernelGGL(sel_maxbelow_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+                hipLaunchKernelGGL(sel_finish_kernel, dim3((sa2.max_big + 255) / 256), dim3(256), 0, c->stream, sa2);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    // A big partition that is STILL flagged holds several keys — typically a hot key next to the ~100 ordinary
+    // keys of its hash partition.  Sorting it whole is what made skewed inputs slow (one key on 90 % of 100 M rows:
+    // 31 ms); instead its rows are partitioned once more with an independent hash, which leaves the hot key (almost
+    // surely) alone in one sub-partition — the selection path — and the ordinary keys in LDS-sized ones.
+    if (use_fast && mode == 0 && depth == 0 && (uint64_t)nv > HOT_MIN_ROWS) {
+        uint32_t *hot = c->work.take<uint32_t>(64);
+        if (!hot) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
+        hipLaunchKernelGGL(list_hot_partitions_kernel, dim3(1), dim3(SK_THREADS), 0, c->stream, only, part.offsets, part.NB, (uint32_t)P, hot);
+        HIP_TRY(hipGetLastError());
+        uint32_t *hh = reinterpret_cast<uint32_t *>(c->pinned);
+        HIP_TRY(hipMemcpyAsync(hh, hot, 4 * (1 + 3 * HOT_MAX), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t n_hot = std::min<uint32_t>(hh[0], HOT_MAX);
+        uint32_t list[3 * HOT_MAX];
+        for (uint32_t i = 0; i < 3 * n_hot; i++) list[i] = hh[1 + i];          // (the pinned buffer is reused by the nested calls)
+        for (uint32_t i = 0; i < n_hot; i++) {
+            const uint32_t pid = list[3 * i], beg = list[3 * i + 1], end = list[3 * i + 2];
+            const KeyDesc sub{pk + beg, nullptr, nullptr, DT_CELL};
+            ST_TRY(median_pairs(c, sub, pv + beg, (int64_t)(end - beg), G, kind, mode, table, cap_tab, 0x7F4A7C15u, 1));
+            HIP_TRY(hipMemsetAsync(only + pid, 0, 1, c->stream));               // done: the general path below skips it
+        }
+    }
+    // general path (every partition, or only the flagged ones): sort by (key, value code), walk the runs
+    hipLaunchKernelGGL(fill_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end, 0ull);
+    SortTiles tiles;
+    ST_TRY(segmented_sort_u64(c, pk, pv, part.offsets, part.NB, (uint32_t)P + 1, nv, kind == 0 ? 1 : 2, only, &tiles));
+    if (tiles.max_tasks == 0) { /* every partition was finished by the fast path */ }
+    else if (mode == 1)
+        hipLaunchKernelGGL(nunique_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
+                           tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
+    else
+        hipLaunchKernelGGL(median_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
+                           tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // Fills aggregate `fin_index` of the retained groupby result (c->gb) with the groups' medians of
 // one value column.  `key` is the engine's key source (original column or packed cells), `kind`
 // 0 = f64, 1 = i64.  Uses c->work from scratch (the engine is done with it).
@@ -700,7 +820,8 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     const size_t ws = engine_workspace_bytes(n_rows, 4, 1) + segsort_workspace_bytes(n_rows, P_MAX + 2, 8)
                     + Arena::padded(size_t(cap_tab + 4) * 16) + (1 << 20)
                     + (size_t(n_rows) / SEL_TILE + size_t(n_rows) / SK_MAX_ROWS + 8) * (sizeof(SelTask) + sizeof(SelState) + SK_BINS * 4 + 16) + 8192;
-    ST_TRY(c->work.ensure(ws, c->stream));
+    const size_t ws_all = 2 * ws + 2 * Arena::padded(size_t(n_rows + 1) * 8);      // + one nested level (hot partitions)
+    ST_TRY(c->work.ensure(ws_all, c->stream));
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     KeyDesc kd = key;
     const uint64_t *vals = reinterpret_cast<const uint64_t *>(vdata);
@@ -728,81 +849,7 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
         hipLaunchKernelGGL(clear_table_values_kernel, dim3((cap_tab + 255) / 256), dim3(256), 0, c->stream, table, cap_tab);
         HIP_TRY(hipGetLastError());
     }
-    if (nv > 0) {
-        uint64_t *pk = c->work.take<uint64_t>(nv + 1), *pv = c->work.take<uint64_t>(nv + 1);
-        if (!pk || !pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
-        // Fast path first: partitions of ~9 K rows (they must fit GS_CAP with room for an uneven hash
-        // split) with at most GS_KEYS distinct keys each are finished in LDS by group_sort_kernel; what it
-        // flags in `only` (oversized partitions: a hot key, a large NULL group) goes through the general
-        // sort below.  With nearly unique keys (more than ~1 K groups per partition even at P_MAX) the
-        // fast path cannot apply anywhere and is skipped.
-        const bool fast = !c->opt.median_generic;
-        int64_t P = std::max<int64_t>(1, (int64_t)std::ceil((double)nv / (fast ? 9000.0 : 4900.0)));
-        if (fast) P = std::max<int64_t>(P, (int64_t)std::ceil((double)G / 1000.0));
-        P = std::min<int64_t>(P, P_MAX);
-        const bool use_fast = fast && (double)G / (double)P <= 1200.0;
-        if (!use_fast) P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)nv / 4900.0)), P_MAX);
-        PartInfo part{};
-        ScatterArgs sa{};
-        sa.key = kd; sa.pkeys = pk; sa.n_rows = nv; sa.P = (uint32_t)P; sa.seed = 0x3C6EF372u;
-        sa.mv[sa.n_move++] = MoveDesc{vals, pv, 0, 0};
-        ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER));
-        const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
-        uint8_t *only = nullptr;
-        if (use_fast) {
-            only = c->work.take<uint8_t>((size_t)P + 16);
-            if (!only) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
-            HIP_TRY(hipMemsetAsync(only, 0, (size_t)P + 16, c->stream));
-            GroupSortArgs ga{};
-            ga.pkeys = pk; ga.pvals = pv; ga.offsets = part.offsets; ga.NB = part.NB; ga.P = (uint32_t)P;
-            ga.kind = kind; ga.mode = mode; ga.table = table; ga.table_mask = cap_tab - 1; ga.only = only;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(group_sort_kernel<uint64_t, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS));
-            hipLaunchKernelGGL((group_sort_kernel<uint64_t, false>), dim3((unsigned)P + 1), dim3(GS_THREADS), GS_LDS, c->stream, ga);
-            if (mode == 0) {    // Median of a flagged partition that holds one key: selection, no sort
-                hipLaunchKernelGGL(single_key_median_kernel, dim3((unsigned)P + 1), dim3(SK_THREADS), 0, c->stream, ga);
-                if ((uint64_t)nv > SK_MAX_ROWS) {       // ... and of the ones too large for one workgroup
-                    SelArgs sa2{};
-                    sa2.pkeys = pk; sa2.pvals = pv; sa2.offsets = part.offsets; sa2.NB = part.NB; sa2.P = (uint32_t)P;
-                    sa2.kind = kind; sa2.table = table; sa2.table_mask = cap_tab - 1; sa2.only = only;
-                    sa2.max_big = (uint32_t)((uint64_t)nv / SK_MAX_ROWS + 2);
-                    sa2.max_tasks = (uint32_t)((uint64_t)nv / SEL_TILE + sa2.max_big + 2);
-                    sa2.tasks = c->work.take<SelTask>(sa2.max_tasks);
-                    sa2.counters = c->work.take<uint32_t>(64);
-                    sa2.st = c->work.take<SelState>(sa2.max_big);
-                    sa2.hist = c->work.take<uint32_t>((size_t)sa2.max_big * SK_BINS);
-                    sa2.maxbelow = c->work.take<unsigned long long>(sa2.max_big);
-                    if (!sa2.tasks || !sa2.counters || !sa2.st || !sa2.hist || !sa2.maxbelow)
-                        return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median selection)");
-                    HIP_TRY(hipMemsetAsync(sa2.counters, 0, 256, c->stream));
-                    HIP_TRY(hipMemsetAsync(sa2.hist, 0, (size_t)sa2.max_big * SK_BINS * 4, c->stream));
-                    HIP_TRY(hipMemsetAsync(sa2.maxbelow, 0, (size_t)sa2.max_big * 8, c->stream));
-                    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(SK_THREADS), 0, c->stream, sa2);
-                    hipLaunchKernelGGL(sel_multi_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
-                    for (int pass = 0; pass < 6; pass++) {
-                        sa2.pass = pass;
-                        hipLaunchKernelGGL(sel_hist_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
-                        hipLaunchKernelGGL(sel_pick_kernel, dim3(sa2.max_big), dim3(SK_THREADS), 0, c->stream, sa2);
-                    }
-                    hipLaunchKernelGGL(sel_maxbelow_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
-                    hipLaunchKernelGGL(sel_finish_kernel, dim3((sa2.max_big + 255) / 256), dim3(256), 0, c->stream, sa2);
-                }
-            }
-            HIP_TRY(hipGetLastError());
-        }
-        // general path (every partition, or only the flagged ones): sort by (key, value code), walk the runs
-        hipLaunchKernelGGL(fill_range_kernel, dim3(256), dim3(256), 0, c->stream, pk, null_beg, null_end, 0ull);
-        SortTiles tiles;
-        ST_TRY(segmented_sort_u64(c, pk, pv, part.offsets, part.NB, (uint32_t)P + 1, nv, kind == 0 ? 1 : 2, only, &tiles));
-        if (tiles.max_tasks == 0) { /* every partition was finished by the fast path */ }
-        else if (mode == 1)
-            hipLaunchKernelGGL(nunique_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
-                               tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
-        else
-            hipLaunchKernelGGL(median_runs_kernel, dim3(tiles.max_tasks), dim3(MR_THREADS), 0, c->stream,
-                               tiles.tasks, tiles.counters, pk, pv, null_beg, kind, table, cap_tab - 1);
-        HIP_TRY(hipGetLastError());
-    }
+    if (nv > 0) ST_TRY(median_pairs(c, kd, vals, nv, G, kind, mode, table, cap_tab, 0x3C6EF372u, 0));
     hipLaunchKernelGGL(median_lookup_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream,
                        res.keys, res.key_null, G, table, cap_tab - 1, res.aggs + (size_t)fin_index * res.cap, mode);
     HIP_TRY(hipGetLastError());
