@@ -526,7 +526,8 @@ constexpr uint32_t SEL_TILE = 1u << 16;
 struct SelTask { uint32_t pbeg, pend, tile, idx; };
 struct SelState {
     unsigned long long prefix, hi, key;
-    uint32_t rank, n, active, multi, part, need_lo, pad0, pad1;
+    unsigned long long region, distinct;   // Nunique: first entry of the partition's hash-set region; values counted so far
+    uint32_t rank, n, active, multi, part, need_lo, region_mask, pad1;
 };
 struct SelArgs {
     const uint64_t *pkeys, *pvals;
@@ -542,6 +543,9 @@ struct SelArgs {
     uint32_t *hist;                     // [max_big][SK_BINS], zero between passes
     unsigned long long *maxbelow;       // [max_big]
     uint32_t max_tasks, max_big;
+    uint32_t min_rows;                  // a flagged partition takes part when it has MORE rows than this
+    unsigned long long *sets;           // Nunique: the hash sets of all partitions (EMPTY_KEY-filled), `sets_cap` entries
+    unsigned long long sets_cap;
 };
 __device__ __forceinline__ uint64_t sel_code(const SelArgs &a, uint32_t row) {
     const uint64_t x = a.pvals[row];
@@ -550,14 +554,14 @@ __device__ __forceinline__ uint64_t sel_code(const SelArgs &a, uint32_t row) {
 // one workgroup: the big flagged partitions get a dense index, a state and their tile tasks
 __global__ __launch_bounds__(SK_THREADS) void sel_init_kernel(SelArgs a) {
     __shared__ uint32_t wt[17];
-    uint32_t task_carry = 0, big_carry = 0;
+    uint32_t task_carry = 0, big_carry = 0, unit_carry = 0;
     for (uint32_t base = 0; base < a.P + 1; base += SK_THREADS) {
         const uint32_t p = base + threadIdx.x;
         uint32_t beg = 0, end = 0;
         bool big = false;
         if (p <= a.P && a.only[p]) {
             beg = a.offsets[(size_t)p * a.NB]; end = a.offsets[(size_t)(p + 1) * a.NB];
-            big = end - beg > SK_MAX_ROWS;
+            big = end - beg > a.min_rows;
         }
         const uint32_t nt = big ? (end - beg + SEL_TILE - 1) / SEL_TILE : 0u;
         uint32_t tot_t, tot_b;
@@ -565,15 +569,23 @@ __global__ __launch_bounds__(SK_THREADS) void sel_init_kernel(SelArgs a) {
         __syncthreads();
         const uint32_t ex_b = block_exclusive_scan<SK_THREADS>(big ? 1u : 0u, wt, &tot_b);
         __syncthreads();
+        // Nunique: a hash-set region of 2^k >= 1.5 n entries (k >= 10), handed out in units of 1024 entries
+        uint32_t units = 0;
+        if (big && a.sets) { uint64_t sz = 1024; while (sz * 2 < 3ull * (end - beg)) sz <<= 1; units = (uint32_t)(sz >> 10); }
+        uint32_t tot_u;
+        const uint32_t ex_u = block_exclusive_scan<SK_THREADS>(units, wt, &tot_u);
+        __syncthreads();
         const uint32_t idx = big_carry + ex_b;
         if (big && idx < a.max_big) {
             SelState s{};
             s.n = end - beg; s.rank = s.n >> 1; s.active = 1; s.part = p; s.key = a.pkeys[beg];
+            s.region = ((unsigned long long)unit_carry + ex_u) << 10; s.region_mask = (units << 10) - 1;
+            if (a.sets && (units >= (1u << 21) || s.region + ((unsigned long long)units << 10) > a.sets_cap)) s.multi = 1;   // (a > 2^31-entry set: leave it to the sort)
             a.st[idx] = s;
             for (uint32_t t = 0; t < nt; t++)
                 if (task_carry + ex_t + t < a.max_tasks) a.tasks[task_carry + ex_t + t] = SelTask{beg, end, t, idx};
         }
-        task_carry += tot_t; big_carry += tot_b;
+        task_carry += tot_t; big_carry += tot_b; unit_carry += tot_u;
     }
     if (threadIdx.x == 0) { a.counters[0] = min(task_carry, a.max_tasks); a.counters[1] = min(big_carry, a.max_big); }
 }
@@ -682,6 +694,53 @@ __global__ void sel_finish_kernel(SelArgs a) {
     a.only[S.part] = 0;
 }
 
+// ---- Nunique of the flagged single-key partitions (few huge groups, the hot key of a skewed column): the number of
+// distinct values WITHOUT a sort — every tile inserts its rows' codes into the partition's open-addressing hash
+// set in global memory (a plain load first: a duplicate, the common case, costs no atomic; an empty slot is
+// claimed with one CAS) and counts the claims.  `==` semantics of Vec::dedup: -0.0 joins 0.0, every NaN counts.
+__global__ __launch_bounds__(SK_THREADS) void distinct_insert_kernel(SelArgs a) {
+    if (blockIdx.x >= a.counters[0]) return;
+    const SelTask t = a.tasks[blockIdx.x];
+    const SelState S = a.st[t.idx];
+    if (S.multi) return;
+    unsigned long long *set = a.sets + S.region;
+    const uint32_t b = t.pbeg + t.tile * SEL_TILE, e = min(b + SEL_TILE, t.pend);
+    const unsigned long long zero_code = enc_f64(0.0);
+    unsigned long long mine = 0;
+    for (uint32_t i = b + threadIdx.x; i < e; i += SK_THREADS) {
+        unsigned long long c;
+        if (a.kind == 0) {
+            const double x = __longlong_as_double((long long)a.pvals[i]);
+            if (x != x) { mine++; continue; }                        // NaN != NaN: each its own value
+            c = x == 0.0 ? zero_code : enc_f64(x);
+        } else c = enc_i64((int64_t)a.pvals[i]);
+        if (c == EMPTY_KEY) { atomicOr(&a.st[t.idx].need_lo, 1u); continue; }      // i64::MAX's code is the empty marker: a flag instead
+        uint32_t slot = hash32(c, 0x51ED270Bu) & S.region_mask;
+        for (uint32_t probes = 0; probes <= S.region_mask; probes++) {
+            unsigned long long cur = set[slot];
+            if (cur == c) break;
+            if (cur == EMPTY_KEY) {
+                cur = atomicCAS(&set[slot], EMPTY_KEY, c);
+                if (cur == EMPTY_KEY) { mine++; break; }
+                if (cur == c) break;
+            }
+            slot = (slot + 1) & S.region_mask;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&a.st[t.idx].distinct, mine);
+}
+__global__ void distinct_finish_kernel(SelArgs a) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.counters[1]) return;
+    const SelState S = a.st[idx];
+    if (S.multi) return;
+    GroupSortArgs ga{};
+    ga.table = a.table; ga.table_mask = a.table_mask;
+    gs_publish(ga, S.part == a.P, S.key, __longlong_as_double((long long)(S.distinct + (S.need_lo ? 1ull : 0ull))));   // a u64 count in the entry's 8 bytes
+    a.only[S.part] = 0;
+}
+
 // Everything after the null compaction, for one set of (key cell, value) pairs; `depth` 1 = the rows of one
 // hot partition of the level above, partitioned again with another hash `seed`.
 constexpr uint32_t HOT_MIN_ROWS = 1u << 22, HOT_MAX = 8;     // (a nested level costs ~0.3 ms of launches and syncs: only where the sort would cost more)
@@ -739,7 +798,7 @@ static int32_t median_pairs(pandrs_hip_ctx *c, const KeyDesc &kd, const uint64_t
             if ((uint64_t)nv > SK_MAX_ROWS) {       // ... and of the ones too large for one workgroup
                 SelArgs sa2{};
                 sa2.pkeys = pk; sa2.pvals = pv; sa2.offsets = part.offsets; sa2.NB = part.NB; sa2.P = (uint32_t)P;
-                sa2.kind = kind; sa2.table = table; sa2.table_mask = cap_tab - 1; sa2.only = only;
+                sa2.kind = kind; sa2.table = table; sa2.table_mask = cap_tab - 1; sa2.only = only; sa2.min_rows = SK_MAX_ROWS;
                 sa2.max_big = (uint32_t)((uint64_t)nv / SK_MAX_ROWS + 2);
                 sa2.max_tasks = (uint32_t)((uint64_t)nv / SEL_TILE + sa2.max_big + 2);
                 sa2.tasks = c->work.take<SelTask>(sa2.max_tasks);
@@ -763,13 +822,33 @@ static int32_t median_pairs(pandrs_hip_ctx *c, const KeyDesc &kd, const uint64_t
                 hipLaunchKernelGGL(sel_finish_kernel, dim3((sa2.max_big + 255) / 256), dim3(256), 0, c->stream, sa2);
             }
         }
+        if (mode == 1 && (uint64_t)nv > GS_CAP) {     // Nunique of the flagged partitions that hold one key: hash sets, no sort
+            SelArgs sa2{};
+            sa2.pkeys = pk; sa2.pvals = pv; sa2.offsets = part.offsets; sa2.NB = part.NB; sa2.P = (uint32_t)P;
+            sa2.kind = kind; sa2.table = table; sa2.table_mask = cap_tab - 1; sa2.only = only; sa2.min_rows = GS_CAP;
+            sa2.max_big = (uint32_t)std::min<uint64_t>((uint64_t)P + 1, (uint64_t)nv / GS_CAP + 2);
+            sa2.max_tasks = (uint32_t)((uint64_t)nv / SEL_TILE + sa2.max_big + 2);
+            sa2.sets_cap = 3ull * (uint64_t)nv + 1024ull * sa2.max_big;
+            sa2.tasks = c->work.take<SelTask>(sa2.max_tasks);
+            sa2.counters = c->work.take<uint32_t>(64);
+            sa2.st = c->work.take<SelState>(sa2.max_big);
+            sa2.sets = c->work.take<unsigned long long>(sa2.sets_cap);
+            if (!sa2.tasks || !sa2.counters || !sa2.st || !sa2.sets)
+                return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (distinct count)");
+            HIP_TRY(hipMemsetAsync(sa2.counters, 0, 256, c->stream));
+            HIP_TRY(hipMemsetAsync(sa2.sets, 0xFF, sa2.sets_cap * 8, c->stream));
+            hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(SK_THREADS), 0, c->stream, sa2);
+            hipLaunchKernelGGL(sel_multi_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+            hipLaunchKernelGGL(distinct_insert_kernel, dim3(sa2.max_tasks), dim3(SK_THREADS), 0, c->stream, sa2);
+            hipLaunchKernelGGL(distinct_finish_kernel, dim3((sa2.max_big + 255) / 256), dim3(256), 0, c->stream, sa2);
+        }
         HIP_TRY(hipGetLastError());
     }
     // A big partition that is STILL flagged holds several keys — typically a hot key next to the ~100 ordinary
     // keys of its hash partition.  Sorting it whole is what made skewed inputs slow (one key on 90 % of 100 M rows:
     // 31 ms); instead its rows are partitioned once more with an independent hash, which leaves the hot key (almost
     // surely) alone in one sub-partition — the selection path — and the ordinary keys in LDS-sized ones.
-    if (use_fast && mode == 0 && depth == 0 && (uint64_t)nv > HOT_MIN_ROWS) {
+    if (use_fast && depth == 0 && (uint64_t)nv > HOT_MIN_ROWS) {
         uint32_t *hot = c->work.take<uint32_t>(64);
         if (!hot) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (median)");
         hipLaunchKernelGGL(list_hot_partitions_kernel, dim3(1), dim3(SK_THREADS), 0, c->stream, only, part.offsets, part.NB, (uint32_t)P, hot);
@@ -820,7 +899,8 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     const size_t ws = engine_workspace_bytes(n_rows, 4, 1) + segsort_workspace_bytes(n_rows, P_MAX + 2, 8)
                     + Arena::padded(size_t(cap_tab + 4) * 16) + (1 << 20)
                     + (size_t(n_rows) / SEL_TILE + size_t(n_rows) / SK_MAX_ROWS + 8) * (sizeof(SelTask) + sizeof(SelState) + SK_BINS * 4 + 16) + 8192;
-    const size_t ws_all = 2 * ws + 2 * Arena::padded(size_t(n_rows + 1) * 8);      // + one nested level (hot partitions)
+    const size_t ws_all = 2 * ws + 2 * Arena::padded(size_t(n_rows + 1) * 8)       // + one nested level (hot partitions)
+                        + (mode == 1 ? 2 * (Arena::padded((3 * size_t(n_rows) + 1024 * size_t(P_MAX + 2)) * 8) + size_t(P_MAX + 4) * sizeof(SelState)) : 0);   // Nunique: hash sets
     ST_TRY(c->work.ensure(ws_all, c->stream));
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     KeyDesc kd = key;
