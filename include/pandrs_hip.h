@@ -190,6 +190,8 @@ int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
  *     Std/Var = two-pass, Bessel; First/Last = value at first/last row, null => 0.0;
  *     Median = middle of the sorted non-null values, even counts average the two middles
  *     (Int64: added in i64 first), no non-null value => 0.0 (aggregation.rs:585-604, :703-722).
+ *     Nunique (not an AggregateOp: the legacy frame's AggFunc::Nunique) = number of distinct non-null
+ *     values under `==` (-0.0 joins 0.0, every NaN counts), none => 0.0 (src/dataframe/groupby.rs:514-519).
  *   - group order in the output is unspecified (reference: HashMap order).
  *   - value dtypes: I64 / F64 for numeric ops; Count accepts any dtype; anything else =>
  *     PANDRS_HIP_ERR_OPERATION_FAILED (aggregation.rs:748).
