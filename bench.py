@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric on BASELINE config 2.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts the N ranks itself)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the groupby-aggregate hot path over one batch of synthetic rows that are
@@ -119,6 +119,69 @@ def emit(record):
         os.dup2(2, 1)
 
 
+def dry_run(args):
+    """PANDRS_BENCH_BACKEND=gloo: a rehearsal of the LAUNCH path on a box without GPUs (tests/test_bench_launch.py).
+    Same rendezvous, barriers, max-over-ranks timing and record as the real run, but the local engine is the
+    numpy stand-in of tests/cpu_engine.py and the record says so.  Never a measurement."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pandrs_amd.dist import DistributedGroupBy
+    from tests.cpu_engine import NumpyEngine
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group("gloo")
+    n, g, ncol = min(args.rows, 200_000), min(args.groups, 5_000), args.cols
+    rng = np.random.default_rng(42 + 1 + 1000 * rank)
+    keys = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    vals = [(rng.normal(100, 10, n), None, 1) for _ in range(ncol)]
+    aggs = [(c, op) for c in range(ncol) for op in (0, 1, 2, 3)]
+    dgb = DistributedGroupBy(NumpyEngine(), dist, "cpu")
+    step = lambda: dgb.groupby_agg([(keys, None, 0)], n, vals, aggs, fetch=False)
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({"metric": "Mrows/sec groupby-agg", "value": n * world / (dt / args.steps) / 1e6, "unit": "Mrows/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                          "data": "synthetic", "dry_run": "gloo rehearsal of the launch path on CPU with the numpy stand-in engine: NOT a measurement",
+                          "config": {"workload": "dry run: %d rows/rank, %d groups, %d f64 cols" % (n, g, ncol)}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N fresh ranks (one per GPU) under
+    torch.distributed.run and relay rank 0's JSON line.  Runs BEFORE torch or any HIP call is made in
+    this process: a process that has touched the GPU must never exec or fork workers."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif p.returncode == 0:
+        sys.stderr.write("bench.py: the ranks printed no record\n")
+        return 1
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,12 +192,22 @@ def main():
     ap.add_argument("--cols", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra configs (north-star sum line, C3, C4 shard, C5 shard) reported beside the headline")
     ap.add_argument("--workload", choices=["groupby", "join"], default="groupby",
                     help="groupby = BASELINE config 2 (the headline line); join = config 5 shape "
                          "(probe --rows per GPU, build rows/10 per GPU, inner join -> groupby(g).sum(v))")
     ap.add_argument("--join-strategy", choices=["auto", "allgather", "shuffle"], default="auto",
                     help="N > 1, --workload join: replicate the build side, or shuffle both sides to the owner of their key")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("PANDRS_BENCH_BACKEND") == "gloo":
+        return dry_run(args)
 
     # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints a version banner
     # on its first collective) write to file descriptor 1 behind Python's back, so fd 1 points at stderr
@@ -149,10 +222,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dist = None

@@ -1,0 +1,63 @@
+// aggregate.hpp — argument block and state helpers shared by the aggregate kernels
+// (groupby.hip: generic / RUNS / MERGE / direct kernels; aggregate2.hip: the lean persistent kernel).
+#pragma once
+#include "engine.hpp"
+
+namespace pandrs {
+
+struct AggTask { uint32_t part, beg, end, multi; };
+
+struct AggArgs {
+    const uint64_t *pkeys;
+    const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
+    const int64_t *pgsize;       // merge mode: partitioned group sizes, else nullptr (=1 per row)
+    uint32_t NB, P, T, seed;
+    int n_src, n_states, n_fin, partials, n_rounds, round_states, second_pass;
+    int direct;                  // 1: no radix partition — workgroup b pre-aggregates rows [b*chunk, (b+1)*chunk) of the
+                                 // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) and emits partial records
+    KeyDesc dkey;
+    uint32_t d_rows, d_chunk, launch_grid, d_task_cap;
+    // oversized partitions are split into row slices handled by different workgroups; their groups
+    // leave as partial records in the side buffers (counters[2]) and are merged afterwards
+    const AggTask *tasks;        // nullptr: workgroup b = partition b
+    const uint32_t *n_tasks;
+    uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
+    int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
+    SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
+    int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
+    int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
+    FinDev fin[MAX_AGGS];
+    // outputs (row capacity = cap)
+    uint64_t *out_keys;
+    uint8_t *out_null;
+    double *out_aggs;            // [n_fin][cap]
+    uint64_t *out_states;        // [1 + n_states][cap] when partials
+    size_t cap;
+    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag
+};
+
+__device__ __forceinline__ uint64_t state_identity(int8_t kind) {
+    switch (kind) {
+    case SK_MIN_F64: return enc_f64(__longlong_as_double(0x7FF0000000000000ll));
+    case SK_MAX_F64: return enc_f64(__longlong_as_double((long long)0xFFF0000000000000ull));
+    case SK_MIN_I64: return enc_i64(INT64_MAX);
+    case SK_MAX_I64: return enc_i64(INT64_MIN);
+    default: return 0ull;   // +0.0 / 0
+    }
+}
+// natural (ABI / partial) representation of an LDS state cell
+__device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
+    switch (kind) {
+    case SK_MIN_F64: case SK_MAX_F64: return (uint64_t)__double_as_longlong(dec_f64(cell));
+    case SK_MIN_I64: case SK_MAX_I64: return (uint64_t)dec_i64(cell);
+    default: return cell;
+    }
+}
+
+
+// aggregate2.hip: lean persistent aggregate for uniform profiles on raw partitioned rows (one round).
+// Returns false when (n_src, profile) has no instantiation: the caller falls back to aggregate_kernel.
+bool aggregate2_has(int n_src, int profile);
+bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
+
+}  // namespace pandrs

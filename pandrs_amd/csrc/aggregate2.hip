@@ -1,0 +1,344 @@
+// aggregate2.hip — the lean persistent LDS hash aggregate for the common case: raw partitioned rows,
+// one round, every aggregated column of the same kind with the same ops (a "uniform profile").
+//
+// Same job as aggregate_kernel (groupby.hip) — the per-group fold of
+// src/optimized/split_dataframe/group/aggregation.rs:500-754 on one radix partition held in LDS —
+// rebuilt around what the round-1 profile showed (profiles/r01_final3_lds_counters.json: 29 LDS
+// instructions per 64 rows, the LDS pipe 53 % busy, one 157 KB workgroup per CU so nothing overlaps
+// a workgroup's prologue / epilogue):
+//   * persistent workgroups: one per CU walks the task list (task = partition or row slice); the first
+//     row batch of the NEXT task is already in flight (registers) while the current task's table is
+//     compacted and written out, so the HBM stream does not stop between partitions;
+//   * max states are kept NEGATED (~enc), so min and max updates are the same ds_min_u64 and a wave
+//     retires its few (lane, state) updates in 2-3 dense instructions instead of 8 sparse ones
+//     (per row a state improves with probability ~1/k at the group's k-th row, but with 64 lanes
+//     nearly every one of the 8 conditional atomics used to issue);
+//   * group sizes are u32 and there is no position map: 12 + 8 x states bytes per slot instead of
+//     20 + 8 x states => more slots per table => fewer radix partitions for the scatter;
+//   * one block scan for the compaction instead of three; per-source pointers live in SGPRs.
+#include "aggregate.hpp"
+
+namespace pandrs {
+
+namespace {
+
+template <int NSRC, int PROFILE, int ABLATE, int DEPTH>
+__global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
+    constexpr bool HAS_V = (PROFILE & 1) != 0, OP_ADD = ((PROFILE >> 1) & 1) != 0;
+    constexpr bool OP_MIN = ((PROFILE >> 2) & 1) != 0, OP_MAX = ((PROFILE >> 3) & 1) != 0;
+    constexpr int KIND = (PROFILE >> 4) & 1;                 // 0 f64, 1 i64
+    constexpr int MM = (OP_MIN ? 1 : 0) + (OP_MAX ? 1 : 0);  // min-type states per source
+    constexpr uint64_t M_IDENT = KIND == 0 ? 0xFFF0000000000000ull : ~0ull;   // enc(+inf) = ~enc(-inf); enc(MAX) = ~enc(MIN)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x;   // slot T: the key equal to the table sentinel
+    // LDS: keys[T1] | states[round_states][T1] | gsz[T1] (u32) | misc[40]
+    // state order (fixed by run_engine for this kernel): adds of source 0..n-1, then per source its
+    // min-type states (min, ~max), then the non-null counts
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *st = keys + T1;
+    uint32_t *gsz = reinterpret_cast<uint32_t *>(st + (size_t)a.round_states * T1);
+    uint32_t *misc = gsz + ((T1 + 3) & ~3u);
+    // misc[0..16] scan scratch, [20] overflow, [21] sentinel-key-present, [22] output base
+    constexpr int n_src = NSRC;                               // exact: the hot loop is straight-line code
+    constexpr uint32_t m_base = OP_ADD ? (uint32_t)NSRC : 0u;
+    const uint64_t *vals[NSRC];
+    const uint8_t *valid[NSRC];
+    int nn_idx[NSRC];
+#pragma unroll
+    for (int c = 0; c < NSRC; c++) {
+        vals[c] = a.src[c].vals; valid[c] = a.src[c].valid; nn_idx[c] = HAS_V ? a.src[c].st_nn : -1;
+    }
+    const uint64_t *pkeys = a.pkeys;
+
+    const uint32_t n_tasks = *a.n_tasks;
+    uint32_t t = blockIdx.x;
+    if (t >= n_tasks) return;
+    AggTask cur = a.tasks[t];
+
+    // Register ring of DEPTH row slots per thread (one row per slot): slot d holds batch (pit + d) of the
+    // current task while the loads of the following DEPTH - 1 batches are in flight.  Batches start at a
+    // 128-byte boundary (16 rows: a wave's 512-byte loads cover whole lines; misaligned streams measured
+    // 15 % slower, experiments/ubench/stream_formats.hip) and a task's batch count is padded to a multiple
+    // of DEPTH so that slot numbers are compile-time constants across task boundaries.
+    uint64_t rk[DEPTH], rv[DEPTH][NSRC];
+    uint32_t rok[DEPTH];
+    auto n_batches = [](const AggTask &tk) {
+        const uint32_t b0 = tk.beg & ~15u;
+        return ((tk.end - b0 + AG_THREADS - 1) / AG_THREADS + DEPTH - 1) / DEPTH * DEPTH;
+    };
+    auto fetch = [&](int d, const AggTask &tk, uint32_t batch) {
+        uint32_t i = (tk.beg & ~15u) + batch * AG_THREADS + tid;
+        i = min(max(i, tk.beg), tk.end - 1);          // rows outside [beg, end) are loaded (in bounds) but never processed
+        if (ABLATE == 6) i = tk.beg + ((i - tk.beg) & 2047u);     // experiments: every load hits L2 (compute time alone)
+        rk[d] = pkeys[i];
+        rok[d] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < NSRC; c++) {
+            rv[d][c] = vals[c][i];
+            if (HAS_V && valid[c][i] == 0) rok[d] &= ~(1u << c);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) fetch(d, cur, d);
+
+    for (;;) {
+        const uint32_t tn = t + gridDim.x;
+        const bool have_next = tn < n_tasks;
+        const AggTask nxt = a.tasks[have_next ? tn : t];
+        const uint32_t beg = cur.beg, end = cur.end, beg0 = cur.beg & ~15u;
+        const bool multi = cur.multi != 0;
+
+        for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
+        for (int k = 0; k < a.round_states; k++) {
+            const uint64_t idv = ((uint32_t)k >= m_base && (uint32_t)k < m_base + (uint32_t)(n_src * MM)) ? M_IDENT : 0ull;
+            uint64_t *dst = st + (size_t)k * T1;
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) dst[s] = idv;
+        }
+        if (tid < 32) misc[tid] = 0;
+        __syncthreads();
+
+        const uint32_t n_it = n_batches(cur);
+        for (uint32_t pit = 0; pit < n_it; pit += DEPTH) {
+            const bool last = pit + DEPTH >= n_it;
+#pragma unroll
+            for (int h = 0; h < DEPTH; h++) {
+                const uint32_t row = beg0 + (pit + h) * AG_THREADS + tid;
+                const uint64_t k = rk[h];
+                uint64_t v[1][NSRC];
+                uint32_t okm[1];
+                okm[0] = rok[h];
+#pragma unroll
+                for (int c = 0; c < NSRC; c++) v[0][c] = rv[h][c];
+                // refill this slot: DEPTH batches ahead, or the next task's batch h (its loads fly under this task's epilogue)
+                if (!last) fetch(h, cur, pit + h + DEPTH);
+                else if (have_next) fetch(h, nxt, h);
+                if (row < beg || row >= end) continue;
+                if (ABLATE >= 2) {          // experiments: keep every load alive without using it
+                    uint64_t x = 0;
+#pragma unroll
+                    for (int c = 0; c < NSRC; c++) x ^= v[0][c];
+                    if (x == 0x1234567ull) misc[30] = 1;
+                    if (ABLATE >= 3 && ABLATE != 6) { if (k == 0x1234567ull) misc[31] = 1; continue; }
+                }
+                uint32_t slot = T;
+                if (k == EMPTY_KEY) {
+                    misc[21] = 1;
+                } else {
+                    // 4-key buckets (32 B, two ds_read_b128): one LDS round trip tests four slots
+                    const uint32_t NBK = T >> 2;
+                    uint32_t bk = slot_of(hash32(k, a.seed), NBK), probe = 0;
+                    bool found = false;
+                    while (probe < NBK) {
+                        const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
+                        const ulonglong2 lo = bp[0], hi = bp[1];
+                        const uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
+                        int hit = -1, emp = -1;
+#pragma unroll
+                        for (int q = 3; q >= 0; q--) {
+                            if (c4[q] == k) hit = q;
+                            if (c4[q] == EMPTY_KEY) emp = q;
+                        }
+                        if (hit >= 0) { slot = 4 * bk + hit; found = true; break; }
+                        if (emp >= 0) {
+                            const uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + emp], EMPTY_KEY, k);
+                            if (old == EMPTY_KEY || old == k) { slot = 4 * bk + emp; found = true; break; }
+                            continue;               // lost the race for that slot: re-read this bucket
+                        }
+                        bk = bk + 1 == NBK ? 0 : bk + 1;
+                        probe++;
+                    }
+                    if (!found) { misc[20] = 1; continue; }   // table full: host retries with more partitions
+                }
+                atomicAdd(&gsz[slot], 1u);
+                if (ABLATE == 2) continue;
+                // current min-type states first (back-to-back ds_read_b64, one wait), then the adds
+                uint64_t cm[NSRC][MM > 0 ? MM : 1];
+                if (MM > 0 && ABLATE != 1) {
+#pragma unroll
+                    for (int c = 0; c < NSRC; c++)
+#pragma unroll
+                        for (int j = 0; j < MM; j++) cm[c][j] = st[(size_t)(m_base + c * MM + j) * T1 + slot];
+                }
+#pragma unroll
+                for (int c = 0; c < NSRC; c++) {
+                    if (!HAS_V || ((okm[0] >> c) & 1)) {
+                        if (OP_ADD) {
+                            if (KIND == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)c * T1 + slot]), __longlong_as_double((long long)v[0][c]));
+                            else atomicAdd((unsigned long long *)&st[(size_t)c * T1 + slot], (unsigned long long)v[0][c]);
+                        }
+                        if (HAS_V && nn_idx[c] >= 0) atomicAdd((unsigned long long *)&st[(size_t)nn_idx[c] * T1 + slot], 1ull);
+                    }
+                }
+                if (MM > 0 && ABLATE != 1) {
+                    // which (source, min/max) states does this row improve?  Skipping on a stale read is
+                    // safe: states only move towards the extreme.  Rust's f64::min/max ignore NaN operands
+                    // (aggregation.rs:653, :666).
+                    uint32_t upd = 0;
+                    uint64_t e[NSRC];
+#pragma unroll
+                    for (int c = 0; c < NSRC; c++) {
+                        {
+                            bool cmp = !HAS_V || ((okm[0] >> c) & 1) != 0;
+                            if (KIND == 0) {
+                                const double d = __longlong_as_double((long long)v[0][c]);
+                                cmp = cmp && d == d;
+                                e[c] = enc_f64(d);
+                            } else {
+                                e[c] = enc_i64((int64_t)v[0][c]);
+                            }
+                            if (OP_MIN && cmp && e[c] < cm[c][0]) upd |= 1u << (c * MM);
+                            if (OP_MAX && cmp && ~e[c] < cm[c][MM - 1]) upd |= 1u << (c * MM + MM - 1);
+                        }
+                    }
+                    // one ds_min_u64 per pending update and lane: lanes hold different states in the same
+                    // instruction, so the wave needs max-popcount iterations, not one per state
+                    while (upd) {
+                        const uint32_t q = (uint32_t)__ffs((int)upd) - 1u;
+                        upd &= upd - 1;
+                        const uint32_t c_ = MM == 2 ? q >> 1 : q;
+                        uint64_t ee = e[0];
+#pragma unroll
+                        for (int c = 1; c < NSRC; c++) if (c_ == (uint32_t)c) ee = e[c];
+                        const bool neg = OP_MIN ? (MM == 2 && (q & 1)) : true;
+                        if (neg) ee = ~ee;
+                        atomicMin((unsigned long long *)&st[(size_t)(m_base + q) * T1 + slot], ee);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
+        if (ABLATE == 4) { if (!have_next) break; t = tn; cur = nxt; continue; }   // experiments: no compaction / outputs
+
+        // ---- compaction + outputs: every thread owns a contiguous run of slots, ONE block scan ----
+        uint64_t *const o_keys = multi ? a.side_keys : a.out_keys;
+        uint8_t *const o_null = multi ? a.side_null : a.out_null;
+        uint64_t *const o_states = multi ? a.side_states : a.out_states;
+        const size_t o_cap = multi ? a.side_cap : a.cap;
+        const bool emit_partials = a.partials != 0 || multi;
+        const bool sentinel = misc[21] != 0;
+        const bool null_part = cur.part == a.P;
+        const uint32_t spt = (T1 + AG_THREADS - 1) / AG_THREADS;
+        const uint32_t s_beg = min(tid * spt, T1), s_end = min(s_beg + spt, T1);
+        auto occupied = [&](uint32_t s) { return s < T ? keys[s] != EMPTY_KEY : (s == T && sentinel); };
+        uint32_t mine = 0;
+        for (uint32_t s = s_beg; s < s_end; s++) mine += occupied(s) ? 1u : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<AG_THREADS>(mine, misc, &total);
+        if (tid == 0) misc[22] = atomicAdd(&a.counters[multi ? 2 : 0], total);
+        __syncthreads();
+        size_t pos = (size_t)misc[22] + ex;
+        for (uint32_t s = s_beg; s < s_end; s++) {
+            if (!occupied(s)) continue;
+            o_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
+            o_null[pos] = null_part ? 1 : 0;
+            const uint64_t g = gsz[s];
+            if (emit_partials) {
+                o_states[pos] = g;
+                for (int k = 0; k < a.n_states; k++) {
+                    const uint32_t l = (uint32_t)a.st_lds[k];
+                    uint64_t cell = st[(size_t)l * T1 + s];
+                    const int8_t kd = a.kinds[k];
+                    if (kd == SK_MAX_F64 || kd == SK_MAX_I64) cell = ~cell;
+                    o_states[(size_t)(k + 1) * o_cap + pos] = state_natural(kd, cell);
+                }
+            } else {
+                for (int f = 0; f < a.n_fin; f++) {
+                    const FinDev &fd = a.fin[f];
+                    auto cell = [&](int8_t l) { return st[(size_t)l * T1 + s]; };
+                    double r = 0.0;
+                    switch (fd.op) {
+                    case PANDRS_HIP_AGG_COUNT: r = (double)g; break;
+                    case PANDRS_HIP_AGG_SUM:
+                        r = KIND == 0 ? __longlong_as_double((long long)cell(fd.st_add)) : (double)(int64_t)cell(fd.st_add);
+                        break;
+                    case PANDRS_HIP_AGG_MEAN: {
+                        const uint64_t nn = fd.st_nn >= 0 ? cell(fd.st_nn) : g;
+                        const double sum = KIND == 0 ? __longlong_as_double((long long)cell(fd.st_add)) : (double)(int64_t)cell(fd.st_add);
+                        r = nn ? sum / (double)nn : 0.0;
+                        break;
+                    }
+                    case PANDRS_HIP_AGG_MIN:
+                    case PANDRS_HIP_AGG_MAX: {
+                        // untouched identity => the reference's sentinel rule: 0.0 (aggregation.rs:640-674)
+                        const bool mx = fd.op == PANDRS_HIP_AGG_MAX;
+                        const uint64_t raw = cell(mx ? fd.st_max : fd.st_min);
+                        if (raw != M_IDENT) {
+                            const uint64_t ce = mx ? ~raw : raw;
+                            r = KIND == 0 ? dec_f64(ce) : (double)dec_i64(ce);
+                        }
+                        break;
+                    }
+                    }
+                    a.out_aggs[(size_t)f * a.cap + pos] = r;
+                }
+            }
+            pos++;
+        }
+        if (!have_next) break;
+        __syncthreads();            // the table is re-initialised next
+        t = tn; cur = nxt;
+    }
+}
+
+template <int NSRC, int PROFILE, int ABLATE = 0, int DEPTH = 0>
+void launch_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds, uint32_t grid) {
+    // rows in flight per thread: as many as the register budget of a 1024-thread workgroup (128 VGPRs) allows
+    constexpr int D = DEPTH > 0 ? DEPTH : (NSRC <= 2 ? 6 : 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aggregate2_kernel<NSRC, PROFILE, ABLATE, D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((aggregate2_kernel<NSRC, PROFILE, ABLATE, D>), dim3(grid), dim3(AG_THREADS), lds, c->stream, a);
+}
+
+template <int NSRC>
+bool launch_profile(pandrs_hip_ctx *c, const AggArgs &a, int profile, size_t lds, uint32_t grid) {
+    switch (profile) {
+#define PROF(K, OPS, V) case ((K) << 4 | (OPS) << 1 | (V)): launch_one<NSRC, ((K) << 4 | (OPS) << 1 | (V))>(c, a, lds, grid); return true;
+        PROF(0, 1, 0) PROF(0, 1, 1) PROF(0, 7, 0) PROF(0, 7, 1) PROF(0, 6, 0) PROF(0, 6, 1)
+        PROF(0, 2, 0) PROF(0, 4, 0) PROF(0, 3, 0) PROF(0, 5, 0)
+        PROF(1, 1, 0) PROF(1, 1, 1) PROF(1, 7, 0) PROF(1, 7, 1) PROF(1, 6, 0)
+#undef PROF
+    default: return false;
+    }
+}
+
+}  // namespace
+
+bool aggregate2_has(int n_src, int profile) {
+    if (n_src < 1 || n_src > 4) return false;
+    switch (profile) {
+    case 2: case 3: case 14: case 15: case 12: case 13: case 4: case 8: case 6: case 10:
+    case 18: case 19: case 30: case 31: case 28: return true;
+    default: return false;
+    }
+}
+
+bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid) {
+    if (c->opt.agg_depth > 0 && c->opt.agg_ablate == 0 && n_src == 4 && profile == 14) {   // experiments: rows in flight per thread
+        switch (c->opt.agg_depth) {
+        case 2: launch_one<4, 14, 0, 2>(c, a, lds, grid); return true;
+        case 3: launch_one<4, 14, 0, 3>(c, a, lds, grid); return true;
+        case 5: launch_one<4, 14, 0, 5>(c, a, lds, grid); return true;
+        case 6: launch_one<4, 14, 0, 6>(c, a, lds, grid); return true;
+        }
+    }
+    if (c->opt.agg_ablate > 0 && n_src == 4 && profile == 14) {       // experiments only: what the C2 kernel's time is made of
+        switch (c->opt.agg_ablate) {
+        case 1: launch_one<4, 14, 1>(c, a, lds, grid); return true;   // no min / max work
+        case 2: launch_one<4, 14, 2>(c, a, lds, grid); return true;   // key lookup + group size only
+        case 3: launch_one<4, 14, 3>(c, a, lds, grid); return true;   // the HBM stream alone
+        case 4: launch_one<4, 14, 4>(c, a, lds, grid); return true;   // the HBM stream alone, no epilogue
+        case 6: launch_one<4, 14, 6>(c, a, lds, grid); return true;   // full work on L2-resident rows
+        case 5: for (int r = 0; r < 5; r++) launch_one<4, 14, 4>(c, a, lds, grid); return true;   // ... five times back to back
+        }
+    }
+    switch (n_src) {
+    case 1: return launch_profile<1>(c, a, profile, lds, grid);
+    case 2: return launch_profile<2>(c, a, profile, lds, grid);
+    case 3: return launch_profile<3>(c, a, profile, lds, grid);
+    case 4: return launch_profile<4>(c, a, profile, lds, grid);
+    default: return false;
+    }
+}
+
+}  // namespace pandrs

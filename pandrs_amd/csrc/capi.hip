@@ -133,6 +133,9 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_slice")) c->opt.no_slice = value;
     else if (!std::strcmp(name, "p_max")) c->opt.p_max = value;
     else if (!std::strcmp(name, "slice_rows")) c->opt.slice_rows = value;
+    else if (!std::strcmp(name, "agg_v1")) c->opt.agg_v1 = value;
+    else if (!std::strcmp(name, "agg_ablate")) c->opt.agg_ablate = value;
+    else if (!std::strcmp(name, "agg_depth")) c->opt.agg_depth = value;
     else return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return PANDRS_HIP_OK;
 }

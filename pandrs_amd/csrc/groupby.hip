@@ -19,7 +19,7 @@
 //             reference's finalisation rules applied in registers.
 // HBM traffic: keys once (histogram) + all columns read/written once (scatter) + read once
 // (aggregate) + outputs.  No MFMA: the path is integer/byte work bounded by HBM.
-#include "engine.hpp"
+#include "aggregate.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -27,8 +27,6 @@
 namespace pandrs {
 
 // ------------------------------------------------------------------------------------ aggregate
-struct AggTask { uint32_t part, beg, end, multi; };
-
 // one workgroup: partition sizes -> task list (a partition of more than slice_rows rows becomes
 // ceil(size / slice_rows) tasks flagged `multi`; empty partitions get no task)
 __global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1,
@@ -57,53 +55,6 @@ __global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offse
         __syncthreads();
     }
     if (threadIdx.x == 0) *n_tasks = min(carry, max_tasks);
-}
-
-struct AggArgs {
-    const uint64_t *pkeys;
-    const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
-    const int64_t *pgsize;       // merge mode: partitioned group sizes, else nullptr (=1 per row)
-    uint32_t NB, P, T, seed;
-    int n_src, n_states, n_fin, partials, n_rounds, round_states, second_pass;
-    int direct;                  // 1: no radix partition — workgroup b pre-aggregates rows [b*chunk, (b+1)*chunk) of the
-                                 // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) and emits partial records
-    KeyDesc dkey;
-    uint32_t d_rows, d_chunk, launch_grid, d_task_cap;
-    // oversized partitions are split into row slices handled by different workgroups; their groups
-    // leave as partial records in the side buffers (counters[2]) and are merged afterwards
-    const AggTask *tasks;        // nullptr: workgroup b = partition b
-    const uint32_t *n_tasks;
-    uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
-    int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
-    SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
-    int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
-    int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
-    FinDev fin[MAX_AGGS];
-    // outputs (row capacity = cap)
-    uint64_t *out_keys;
-    uint8_t *out_null;
-    double *out_aggs;            // [n_fin][cap]
-    uint64_t *out_states;        // [1 + n_states][cap] when partials
-    size_t cap;
-    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag
-};
-
-__device__ __forceinline__ uint64_t state_identity(int8_t kind) {
-    switch (kind) {
-    case SK_MIN_F64: return enc_f64(__longlong_as_double(0x7FF0000000000000ll));
-    case SK_MAX_F64: return enc_f64(__longlong_as_double((long long)0xFFF0000000000000ull));
-    case SK_MIN_I64: return enc_i64(INT64_MAX);
-    case SK_MAX_I64: return enc_i64(INT64_MIN);
-    default: return 0ull;   // +0.0 / 0
-    }
-}
-// natural (ABI / partial) representation of an LDS state cell
-__device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
-    switch (kind) {
-    case SK_MIN_F64: case SK_MAX_F64: return (uint64_t)__double_as_longlong(dec_f64(cell));
-    case SK_MIN_I64: case SK_MAX_I64: return (uint64_t)dec_i64(cell);
-    default: return cell;
-    }
 }
 
 // The reference's finalisation of one aggregate from the group's states
@@ -901,6 +852,20 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     int n_rounds = 1, round_states = 0, max_spr = 0;
     int64_t T = 0, P = 0, auto_slice_rows = 0;
     int8_t round_begin[MAX_ROUNDS + 1];
+    // uniform profile: raw rows, every source the same kind / ops / validity (one kernel instantiation)
+    auto prof_of = [](const EngSrc &e) {
+        int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
+        return (e.kind << 4) | (ops << 1) | ((e.null_bits || e.valid_bytes) ? 1 : 0);
+    };
+    int uni_profile = -1;
+    if (!merge && n_src > 0 && !c->opt.generic_aggregate && pl.mergeable) {
+        uni_profile = prof_of(srcs[0]);
+        for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != uni_profile) uni_profile = -1;
+    }
+    // the lean persistent kernel (aggregate2.hip): one round of a uniform profile over unclustered raw rows
+    const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && !c->clustered_rows && !c->opt.agg_v1 &&
+                       aggregate2_has(n_src, uni_profile);
+    bool use_v2 = false;
     for (;; spr = (spr + 1) / 2) {
         if (c->opt.src_per_round > 0 && !pl.needs_second_pass) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
         n_rounds = n_src ? (n_src + spr - 1) / spr : 1;
@@ -914,14 +879,15 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             max_spr = std::max(max_spr, b1 - b0);
         }
         if (n_src == 0) { round_begin[0] = round_begin[1] = 0; }
-        const size_t slot_bytes = 20 + 8 * (size_t)round_states;
+        use_v2 = v2_ok && n_rounds == 1;
+        const size_t slot_bytes = (use_v2 ? 12 : 20) + 8 * (size_t)round_states;    // aggregate2: u32 group sizes, no position map
         T = (int64_t)((lds_budget - 192) / slot_bytes) - 3;
         T = std::min<int64_t>(T, 32768) & ~int64_t(3);   // 4-key buckets
         P = (int64_t)std::ceil((double)est / ((double)T * LOAD));
         if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET || pl.needs_second_pass) break;
     }
     if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
-    const size_t slot_bytes = 20 + 8 * (size_t)round_states;
+    const size_t slot_bytes = (use_v2 ? 12 : 20) + 8 * (size_t)round_states;
     if (c->opt.partitions > 0) P = c->opt.partitions;
     else {
         // enough workgroups to fill 256 CUs (a partial record carries every state: fewer per workgroup)
@@ -937,7 +903,13 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (std::max(P, p_rec) <= 64) { P = std::max(P, p_rec); auto_slice_rows = N / p_par; p_par = 1; }
         }
         P = std::max<int64_t>(std::max<int64_t>(P, p_par), 1);
-        if (P > 256) P = (P + 127) / 128 * 128;
+        if (use_v2 && P > c->n_cu && auto_slice_rows == 0) {
+            // one persistent workgroup per CU walks P near-equal partitions: a multiple of the CU count has no
+            // ragged last round (1152 partitions on 256 CUs = 4.5 rounds, paid as 5).  Round down while the
+            // table load stays <= 0.80, else up.
+            const int64_t down = P / c->n_cu * c->n_cu, up = down + c->n_cu;
+            P = (double)est / ((double)down * (double)T) <= 0.80 ? down : up;
+        } else if (P > 256) P = (P + 127) / 128 * 128;
     }
     const int64_t P_LIMIT = c->opt.p_max > 0 ? std::min<int64_t>(c->opt.p_max, P_MAX) : P_MAX;
     if (P > P_LIMIT && c->opt.partitions <= 0 && res_slot == 0 && !c->quiet)
@@ -969,6 +941,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // LDS index of every state inside its round
         int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
         for (int k = 0; k < MAX_STATES; k++) { st_round[k] = -1; st_lds[k] = -1; }
+        // aggregate2's fixed LDS state order: the adds of source 0..n-1, then per source its min-type states
+        // (min, ~max), then the non-null counts
+        const int v2_mm = use_v2 ? ((uni_profile >> 2) & 1) + ((uni_profile >> 3) & 1) : 0;
+        const int v2_mbase = use_v2 && ((uni_profile >> 1) & 1) ? n_src : 0;
+        int v2_next_nn = v2_mbase + n_src * v2_mm;
         for (int r = 0; r < n_rounds; r++) {
             int next = 0;
             for (int s = round_begin[r]; s < round_begin[r + 1]; s++) {
@@ -988,6 +965,17 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                     if (abs_id < 0) return;
                     st_round[abs_id] = (int8_t)r; st_lds[abs_id] = (int8_t)next; lds_id = (int8_t)next; next++;
                 };
+                if (use_v2) {
+                    auto put = [&](int8_t abs_id, int8_t &lds_id, int at) {
+                        if (abs_id < 0) return;
+                        st_round[abs_id] = 0; st_lds[abs_id] = (int8_t)at; lds_id = (int8_t)at;
+                    };
+                    put(e.st_add, sd.st_add, s);
+                    put(e.st_min, sd.st_min, v2_mbase + s * v2_mm);
+                    put(e.st_max, sd.st_max, v2_mbase + s * v2_mm + v2_mm - 1);
+                    if (e.st_nn >= 0) put(e.st_nn, sd.st_nn, v2_next_nn++);
+                    continue;
+                }
                 place(e.st_add, sd.st_add); place(e.st_min, sd.st_min); place(e.st_max, sd.st_max); place(e.st_nn, sd.st_nn);
                 place(e.st_fadd, sd.st_fadd); place(e.st_ssq, sd.st_ssq);
             }
@@ -1045,7 +1033,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
         aa.out_states = res.states; aa.cap = cap; aa.counters = counters; aa.launch_grid = (uint32_t)P + 1;
-        if (slicing) {
+        if (slicing || use_v2) {
             const uint32_t max_tasks = (uint32_t)(P1 + max_slices);
             const size_t n_state_all = 1 + (size_t)pl.n_states;
             ST_TRY(c->side.ensure(Arena::padded(side_cap * 8) + Arena::padded(side_cap) + n_state_all * Arena::padded(side_cap * 8 + 256) + 8192, c->stream));
@@ -1058,23 +1046,15 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !n_tasks)
                 return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (slices)");
             hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1,
-                               (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll), tasks, n_tasks, max_tasks);
+                               slicing ? (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu, tasks, n_tasks, max_tasks);
             aa.tasks = tasks; aa.n_tasks = n_tasks; aa.launch_grid = max_tasks;
         }
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
             size_t lds = (size_t)(T + 3) * slot_bytes + 192;
-            // uniform profile: raw rows, one round, every source same kind / ops / validity
-            int profile = -1;
-            if (!merge && n_rounds == 1 && n_src > 0 && !c->opt.generic_aggregate && pl.mergeable) {
-                auto prof_of = [](const EngSrc &e) {
-                    int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
-                    return (e.kind << 4) | (ops << 1) | ((e.null_bits || e.valid_bytes) ? 1 : 0);
-                };
-                profile = prof_of(srcs[0]);
-                for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != profile) profile = -1;
-            }
-            launch_aggregate(c, aa, max_spr, profile, lds);
+            const int profile = n_rounds == 1 ? uni_profile : -1;
+            if (!(use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))))
+                launch_aggregate(c, aa, max_spr, profile, lds);
             HIP_TRY(hipGetLastError());
         }
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
