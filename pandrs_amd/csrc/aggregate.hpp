@@ -57,6 +57,7 @@ __device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
 
 // aggregate2.hip: lean persistent aggregate for uniform profiles on raw partitioned rows (one round).
 // Returns false when (n_src, profile) has no instantiation: the caller falls back to aggregate_kernel.
+constexpr size_t AGG2_LDS_EXTRA = 16 * 128 * 4 + 64;   // per-wave retry queues of aggregate2_kernel
 bool aggregate2_has(int n_src, int profile);
 bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
 

@@ -22,6 +22,67 @@ namespace pandrs {
 
 namespace {
 
+// Key -> slot in the partition's LDS table, insert on first sight.  Swiss-table layout: groups of 16
+// slots; a group's 16 one-byte tags (0 = empty, else 1 + hash byte) are ONE ds_read_b128, matched with
+// SWAR byte compares; the candidate's 8-byte key is then verified with one ds_read_b64.  16-slot groups
+// keep a wave's longest probe chain at ~1.4 groups at 65 % load (4-key buckets: 4.1 bucket reads per
+// wave and lookup — the dominant cost of the round-1 kernel, instructions and LDS bytes alike).
+// keys[] is the truth (claimed with ds_cmpst_b64); a tag is written after its key and may lag: a
+// lagging tag only sends a lane to the CAS, which answers "already yours" or "taken".
+__device__ __forceinline__ uint32_t swiss_find(uint64_t k, uint64_t *keys, uint8_t *ctrl, uint32_t T, uint32_t seed) {
+    const uint32_t NG = T >> 4;
+    const uint32_t h = hash32(k, seed);
+    uint32_t g = slot_of(h, NG);
+    const uint32_t tag = 1u + (h & 0xFFu) % 255u;
+    const uint32_t tag4 = tag * 0x01010101u;
+    for (uint32_t probe = 0; probe < NG; probe++) {
+        const uint4 cw = *reinterpret_cast<const uint4 *>(ctrl + 16 * g);
+        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+        uint32_t cand[4], emp[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t x = w[q] ^ tag4;
+            cand[q] = (x - 0x01010101u) & ~x & 0x80808080u;          // bytes equal to the tag (a 0x01 byte above a match may be flagged too: verified below)
+            emp[q] = (w[q] - 0x01010101u) & ~w[q] & 0x80808080u;     // empty bytes (same caveat; the CAS decides)
+        }
+        // candidates in slot order: verify the full key
+        for (;;) {
+            int q = cand[0] ? 0 : cand[1] ? 1 : cand[2] ? 2 : cand[3] ? 3 : -1;
+            if (q < 0) break;
+            const uint32_t z = q == 0 ? cand[0] : q == 1 ? cand[1] : q == 2 ? cand[2] : cand[3];
+            const uint32_t bit = (uint32_t)__ffs((int)z) - 1u;
+            const uint32_t idx = 16 * g + 4 * q + (bit >> 3);
+            if (keys[idx] == k) return idx;
+            const uint32_t clr = ~(1u << bit);
+            if (q == 0) cand[0] &= clr; else if (q == 1) cand[1] &= clr; else if (q == 2) cand[2] &= clr; else cand[3] &= clr;
+        }
+        // not in this group: claim its first free slot, or move on when it has none
+        for (;;) {
+            int q = emp[0] ? 0 : emp[1] ? 1 : emp[2] ? 2 : emp[3] ? 3 : -1;
+            if (q < 0) break;
+            const uint32_t z = q == 0 ? emp[0] : q == 1 ? emp[1] : q == 2 ? emp[2] : emp[3];
+            const uint32_t bit = (uint32_t)__ffs((int)z) - 1u;
+            const uint32_t idx = 16 * g + 4 * q + (bit >> 3);
+            const uint64_t old = atomicCAS((unsigned long long *)&keys[idx], EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { ctrl[idx] = (uint8_t)tag; return idx; }
+            if (old == k) return idx;
+            const uint32_t clr = ~(1u << bit);
+            if (q == 0) emp[0] &= clr; else if (q == 1) emp[1] &= clr; else if (q == 2) emp[2] &= clr; else emp[3] &= clr;
+        }
+        g = g + 1 == NG ? 0 : g + 1;
+    }
+    return T + 2;
+}
+
+// enc of a value for the min-type states: order-preserving u64 (f64: sign-magnitude flip, 4 VALU)
+template <int KIND>
+__device__ __forceinline__ uint64_t enc_val(uint64_t bits) {
+    if (KIND == 1) return bits ^ 0x8000000000000000ull;
+    const uint32_t hi = (uint32_t)(bits >> 32), lo = (uint32_t)bits;
+    const uint32_t sm = (uint32_t)((int32_t)hi >> 31);
+    return ((uint64_t)(hi ^ (sm | 0x80000000u)) << 32) | (uint32_t)(lo ^ sm);
+}
+
 template <int NSRC, int PROFILE, int ABLATE, int DEPTH>
 __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr bool HAS_V = (PROFILE & 1) != 0, OP_ADD = ((PROFILE >> 1) & 1) != 0;
@@ -29,17 +90,19 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr int KIND = (PROFILE >> 4) & 1;                 // 0 f64, 1 i64
     constexpr int MM = (OP_MIN ? 1 : 0) + (OP_MAX ? 1 : 0);  // min-type states per source
     constexpr uint64_t M_IDENT = KIND == 0 ? 0xFFF0000000000000ull : ~0ull;   // enc(+inf) = ~enc(-inf); enc(MAX) = ~enc(MIN)
+    constexpr uint32_t QCAP = 128;                           // per-wave retry queue (row indices)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x;   // slot T: the key equal to the table sentinel
-    // LDS: keys[T1] | states[round_states][T1] | gsz[T1] (u32) | misc[40]
+    // LDS: keys[T1] | states[round_states][T1] | gsz[T1] (u32) | ctrl[T] (u8) | misc[40] | queue[16][QCAP]   (T multiple of 16)
     // state order (fixed by run_engine for this kernel): adds of source 0..n-1, then per source its
     // min-type states (min, ~max), then the non-null counts
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *st = keys + T1;
     uint32_t *gsz = reinterpret_cast<uint32_t *>(st + (size_t)a.round_states * T1);
-    uint32_t *misc = gsz + ((T1 + 3) & ~3u);
+    uint8_t *ctrl = reinterpret_cast<uint8_t *>(gsz + ((T1 + 3) & ~3u));      // [T] slot tags, 16-byte groups
+    uint32_t *misc = reinterpret_cast<uint32_t *>(ctrl + T);
+    uint32_t *queue = misc + 40 + (tid >> 6) * QCAP;
     // misc[0..16] scan scratch, [20] overflow, [21] sentinel-key-present, [22] output base
-    constexpr int n_src = NSRC;                               // exact: the hot loop is straight-line code
     constexpr uint32_t m_base = OP_ADD ? (uint32_t)NSRC : 0u;
     const uint64_t *vals[NSRC];
     const uint8_t *valid[NSRC];
@@ -49,6 +112,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         vals[c] = a.src[c].vals; valid[c] = a.src[c].valid; nn_idx[c] = HAS_V ? a.src[c].st_nn : -1;
     }
     const uint64_t *pkeys = a.pkeys;
+    const uint32_t seed = a.seed, NG = T >> 4, lane = tid & 63;
 
     const uint32_t n_tasks = *a.n_tasks;
     uint32_t t = blockIdx.x;
@@ -56,10 +120,11 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     AggTask cur = a.tasks[t];
 
     // Register ring of DEPTH row slots per thread (one row per slot): slot d holds batch (pit + d) of the
-    // current task while the loads of the following DEPTH - 1 batches are in flight.  Batches start at a
-    // 128-byte boundary (16 rows: a wave's 512-byte loads cover whole lines; misaligned streams measured
-    // 15 % slower, experiments/ubench/stream_formats.hip) and a task's batch count is padded to a multiple
-    // of DEPTH so that slot numbers are compile-time constants across task boundaries.
+    // current task while the loads of the following batches are in flight.  Batches start at a 128-byte
+    // boundary (16 rows: a wave's 512-byte loads cover whole lines; misaligned streams measured 15 %
+    // slower, experiments/ubench/stream_formats.hip) and a task's batch count is padded to a multiple of
+    // DEPTH so that slot numbers are compile-time constants across task boundaries.  Plain loads: the first
+    // read of freshly written lines is faster with them than with nt loads (experiments/ubench/fresh_read.hip).
     uint64_t rk[DEPTH], rv[DEPTH][NSRC];
     uint32_t rok[DEPTH];
     auto n_batches = [](const AggTask &tk) {
@@ -78,6 +143,80 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             if (HAS_V && valid[c][i] == 0) rok[d] &= ~(1u << c);
         }
     };
+
+    // ---- the fold of one row into its group's states (aggregation.rs:625-674) ----
+    auto update = [&](uint32_t slot, const uint64_t (&v)[NSRC], uint32_t okm) {
+        atomicAdd(&gsz[slot], 1u);
+        if (ABLATE == 2) return;
+        // current min-type states first (back-to-back ds_read_b64, one wait), then the adds
+        uint64_t cm[NSRC][MM > 0 ? MM : 1];
+        if (MM > 0 && ABLATE != 1) {
+#pragma unroll
+            for (int c = 0; c < NSRC; c++)
+#pragma unroll
+                for (int j = 0; j < MM; j++) cm[c][j] = st[(size_t)(m_base + c * MM + j) * T1 + slot];
+        }
+#pragma unroll
+        for (int c = 0; c < NSRC; c++) {
+            if (!HAS_V || ((okm >> c) & 1)) {
+                if (OP_ADD) {
+                    if (KIND == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)c * T1 + slot]), __longlong_as_double((long long)v[c]));
+                    else atomicAdd((unsigned long long *)&st[(size_t)c * T1 + slot], (unsigned long long)v[c]);
+                }
+                if (HAS_V && nn_idx[c] >= 0) atomicAdd((unsigned long long *)&st[(size_t)nn_idx[c] * T1 + slot], 1ull);
+            }
+        }
+        if (MM > 0 && ABLATE != 1) {
+            // which (source, min/max) states does this row improve?  Skipping on a stale read is safe: states
+            // only move towards the extreme.  Rust's f64::min/max ignore NaN operands (aggregation.rs:653, :666).
+            uint32_t upd = 0;
+            uint64_t e[NSRC];
+#pragma unroll
+            for (int c = 0; c < NSRC; c++) {
+                bool cmp = !HAS_V || ((okm >> c) & 1) != 0;
+                if (KIND == 0) { const double d = __longlong_as_double((long long)v[c]); cmp = cmp && d == d; }
+                e[c] = enc_val<KIND>(v[c]);
+                if (OP_MIN) upd |= (cmp && e[c] < cm[c][0]) ? 1u << (c * MM) : 0u;
+                if (OP_MAX) upd |= (cmp && e[c] > ~cm[c][MM - 1]) ? 1u << (c * MM + MM - 1) : 0u;
+            }
+            // one ds_min_u64 per pending update and lane: lanes hold different states in the same
+            // instruction, so the wave needs max-popcount iterations, not one per state
+            while (upd) {
+                const uint32_t q = (uint32_t)__ffs((int)upd) - 1u;
+                upd &= upd - 1;
+                const uint32_t c_ = MM == 2 ? q >> 1 : q;
+                uint64_t ee = e[0];
+#pragma unroll
+                for (int c = 1; c < NSRC; c++) ee = c_ == (uint32_t)c ? e[c] : ee;
+                const uint64_t neg = OP_MIN ? (MM == 2 ? 0ull - (uint64_t)(q & 1) : 0ull) : ~0ull;
+                atomicMin((unsigned long long *)&st[(size_t)(m_base + q) * T1 + slot], ee ^ neg);
+            }
+        }
+    };
+    // ---- rows the fast path could not place (first sight of a key, a key outside its home group, a tag
+    // collision, the sentinel-valued key): the wave keeps their row indices and handles 64 at a time, one
+    // per lane, with the general probe — so the rare path costs per ROW, not per wave that contains one.
+    uint32_t qn = 0;                                   // wave-uniform
+    auto drain = [&](uint32_t n_take) {                // n_take <= 64 entries from the top of the wave's queue
+        qn -= n_take;
+        if (lane < n_take) {
+            const uint32_t i = queue[qn + lane];
+            const uint64_t k = pkeys[i];
+            uint64_t v[NSRC];
+            uint32_t okm = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < NSRC; c++) {
+                v[c] = vals[c][i];
+                if (HAS_V && valid[c][i] == 0) okm &= ~(1u << c);
+            }
+            uint32_t slot = T;
+            if (k == EMPTY_KEY) misc[21] = 1;
+            else slot = swiss_find(k, keys, ctrl, T, seed);
+            if (slot > T) misc[20] = 1;                // table full: host retries with more partitions
+            else update(slot, v, okm);
+        }
+    };
+
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, cur, d);
 
@@ -89,8 +228,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         const bool multi = cur.multi != 0;
 
         for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
+        for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;
         for (int k = 0; k < a.round_states; k++) {
-            const uint64_t idv = ((uint32_t)k >= m_base && (uint32_t)k < m_base + (uint32_t)(n_src * MM)) ? M_IDENT : 0ull;
+            const uint64_t idv = ((uint32_t)k >= m_base && (uint32_t)k < m_base + (uint32_t)(NSRC * MM)) ? M_IDENT : 0ull;
             uint64_t *dst = st + (size_t)k * T1;
             for (uint32_t s = tid; s < T1; s += AG_THREADS) dst[s] = idv;
         }
@@ -104,108 +244,47 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             for (int h = 0; h < DEPTH; h++) {
                 const uint32_t row = beg0 + (pit + h) * AG_THREADS + tid;
                 const uint64_t k = rk[h];
-                uint64_t v[1][NSRC];
-                uint32_t okm[1];
-                okm[0] = rok[h];
+                uint64_t v[NSRC];
+                const uint32_t okm = rok[h];
 #pragma unroll
-                for (int c = 0; c < NSRC; c++) v[0][c] = rv[h][c];
+                for (int c = 0; c < NSRC; c++) v[c] = rv[h][c];
                 // refill this slot: DEPTH batches ahead, or the next task's batch h (its loads fly under this task's epilogue)
                 if (!last) fetch(h, cur, pit + h + DEPTH);
                 else if (have_next) fetch(h, nxt, h);
-                if (row < beg || row >= end) continue;
-                if (ABLATE >= 2) {          // experiments: keep every load alive without using it
-                    uint64_t x = 0;
+                const bool act = row >= beg && row < end;
+                if (ABLATE >= 3 && ABLATE != 6) {          // experiments: keep every load alive without using it
+                    uint64_t x = k;
 #pragma unroll
-                    for (int c = 0; c < NSRC; c++) x ^= v[0][c];
+                    for (int c = 0; c < NSRC; c++) x ^= v[c];
                     if (x == 0x1234567ull) misc[30] = 1;
-                    if (ABLATE >= 3 && ABLATE != 6) { if (k == 0x1234567ull) misc[31] = 1; continue; }
+                    continue;
                 }
-                uint32_t slot = T;
-                if (k == EMPTY_KEY) {
-                    misc[21] = 1;
-                } else {
-                    // 4-key buckets (32 B, two ds_read_b128): one LDS round trip tests four slots
-                    const uint32_t NBK = T >> 2;
-                    uint32_t bk = slot_of(hash32(k, a.seed), NBK), probe = 0;
-                    bool found = false;
-                    while (probe < NBK) {
-                        const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
-                        const ulonglong2 lo = bp[0], hi = bp[1];
-                        const uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
-                        int hit = -1, emp = -1;
-#pragma unroll
-                        for (int q = 3; q >= 0; q--) {
-                            if (c4[q] == k) hit = q;
-                            if (c4[q] == EMPTY_KEY) emp = q;
-                        }
-                        if (hit >= 0) { slot = 4 * bk + hit; found = true; break; }
-                        if (emp >= 0) {
-                            const uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + emp], EMPTY_KEY, k);
-                            if (old == EMPTY_KEY || old == k) { slot = 4 * bk + emp; found = true; break; }
-                            continue;               // lost the race for that slot: re-read this bucket
-                        }
-                        bk = bk + 1 == NBK ? 0 : bk + 1;
-                        probe++;
-                    }
-                    if (!found) { misc[20] = 1; continue; }   // table full: host retries with more partitions
+                // ---- fast path, branch-free: home group's 16 tags (one ds_read_b128), SWAR match, first
+                // candidate's key verified (one ds_read_b64)
+                const uint32_t hsh = hash32(k, seed);
+                const uint32_t g = slot_of(hsh, NG);
+                const uint32_t tag4 = (1u + (hsh & 0xFFu) % 255u) * 0x01010101u;
+                const uint4 cw = *reinterpret_cast<const uint4 *>(ctrl + 16 * g);
+                const uint32_t x0 = cw.x ^ tag4, x1 = cw.y ^ tag4, x2 = cw.z ^ tag4, x3 = cw.w ^ tag4;
+                const uint32_t c0 = (x0 - 0x01010101u) & ~x0 & 0x80808080u, c1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
+                const uint32_t c2 = (x2 - 0x01010101u) & ~x2 & 0x80808080u, c3 = (x3 - 0x01010101u) & ~x3 & 0x80808080u;
+                uint32_t sel = c3, off = 12;
+                sel = c2 ? c2 : sel; off = c2 ? 8u : off;
+                sel = c1 ? c1 : sel; off = c1 ? 4u : off;
+                sel = c0 ? c0 : sel; off = c0 ? 0u : off;
+                uint32_t idx = 16 * g + off + (((uint32_t)__ffs((int)sel) - 1u) >> 3);
+                idx = sel ? idx : T;                       // no candidate: slot T never holds a real key
+                const bool ok = act && keys[idx] == k && k != EMPTY_KEY;
+                const unsigned long long miss = __ballot(act && !ok);
+                if (miss) {                                // wave-uniform
+                    if (act && !ok) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(miss >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)miss, 0u))] = row;
+                    qn += (uint32_t)__popcll(miss);
+                    if (qn >= 64) drain(64);
                 }
-                atomicAdd(&gsz[slot], 1u);
-                if (ABLATE == 2) continue;
-                // current min-type states first (back-to-back ds_read_b64, one wait), then the adds
-                uint64_t cm[NSRC][MM > 0 ? MM : 1];
-                if (MM > 0 && ABLATE != 1) {
-#pragma unroll
-                    for (int c = 0; c < NSRC; c++)
-#pragma unroll
-                        for (int j = 0; j < MM; j++) cm[c][j] = st[(size_t)(m_base + c * MM + j) * T1 + slot];
-                }
-#pragma unroll
-                for (int c = 0; c < NSRC; c++) {
-                    if (!HAS_V || ((okm[0] >> c) & 1)) {
-                        if (OP_ADD) {
-                            if (KIND == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)c * T1 + slot]), __longlong_as_double((long long)v[0][c]));
-                            else atomicAdd((unsigned long long *)&st[(size_t)c * T1 + slot], (unsigned long long)v[0][c]);
-                        }
-                        if (HAS_V && nn_idx[c] >= 0) atomicAdd((unsigned long long *)&st[(size_t)nn_idx[c] * T1 + slot], 1ull);
-                    }
-                }
-                if (MM > 0 && ABLATE != 1) {
-                    // which (source, min/max) states does this row improve?  Skipping on a stale read is
-                    // safe: states only move towards the extreme.  Rust's f64::min/max ignore NaN operands
-                    // (aggregation.rs:653, :666).
-                    uint32_t upd = 0;
-                    uint64_t e[NSRC];
-#pragma unroll
-                    for (int c = 0; c < NSRC; c++) {
-                        {
-                            bool cmp = !HAS_V || ((okm[0] >> c) & 1) != 0;
-                            if (KIND == 0) {
-                                const double d = __longlong_as_double((long long)v[0][c]);
-                                cmp = cmp && d == d;
-                                e[c] = enc_f64(d);
-                            } else {
-                                e[c] = enc_i64((int64_t)v[0][c]);
-                            }
-                            if (OP_MIN && cmp && e[c] < cm[c][0]) upd |= 1u << (c * MM);
-                            if (OP_MAX && cmp && ~e[c] < cm[c][MM - 1]) upd |= 1u << (c * MM + MM - 1);
-                        }
-                    }
-                    // one ds_min_u64 per pending update and lane: lanes hold different states in the same
-                    // instruction, so the wave needs max-popcount iterations, not one per state
-                    while (upd) {
-                        const uint32_t q = (uint32_t)__ffs((int)upd) - 1u;
-                        upd &= upd - 1;
-                        const uint32_t c_ = MM == 2 ? q >> 1 : q;
-                        uint64_t ee = e[0];
-#pragma unroll
-                        for (int c = 1; c < NSRC; c++) if (c_ == (uint32_t)c) ee = e[c];
-                        const bool neg = OP_MIN ? (MM == 2 && (q & 1)) : true;
-                        if (neg) ee = ~ee;
-                        atomicMin((unsigned long long *)&st[(size_t)(m_base + q) * T1 + slot], ee);
-                    }
-                }
+                if (ok) update(idx, v, okm);
             }
         }
+        if (qn) drain(qn);
         __syncthreads();
         if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
         if (ABLATE == 4) { if (!have_next) break; t = tn; cur = nxt; continue; }   // experiments: no compaction / outputs
@@ -284,7 +363,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
 template <int NSRC, int PROFILE, int ABLATE = 0, int DEPTH = 0>
 void launch_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds, uint32_t grid) {
     // rows in flight per thread: as many as the register budget of a 1024-thread workgroup (128 VGPRs) allows
-    constexpr int D = DEPTH > 0 ? DEPTH : (NSRC <= 2 ? 6 : 4);
+    constexpr int D = DEPTH > 0 ? DEPTH : (NSRC <= 2 ? 4 : 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aggregate2_kernel<NSRC, PROFILE, ABLATE, D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((aggregate2_kernel<NSRC, PROFILE, ABLATE, D>), dim3(grid), dim3(AG_THREADS), lds, c->stream, a);

@@ -880,14 +880,14 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
         if (n_src == 0) { round_begin[0] = round_begin[1] = 0; }
         use_v2 = v2_ok && n_rounds == 1;
-        const size_t slot_bytes = (use_v2 ? 12 : 20) + 8 * (size_t)round_states;    // aggregate2: u32 group sizes, no position map
-        T = (int64_t)((lds_budget - 192) / slot_bytes) - 3;
-        T = std::min<int64_t>(T, 32768) & ~int64_t(3);   // 4-key buckets
+        const size_t slot_bytes = (use_v2 ? 13 : 20) + 8 * (size_t)round_states;    // aggregate2: u32 group sizes, one tag byte, no position map
+        T = (int64_t)((lds_budget - 192 - (use_v2 ? AGG2_LDS_EXTRA : 0)) / slot_bytes) - 3;
+        T = std::min<int64_t>(T, 32768) & (use_v2 ? ~int64_t(15) : ~int64_t(3));   // 16-slot groups / 4-key buckets
         P = (int64_t)std::ceil((double)est / ((double)T * LOAD));
         if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET || pl.needs_second_pass) break;
     }
     if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
-    const size_t slot_bytes = (use_v2 ? 12 : 20) + 8 * (size_t)round_states;
+    const size_t slot_bytes = (use_v2 ? 13 : 20) + 8 * (size_t)round_states;
     if (c->opt.partitions > 0) P = c->opt.partitions;
     else {
         // enough workgroups to fill 256 CUs (a partial record carries every state: fewer per workgroup)
@@ -1051,7 +1051,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
-            size_t lds = (size_t)(T + 3) * slot_bytes + 192;
+            size_t lds = (size_t)(T + 3) * slot_bytes + 192 + (use_v2 ? AGG2_LDS_EXTRA : 0);
             const int profile = n_rounds == 1 ? uni_profile : -1;
             if (!(use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))))
                 launch_aggregate(c, aa, max_spr, profile, lds);
