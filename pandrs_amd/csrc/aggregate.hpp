@@ -6,6 +6,11 @@
 namespace pandrs {
 
 struct AggTask { uint32_t part, beg, end, multi; };
+// aggregate2: one LDS table = one partition, or one row slice of an oversized partition (multi), fed by
+// the row ranges tasks[task_beg .. task_beg + n_tasks) (1 in the exact layout, up to 8 in the capacity layout)
+struct AggTable { uint32_t task_beg, n_tasks, part, multi; };
+// where a partition's rows are: exact layout (histogram) or capacity layout (radix_partition_sampled)
+struct SegSource { const uint32_t *offsets; uint32_t NB; const uint32_t *gbeg, *gcur, *gend; };
 
 struct AggArgs {
     const uint64_t *pkeys;
@@ -21,6 +26,7 @@ struct AggArgs {
     // leave as partial records in the side buffers (counters[2]) and are merged afterwards
     const AggTask *tasks;        // nullptr: workgroup b = partition b
     const uint32_t *n_tasks;
+    const AggTable *tables;      // aggregate2 only; n_tasks[1] = number of tables
     uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
     SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round

@@ -114,10 +114,12 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     const uint64_t *pkeys = a.pkeys;
     const uint32_t seed = a.seed, NG = T >> 4, lane = tid & 63;
 
-    const uint32_t n_tasks = *a.n_tasks;
-    uint32_t t = blockIdx.x;
-    if (t >= n_tasks) return;
-    AggTask cur = a.tasks[t];
+    const uint32_t n_tables = a.n_tasks[1];
+    uint32_t tb = blockIdx.x;
+    if (tb >= n_tables) return;
+    AggTable tab = a.tables[tb];
+    uint32_t ti = tab.task_beg;
+    AggTask cur = a.tasks[ti];
 
     // Register ring of DEPTH row slots per thread (one row per slot): slot d holds batch (pit + d) of the
     // current task while the loads of the following batches are in flight.  Batches start at a 128-byte
@@ -220,12 +222,12 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, cur, d);
 
-    for (;;) {
-        const uint32_t tn = t + gridDim.x;
-        const bool have_next = tn < n_tasks;
-        const AggTask nxt = a.tasks[have_next ? tn : t];
-        const uint32_t beg = cur.beg, end = cur.end, beg0 = cur.beg & ~15u;
-        const bool multi = cur.multi != 0;
+    for (;;) {                                         // one LDS table per iteration
+        const uint32_t tbn = tb + gridDim.x;
+        const bool have_next_tab = tbn < n_tables;
+        const AggTable ntab = a.tables[have_next_tab ? tbn : tb];
+        const bool multi = tab.multi != 0;
+        const uint32_t t_end = tab.task_beg + tab.n_tasks;
 
         for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
         for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;
@@ -237,6 +239,11 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         if (tid < 32) misc[tid] = 0;
         __syncthreads();
 
+      for (;;) {                                       // the row ranges that feed this table
+        const bool more_in_tab = ti + 1 < t_end;
+        const bool have_next = more_in_tab || have_next_tab;
+        const AggTask nxt = a.tasks[more_in_tab ? ti + 1 : (have_next_tab ? ntab.task_beg : ti)];
+        const uint32_t beg = cur.beg, end = cur.end, beg0 = cur.beg & ~15u;
         const uint32_t n_it = n_batches(cur);
         for (uint32_t pit = 0; pit < n_it; pit += DEPTH) {
             const bool last = pit + DEPTH >= n_it;
@@ -284,10 +291,13 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 if (ok) update(idx, v, okm);
             }
         }
+        if (!more_in_tab) { cur = nxt; break; }         // nxt = the next table's first range (already in flight)
+        ti++; cur = nxt;
+      }
         if (qn) drain(qn);
         __syncthreads();
         if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
-        if (ABLATE == 4) { if (!have_next) break; t = tn; cur = nxt; continue; }   // experiments: no compaction / outputs
+        if (ABLATE == 4) { if (!have_next_tab) break; tb = tbn; tab = ntab; ti = tab.task_beg; continue; }   // experiments: no compaction / outputs
 
         // ---- compaction + outputs: every thread owns a contiguous run of slots, ONE block scan ----
         uint64_t *const o_keys = multi ? a.side_keys : a.out_keys;
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         const size_t o_cap = multi ? a.side_cap : a.cap;
         const bool emit_partials = a.partials != 0 || multi;
         const bool sentinel = misc[21] != 0;
-        const bool null_part = cur.part == a.P;
+        const bool null_part = tab.part == a.P;
         const uint32_t spt = (T1 + AG_THREADS - 1) / AG_THREADS;
         const uint32_t s_beg = min(tid * spt, T1), s_end = min(s_beg + spt, T1);
         auto occupied = [&](uint32_t s) { return s < T ? keys[s] != EMPTY_KEY : (s == T && sentinel); };
@@ -354,9 +364,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             }
             pos++;
         }
-        if (!have_next) break;
+        if (!have_next_tab) break;
         __syncthreads();            // the table is re-initialised next
-        t = tn; cur = nxt;
+        tb = tbn; tab = ntab; ti = tab.task_beg;
     }
 }
 

@@ -52,6 +52,11 @@ struct ScatterArgs {
     uint64_t *pkeys;
     const uint32_t *offsets;   // partition-major exclusive scan of the histogram
     uint32_t *gcur;            // [P+1][8] shared write cursors per (partition, group); nullptr = private cursors
+    // capacity mode (radix_partition_sampled): no histogram ran; region (p, g) is [gbeg, gend) rows, sized from a
+    // sample.  A run that does not fit raises flags[0] and is dropped (the caller falls back to the exact path).
+    const uint32_t *gend;      // nullptr = exact mode
+    uint32_t *flags;
+    uint32_t total_cap;        // rows of the partitioned arrays in capacity mode
     int64_t n_rows, chunk;
     uint32_t P, seed;
     int n_move, n_move8;       // mv[0 .. n_move8) are 8-byte columns, the rest byte-wide
@@ -101,12 +106,22 @@ struct RowSource {
 struct PartInfo {
     uint32_t P = 0, NB = 0;
     uint32_t *offsets = nullptr;
+    // capacity mode: partition p = the 8 row ranges [gbeg[p*8+g], min(gcur[p*8+g], gend[p*8+g]))
+    uint32_t *gbeg = nullptr, *gcur = nullptr, *gend = nullptr, *flags = nullptr;
+    uint32_t total_cap = 0;
 };
 
 // histogram -> scan -> scatter.  The caller fills sa.key, sa.pkeys, sa.mv[0..n_move), sa.n_rows,
 // sa.P, sa.seed; workspace comes from c->work (not reset here).
 int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
                         int phase_scatter);
+// The same partition WITHOUT the exact histogram pass: per-(partition, group) region capacities come from a
+// 1-in-8 sample of the keys (+ 6 sigma), the scatter appends with the shared cursors and drops what does not
+// fit (flags[0]: the caller re-runs with radix_partition).  The caller allocates every destination column with
+// sampled_partition_rows(n_rows, P) rows.
+int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scatter);
+uint32_t sampled_partition_rows(int64_t n_rows, int64_t P);
+bool sampled_partition_ok(int64_t n_rows, int64_t P);
 int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out, uint32_t *seg);
 size_t scan_seg_count(size_t n);     // entries the `seg` scratch of exclusive_scan_u32 needs
 // sampled cardinality estimate (also sets c->clustered_rows); synchronises the stream

@@ -57,6 +57,69 @@ __global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offse
     if (threadIdx.x == 0) *n_tasks = min(carry, max_tasks);
 }
 
+// aggregate2's work list: tables (one per partition; an oversized partition is cut into tables of <= slice_rows
+// rows flagged `multi`) and, per table, the row ranges that feed it.  One workgroup; counts[0] = tasks, [1] = tables.
+__global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32_t P1, uint32_t slice_rows, AggTask *tasks,
+                                                            AggTable *tables, uint32_t *counts, uint32_t max_tasks,
+                                                            uint32_t max_tables) {
+    __shared__ uint32_t wt[17];
+    __shared__ uint32_t carry[2];
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < P1; base += 1024) {
+        const uint32_t p = base + threadIdx.x;
+        uint32_t sb[8], se[8], n_seg = 0;
+        uint64_t R = 0;
+        if (p < P1) {
+            if (ss.gbeg) {
+                n_seg = 8;
+                for (int g = 0; g < 8; g++) { sb[g] = ss.gbeg[p * 8 + g]; se[g] = max(min(ss.gcur[p * 8 + g], ss.gend[p * 8 + g]), sb[g]); }
+            } else {
+                n_seg = 1;
+                sb[0] = ss.offsets[(size_t)p * ss.NB]; se[0] = ss.offsets[(size_t)(p + 1) * ss.NB];
+            }
+            for (uint32_t g = 0; g < n_seg; g++) R += se[g] - sb[g];
+        }
+        const uint32_t n_tab = R ? (uint32_t)((R + slice_rows - 1) / slice_rows) : 0u;
+        // tasks = non-empty intersections of the segments with the tables' virtual row ranges
+        uint32_t n_task = 0;
+        {
+            uint64_t v0 = 0;
+            for (uint32_t g = 0; g < n_seg; g++) {
+                const uint64_t len = se[g] - sb[g];
+                if (len) n_task += (uint32_t)((v0 + len - 1) / slice_rows - v0 / slice_rows) + 1u;
+                v0 += len;
+            }
+        }
+        uint32_t tot_tab, tot_task;
+        const uint32_t ex_tab = block_exclusive_scan<1024>(n_tab, wt, &tot_tab) + carry[1];
+        const uint32_t ex_task = block_exclusive_scan<1024>(n_task, wt, &tot_task) + carry[0];
+        if (n_tab && ex_tab + n_tab <= max_tables && ex_task + n_task <= max_tasks) {
+            uint32_t ti = ex_task, tb = ex_tab, g = 0;
+            uint64_t v0 = 0;                       // virtual row where segment g starts
+            for (uint32_t j = 0; j < n_tab; j++) {
+                const uint64_t lo = (uint64_t)j * slice_rows, hi = min((uint64_t)(j + 1) * slice_rows, R);
+                const uint32_t first = ti;
+                while (g < n_seg) {
+                    const uint64_t len = se[g] - sb[g];
+                    const uint64_t a0 = max(lo, v0), a1 = min(hi, v0 + len);
+                    if (a1 > a0) tasks[ti++] = AggTask{p, sb[g] + (uint32_t)(a0 - v0), sb[g] + (uint32_t)(a1 - v0), n_tab > 1 ? 1u : 0u};
+                    if (v0 + len > hi) break;      // the segment continues in the next table
+                    v0 += len; g++;
+                }
+                tables[tb++] = AggTable{first, ti - first, p, n_tab > 1 ? 1u : 0u};
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += tot_task; carry[1] += tot_tab; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[0] = min(carry[0], max_tasks); counts[1] = min(carry[1], max_tables);
+        counts[2] = (carry[0] > max_tasks || carry[1] > max_tables) ? 1u : 0u;     // cannot happen with the caller's bounds
+    }
+}
+
 // The reference's finalisation of one aggregate from the group's states
 // (aggregation.rs:507-556, :625-674, :743).
 __device__ __forceinline__ double finalize(const FinDev &f, const uint64_t *st, uint32_t stride,
@@ -747,7 +810,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
     // ---- workspace upper bound so that one ensure() covers the whole call (incl. retries)
-    size_t ws = engine_workspace_bytes(N, 1 + n_src + (merge ? 1 : 0), n_src);
+    // the capacity layout of radix_partition_sampled over-allocates the partitioned columns by <= 25 %
+    size_t ws = engine_workspace_bytes(N + N / 4 + 131072, 1 + n_src + (merge ? 1 : 0), n_src);
     ST_TRY(c->work.ensure(ws, c->stream));
     int64_t est = c->opt.groups_hint;
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
@@ -920,12 +984,17 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     P = std::min<int64_t>(std::max<int64_t>(P, 1), P_LIMIT);
 
     const uint32_t seed = 0x9E3779B9u;
+    bool sampled_failed = false;       // a capacity-mode run overflowed a region: repeat with the exact histogram
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
         const uint32_t P1 = (uint32_t)P + 1;
+        // capacity mode (no histogram pass): aggregate2 only (it walks a partition's 8 row ranges), unclustered rows
+        const bool sampled = use_v2 && !sampled_failed && !c->opt.exact_partition && c->opt.shared_cursors &&
+                             c->opt.scatter_threads != 512 && c->opt.scatter_staged && sampled_partition_ok(N, P);
+        const size_t NP = sampled ? (size_t)sampled_partition_rows(N, P) : (size_t)N;     // rows of the partitioned columns
         uint32_t *counters = c->work.take<uint32_t>(64);
-        uint64_t *pkeys = c->work.take<uint64_t>(N);
+        uint64_t *pkeys = c->work.take<uint64_t>(NP);
         if (!counters || !pkeys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
         HIP_TRY(hipMemsetAsync(counters, 0, 64 * 4, c->stream));
 
@@ -950,12 +1019,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             int next = 0;
             for (int s = round_begin[r]; s < round_begin[r + 1]; s++) {
                 EngSrc &e = srcs[s];
-                uint64_t *pv = c->work.take<uint64_t>(N);
+                uint64_t *pv = c->work.take<uint64_t>(NP);
                 if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
                 sa.mv[sa.n_move++] = MoveDesc{e.data, pv, (e.rowidx && !e.data) ? 5 : 0, 0};
                 uint8_t *pvalid = nullptr;
                 if (e.null_bits || e.valid_bytes) {
-                    pvalid = c->work.take<uint8_t>(N);
+                    pvalid = c->work.take<uint8_t>(NP);
                     if (!pvalid) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
                     sa.mv[sa.n_move++] = e.null_bits ? MoveDesc{e.null_bits, pvalid, 1, 0} : MoveDesc{e.valid_bytes, pvalid, 2, 0};
                 }
@@ -981,7 +1050,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             }
         }
         PartInfo part;
-        ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+        if (sampled) ST_TRY(radix_partition_sampled(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCATTER));
+        else ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
         const uint32_t NB = part.NB;
         uint32_t *offsets = part.offsets;
 
@@ -1034,7 +1104,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs;
         aa.out_states = res.states; aa.cap = cap; aa.counters = counters; aa.launch_grid = (uint32_t)P + 1;
         if (slicing || use_v2) {
-            const uint32_t max_tasks = (uint32_t)(P1 + max_slices);
+            const uint32_t max_tables = (uint32_t)(P1 + max_slices);
+            const uint32_t max_tasks = use_v2 ? 8 * P1 + max_tables : max_tables;
             const size_t n_state_all = 1 + (size_t)pl.n_states;
             ST_TRY(c->side.ensure(Arena::padded(side_cap * 8) + Arena::padded(side_cap) + n_state_all * Arena::padded(side_cap * 8 + 256) + 8192, c->stream));
             aa.side_keys = c->side.take<uint64_t>(side_cap);
@@ -1042,12 +1113,21 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             aa.side_states = c->side.take<uint64_t>(side_cap * n_state_all + 32);
             aa.side_cap = side_cap;
             AggTask *tasks = c->work.take<AggTask>(max_tasks + 8);
+            AggTable *tables = c->work.take<AggTable>(max_tables + 8);
             uint32_t *n_tasks = c->work.take<uint32_t>(64);
-            if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !n_tasks)
+            if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !tables || !n_tasks)
                 return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (slices)");
-            hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1,
-                               slicing ? (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu, tasks, n_tasks, max_tasks);
-            aa.tasks = tasks; aa.n_tasks = n_tasks; aa.launch_grid = max_tasks;
+            const uint32_t srows = slicing ? (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu;
+            if (use_v2) {
+                const SegSource ss{offsets, NB, part.gbeg, part.gcur, part.gend};
+                hipLaunchKernelGGL(build_tables_kernel, dim3(1), dim3(1024), 0, c->stream, ss, P1, srows, tasks, tables, n_tasks,
+                                   max_tasks, max_tables);
+                aa.tables = tables; aa.launch_grid = max_tables;
+            } else {
+                hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1, srows, tasks, n_tasks, max_tasks);
+                aa.launch_grid = max_tasks;
+            }
+            aa.tasks = tasks; aa.n_tasks = n_tasks;
         }
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
@@ -1058,8 +1138,15 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             HIP_TRY(hipGetLastError());
         }
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-        HIP_TRY(hipMemcpyAsync(h, counters, 12, hipMemcpyDeviceToHost, c->stream));
+        if (sampled)         // the scatter's overflow flag rides on the same read-back
+            HIP_TRY(hipMemcpyAsync(counters + 3, part.flags, 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(h, counters, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (sampled && h[3]) {           // a region's sampled capacity was too small (skew the sample did not show)
+            sampled_failed = true;
+            attempt--;
+            continue;
+        }
         if (h[1] == 0) {
             res.n_groups = h[0]; res.valid = true;
             const int64_t n_side = h[2];

@@ -265,7 +265,7 @@ __global__ void init_group_cursors_kernel(const uint32_t *offsets, uint32_t NB, 
 
 // One tile of the scatter.  FULL = the tile has all TILE rows (every tile but the input's last):
 // no per-row predicates anywhere on that path.
-template <int THREADS, bool STAGED, bool FULL>
+template <int THREADS, bool STAGED, bool FULL, bool CAPPED>
 __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase, uint32_t tile_n,
                                              uint32_t *cursor, uint32_t *cnt, uint32_t *delta,
                                              uint32_t *wave_tot, uint16_t *pid, uint64_t *stage) {
@@ -311,6 +311,10 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
         for (uint32_t p = tid; p < P1; p += THREADS) {
             uint32_t n = cnt[p];
             uint32_t c = n ? atomicAdd(&a.gcur[p * 8 + g], n) : 0u;
+            if (CAPPED && n && c + n > a.gend[p * 8 + g]) {          // the sampled capacity was too small: drop the run
+                a.flags[0] = 1;
+                delta[p] = a.total_cap;                                // dst >= total_cap: no store below is issued
+            } else
             delta[p] = c - delta[p];
         }
     } else {
@@ -335,7 +339,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 #pragma unroll
         for (int r = 0; r < SC_RPT; r++) {
             uint32_t j = r * THREADS + tid;
-            if (live(r)) { dst[r] = delta[pid[j]] + j; a.pkeys[dst[r]] = stage[j]; }
+            if (live(r)) { dst[r] = delta[pid[j]] + j; if (!CAPPED || dst[r] < a.total_cap) a.pkeys[dst[r]] = stage[j]; }
         }
         for (int m = 0; m < a.n_move8; m++) {
             uint64_t *out = reinterpret_cast<uint64_t *>(a.mv[m].dst);
@@ -351,7 +355,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++) {
                 uint32_t j = r * THREADS + tid;
-                if (live(r)) out[dst[r]] = stage[j];
+                if (live(r) && (!CAPPED || dst[r] < a.total_cap)) out[dst[r]] = stage[j];
             }
         }
         for (int m = a.n_move8; m < a.n_move; m++) {      // validity bytes / byte columns
@@ -364,7 +368,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++) {
                 uint32_t j = r * THREADS + tid;
-                if (live(r)) move_store(mv, dst[r], stage[j]);
+                if (live(r) && (!CAPPED || dst[r] < a.total_cap)) move_store(mv, dst[r], stage[j]);
             }
         }
         block_sync_lds();
@@ -372,18 +376,18 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
         uint32_t dst[SC_RPT];
 #pragma unroll
         for (int r = 0; r < SC_RPT; r++)
-            if (live(r)) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); a.pkeys[dst[r]] = kc[r]; }
+            if (live(r)) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); if (!CAPPED || dst[r] < a.total_cap) a.pkeys[dst[r]] = kc[r]; }
         for (int m = 0; m < a.n_move; m++) {
             const MoveDesc mv = a.mv[m];
 #pragma unroll
             for (int r = 0; r < SC_RPT; r++)
-                if (live(r)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
+                if (live(r) && (!CAPPED || dst[r] < a.total_cap)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
         }
         block_sync_lds();
     }
 }
 
-template <int THREADS, bool STAGED>
+template <int THREADS, bool STAGED, bool CAPPED = false>
 __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     constexpr int TILE = THREADS * SC_RPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -399,13 +403,119 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
 
     const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
     if (!a.gcur) for (uint32_t p = tid; p < P1; p += THREADS) cursor[p] = a.offsets[(size_t)p * NB + group_slot(b, NB)];
+    if (CAPPED && a.chunk == 0) {
+        // capacity mode: tiles are dealt round-robin, so group g = b % 8 takes every 8th tile of the input and
+        // its share of a partition is 1/8 whenever the key distribution is stationary over 8 tiles (64 K rows)
+        for (int64_t tbase = (int64_t)b * TILE; tbase < a.n_rows; tbase += (int64_t)NB * TILE) {
+            const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, a.n_rows - tbase);
+            if (tile_n == TILE)
+                scatter_tile<THREADS, STAGED, true, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+            else
+                scatter_tile<THREADS, STAGED, false, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+        }
+        return;
+    }
+    if (CAPPED) {
+        const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
+        for (int64_t tbase = beg; tbase < end; tbase += TILE) {
+            const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
+            if (tile_n == TILE)
+                scatter_tile<THREADS, STAGED, true, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+            else
+                scatter_tile<THREADS, STAGED, false, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+        }
+        return;
+    }
     const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
     for (int64_t tbase = beg; tbase < end; tbase += TILE) {
         const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
         if (tile_n == TILE)
-            scatter_tile<THREADS, STAGED, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+            scatter_tile<THREADS, STAGED, true, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
         else
-            scatter_tile<THREADS, STAGED, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+            scatter_tile<THREADS, STAGED, false, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+    }
+}
+
+// ---- capacity mode: regions from a sample instead of the exact histogram ---------------------------
+constexpr uint32_t SAMPLE_BLOCK = 1024, SAMPLE_PERIOD = 8;     // rows of every 8th 1024-row block are counted
+constexpr uint32_t SAMPLE_REPL = 16;        // replicas of the global histogram (same-address global atomics serialise)
+__global__ __launch_bounds__(1024) void sample_histogram_kernel(KeyDesc key, int64_t n_rows, uint32_t P, uint32_t seed,
+                                                                uint32_t *hist /* [SAMPLE_REPL][P + 2]; [P + 1] = rows sampled */) {
+    extern __shared__ uint32_t cnt[];  // P + 1
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = tid; p <= P; p += 1024) cnt[p] = 0;
+    __syncthreads();
+    const int64_t n_blocks = (n_rows + (int64_t)SAMPLE_BLOCK * SAMPLE_PERIOD - 1) / ((int64_t)SAMPLE_BLOCK * SAMPLE_PERIOD);
+    uint32_t mine = 0;
+    constexpr int U = 4;                // sample blocks in flight per workgroup step
+    for (int64_t j0 = (int64_t)blockIdx.x * U; j0 < n_blocks; j0 += (int64_t)gridDim.x * U) {
+        uint64_t kc[U];
+        bool nul[U], live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = (j0 + u) * SAMPLE_BLOCK * SAMPLE_PERIOD + tid;
+            live[u] = j0 + u < n_blocks && i < n_rows;
+            const int64_t ic = live[u] ? i : 0;
+            kc[u] = key_cell(key, ic);
+            nul[u] = key_is_null(key, ic);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (live[u]) {
+                atomicAdd(&cnt[nul[u] ? P : part_of(hash32(kc[u], seed), P)], 1u);
+                mine++;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *myhist = hist + (size_t)(blockIdx.x % SAMPLE_REPL) * (P + 2);
+    for (uint32_t p = tid; p <= P; p += 1024) if (cnt[p]) atomicAdd(&myhist[p], cnt[p]);
+    const unsigned long long any = __ballot(mine != 0);
+    (void)any;
+    uint32_t w = mine;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) w += __shfl_down(w, d, 64);
+    if ((tid & 63) == 0 && w) atomicAdd(&myhist[P + 1], w);
+}
+
+// one workgroup: region (p, g) = [gbeg, gend), 16-row aligned (128-byte lines), capacity = the partition's sampled
+// share scaled up + 6 sigma of the sampling noise + 6 sigma of the split over the 8 groups + a constant
+__global__ __launch_bounds__(1024) void plan_regions_kernel(const uint32_t *hist, int64_t n_rows,
+                                                            uint32_t P1, uint32_t total_cap, uint32_t *gbeg, uint32_t *gcur,
+                                                            uint32_t *gend, uint32_t *flags) {
+    __shared__ uint32_t wt[17];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    uint32_t n_sampled = 0;
+    for (uint32_t r = 0; r < SAMPLE_REPL; r++) n_sampled += hist[(size_t)r * (P1 + 1) + P1];
+    const double scale = (double)n_rows / (double)max(n_sampled, 1u);
+    for (uint32_t base = 0; base < P1; base += 1024) {
+        const uint32_t p = base + threadIdx.x;
+        uint32_t cap = 0;
+        if (p < P1) {
+            uint32_t ci = 0;
+            for (uint32_t r = 0; r < SAMPLE_REPL; r++) ci += hist[(size_t)r * (P1 + 1) + p];
+            const double c = (double)ci;
+            const double share = (c + 6.0 * sqrt(c) + 4.0) * scale * 0.125;
+            const double want = share + 6.0 * sqrt(share) + 32.0;
+            cap = want >= 4.0e9 ? 0xFFFFFFF0u : ((uint32_t)want + 15u) & ~15u;
+        }
+        uint32_t tot;
+        // 8 regions per partition; saturate instead of wrapping when the plan is absurd (flagged below)
+        const uint32_t mine = cap > 0x0FFFFFFFu ? 0x7FFFFFF8u : cap * 8u;
+        const uint32_t ex = block_exclusive_scan<1024>(mine, wt, &tot) + carry;
+        const bool fits = (uint64_t)ex + mine <= total_cap;
+        if (p < P1) {
+            for (uint32_t g = 0; g < 8; g++) {
+                const uint32_t b = fits ? ex + g * cap : 0u;
+                gbeg[p * 8 + g] = b; gcur[p * 8 + g] = b; gend[p * 8 + g] = fits ? b + cap : 0u;
+            }
+            if (!fits) flags[0] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry = (uint64_t)carry + tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : carry + tot;
+        __syncthreads();
     }
 }
 
@@ -473,7 +583,10 @@ static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t
     constexpr int TILE = THREADS * SC_RPT;
     size_t lds = (size_t)(sa.P + 1) * (sa.gcur ? 8 : 12) + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
     if (lds > 160 * 1024) return fail(PANDRS_HIP_ERR_COMPUTATION, "radix fan-out %u does not fit the scatter's LDS", sa.P);
-    if (staged) {
+    if (sa.gend) {
+        ST_TRY(set_max_lds(scatter_kernel<THREADS, true, true>, (int)lds));
+        hipLaunchKernelGGL((scatter_kernel<THREADS, true, true>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
+    } else if (staged) {
         ST_TRY(set_max_lds(scatter_kernel<THREADS, true>, (int)lds));
         hipLaunchKernelGGL((scatter_kernel<THREADS, true>), dim3(NB), dim3(THREADS), lds, c->stream, sa);
     } else {
@@ -535,6 +648,54 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
         else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
     }
     out->P = sa.P; out->NB = NB; out->offsets = offsets;
+    return 0;
+}
+
+uint32_t sampled_partition_rows(int64_t n_rows, int64_t P) {
+    // budget: the sampled shares + 6 sigma twice (<= ~19 % at the sizes sampled_partition_ok admits) + per-region constants
+    const double rows = (double)n_rows * 1.22 + (double)(P + 1) * 8.0 * 96.0 + 65536.0;
+    return rows >= 4.2e9 ? 0u : (uint32_t)rows;
+}
+bool sampled_partition_ok(int64_t n_rows, int64_t P) {
+    // enough rows per (partition, group) region and enough samples per partition for tight 6-sigma margins
+    return P >= 1 && P <= P_MAX && n_rows / (P * 8) >= 4096 && n_rows / ((int64_t)SAMPLE_PERIOD * P) >= 4096 &&
+           sampled_partition_rows(n_rows, P) != 0;
+}
+
+int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scatter) {
+    const int64_t N = sa.n_rows;
+    const uint32_t P1 = sa.P + 1;
+    constexpr int SC_TILE = 1024 * SC_RPT;
+    const int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
+    uint32_t NB = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_tiles, 8), 1024);
+    NB = (NB + 7) & ~7u;
+    uint32_t *hist = c->work.take<uint32_t>((size_t)SAMPLE_REPL * (P1 + 1) + 64);      // + the flags word block
+    uint32_t *gbeg = c->work.take<uint32_t>((size_t)P1 * 8);
+    uint32_t *gcur = c->work.take<uint32_t>((size_t)P1 * 8);
+    uint32_t *gend = c->work.take<uint32_t>((size_t)P1 * 8);
+    uint32_t *flags = hist ? hist + (size_t)SAMPLE_REPL * (P1 + 1) : nullptr;
+    if (!hist || !gbeg || !gcur || !gend || !flags) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (partition)");
+    const uint32_t total_cap = sampled_partition_rows(N, sa.P);
+    {
+        PhaseTimer pt(c, phase_hist);
+        HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)SAMPLE_REPL * (P1 + 1) + 64) * 4, c->stream));
+        const int64_t n_sb = (N + (int64_t)SAMPLE_BLOCK * SAMPLE_PERIOD - 1) / ((int64_t)SAMPLE_BLOCK * SAMPLE_PERIOD);
+        hipLaunchKernelGGL(sample_histogram_kernel, dim3((unsigned)std::min<int64_t>((n_sb + 3) / 4, 256)), dim3(1024), P1 * 4, c->stream,
+                           sa.key, N, sa.P, sa.seed, hist);
+        hipLaunchKernelGGL(plan_regions_kernel, dim3(1), dim3(1024), 0, c->stream, hist, N, P1, total_cap,
+                           gbeg, gcur, gend, flags);
+        HIP_TRY(hipGetLastError());
+    }
+    sa.offsets = nullptr; sa.chunk = c->opt.sampled_chunked ? ((n_tiles + NB - 1) / NB) * SC_TILE : 0; sa.gcur = gcur; sa.gend = gend; sa.flags = flags; sa.total_cap = total_cap;
+    std::stable_sort(sa.mv, sa.mv + sa.n_move, [](const MoveDesc &x, const MoveDesc &y) { return (x.kind != 0) < (y.kind != 0); });
+    sa.n_move8 = 0;
+    while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
+    {
+        PhaseTimer pt(c, phase_scatter);
+        ST_TRY(launch_scatter<1024>(c, sa, NB, true));
+    }
+    out->P = sa.P; out->NB = NB; out->offsets = nullptr;
+    out->gbeg = gbeg; out->gcur = gcur; out->gend = gend; out->flags = flags; out->total_cap = total_cap;
     return 0;
 }
 

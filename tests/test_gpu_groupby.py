@@ -157,7 +157,8 @@ def test_low_cardinality_direct_and_partitioned_paths_agree(ctx, no_direct):
     ctx.set_option("no_direct", no_direct)
     try:
         check(ctx, keys, n, vals, aggs, [O.I64], exact=[2, 3, 4, 5, 6, 7])
-        assert (ctx.timings()["n_partitions"] == 0) == (no_direct == 0) or True
+        # the path actually taken: the direct path reports 0 radix partitions, the partitioned one >= 1
+        assert (ctx.timings()["n_partitions"] == 0) == (no_direct == 0), ctx.timings()
         kb = [(np.packbits(rng.random(n) < 0.3, bitorder="little"), None, O.BOOLBITS)]
         check(ctx, kb, n, vals, aggs, [O.BOOLBITS], exact=[2, 3, 4, 5, 6, 7])
     finally:
@@ -823,3 +824,171 @@ def test_device_resident_inputs_for_the_newer_entry_points(ctx):
     b = np.lexsort((h[0].view(np.int64)[1], h[0].view(np.int64)[0], h[1][0]))
     np.testing.assert_array_equal(cells.cpu().numpy()[:, a], h[0].view(np.int64)[:, b])
     np.testing.assert_array_equal(np.diff(off.cpu().numpy())[a], np.diff(h[2])[b])
+
+
+# ---- round 2: the sampled-capacity partition (no histogram pass) and the lean aggregate kernel ----------
+def _took_sampled_partition(t):
+    """The capacity-mode partition has no scan phase (its regions come from a sample); the exact one does."""
+    return t["n_partitions"] > 0 and "scan" not in t["phase_ms"] and "scatter" in t["phase_ms"]
+
+
+@pytest.mark.parametrize("nulls", [False, True])
+def test_sampled_partition_matches_oracle(ctx, nulls):
+    """20 M rows / 600 K groups: enough rows per (partition, XCD group) region for the sampled-capacity
+    partition.  Same answers as the oracle, and as the exact-histogram path."""
+    rng = np.random.default_rng(4242 + nulls)
+    n, g = 20_000_000, 600_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.001] = -1                                 # the table-sentinel value among the keys
+    keys = [(k, O.pack_mask(rng.random(n) < 0.01) if nulls else None, O.I64)]
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.05) if nulls else None, O.F64),
+            (rng.normal(-3, 1, n), O.pack_mask(rng.random(n) < 0.05) if nulls else None, O.F64)]
+    aggs = [(c, op) for c in range(2) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    got = ctx.groupby_agg(keys, n, vals, aggs)
+    assert _took_sampled_partition(ctx.timings()), ctx.timings()
+    want = O.groupby_agg(keys, n, vals, aggs)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 6, 7, 8])
+    ctx.set_option("exact_partition", 1)
+    try:
+        got2 = ctx.groupby_agg(keys, n, vals, aggs)
+        assert not _took_sampled_partition(ctx.timings())
+    finally:
+        ctx.set_option("exact_partition", 0)
+    assert_groupby_equal(got2, want, [O.I64], int_exact_rows=[2, 3, 6, 7, 8])
+
+
+def test_sampled_partition_falls_back_when_the_sample_misleads(ctx):
+    """Keys whose set depends on the tile index (mod 8) AND on a slow drift: the 1-in-8 block sample and the
+    1/8 split over the XCD groups both mislead, some region overflows, the scatter drops the run, and the call
+    must come back exact through the histogram path (retried inside the library)."""
+    rng = np.random.default_rng(99)
+    n, g = 24_000_000, 500_000
+    tile = np.arange(n) // 8192
+    ids = rng.integers(0, g // 16, n) + (tile % 8) * (g // 16)    # group g of tiles only ever sees its own 1/8 of half the keys
+    ids[n // 2:] += g // 2                                       # and the second half of the table uses the other half
+    keys = [(sparse_keys_from(ids), None, O.I64)]
+    vals = [(rng.normal(0, 1, n), None, O.F64)]
+    check(ctx, keys, n, vals, FIVE, [O.I64], exact=EXACT5)
+    assert "scan" in ctx.timings()["phase_ms"], "the exact histogram path did not run: the input no longer defeats the sample"
+
+
+@pytest.mark.parametrize("ncols,ops", [(1, (O.SUM,)), (2, (O.MIN, O.MAX)), (3, (O.SUM, O.MIN, O.MAX)), (4, (O.SUM, O.MEAN, O.MIN, O.MAX))])
+def test_lean_aggregate_kernel_agrees_with_the_generic_one(ctx, ncols, ops):
+    """aggregate2 (Swiss-table lookup, retry queue, negated max states) against the round-1 kernel (agg_v1) and
+    the oracle, with NaN / +-inf / -0.0 values, int64 extremes, a hot key and the sentinel key."""
+    rng = np.random.default_rng(7 + ncols)
+    n, g = 3_000_000, 200_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.2] = 777                                  # hot key -> sliced partition (multi tables)
+    k[rng.random(n) < 0.01] = -1
+    keys = [(k, O.pack_mask(rng.random(n) < 0.01), O.I64)]
+    def col(i):
+        v = rng.normal(0, 1e3, n)
+        v[rng.random(n) < 0.01] = np.nan
+        v[rng.random(n) < 0.005] = np.inf
+        v[rng.random(n) < 0.005] = -np.inf
+        v[rng.random(n) < 0.01] = -0.0 if i % 2 else 0.0
+        return (v, O.pack_mask(rng.random(n) < 0.03) if i % 2 else None, O.F64)
+    for kind in ("f64", "i64"):
+        if kind == "f64":
+            vals = [col(i) for i in range(ncols)]
+        else:
+            vals = [(rng.integers(-2**62, 2**62, n).astype(np.int64) if i == 0 else rng.integers(-1000, 1000, n).astype(np.int64),
+                     None, O.I64) for i in range(ncols)]
+        aggs = [(c, op) for c in range(ncols) for op in ops] + [(0, O.COUNT)]
+        exact = [i for i, (_, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT) or kind == "i64" and op == O.SUM]
+        want = O.groupby_agg(keys, n, vals, aggs)
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+        assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+        ctx.set_option("agg_v1", 1)
+        try:
+            got1 = ctx.groupby_agg(keys, n, vals, aggs)
+        finally:
+            ctx.set_option("agg_v1", 0)
+        assert_groupby_equal(got1, want, [O.I64], int_exact_rows=exact)
+
+
+def _full_size_properties(ctx, keys_t, key_dtype, ids, n, vals, aggs_per_col, torch):
+    """Size-independent checks for inputs too large for the oracle (see test_full_size_properties)."""
+    import pandrs_amd as pa
+    ncol = len(vals)
+    aggs = [(c, op) for c in range(ncol) for op in aggs_per_col] + [(0, O.COUNT)]
+    ng = ctx.groupby_compute([(keys_t, None, key_dtype)], n, [(v, None, O.F64) for v in vals], aggs)
+    kc, kn, oa = ctx.groupby_fetch()
+    assert ng == torch.unique(ids).numel()
+    assert torch.unique(kc[0]).numel() == ng and int(kn.sum()) == 0
+    cnt = oa[-1]
+    assert float(cnt.sum()) == n
+    w = len(aggs_per_col)
+    for col in range(ncol):
+        row = dict(zip(aggs_per_col, oa[w * col:w * col + w]))
+        tot = float(vals[col].sum())
+        if O.SUM in row:
+            assert abs(float(row[O.SUM].sum()) - tot) <= 1e-9 * abs(tot)
+        if O.MIN in row:
+            assert float(row[O.MIN].min()) == float(vals[col].min()) and float(row[O.MAX].max()) == float(vals[col].max())
+        if O.MEAN in row and O.SUM in row:
+            assert torch.allclose(row[O.MEAN] * cnt, row[O.SUM], rtol=1e-12, atol=0)
+    return ng, kc, oa
+
+
+def test_config3_full_size_properties():
+    """BASELINE C3 at full size: 100 M rows, u32 string-pool codes, 10 K groups with 80/20 skew, 2 f64 columns x
+    sum/mean/min/max + count.  Property run (group count, sum of counts, linearity of the sums, global extremes,
+    mean x count = sum); the same shape is oracle-checked at 17 M rows in test_mid_cardinality_*."""
+    import torch
+    import pandrs_amd as pa
+    n, g, d = 100_000_000, 10_000, "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(45)
+    hot = torch.rand(n, device=d, generator=gen) < 0.8
+    ids = torch.where(hot, torch.randint(0, g // 5, (n,), device=d, generator=gen), torch.randint(0, g, (n,), device=d, generator=gen))
+    del hot
+    codes = ids.to(torch.int32)
+    vals = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100 for _ in range(2)]
+    c = pa.Context(0)
+    try:
+        _full_size_properties(c, codes, O.U32CODE, ids, n, vals, (O.SUM, O.MEAN, O.MIN, O.MAX), torch)
+    finally:
+        c.close()
+
+
+def test_config4_shard_full_size_properties_and_scaled_oracle():
+    """BASELINE C4's per-GPU shard at full size: 125 M rows, sparse i64 key, 10 M groups, sum + count.
+    Property run at full size; the same plan (fan-out forced to the full-size one) against the oracle at 1/50 scale."""
+    import torch
+    import pandrs_amd as pa
+    n, g, d = 125_000_000, 10_000_000, "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(46)
+    ids = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64)
+    keys = ids * -7046029254386353131 ^ 0x5555AAAA5555AAAA
+    v = torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100
+    c = pa.Context(0)
+    try:
+        aggs = [(0, O.SUM), (0, O.COUNT)]
+        ng = c.groupby_compute([(keys, None, O.I64)], n, [(v, None, O.F64)], aggs)
+        t_full = c.timings()
+        kc, kn, oa = c.groupby_fetch()
+        assert ng == torch.unique(ids).numel()
+        assert torch.unique(kc[0]).numel() == ng and int(kn.sum()) == 0
+        assert float(oa[1].sum()) == n
+        tot = float(v.sum())
+        assert abs(float(oa[0].sum()) - tot) <= 1e-9 * abs(tot)
+        del ids, keys, v, kc, kn, oa
+        torch.cuda.empty_cache()
+        # 1/50 scale on the same plan: same fan-out, so the same kernels and table load per partition
+        rng = np.random.default_rng(47)
+        n2, g2 = n // 50, g // 50
+        k2 = sparse_keys(rng, n2, g2)
+        v2 = rng.normal(100, 10, n2)
+        c.set_option("partitions", int(t_full["n_partitions"]))
+        try:
+            got = c.groupby_agg([(k2, None, O.I64)], n2, [(v2, None, O.F64)], aggs)
+            assert c.timings()["n_partitions"] == t_full["n_partitions"]
+        finally:
+            c.set_option("partitions", 0)
+        want = O.groupby_agg([(k2, None, O.I64)], n2, [(v2, None, O.F64)], aggs)
+        assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1])
+    finally:
+        c.close()
