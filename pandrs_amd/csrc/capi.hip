@@ -95,6 +95,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->est_table) (void)hipFree(c->est_table);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PANDRS_HIP_OK;

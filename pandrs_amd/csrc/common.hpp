@@ -179,6 +179,7 @@ struct pandrs_hip_ctx {
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
     hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
     void *pinned = nullptr;      // small pinned host block for readbacks
+    uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)
     bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)
     bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
     int quiet = 0;               // > 0: nested engine runs (slice / direct merges) do not record phase events

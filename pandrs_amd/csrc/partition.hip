@@ -16,14 +16,36 @@ static int32_t set_max_lds(K kernel, int bytes) {
 }
 
 // ------------------------------------------------------------------------------------ estimate
-__global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
+// distinct[0] = distinct keys in the sample, [2] = adjacent pairs that differ, [3] = adjacent pairs (one u64, one atomic), [4] = blocks done.
+// The last block to finish copies [0..2] to `host_out` (pinned, device-visible), so the host needs one stream
+// synchronise and no copy; estimate_clear_kernel then re-arms table and counters for the next call (off the
+// critical path: it runs while the host plans).
+__device__ __forceinline__ void estimate_publish(uint32_t *distinct, uint32_t *host_out) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&distinct[4], 1u) == gridDim.x - 1) {
+            __threadfence();
+            host_out[0] = __hip_atomic_load(&distinct[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[1] = __hip_atomic_load(&distinct[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[2] = __hip_atomic_load(&distinct[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ void estimate_clear_kernel(uint64_t *table, uint32_t slots, uint32_t *distinct) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < slots) table[i] = EMPTY_KEY;
+    if (i < 8) distinct[i] = 0;
+}
+__device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
                                 uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = s < n_sample && s * stride < n_rows;
     uint64_t k = 0;
     // second signal, for CLUSTERED inputs (e.g. rows sorted by key), where a strided sample shows no
     // repeats at all: the share of adjacent row pairs whose keys differ.  #groups <= #runs = boundaries + 1
-    // whatever the order, so it bounds the estimate from above.  distinct[1] = boundaries, [2] = pairs.
+    // whatever the order, so it bounds the estimate from above.  distinct[2] = boundaries, [3] = pairs.
     bool pair = false, differs = false;
     if (live) {
         int64_t i = s * stride;
@@ -43,7 +65,8 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
         const unsigned long long mp = __ballot(pair), md = __ballot(differs);
         if ((threadIdx.x & 63) == 0) { if (mp) atomicAdd(&sb[0], (uint32_t)__popcll(mp)); if (md) atomicAdd(&sb[1], (uint32_t)__popcll(md)); }
         __syncthreads();
-        if (threadIdx.x == 0 && sb[0]) { atomicAdd(&distinct[2], sb[0]); if (sb[1]) atomicAdd(&distinct[1], sb[1]); }
+        if (threadIdx.x == 0 && sb[0])
+            atomicAdd(reinterpret_cast<unsigned long long *>(&distinct[2]), ((unsigned long long)sb[0] << 32) | sb[1]);
     }
     // a dominant key would make every lane CAS the same address: peel the wave's two most common
     // leading keys first (one lane inserts for all lanes that hold the same key)
@@ -58,18 +81,32 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
             if ((int)(threadIdx.x & 63) != leader) live = false;           // the leader inserts on their behalf
         }
     }
-    if (!live) return;
-    uint32_t slot = hash32(k, 0x1234567u) & table_mask;
-    for (uint32_t probe = 0; probe <= table_mask; probe++) {
-        uint64_t cur = table[slot];
-        if (cur == k) return;
-        if (cur == EMPTY_KEY) {
-            uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
-            if (old == EMPTY_KEY) { atomicAdd(distinct, 1u); return; }
-            if (old == k) return;
+    // new keys are counted per workgroup in LDS and added to the global counter ONCE: a device-scope atomic per
+    // inserted key on one address (even wave-aggregated: ~20 K of them) was most of this kernel's 80 us
+    __shared__ uint32_t inserted;
+    if (threadIdx.x == 0) inserted = 0;
+    __syncthreads();
+    if (live) {
+        uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+        for (uint32_t probe = 0; probe <= table_mask; probe++) {
+            uint64_t cur = table[slot];
+            if (cur == k) break;
+            if (cur == EMPTY_KEY) {
+                uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
+                if (old == EMPTY_KEY) { atomicAdd(&inserted, 1u); break; }
+                if (old == k) break;
+            }
+            slot = (slot + 1) & table_mask;
         }
-        slot = (slot + 1) & table_mask;
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && inserted) atomicAdd(distinct, inserted);
+}
+
+__global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
+                                uint64_t *table, uint32_t table_mask, uint32_t *distinct, uint32_t *host_out) {
+    estimate_body(key, n_rows, stride, n_sample, table, table_mask, distinct);
+    estimate_publish(distinct, host_out);
 }
 
 // ------------------------------------------------------------------------------------ histogram
@@ -535,20 +572,32 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
     const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
     const int64_t stride = n_rows / n_sample;
-    uint32_t slots = 1;
-    while (slots < 2 * n_sample) slots <<= 1;
-    uint64_t *table = c->work.take<uint64_t>(slots);
-    uint32_t *distinct = c->work.take<uint32_t>(64);
-    if (!table || !distinct) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (estimate)");
-    HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(slots) * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(distinct, 0, 16, c->stream));
-    hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, c->stream,
-                       key, n_rows, stride, n_sample, table, slots - 1, distinct);
+    constexpr uint32_t slots = 1u << 19;                  // >= 2 x the largest sample
+    // a dedicated block that stays armed (table = EMPTY, counters = 0) between calls: cleared behind the previous
+    // estimate instead of in front of this one
+    if (!c->est_table) {
+        HIP_TRY(hipMalloc((void **)&c->est_table, size_t(slots) * 8 + 256));
+        uint32_t *cnt0 = reinterpret_cast<uint32_t *>(c->est_table + slots);
+        hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->est_table, slots, cnt0);
+    }
+    uint64_t *table = c->est_table;
+    uint32_t *distinct = reinterpret_cast<uint32_t *>(c->est_table + slots);
+    volatile uint32_t *h = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1024;     // own corner of the pinned block
+    h[3] = 0;
+    hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((n_sample + 1023) / 1024)), dim3(1024), 0, c->stream,
+                       key, n_rows, stride, n_sample, table, slots - 1, distinct, const_cast<uint32_t *>(h));
     HIP_TRY(hipGetLastError());
-    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-    HIP_TRY(hipMemcpyAsync(h, distinct, 12, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    double d = std::max<uint32_t>(h[0], 1), s = (double)n_sample;
+    // poll the pinned word the kernel's last block sets (a PCIe write away) before falling back to the runtime's
+    // wait, which costs tens of microseconds to wake up
+    for (int spin = 0; spin < 200000 && h[3] != 1; spin++) __builtin_ia32_pause();
+    if (h[3] != 1) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[3] != 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "estimate kernel did not publish its counters");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const uint32_t hv[3] = {h[0], h[1], h[2]};
+    hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct);
+    double d = std::max<uint32_t>(hv[0], 1), s = (double)n_sample;
     double est;
     if (n_sample == n_rows) est = d;
     else if (s - d < 64.0) est = (double)n_rows;                  // too few repeats in the sample to measure: (nearly) all distinct
@@ -566,11 +615,11 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         est = std::min<double>(std::max(G, d), (double)n_rows);
     }
     c->clustered_rows = false;
-    if (h[2] >= 1024) {
-        c->clustered_rows = (double)h[1] < 0.5 * (double)h[2] && !c->opt.no_runs;    // most neighbours share their key
+    if (hv[2] >= 1024) {
+        c->clustered_rows = (double)hv[1] < 0.5 * (double)hv[2] && !c->opt.no_runs;    // most neighbours share their key
         // runs of equal keys: an upper bound on the group count in any row order (exact for sorted
         // input); + 3 sigma of the sampled share so that noise cannot push it below the truth
-        const double pairs = (double)h[2], b = (double)h[1];
+        const double pairs = (double)hv[2], b = (double)hv[1];
         const double share = std::min(1.0, (b + 3.0 * std::sqrt(b + 1.0)) / pairs);
         est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
     }
