@@ -39,7 +39,11 @@ struct AggArgs {
     double *out_aggs;            // [n_fin][cap]
     uint64_t *out_states;        // [1 + n_states][cap] when partials
     size_t cap;
-    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag
+    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag, [2] = side records; aggregate2: [8] = workgroups done
+    // aggregate2: the last workgroup to finish copies counters[0..2] and *scatter_flags to host_out[0..3] (pinned,
+    // device-visible) and sets host_out[4] = 1, so the host polls one word instead of copying and synchronising
+    const uint32_t *scatter_flags;
+    uint32_t *host_out;
 };
 
 __device__ __forceinline__ uint64_t state_identity(int8_t kind) {

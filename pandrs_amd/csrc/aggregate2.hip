@@ -119,9 +119,22 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     const uint64_t *pkeys = a.pkeys;
     const uint32_t seed = a.seed, NG = T >> 4, lane = tid & 63;
 
+    // every workgroup ends here: the last one publishes the call's counters to the host
+    auto finish = [&]() {
+        __syncthreads();
+        if (tid == 0 && a.host_out) {
+            __threadfence();
+            if (atomicAdd(&a.counters[8], 1u) == gridDim.x - 1) {
+                __threadfence();
+                for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.host_out[3] = a.scatter_flags ? __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     const uint32_t n_tables = a.n_tasks[1];
     uint32_t tb = blockIdx.x;
-    if (tb >= n_tables) return;
+    if (tb >= n_tables) { finish(); return; }
     AggTable tab = a.tables[tb];
     uint32_t ti = tab.task_beg;
     AggTask cur = a.tasks[ti];
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
       }
         if (qn) drain(qn);
         __syncthreads();
-        if (misc[20]) { if (tid == 0) a.counters[1] = 1; return; }
+        if (misc[20]) { if (tid == 0) a.counters[1] = 1; finish(); return; }
         if (ABLATE == 4) { if (!have_next_tab) break; tb = tbn; tab = ntab; ti = tab.task_beg; continue; }   // experiments: no compaction / outputs
 
         // ---- compaction + outputs: every thread owns a contiguous run of slots, ONE block scan ----
@@ -373,6 +386,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         __syncthreads();            // the table is re-initialised next
         tb = tbn; tab = ntab; ti = tab.task_beg;
     }
+    finish();
 }
 
 template <int NSRC, int PROFILE, int ABLATE = 0, int DEPTH = 0>

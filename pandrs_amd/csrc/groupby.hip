@@ -985,6 +985,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
 
     const uint32_t seed = 0x9E3779B9u;
     bool sampled_failed = false;       // a capacity-mode run overflowed a region: repeat with the exact histogram
+    bool polled = false;
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
@@ -1133,15 +1134,29 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
             size_t lds = (size_t)(T + 3) * slot_bytes + 192 + (use_v2 ? AGG2_LDS_EXTRA : 0);
             const int profile = n_rounds == 1 ? uni_profile : -1;
-            if (!(use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))))
-                launch_aggregate(c, aa, max_spr, profile, lds);
+            volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;      // aggregate2's own corner
+            if (use_v2) { hp[4] = 0; aa.host_out = const_cast<uint32_t *>(hp); aa.scatter_flags = sampled ? part.flags : nullptr; }
+            polled = use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
+            if (!polled) launch_aggregate(c, aa, max_spr, profile, lds);
             HIP_TRY(hipGetLastError());
         }
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
-        if (sampled)         // the scatter's overflow flag rides on the same read-back
-            HIP_TRY(hipMemcpyAsync(counters + 3, part.flags, 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(h, counters, 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        bool have = false;
+        if (polled) {        // aggregate2's last workgroup wrote counters + scatter flag to pinned memory: poll, then fall back
+            volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;
+            for (int spin = 0; spin < 4000000 && hp[4] != 1; spin++) __builtin_ia32_pause();
+            if (hp[4] == 1) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                for (int i = 0; i < 4; i++) h[i] = hp[i];
+                have = true;
+            }
+        }
+        if (!have) {
+            if (sampled)         // the scatter's overflow flag rides on the same read-back
+                HIP_TRY(hipMemcpyAsync(counters + 3, part.flags, 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(h, counters, 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         if (sampled && h[3]) {           // a region's sampled capacity was too small (skew the sample did not show)
             sampled_failed = true;
             attempt--;
