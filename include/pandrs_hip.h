@@ -358,6 +358,33 @@ int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space,
                                   const pandrs_hip_column *col, int64_t n,
                                   double *out_sum, double *out_sum_sq, int64_t *out_count);
 
+/* Everything K1's three families of reference functions need, from ONE pass over the column:
+ *  (A) OptimizedDataFrame::{sum,mean,min,max}  (src/optimized/split_dataframe/aggregate.rs:21-215): values as f64
+ *      ((v as f64) for Int64), sum = sum_f64 (0.0 when count == 0), mean = sum_f64 / count and min / max = `min` /
+ *      `max` (fold with f64::min / f64::max from +-inf: NaN operands are ignored, infinities are not), each
+ *      Err(Error::Empty) when count == 0;
+ *  (B) Float64Column::{sum,mean,min,max} (src/column/float64_column.rs:100-199) and Int64Column's
+ *      (src/column/int64_column.rs:100-199): min / max skip NON-FINITE values -> `min_finite` / `max_finite`, None when
+ *      count_finite == 0; Int64Column::sum is the wrapping i64 sum `sum_i64`, its mean sum_i64 as f64 / count;
+ *  (C) simd_{sum,mean,min,max}_{f64,i64} (src/optimized/jit/simd.rs:9-112): simd_mean_i64 is the INTEGER division
+ *      sum_i64 / count (:77-82), empties give 0 / 0.0 and the fold identities (+-inf, i64::MAX / MIN).
+ * f64 sums are accumulated pairwise on the device (the reference: Kahan per chunk + Kahan combine,
+ * src/optimized/jit/parallel.rs:71-102); they agree to 1e-9 relative, not bit for bit.
+ * +0.0 / -0.0 ties: -0.0 < +0.0 here; f64::min leaves the tie unspecified. */
+typedef struct pandrs_hip_column_stats {
+    int64_t count;          /* non-null values */
+    int64_t count_finite;   /* f64: finite ones among them; i64: = count */
+    double sum_f64;         /* sum of the values as f64 */
+    double sum_sq;          /* sum of their squares as f64 */
+    int64_t sum_i64;        /* i64 columns: wrapping integer sum; 0 for f64 columns */
+    int64_t min_i64, max_i64; /* i64 columns: exact extremes (i64::MAX / MIN when count == 0); 0 for f64 columns */
+    double min, max;        /* NaN-ignoring extremes over the non-null values; +inf / -inf when there is none; i64: as f64 */
+    double min_finite, max_finite; /* the same over finite values only */
+} pandrs_hip_column_stats;
+
+int32_t pandrs_hip_reduce_stats(pandrs_hip_ctx *ctx, int32_t mem_space,
+                                const pandrs_hip_column *col, int64_t n, pandrs_hip_column_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

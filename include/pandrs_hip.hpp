@@ -39,7 +39,7 @@ namespace pandrs {
 
 // ---- errors (src/core/error.rs) ---------------------------------------------------------------------
 struct Error : std::runtime_error {
-    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount };
+    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount, Empty, Type };
     Kind kind;
     Error(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
 };
@@ -226,11 +226,12 @@ public:
     OptimizedDataFrame right_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Right); }
     OptimizedDataFrame outer_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Outer); }
 
-    // whole-column reductions (split_dataframe/aggregate.rs:21-217)
-    double sum(const std::string &name) const { return reduce(name)[0]; }
-    double mean(const std::string &name) const { return reduce(name)[1]; }
-    double min(const std::string &name) const { return reduce(name)[2]; }
-    double max(const std::string &name) const { return reduce(name)[3]; }
+    // whole-column reductions (split_dataframe/aggregate.rs:21-215): the non-null values as f64, sum 0.0 when
+    // there is none, mean / min / max Err(Error::Empty) then; min / max fold with f64::min / f64::max from +-inf
+    double sum(const std::string &name) const { return stats(name).sum_f64; }
+    double mean(const std::string &name) const { auto s = non_empty(name); return s.sum_f64 / (double)s.count; }
+    double min(const std::string &name) const { return non_empty(name).min; }
+    double max(const std::string &name) const { return non_empty(name).max; }
 
     // data_ops.rs:124-209: row gather of every column; nulls become 0 / 0.0 / "" / false
     OptimizedDataFrame filter_by_indices(const std::vector<int64_t> &indices) const {
@@ -244,14 +245,18 @@ public:
 private:
     size_t row_count_ = 0;
 
-    std::vector<double> reduce(const std::string &name) const {
+    pandrs_hip_column_stats stats(const std::string &name) const {
         const Column &c = column(name);
-        if (c.index() > 1) throw Error(Error::OperationFailed, "column '" + name + "' is not numeric");
+        if (c.index() > 1) throw Error(Error::Type, "Column '" + name + "' is not a numeric type");      // aggregate.rs:57
         pandrs_hip_column v = detail::view(c);
-        std::vector<double> out(4);
-        int64_t cnt = 0;
-        detail::check(pandrs_hip_reduce_column(detail::context(), PANDRS_HIP_MEM_HOST, &v, (int64_t)detail::col_len(c), out.data(), &cnt));
-        return out;
+        pandrs_hip_column_stats st{};
+        detail::check(pandrs_hip_reduce_stats(detail::context(), PANDRS_HIP_MEM_HOST, &v, (int64_t)detail::col_len(c), &st));
+        return st;
+    }
+    pandrs_hip_column_stats non_empty(const std::string &name) const {
+        auto st = stats(name);
+        if (st.count == 0) throw Error(Error::Empty, "Column '" + name + "' is empty");                    // aggregate.rs:87
+        return st;
     }
     // join_impl's / filter_by_indices' per-column gather on the device (join.rs:296-357, :475-552)
     static Column gather(const Column &src, const std::vector<int64_t> &idx) {

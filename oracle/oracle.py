@@ -194,6 +194,26 @@ def reduce_column(col, n):
     return np.array(list(out)), cnt.value
 
 
+class K1(C.Structure):
+    """oracle_k1 (pandrs_oracle.c): the three K1 families restated."""
+    _fields_ = [("a_empty", C.c_int32), ("a_sum", C.c_double), ("a_mean", C.c_double), ("a_min", C.c_double), ("a_max", C.c_double),
+                ("b_data_empty", C.c_int32), ("b_mean_none", C.c_int32), ("b_minmax_none", C.c_int32),
+                ("b_sum_f64", C.c_double), ("b_mean", C.c_double), ("b_min", C.c_double), ("b_max", C.c_double),
+                ("b_sum_i64", C.c_int64), ("b_min_i64", C.c_int64), ("b_max_i64", C.c_int64),
+                ("c_sum_f64", C.c_double), ("c_mean_f64", C.c_double), ("c_min_f64", C.c_double), ("c_max_f64", C.c_double),
+                ("c_sum_i64", C.c_int64), ("c_mean_i64", C.c_int64), ("c_min_i64", C.c_int64), ("c_max_i64", C.c_int64)]
+
+
+def k1_stats(col, n):
+    keep = []
+    cc = _cols([col], keep)
+    out = K1()
+    rc = lib().oracle_k1_stats(cc, C.c_int64(n), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
 def join_groupby_sum(lkey, lval, n_left, rkey, rgroup, n_right):
     keep = []
     a, b, c, d = (_cols([x], keep) for x in (lkey, lval, rkey, rgroup))

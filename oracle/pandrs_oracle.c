@@ -630,6 +630,81 @@ int oracle_reduce_column(const ocol *c, int64_t n, double out[4], int64_t *out_c
     return 0;
 }
 
+/* ---- K1, restated family by family ------------------------------------
+ * (A) OptimizedDataFrame::{sum,mean,max,min}      src/optimized/split_dataframe/aggregate.rs:21-215
+ *     non-null values collected as f64 (`v as f64` for Int64), empty => sum 0.0 / the others Err(Error::Empty);
+ *     sum = parallel_sum_f64: Kahan per chunk + Kahan over the chunk sums (src/optimized/jit/parallel.rs:71-102;
+ *     restated with one chunk: the chunking depends on the thread pool, the result only in the last bits);
+ *     min / max = fold(+-inf, f64::min / f64::max): NaN operands dropped, infinities kept.
+ * (B) Float64Column::{sum,mean,min,max}           src/column/float64_column.rs:100-199
+ *     Int64Column::{sum,mean,min,max}             src/column/int64_column.rs:100-199
+ *     empty data => None; mean None when no non-null value; f64 min / max skip NON-FINITE values (is_finite) and are
+ *     None when none is left; Int64 sum is i64 (wrapping in release builds), mean = sum as f64 / count as f64.
+ * (C) simd_{sum,mean,min,max}_{f64,i64}           src/optimized/jit/simd.rs:9-112   (no null masks: whole slices)
+ *     simd_mean_i64 = simd_sum_i64 / len as i64 (INTEGER division, :77-82); empty => 0 / 0.0 and the fold identities. */
+typedef struct oracle_k1 {
+    int32_t a_empty; double a_sum, a_mean, a_min, a_max;
+    int32_t b_data_empty, b_mean_none, b_minmax_none;
+    double b_sum_f64, b_mean, b_min, b_max; int64_t b_sum_i64, b_min_i64, b_max_i64;
+    double c_sum_f64, c_mean_f64, c_min_f64, c_max_f64; int64_t c_sum_i64, c_mean_i64, c_min_i64, c_max_i64;
+} oracle_k1;
+
+static double kahan_sum(const double *v, int64_t n) {            /* parallel.rs:76-85 */
+    double sum = 0.0, c = 0.0;
+    for (int64_t i = 0; i < n; i++) { double y = v[i] - c, t = sum + y; c = (t - sum) - y; sum = t; }
+    return sum;
+}
+
+int oracle_k1_stats(const ocol *c, int64_t n, oracle_k1 *o) {
+    if (c->dtype != PANDRS_HIP_F64 && c->dtype != PANDRS_HIP_I64) return PANDRS_HIP_ERR_TYPE_MISMATCH;   /* Error::Type */
+    memset(o, 0, sizeof *o);
+    const int f64 = c->dtype == PANDRS_HIP_F64;
+    const double *d = (const double *)c->data; const int64_t *q = (const int64_t *)c->data;
+    /* (A) */
+    double *vals = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) if (!is_null(c->null_mask, i)) vals[m++] = f64 ? d[i] : (double)q[i];
+    o->a_empty = m == 0;
+    o->a_sum = m ? kahan_sum(vals, m) : 0.0;
+    o->a_mean = m ? o->a_sum / (double)m : 0.0;          /* parallel_mean_f64_value: Kahan sum / count */
+    o->a_min = INFINITY; o->a_max = -INFINITY;
+    for (int64_t i = 0; i < m; i++) { o->a_min = rust_min(o->a_min, vals[i]); o->a_max = rust_max(o->a_max, vals[i]); }
+    free(vals);
+    /* (B) */
+    o->b_data_empty = n == 0;
+    int64_t cnt = 0, fin = 0; double bs = 0.0; uint64_t bi = 0;
+    o->b_min = INFINITY; o->b_max = -INFINITY; o->b_min_i64 = INT64_MAX; o->b_max_i64 = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) if (!is_null(c->null_mask, i)) {
+        cnt++;
+        if (f64) {
+            bs += d[i];
+            if (isfinite(d[i])) { fin++; o->b_min = rust_min(o->b_min, d[i]); o->b_max = rust_max(o->b_max, d[i]); }
+        } else {
+            bi += (uint64_t)q[i]; fin++;
+            if (q[i] < o->b_min_i64) o->b_min_i64 = q[i];
+            if (q[i] > o->b_max_i64) o->b_max_i64 = q[i];
+        }
+    }
+    o->b_sum_f64 = bs; o->b_sum_i64 = (int64_t)bi;
+    o->b_mean_none = n == 0 || cnt == 0;
+    o->b_mean = cnt ? (f64 ? bs : (double)(int64_t)bi) / (double)cnt : 0.0;
+    o->b_minmax_none = n == 0 || fin == 0;
+    if (!f64) { o->b_min = (double)o->b_min_i64; o->b_max = (double)o->b_max_i64; }
+    /* (C): the whole slice, masks do not exist at this level */
+    if (f64) {
+        double s = 0.0; o->c_min_f64 = INFINITY; o->c_max_f64 = -INFINITY;
+        for (int64_t i = 0; i < n; i++) { s += d[i]; o->c_min_f64 = rust_min(o->c_min_f64, d[i]); o->c_max_f64 = rust_max(o->c_max_f64, d[i]); }
+        o->c_sum_f64 = s; o->c_mean_f64 = n ? s / (double)n : 0.0;
+    } else {
+        uint64_t s = 0; o->c_min_i64 = INT64_MAX; o->c_max_i64 = INT64_MIN;
+        for (int64_t i = 0; i < n; i++) { s += (uint64_t)q[i]; if (q[i] < o->c_min_i64) o->c_min_i64 = q[i]; if (q[i] > o->c_max_i64) o->c_max_i64 = q[i]; }
+        o->c_sum_i64 = (int64_t)s;
+        /* Rust's i64 `/` truncates toward zero, like C's; i64::MIN / -1 cannot occur (len > 0) */
+        o->c_mean_i64 = n ? (int64_t)s / n : 0;
+    }
+    return 0;
+}
+
 /* Fused C5 shape: inner_join (join.rs:32) then group_by(g).aggregate([(v, Sum)]). */
 int oracle_join_groupby_sum(const ocol *lkey, const ocol *lval, int64_t n_left,
                             const ocol *rkey, const ocol *rgroup, int64_t n_right,

@@ -38,6 +38,12 @@ class AggSpec(C.Structure):
     _fields_ = [("col", C.c_int32), ("op", C.c_int32)]
 
 
+class ColumnStats(C.Structure):            # pandrs_hip_column_stats
+    _fields_ = [("count", C.c_int64), ("count_finite", C.c_int64), ("sum_f64", C.c_double), ("sum_sq", C.c_double),
+                ("sum_i64", C.c_int64), ("min_i64", C.c_int64), ("max_i64", C.c_int64),
+                ("min", C.c_double), ("max", C.c_double), ("min_finite", C.c_double), ("max_finite", C.c_double)]
+
+
 class Timings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("phase_ms", C.c_double * MAX_PHASES),
                 ("algorithmic_bytes", C.c_int64), ("n_partitions", C.c_int64),
@@ -92,6 +98,7 @@ SYMBOLS = {
                                                 C.POINTER(C.c_int64)]),
     "pandrs_hip_reduce_column": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64,
                                              C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pandrs_hip_reduce_stats": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64, C.POINTER(ColumnStats)]),
 }
 
 _lib = None

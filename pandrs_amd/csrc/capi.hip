@@ -334,4 +334,9 @@ int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const 
     return 0;
 }
 
+int32_t pandrs_hip_reduce_stats(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
+                                pandrs_hip_column_stats *out) {
+    return pandrs::reduce_stats_entry(ctx, mem_space, col, n, out);
+}
+
 }  // extern "C"

@@ -254,6 +254,8 @@ int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_h
                             const int64_t *idx, int64_t n, uint64_t fill_bits, void *out);
 int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
                      double out[4], int64_t *out_count, double *out_sumsq = nullptr);
+int32_t reduce_stats_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
+                           pandrs_hip_column_stats *st);
 
 inline size_t dtype_bytes(int dtype, int64_t n) {
     switch (dtype) {

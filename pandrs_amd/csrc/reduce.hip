@@ -8,75 +8,133 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 
+#include <cmath>
+#include <limits>
+
 namespace pandrs {
 
-constexpr int RD_THREADS = 256;
-constexpr int RD_BLOCKS = 2048;
+constexpr int RD_THREADS = 512;
+constexpr int RD_BLOCKS = 512;        // partials: 512 x 80 B = 40 KB, inside the 64 KB pinned read-back block
+constexpr int RD_VEC = 4;             // 16-byte loads in flight per lane and step (8 values)
 
 struct RedPartial {
-    double fsum, fsq;   // sum and sum of squares (as f64)
-    uint64_t isum;
-    uint64_t mn, mx;   // order-preserving encodings
-    uint64_t cnt;
+    double fsum, fsq;      // sum of the values as f64 ((double)v for i64) and of their squares
+    uint64_t isum;         // i64: wrapping integer sum
+    double mn, mx;         // min / max over the non-null values, NaN operands ignored (f64::min / f64::max); i64: as bits
+    double fmn, fmx;       // f64: over the FINITE values only (Float64Column::min/max, float64_column.rs:147-199)
+    uint64_t cnt, cnt_fin; // non-null values; f64: finite ones among them
+    uint64_t pad;
+};
+
+struct RedAcc {
+    double fs = 0.0, fq = 0.0;
+    uint64_t is = 0, cnt = 0, cfin = 0;
+    double mn, mx, fmn, fmx;
+    int64_t imn, imx;
 };
 
 template <bool IS_F64>
-__global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data, const uint8_t *null_bits,
-                                                            int64_t n, RedPartial *partials) {
-    double fs = 0.0, fq = 0.0;
-    uint64_t is = 0, cnt = 0;
-    uint64_t mn = IS_F64 ? enc_f64(__longlong_as_double(0x7FF0000000000000ll)) : enc_i64(INT64_MAX);
-    uint64_t mx = IS_F64 ? enc_f64(__longlong_as_double((long long)0xFFF0000000000000ull)) : enc_i64(INT64_MIN);
-    for (int64_t i = (int64_t)blockIdx.x * RD_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * RD_THREADS) {
-        if (null_bits && bit_at(null_bits, i)) continue;
-        uint64_t b = data[i];
-        cnt++;
-        if (IS_F64) {
-            double d = __longlong_as_double((long long)b);
-            fs += d; fq += d * d;
-            if (d == d) { uint64_t e = enc_f64(d); mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
-        } else {
-            is += b;
-            const double d = (double)(int64_t)b; fq += d * d;
-            uint64_t e = enc_i64((int64_t)b);
-            mn = e < mn ? e : mn; mx = e > mx ? e : mx;
+__device__ __forceinline__ void red_take(RedAcc &a, uint64_t b) {
+    a.cnt++;
+    if (IS_F64) {
+        const double d = __longlong_as_double((long long)b);
+        a.fs += d; a.fq = fma(d, d, a.fq);
+        a.mn = fmin(a.mn, d); a.mx = fmax(a.mx, d);                       // v_min_f64 / v_max_f64: a NaN operand is dropped
+        const bool fin = (b & 0x7FF0000000000000ull) != 0x7FF0000000000000ull;
+        a.cfin += fin ? 1 : 0;
+        a.fmn = fmin(a.fmn, fin ? d : __longlong_as_double(0x7FF0000000000000ll));
+        a.fmx = fmax(a.fmx, fin ? d : __longlong_as_double((long long)0xFFF0000000000000ull));
+    } else {
+        const int64_t v = (int64_t)b;
+        const double d = (double)v;
+        a.is += b; a.fs += d; a.fq = fma(d, d, a.fq);
+        a.imn = v < a.imn ? v : a.imn; a.imx = v > a.imx ? v : a.imx;
+    }
+}
+
+// One HBM stream: every lane keeps RD_VEC 16-byte non-temporal loads in flight (the round-1 kernel issued single
+// 8-byte loads from 2048 x 256 threads and ran at 2.6 TB/s).  HAS_NULLS: the bitmap byte of an 8-row group rides along.
+template <bool IS_F64, bool HAS_NULLS>
+__global__ __launch_bounds__(RD_THREADS) void reduce_kernel(const uint64_t *data0, const uint8_t *null_bits,
+                                                            int64_t n0, RedPartial *partials) {
+    // a column that starts 8 bytes off a 16-byte boundary (a sliced Arc<[T]>): row 0 is taken on its own
+    const int64_t head = (n0 > 0 && (reinterpret_cast<uintptr_t>(data0) & 8)) ? 1 : 0;
+    const uint64_t *data = data0 + head;
+    const int64_t n = n0 - head;
+    RedAcc a;
+    a.mn = a.fmn = __longlong_as_double(0x7FF0000000000000ll);
+    a.mx = a.fmx = __longlong_as_double((long long)0xFFF0000000000000ull);
+    a.imn = INT64_MAX; a.imx = INT64_MIN;
+    struct alignas(16) U2 { uint64_t x, y; };
+    const int64_t n2 = n >> 1;                                   // 16-byte pairs
+    const U2 *d2 = reinterpret_cast<const U2 *>(data);           // column bases are >= 16-byte aligned (Arc<[T]> / arena)
+    const int64_t stride = (int64_t)gridDim.x * RD_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * RD_THREADS + threadIdx.x; i < n2; i += stride * RD_VEC) {
+        U2 v[RD_VEC];
+        uint32_t nb[RD_VEC];
+#pragma unroll
+        for (int u = 0; u < RD_VEC; u++) {
+            const int64_t j = i + u * stride;
+            const int64_t jc = j < n2 ? j : n2 - 1;
+            v[u].x = __builtin_nontemporal_load(&d2[jc].x);
+            v[u].y = __builtin_nontemporal_load(&d2[jc].y);
+            nb[u] = !HAS_NULLS ? 0u : head ? (uint32_t)bit_at(null_bits, 2 * jc + 1) | (uint32_t)bit_at(null_bits, 2 * jc + 2) << 1
+                                          : (uint32_t)(null_bits[jc >> 2] >> ((jc & 3) * 2)) & 3u;      // rows 2 jc, 2 jc + 1 (+ head)
+        }
+#pragma unroll
+        for (int u = 0; u < RD_VEC; u++) {
+            if (i + u * stride < n2) {
+                if (!(nb[u] & 1)) red_take<IS_F64>(a, v[u].x);
+                if (!(nb[u] & 2)) red_take<IS_F64>(a, v[u].y);
+            }
         }
     }
-    // wave reduce
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n & 1) {                                             // odd tail
+            const int64_t j = n - 1;
+            if (!(HAS_NULLS && bit_at(null_bits, j + head))) red_take<IS_F64>(a, data[j]);
+        }
+        if (head && !(HAS_NULLS && bit_at(null_bits, 0))) red_take<IS_F64>(a, data0[0]);
+    }
+    if (!IS_F64) { a.mn = __longlong_as_double(a.imn); a.mx = __longlong_as_double(a.imx); }
+    auto lo = [](double x, double y, bool f64) { return f64 ? fmin(x, y) : ((int64_t)__double_as_longlong(x) < (int64_t)__double_as_longlong(y) ? x : y); };
+    auto hi = [](double x, double y, bool f64) { return f64 ? fmax(x, y) : ((int64_t)__double_as_longlong(x) > (int64_t)__double_as_longlong(y) ? x : y); };
     for (int d = 32; d >= 1; d >>= 1) {
-        fs += __shfl_down(fs, d, 64);
-        fq += __shfl_down(fq, d, 64);
-        is += __shfl_down(is, d, 64);
-        cnt += __shfl_down(cnt, d, 64);
-        uint64_t a = __shfl_down(mn, d, 64), b2 = __shfl_down(mx, d, 64);
-        mn = a < mn ? a : mn; mx = b2 > mx ? b2 : mx;
+        a.fs += __shfl_down(a.fs, d, 64);
+        a.fq += __shfl_down(a.fq, d, 64);
+        a.is += __shfl_down(a.is, d, 64);
+        a.cnt += __shfl_down(a.cnt, d, 64);
+        a.cfin += __shfl_down(a.cfin, d, 64);
+        a.mn = lo(a.mn, __shfl_down(a.mn, d, 64), IS_F64); a.mx = hi(a.mx, __shfl_down(a.mx, d, 64), IS_F64);
+        a.fmn = fmin(a.fmn, __shfl_down(a.fmn, d, 64)); a.fmx = fmax(a.fmx, __shfl_down(a.fmx, d, 64));
     }
     __shared__ RedPartial sh[RD_THREADS / 64];
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) sh[w] = RedPartial{fs, fq, is, mn, mx, cnt};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = RedPartial{a.fs, a.fq, a.is, a.mn, a.mx, a.fmn, a.fmx, a.cnt, a.cfin, 0};
     __syncthreads();
     if (threadIdx.x == 0) {
         RedPartial r = sh[0];
         for (int j = 1; j < RD_THREADS / 64; j++) {
-            r.fsum += sh[j].fsum; r.fsq += sh[j].fsq; r.isum += sh[j].isum; r.cnt += sh[j].cnt;
-            r.mn = sh[j].mn < r.mn ? sh[j].mn : r.mn; r.mx = sh[j].mx > r.mx ? sh[j].mx : r.mx;
+            r.fsum += sh[j].fsum; r.fsq += sh[j].fsq; r.isum += sh[j].isum; r.cnt += sh[j].cnt; r.cnt_fin += sh[j].cnt_fin;
+            r.mn = lo(r.mn, sh[j].mn, IS_F64); r.mx = hi(r.mx, sh[j].mx, IS_F64);
+            r.fmn = fmin(r.fmn, sh[j].fmn); r.fmx = fmax(r.fmx, sh[j].fmx);
         }
         partials[blockIdx.x] = r;
     }
 }
 
-int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
-                     double out[4], int64_t *out_count, double *out_sumsq) {
-    if (!c || !col || !out || !out_count || n < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce: bad arguments");
+// All the statistics K1's three families of reference functions need (see pandrs_hip_reduce_stats in the header).
+int32_t reduce_stats_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
+                           pandrs_hip_column_stats *st) {
+    if (!c || !col || !st || n < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce: bad arguments");
     if (col->dtype != PANDRS_HIP_I64 && col->dtype != PANDRS_HIP_F64)
-        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "reduce: dtype %d is not numeric", col->dtype);
+        return fail(PANDRS_HIP_ERR_TYPE_MISMATCH, "reduce: dtype %d is not numeric", col->dtype);       // Error::Type (aggregate.rs:57)
     const bool f64 = col->dtype == PANDRS_HIP_F64;
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     timings_begin(c);
-    int blocks = (int)std::min<int64_t>(RD_BLOCKS, std::max<int64_t>(1, (n + RD_THREADS - 1) / RD_THREADS));
-    RedPartial *h = reinterpret_cast<RedPartial *>(c->pinned);   // 2048 * 40 B = 80 KB > 64 KB pinned: use blocks <= 1024
-    blocks = std::min(blocks, 1024);
+    int blocks = (int)std::min<int64_t>(RD_BLOCKS, std::max<int64_t>(1, (n / 2 + RD_THREADS * RD_VEC - 1) / (RD_THREADS * RD_VEC)));
+    RedPartial *h = reinterpret_cast<RedPartial *>(c->pinned);
     size_t need = Arena::padded(sizeof(RedPartial) * blocks) + (mem_space == PANDRS_HIP_MEM_HOST ? size_t(n) * 8 + (n + 7) / 8 + 4096 : 0) + 4096;
     ST_TRY(c->work.ensure(need, c->stream));
     RedPartial *dp = c->work.take<RedPartial>(blocks);
@@ -92,32 +150,64 @@ int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_colu
             mask = dm;
         }
     }
+    if (n > 0 && (reinterpret_cast<uintptr_t>(data) & 7))
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce: the column must be 8-byte aligned");
     {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
-        if (f64) hipLaunchKernelGGL(reduce_kernel<true>, dim3(blocks), dim3(RD_THREADS), 0, c->stream, data, mask, n, dp);
-        else hipLaunchKernelGGL(reduce_kernel<false>, dim3(blocks), dim3(RD_THREADS), 0, c->stream, data, mask, n, dp);
+        if (f64 && mask) hipLaunchKernelGGL((reduce_kernel<true, true>), dim3(blocks), dim3(RD_THREADS), 0, c->stream, data, mask, n, dp);
+        else if (f64) hipLaunchKernelGGL((reduce_kernel<true, false>), dim3(blocks), dim3(RD_THREADS), 0, c->stream, data, mask, n, dp);
+        else if (mask) hipLaunchKernelGGL((reduce_kernel<false, true>), dim3(blocks), dim3(RD_THREADS), 0, c->stream, data, mask, n, dp);
+        else hipLaunchKernelGGL((reduce_kernel<false, false>), dim3(blocks), dim3(RD_THREADS), 0, c->stream, data, mask, n, dp);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(h, dp, sizeof(RedPartial) * blocks, hipMemcpyDeviceToHost, c->stream));
     c->timings.algorithmic_bytes = n * 8 + (col->null_mask ? n / 8 : 0);
     ST_TRY(timings_end(c));
-    // host combine of <= 1024 partials, in block order (deterministic)
-    double fs = 0.0, fq = 0.0; uint64_t is = 0, cnt = 0;
-    uint64_t mn = ~0ull, mx = 0;
+    // host combine of <= 512 partials, in block order (deterministic)
+    double fs = 0.0, fq = 0.0; uint64_t is = 0, cnt = 0, cfin = 0;
+    const double PINF = std::numeric_limits<double>::infinity();
+    double mn = PINF, mx = -PINF, fmn = PINF, fmx = -PINF;
+    int64_t imn = INT64_MAX, imx = INT64_MIN;
     for (int b = 0; b < blocks; b++) {
-        fs += h[b].fsum; fq += h[b].fsq; is += h[b].isum; cnt += h[b].cnt;
-        mn = h[b].mn < mn ? h[b].mn : mn; mx = h[b].mx > mx ? h[b].mx : mx;
+        fs += h[b].fsum; fq += h[b].fsq; is += h[b].isum; cnt += h[b].cnt; cfin += h[b].cnt_fin;
+        if (f64) {
+            mn = std::fmin(mn, h[b].mn); mx = std::fmax(mx, h[b].mx);
+            // +0.0 / -0.0: std::fmin may keep either; the kernel's v_min_f64 orders -0 < +0, do the same here
+            if (h[b].mn == 0.0 && mn == 0.0 && std::signbit(h[b].mn)) mn = h[b].mn;
+            if (h[b].mx == 0.0 && mx == 0.0 && !std::signbit(h[b].mx)) mx = h[b].mx;
+            fmn = std::fmin(fmn, h[b].fmn); fmx = std::fmax(fmx, h[b].fmx);
+            if (h[b].fmn == 0.0 && fmn == 0.0 && std::signbit(h[b].fmn)) fmn = h[b].fmn;
+            if (h[b].fmx == 0.0 && fmx == 0.0 && !std::signbit(h[b].fmx)) fmx = h[b].fmx;
+        } else {
+            int64_t a, b2; std::memcpy(&a, &h[b].mn, 8); std::memcpy(&b2, &h[b].mx, 8);
+            imn = std::min(imn, a); imx = std::max(imx, b2);
+        }
     }
-    auto dec_f = [](uint64_t e) { uint64_t b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e; double d; std::memcpy(&d, &b, 8); return d; };
+    *st = pandrs_hip_column_stats{};
+    st->count = (int64_t)cnt; st->sum_f64 = fs; st->sum_sq = fq;
     if (f64) {
-        out[0] = fs; out[1] = cnt ? fs / (double)cnt : 0.0;
-        out[2] = dec_f(mn); out[3] = dec_f(mx);
+        st->count_finite = (int64_t)cfin; st->min = mn; st->max = mx; st->min_finite = fmn; st->max_finite = fmx;
     } else {
-        out[0] = (double)(int64_t)is; out[1] = cnt ? (double)(int64_t)is / (double)cnt : 0.0;
-        out[2] = (double)(int64_t)(mn ^ 0x8000000000000000ull); out[3] = (double)(int64_t)(mx ^ 0x8000000000000000ull);
+        st->sum_i64 = (int64_t)is; st->count_finite = (int64_t)cnt;
+        st->min_i64 = imn; st->max_i64 = imx;
+        st->min = st->min_finite = (double)imn; st->max = st->max_finite = (double)imx;
     }
-    *out_count = (int64_t)cnt;
-    if (out_sumsq) *out_sumsq = fq;
+    return 0;
+}
+
+int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
+                     double out[4], int64_t *out_count, double *out_sumsq) {
+    if (!out || !out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce: bad arguments");
+    pandrs_hip_column_stats st;
+    if (col && col->dtype != PANDRS_HIP_I64 && col->dtype != PANDRS_HIP_F64)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "reduce: dtype %d is not numeric", col->dtype);
+    ST_TRY(reduce_stats_entry(c, mem_space, col, n, &st));
+    const bool f64 = col->dtype == PANDRS_HIP_F64;
+    out[0] = f64 ? st.sum_f64 : (double)st.sum_i64;
+    out[1] = st.count ? out[0] / (double)st.count : 0.0;
+    out[2] = st.min; out[3] = st.max;
+    *out_count = st.count;
+    if (out_sumsq) *out_sumsq = st.sum_sq;
     return 0;
 }
 

@@ -30,6 +30,10 @@ class OperationFailed(PandrsHipError):
     pass
 
 
+class EmptyError(PandrsHipError):
+    """Error::Empty (src/optimized/split_dataframe/aggregate.rs:87): no non-null value to aggregate."""
+
+
 def _raise(status):
     msg = L.last_error()
     if status == L.ERR_TYPE_MISMATCH:
@@ -437,6 +441,16 @@ class Context:
         if not population:
             var *= m / (m - 1.0)
         return var ** 0.5, var
+
+    def column_stats(self, col, n):
+        """pandrs_hip_reduce_stats: one pass, everything K1's reference functions need.  -> dict."""
+        keep = []
+        cc, sp = self._cols([col], keep)
+        out = L.ColumnStats()
+        st = self.lib.pandrs_hip_reduce_stats(self.h, sp, cc, int(n), C.byref(out))
+        if st:
+            _raise(st)
+        return {name: getattr(out, name) for name, _ in L.ColumnStats._fields_}
 
     def reduce_column(self, col, n):
         keep = []

@@ -23,7 +23,7 @@ from enum import IntEnum
 import numpy as np
 
 from . import _lib as L
-from .engine import Context, PandrsHipError, ColumnTypeMismatch, OperationFailed
+from .engine import Context, PandrsHipError, ColumnTypeMismatch, OperationFailed, EmptyError
 
 
 class AggregateOp(IntEnum):          # types.rs:11-34, same order
@@ -129,7 +129,43 @@ class _Column:
         return create_bitmask(nulls)
 
 
-class Int64Column(_Column):          # src/column/int64_column.rs:52-66
+class _NumericColumn(_Column):
+    """The null-skipping column folds of src/column/{int64,float64}_column.rs:100-199 on the device
+    (pandrs_hip_reduce_stats): None exactly where the reference returns None."""
+
+    def _stats(self):
+        return get_context().column_stats(self.view(), self.length)
+
+    def sum(self):
+        if self.length == 0:
+            return 0 if self.dtype == L.I64 else 0.0
+        st = self._stats()
+        return int(st["sum_i64"]) if self.dtype == L.I64 else float(st["sum_f64"])
+
+    def mean(self):
+        if self.length == 0:
+            return None
+        st = self._stats()
+        if st["count"] == 0:
+            return None
+        return (float(st["sum_i64"]) if self.dtype == L.I64 else st["sum_f64"]) / st["count"]
+
+    def _extreme(self, which):
+        if self.length == 0:
+            return None
+        st = self._stats()
+        if self.dtype == L.I64:
+            return None if st["count"] == 0 else int(st[which + "_i64"])
+        return None if st["count_finite"] == 0 else float(st[which + "_finite"])      # non-finite values are skipped
+
+    def min(self):
+        return self._extreme("min")
+
+    def max(self):
+        return self._extreme("max")
+
+
+class Int64Column(_NumericColumn):   # src/column/int64_column.rs:52-66
     dtype, type_name = L.I64, "Int64"
 
     def __init__(self, data, nulls=None):
@@ -144,7 +180,7 @@ class Int64Column(_Column):          # src/column/int64_column.rs:52-66
         return None if self.is_null(i) else int(self.data[i])
 
 
-class Float64Column(_Column):        # src/column/float64_column.rs:9-13
+class Float64Column(_NumericColumn): # src/column/float64_column.rs:9-13
     dtype, type_name = L.F64, "Float64"
 
     def __init__(self, data, nulls=None):
@@ -324,24 +360,34 @@ class OptimizedDataFrame:
             result.add_column(name, g.take(self.column(name), left=True))
         return result
 
-    # -- whole-column reductions (K1: split_dataframe/aggregate.rs:21-62) ---------------------------------
-    def _reduce(self, name):
+    # -- whole-column reductions (K1: split_dataframe/aggregate.rs:21-215) ----------------------------------
+    def _stats(self, name):
         col = self.column(name)
-        if col.dtype not in (L.I64, L.F64):
-            raise OperationFailed(L.ERR_OPERATION_FAILED, "column '%s' is not numeric" % name)
-        return get_context().reduce_column(col.view(), col.len())
+        if col.dtype not in (L.I64, L.F64):        # Error::Type (aggregate.rs:57)
+            raise ColumnTypeMismatch(L.ERR_TYPE_MISMATCH, "Column '%s' is not a numeric type" % name)
+        return get_context().column_stats(col.view(), col.len())
 
     def sum(self, name):
-        return float(self._reduce(name)[0][0])
+        """aggregate.rs:21-62: the non-null values as f64 (`v as f64` for Int64), 0.0 when there is none."""
+        return float(self._stats(name)["sum_f64"])
 
     def mean(self, name):
-        return float(self._reduce(name)[0][1])
+        st = self._stats(name)
+        if st["count"] == 0:                       # aggregate.rs:87, :99
+            raise EmptyError(L.ERR_OPERATION_FAILED, "Column '%s' is empty" % name)
+        return float(st["sum_f64"]) / st["count"]
 
     def min(self, name):
-        return float(self._reduce(name)[0][2])
+        st = self._stats(name)
+        if st["count"] == 0:                       # aggregate.rs:185, :198
+            raise EmptyError(L.ERR_OPERATION_FAILED, "Column '%s' is empty" % name)
+        return float(st["min"])                    # fold(+inf, f64::min): NaN dropped, infinities kept
 
     def max(self, name):
-        return float(self._reduce(name)[0][3])
+        st = self._stats(name)
+        if st["count"] == 0:                       # aggregate.rs:135, :148
+            raise EmptyError(L.ERR_OPERATION_FAILED, "Column '%s' is empty" % name)
+        return float(st["max"])
 
     # -- joins (join.rs:32-73) -----------------------------------------------------------------------------
     def inner_join(self, other, left_on, right_on):

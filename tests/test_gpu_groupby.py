@@ -2,6 +2,8 @@
 inputs, against the reference's golden vectors, and — at BASELINE scale — through
 size-independent properties.  Tolerances: keys / counts / min / max bit-exact; f64 sums and means
 within 1e-9 relative (BASELINE.json north_star)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -990,5 +992,106 @@ def test_config4_shard_full_size_properties_and_scaled_oracle():
             c.set_option("partitions", 0)
         want = O.groupby_agg([(k2, None, O.I64)], n2, [(v2, None, O.F64)], aggs)
         assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1])
+    finally:
+        c.close()
+
+
+# ---- K1: the three reference families from one device pass (pandrs_hip_reduce_stats) -----------------------
+def _k1_check(ctx, col, n):
+    st = ctx.column_stats(col, n)
+    k = O.k1_stats(col, n)
+    f64 = col[2] == O.F64
+    assert st["count"] == (0 if k.a_empty else st["count"])
+    # (A) frame level
+    if k.a_empty:
+        assert st["count"] == 0 and st["sum_f64"] == 0.0
+    else:
+        if math.isnan(k.a_sum) or math.isinf(k.a_sum):
+            assert str(st["sum_f64"]) == str(k.a_sum)
+        else:
+            assert st["sum_f64"] == pytest.approx(k.a_sum, rel=1e-9, abs=1e-9 * abs(k.a_sum) + 1e-300)
+        assert st["min"] == k.a_min and st["max"] == k.a_max
+    # (B) column level
+    if f64:
+        assert (st["count_finite"] == 0) == bool(k.b_minmax_none) or n == 0
+        if not k.b_minmax_none:
+            assert st["min_finite"] == k.b_min and st["max_finite"] == k.b_max
+    else:
+        assert st["sum_i64"] == k.b_sum_i64
+        if not k.b_minmax_none:
+            assert st["min_i64"] == k.b_min_i64 and st["max_i64"] == k.b_max_i64
+    return st, k
+
+
+def test_k1_statistics_match_the_three_reference_families(ctx):
+    import math
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 2, 7, 1000, 1_000_003):
+        v = rng.normal(5, 2, n)
+        if n >= 7:
+            v[rng.integers(0, n, max(n // 50, 1))] = np.inf
+            v[rng.integers(0, n, max(n // 50, 1))] = -np.inf
+            v[rng.integers(0, n, max(n // 50, 1))] = np.nan
+            v[rng.integers(0, n, 2)] = [0.0, -0.0]
+        for mask in (None, O.pack_mask(rng.random(n) < 0.2) if n else None):
+            _k1_check(ctx, (v, mask, O.F64), n)
+        q = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        for mask in (None, O.pack_mask(rng.random(n) < 0.2) if n else None):
+            _k1_check(ctx, (q, mask, O.I64), n)
+    # only non-finite values: column min / max are None, the frame keeps the infinities
+    st, k = _k1_check(ctx, (np.array([np.inf, np.nan, -np.inf]), None, O.F64), 3)
+    assert st["count_finite"] == 0 and st["min"] == -np.inf and st["max"] == np.inf
+    # all null
+    st, k = _k1_check(ctx, (np.array([1.0, 2.0, 3.0]), O.pack_mask([1, 1, 1]), O.F64), 3)
+    assert st["count"] == 0
+    # a column that starts 8 bytes off a 16-byte boundary (sliced buffer), with a mask
+    import torch
+    base = torch.arange(0, 100_001, dtype=torch.float64, device="cuda:0")
+    view = base[1:]
+    st = ctx.column_stats((view, None, O.F64), 100_000)
+    assert st["sum_f64"] == 100_000 * 100_001 / 2 and st["min"] == 1.0 and st["max"] == 100_000.0
+
+
+def test_k1_mirrors_follow_the_reference(ctx):
+    """frame level: Err(Empty) / Error::Type / `v as f64` sums (aggregate.rs:21-215); column level: None where the
+    reference returns None, non-finite values skipped; slice level: simd_mean_i64's integer division."""
+    import pandrs_amd as pa
+    from pandrs_amd import frame as F, simd as S
+    df = F.OptimizedDataFrame()
+    df.add_column("x", F.Float64Column([1.0, np.inf, -2.0, np.nan], [False, False, False, False]))
+    df.add_column("e", F.Float64Column([1.0, 2.0, 3.0, 4.0], [True, True, True, True]))
+    df.add_column("q", F.Int64Column([2**62, 2**62, 2**62, 1]))
+    df.add_column("s", F.StringColumn(["a", "b", "c", "d"]))
+    assert df.max("x") == np.inf and df.min("x") == -2.0 and math.isnan(df.sum("x"))
+    assert df.sum("e") == 0.0
+    for fn in (df.mean, df.min, df.max):
+        with pytest.raises(pa.EmptyError):
+            fn("e")
+    with pytest.raises(pa.ColumnTypeMismatch):
+        df.sum("s")
+    assert df.sum("q") == 3.0 * 2.0**62 + 1.0                       # no i64 wrap at frame level
+    x, e, q = df.column("x"), df.column("e"), df.column("q")
+    assert (x.min(), x.max()) == (-2.0, 1.0) and e.mean() is None and e.min() is None and e.max() is None
+    assert q.sum() == int(np.int64(np.uint64((3 * 2**62 + 1) % 2**64).astype(np.int64)))
+    assert F.Float64Column([]).mean() is None and F.Int64Column([]).min() is None and F.Float64Column([]).sum() == 0.0
+    assert S.simd_mean_i64(np.array([-7, 2, 2], np.int64)) == -1 and S.simd_mean_i64(np.array([], np.int64)) == 0
+    assert S.simd_min_i64(np.array([], np.int64)) == 2**63 - 1 and S.simd_max_f64(np.array([], np.float64)) == -np.inf
+    assert S.simd_sum_f64(np.arange(1.0, 9.0)) == 36.0 and S.simd_mean_f64(np.array([1.0, 2, 3, 4, 5])) == 3.0
+
+
+def test_k1_stream_rate():
+    """100 M f64 (0.8 GB): the rewritten reduce kernel must stream at >= 4 TB/s (round 1: 2.6 TB/s)."""
+    import torch
+    import pandrs_amd as pa
+    c = pa.Context(0)
+    try:
+        x = torch.randn(100_000_000, dtype=torch.float64, device="cuda:0")
+        best = 1e9
+        for _ in range(5):
+            st = c.column_stats((x, None, O.F64), x.numel())
+            best = min(best, c.timings()["phase_ms"]["other"])
+        assert st["count"] == x.numel() and st["min"] == float(x.min()) and st["max"] == float(x.max())
+        assert abs(st["sum_f64"] - float(x.sum())) <= 1e-9 * abs(float(x.abs().sum()))
+        assert 0.8 / best >= 4.0, "reduce kernel %.3f ms = %.2f TB/s" % (best, 0.8 / best)
     finally:
         c.close()

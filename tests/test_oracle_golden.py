@@ -305,3 +305,44 @@ def test_parallel_faithful_restatement_equals_the_serial_one():
     b = sort_groups(*O.groupby_agg(keys, n, vals, aggs, faithful=True, threads=5), [O.I64, O.U32CODE])
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_k1_families_restated(golden):
+    """K1's three families (oracle_k1_stats): the reference's own vectors (simd.rs:451-506, parallel.rs:354-372) through
+    family (C) and (A), and the source-derived corner cases the reference holds no test for."""
+    for c in golden["reductions"]:
+        if "f64_range" in c:
+            col = (np.arange(c["f64_range"][0], c["f64_range"][1] + 1, dtype=np.float64), None, O.F64)
+        elif "f64" in c:
+            col = (np.array(c["f64"], np.float64), None, O.F64)
+        else:
+            col = (np.array(c["i64"], np.int64), None, O.I64)
+        k = O.k1_stats(col, len(col[0]))
+        f64 = col[2] == O.F64
+        got = {"sum": k.c_sum_f64 if f64 else float(k.c_sum_i64), "mean": k.c_mean_f64 if f64 else float(k.c_mean_i64),
+               "min": k.c_min_f64 if f64 else float(k.c_min_i64), "max": k.c_max_f64 if f64 else float(k.c_max_i64)}
+        for name in ("sum", "mean", "min", "max"):
+            if name in c:
+                assert got[name] == pytest.approx(float(c[name]), abs=1e-10), (c["cite"], name)
+        if "sum" in c and len(col[0]):
+            assert k.a_sum == pytest.approx(float(c["sum"]), abs=1e-10)
+    # source-derived: simd_mean_i64 truncates toward zero (simd.rs:77-82)
+    k = O.k1_stats((np.array([-7, 2, 2], np.int64), None, O.I64), 3)
+    assert k.c_mean_i64 == -1 and k.b_mean == -1.0 and k.b_sum_i64 == -3
+    k = O.k1_stats((np.array([7, -2, -2, 0], np.int64), None, O.I64), 4)
+    assert k.c_mean_i64 == 0 and k.b_mean == 0.75
+    # Float64Column::min/max skip non-finite values, None when nothing finite is left (float64_column.rs:147-199);
+    # the frame-level fold keeps infinities and drops NaN (aggregate.rs:119-215)
+    k = O.k1_stats((np.array([1.0, np.inf, -2.0, np.nan, -np.inf]), None, O.F64), 5)
+    assert (k.b_min, k.b_max, k.b_minmax_none) == (-2.0, 1.0, 0) and (k.a_min, k.a_max) == (-np.inf, np.inf)
+    k = O.k1_stats((np.array([np.inf, np.nan]), None, O.F64), 2)
+    assert k.b_minmax_none == 1 and k.b_mean_none == 0 and k.a_empty == 0 and k.a_max == np.inf
+    # all null: frame sum 0.0 and Err(Empty) for the rest; column mean / min / max None
+    k = O.k1_stats((np.array([3.0, 4.0]), O.pack_mask([1, 1]), O.F64), 2)
+    assert k.a_empty == 1 and k.a_sum == 0.0 and k.b_mean_none == 1 and k.b_minmax_none == 1
+    k = O.k1_stats((np.array([], np.int64), None, O.I64), 0)
+    assert k.a_empty == 1 and k.b_data_empty == 1 and (k.c_min_i64, k.c_max_i64, k.c_mean_i64) == (2**63 - 1, -2**63, 0)
+    # Int64: the frame sums (v as f64), the column wraps in i64
+    big = np.array([2**62, 2**62, 2**62], np.int64)
+    k = O.k1_stats((big, None, O.I64), 3)
+    assert k.a_sum == 3.0 * 2.0**62 and k.b_sum_i64 == np.int64(np.uint64(3 * 2**62 % 2**64).astype(np.int64))
