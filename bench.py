@@ -300,6 +300,12 @@ def main():
     force_dist = os.environ.get("PANDRS_BENCH_FORCE_DIST") == "1" and dist is not None
     if world > 1 or force_dist:
         from pandrs_amd.dist import DistributedGroupBy
+        if os.environ.get("PANDRS_BENCH_DIST", "library") != "torch":
+            # the exchange runs INSIDE libpandrs_hip.so (pandrs_hip_dist_groupby_agg: RCCL behind the C ABI); torch.distributed
+            # only carries the 128-byte communicator id from rank 0 to the others
+            box = [pa.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], rank, world)
         dgb = DistributedGroupBy(ctx, dist, device)
 
         def step():
@@ -347,7 +353,7 @@ def main():
             "config": {"workload": "BASELINE config 2: %d rows/GPU, 1 sparse i64 key (%d groups), "
                                    "sum/mean/min/max over %d f64 cols" % (n, g, ncol),
                        "rows_per_gpu": n, "groups": g, "value_cols": ncol, "aggregates": len(aggs),
-                       "parallelism": "row-range shards + 1 all-to-all of partials" if world > 1 else "1 GPU"},
+                       "parallelism": "row-range shards + 1 RCCL all-to-all of partial records inside the library (pandrs_hip_dist_groupby_agg)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(n, g, ncol) if world == 1 else None,
                          "algorithmic_bytes": bytes_alg, "device_ms": dev_ms, "phase_ms": phases,
@@ -396,6 +402,10 @@ def bench_join(args, torch, pa, dist, rank, local_rank, world, device):
     cols = ((lkey, None, pa.I64), (lval, None, pa.F64), nl, (rkey, None, pa.I64), (rgrp, None, pa.I64), nr)
     if world > 1 or (os.environ.get("PANDRS_BENCH_FORCE_DIST") == "1" and dist is not None):
         from pandrs_amd.dist import DistributedJoinGroupBy
+        if os.environ.get("PANDRS_BENCH_DIST", "library") != "torch":
+            box = [pa.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], rank, world)
         djg = DistributedJoinGroupBy(ctx, dist, device)
         step = lambda: djg.join_groupby_sum(*cols, strategy=args.join_strategy)
     else:

@@ -358,6 +358,36 @@ int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space,
                                   const pandrs_hip_column *col, int64_t n,
                                   double *out_sum, double *out_sum_sq, int64_t *out_count);
 
+/* ---- multi-GPU: the exchange inside the library (no reference counterpart: ---------------------
+ * src/gpu/multi_gpu.rs:326-360 splits rows on the host, src/distributed is an in-process DataFusion wrapper).
+ * One process per GPU; every rank calls the same entry point with its own row-range shard.  RCCL is opened at run
+ * time (librccl.so.1), so single-GPU users do not need it.
+ *
+ * pandrs_hip_comm wraps an ncclComm_t: rank 0 calls comm_unique_id, the host distributes the 128 bytes (any
+ * channel), every rank calls comm_init; or comm_adopt takes an ncclComm_t the host already owns. */
+typedef struct pandrs_hip_comm pandrs_hip_comm;
+int32_t pandrs_hip_comm_unique_id(char out_id[128]);
+int32_t pandrs_hip_comm_init(pandrs_hip_ctx *ctx, const char id[128], int32_t rank, int32_t world, pandrs_hip_comm **out_comm);
+int32_t pandrs_hip_comm_adopt(void *nccl_comm, int32_t rank, int32_t world, pandrs_hip_comm **out_comm);
+int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *comm);
+
+/* Row-range-sharded group_by(..).aggregate(..) (aggregation.rs:763) over all ranks' rows: local partial states ->
+ * owner split -> count exchange -> ONE grouped ncclSend / ncclRecv all-to-all of packed records on the context's
+ * stream -> merge.  The result (fetch with groupby_fetch) holds the groups this rank owns; the ranks' key sets are
+ * disjoint.  Sum / Mean / Min / Max / Count, one key column; null-mask presence may differ between ranks. */
+int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, int32_t mem_space,
+                                    const pandrs_hip_column *keys, int32_t n_keys, int64_t n_rows,
+                                    const pandrs_hip_column *vals, int32_t n_vals,
+                                    const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups);
+
+/* BASELINE config 5 across ranks: inner_join (join.rs:32) of row-range-sharded sides + group_by(g).sum(v).  The
+ * build (right) side is all-gathered, the probe side stays on its GPU, the local fused result goes through the
+ * groupby exchange.  Device-resident shards, 8-byte build-side columns. */
+int32_t pandrs_hip_dist_join_groupby_sum(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, int32_t mem_space,
+                                         const pandrs_hip_column *left_key, const pandrs_hip_column *left_val, int64_t n_left,
+                                         const pandrs_hip_column *right_key, const pandrs_hip_column *right_group, int64_t n_right,
+                                         int64_t *out_n_groups);
+
 /* Everything K1's three families of reference functions need, from ONE pass over the column:
  *  (A) OptimizedDataFrame::{sum,mean,min,max}  (src/optimized/split_dataframe/aggregate.rs:21-215): values as f64
  *      ((v as f64) for Int64), sum = sum_f64 (0.0 when count == 0), mean = sum_f64 / count and min / max = `min` /

@@ -98,6 +98,15 @@ SYMBOLS = {
                                                 C.POINTER(C.c_int64)]),
     "pandrs_hip_reduce_column": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64,
                                              C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pandrs_hip_comm_unique_id": (C.c_int32, [C.c_char_p]),
+    "pandrs_hip_comm_init": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "pandrs_hip_comm_adopt": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "pandrs_hip_comm_destroy": (C.c_int32, [_P]),
+    "pandrs_hip_dist_groupby_agg": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64,
+                                                C.POINTER(Column), C.c_int32, C.POINTER(AggSpec), C.c_int32,
+                                                C.POINTER(C.c_int64)]),
+    "pandrs_hip_dist_join_groupby_sum": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(Column), C.POINTER(Column), C.c_int64,
+                                                     C.POINTER(Column), C.POINTER(Column), C.c_int64, C.POINTER(C.c_int64)]),
     "pandrs_hip_reduce_stats": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64, C.POINTER(ColumnStats)]),
 }
 

@@ -662,6 +662,22 @@ int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dt
     return 0;
 }
 
+// device-to-device copy of the retained result's first key row, its null bytes and its first aggregate row
+// (the fused join's <= G local sums on their way into the groupby exchange, dist.hip)
+int32_t export_result_columns(pandrs_hip_ctx *c, uint64_t *cells, uint8_t *nulls, double *agg0, int64_t *out_n) {
+    std::lock_guard<std::mutex> lock(c->mu);
+    GroupbyResult &res = c->gb;
+    if (!res.valid || res.partials || res.n_aggs < 1) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no finished groupby result in this context");
+    const size_t n = (size_t)res.n_groups;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(cells, res.keys, n * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(nulls, res.key_null, n, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(agg0, res.aggs, n * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    *out_n = res.n_groups;
+    return 0;
+}
+
 // ---- partial split for the all-to-all -------------------------------------------------------------
 // Owner bucketing with workgroup-level aggregation: LDS counters per rank, ONE global atomic per
 // (workgroup, rank) — a per-record global atomic on n_ranks addresses serialises at the memory side.

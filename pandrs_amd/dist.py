@@ -54,6 +54,27 @@ class DistributedGroupBy:
 
     MERGEABLE_OPS = (0, 1, 2, 3, 4)      # Sum, Mean, Min, Max, Count: pre-aggregate, exchange partial states
 
+    def _agree_on_null_masks(self, cols, n_rows):
+        """All-reduce (MAX) one has-null-mask bit per column; where another rank has a mask and this one does not, an
+        all-valid bitmap is materialised so that every rank plans the same states and issues the same collectives."""
+        if not cols:
+            return cols
+        torch = self._torch()
+        dev = self.device if str(self.device) != "cpu" else "cpu"
+        flags = torch.tensor([1 if c[1] is not None else 0 for c in cols], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
+        out = []
+        for (data, mask, dt), f in zip(cols, flags.tolist()):
+            if f and mask is None:
+                nb = (int(n_rows) + 7) // 8
+                if hasattr(data, "is_cuda"):
+                    mask = torch.zeros(nb, dtype=torch.uint8, device=data.device)
+                else:
+                    import numpy as np
+                    mask = np.zeros(nb, np.uint8)
+            out.append((data, mask, dt))
+        return out
+
     def exchange_columns(self, columns, counts):
         """All-to-all of several row-aligned columns that share the same rank-contiguous split."""
         torch = self._torch()
@@ -99,6 +120,8 @@ class DistributedGroupBy:
         A composite key is shuffled on a hash cell of the whole tuple (pandrs_hip_key_hash_cells) with
         the key columns travelling as payload, so each rank packs complete tuples only."""
         eng = self.engine
+        vals = self._agree_on_null_masks(vals, n_rows)
+        keys = self._agree_on_null_masks(keys, n_rows)
         if any(op in (8, 9) for _, op in aggs):
             raise NotImplementedError("First/Last need the global row order and are not sharded")
         if any(k[2] == 3 for k in keys) and len(keys) > 1:
@@ -129,6 +152,18 @@ class DistributedGroupBy:
             return self.groupby_by_shuffle(keys, n_rows, vals, aggs)
         torch = self._torch()
         eng = self.engine
+        if getattr(eng, "comm", None):
+            # the exchange lives in the library (pandrs_hip_dist_groupby_agg: count all-gather + ONE grouped
+            # ncclSend / ncclRecv all-to-all on the context's stream); this class is only its caller
+            t0 = time.perf_counter()
+            eng.dist_groupby_compute(keys, n_rows, vals, aggs)
+            t = eng.timings()
+            self.last_timings = {"total_ms": (time.perf_counter() - t0) * 1e3, "phase_ms": {"merge_" + k: v for k, v in t["phase_ms"].items()},
+                                 "algorithmic_bytes": n_rows * (8 + 8 * len(vals)), "wall_ms": {"in_library": (time.perf_counter() - t0) * 1e3}}
+            return eng.groupby_fetch() if fetch else None
+        # torch.distributed transport (gloo rehearsals, engines without a communicator): agree on the partial-record
+        # layout first — a null mask present on some ranks only must not change the record width on those ranks
+        vals = self._agree_on_null_masks(vals, n_rows)
         t0 = time.perf_counter()
         ng_local, n_state = eng.groupby_partials(keys, n_rows, vals, aggs)
         t_local = eng.timings() if hasattr(eng, "timings") else None
@@ -269,6 +304,10 @@ class DistributedJoinGroupBy:
         "shuffle": both sides go to the owner of their join key (SURVEY.md 8e's radix all-to-all) —
         every GPU then builds only 1/world of the build side, at the price of moving the probe rows."""
         t0 = time.perf_counter()
+        if getattr(self.engine, "comm", None) and strategy in ("auto", "allgather"):
+            out = self.engine.dist_join_groupby_sum(lkey, lval, n_left, rkey, rgroup, n_right)
+            self.last_wall_ms = {"in_library": (time.perf_counter() - t0) * 1e3}
+            return out
         if strategy == "auto":
             # replicating the build side makes EVERY rank build all of it; shuffling moves the probe rows once.
             # By the single-GPU numbers (DESIGN.md 8e) the shuffle wins from 4 ranks up once the build side is large.

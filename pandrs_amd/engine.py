@@ -66,6 +66,7 @@ class Context:
         self.device = device
 
     def close(self):
+        self.comm_destroy()
         if getattr(self, "h", None):
             self.lib.pandrs_hip_ctx_destroy(self.h)
             self.h = None
@@ -441,6 +442,56 @@ class Context:
         if not population:
             var *= m / (m - 1.0)
         return var ** 0.5, var
+
+    # -- the in-library RCCL exchange (pandrs_hip_dist_*) -------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from rank 0 (ncclGetUniqueId); the host hands them to every rank over any channel."""
+        buf = C.create_string_buffer(128)
+        st = L.load().pandrs_hip_comm_unique_id(buf)
+        if st:
+            _raise(st)
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        h = C.c_void_p()
+        st = self.lib.pandrs_hip_comm_init(self.h, C.c_char_p(bytes(unique_id)), int(rank), int(world), C.byref(h))
+        if st:
+            _raise(st)
+        self.comm = h
+        self.comm_world = world
+        return h
+
+    def comm_destroy(self):
+        if getattr(self, "comm", None):
+            self.lib.pandrs_hip_comm_destroy(self.comm)
+            self.comm = None
+
+    def dist_groupby_compute(self, keys, n_rows, vals, aggs):
+        """pandrs_hip_dist_groupby_agg: every rank passes its own row range.  -> groups owned by this rank."""
+        keep = []
+        kc, sp1 = self._cols(keys, keep)
+        vc, _ = self._cols(vals, keep) if vals else ((L.Column * 1)(), sp1)
+        ng = C.c_int64(0)
+        st = self.lib.pandrs_hip_dist_groupby_agg(self.h, self.comm, sp1, kc, len(keys), int(n_rows), vc, len(vals),
+                                                  self._aggs(aggs), len(aggs), C.byref(ng))
+        if st:
+            _raise(st)
+        self._last = (len(keys), len(aggs), sp1, ng.value)
+        return ng.value
+
+    def dist_join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
+        keep = []
+        a, sp = self._cols([lkey], keep)
+        b, _ = self._cols([lval], keep)
+        c, _ = self._cols([rkey], keep)
+        d, _ = self._cols([rgroup], keep)
+        ng = C.c_int64(0)
+        st = self.lib.pandrs_hip_dist_join_groupby_sum(self.h, self.comm, sp, a, b, int(n_left), c, d, int(n_right), C.byref(ng))
+        if st:
+            _raise(st)
+        self._last = (1, 1, sp, ng.value)
+        return self.groupby_fetch()
 
     def column_stats(self, col, n):
         """pandrs_hip_reduce_stats: one pass, everything K1's reference functions need.  -> dict."""

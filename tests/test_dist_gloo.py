@@ -217,3 +217,47 @@ def test_multi_key_groupby_across_ranks(world):
                          [(0, O.SUM), (0, O.COUNT), (0, O.MEDIAN)])
     assert got[0].shape[1] == want[0].shape[1]
     assert_groupby_equal(got, want, [O.I64, O.U32CODE, O.F64], int_exact_rows=[1, 2])
+
+
+# ---- null masks on ONE rank only: every rank must still plan the same partial-record layout -----------
+def _one_sided_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from pandrs_amd.dist import DistributedGroupBy
+    from tests.cpu_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys, km, v0, v1, m1 = _data()
+    n = len(keys)
+    lo, hi = (n // world // 8 * 8) * rank, n if rank == world - 1 else (n // world // 8 * 8) * (rank + 1)
+    bits = lambda m: np.packbits(np.unpackbits(m, bitorder="little")[:n][lo:hi], bitorder="little")
+    d = DistributedGroupBy(NumpyEngine(), dist, "cpu")
+    # rank 0 passes masks, the others pass None (what io.py does for a shard with null_count == 0)
+    vmask = bits(m1) if rank == 0 else None
+    kmask = bits(km) if rank == 0 else None
+    kc, kn, oa = d.groupby_agg([(keys[lo:hi], kmask, 0)], hi - lo, [(v0[lo:hi], None, 1), (v1[lo:hi], vmask, 1)], AGGS)
+    np.savez(os.path.join(outdir, "o%d.npz" % rank), kc=kc, kn=kn, oa=oa)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_null_masks_on_one_rank_only(world):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from tests.helpers import assert_groupby_equal
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_one_sided_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, "o%d.npz" % r)) for r in range(world)]
+    got = tuple(np.concatenate([p[name] for p in parts], axis=1) for name in ("kc", "kn", "oa"))
+    keys, km, v0, v1, m1 = _data()
+    n = len(keys)
+    cut = n // world // 8 * 8
+    # the masks only cover rank 0's rows
+    keep = np.arange(n) < cut
+    km2 = np.packbits(np.unpackbits(km, bitorder="little")[:n] & keep, bitorder="little")
+    m12 = np.packbits(np.unpackbits(m1, bitorder="little")[:n] & keep, bitorder="little")
+    want = O.groupby_agg([(keys, km2, O.I64)], n, [(v0, None, O.F64), (v1, m12, O.F64)], AGGS)
+    exact = [i for i, (_, op) in enumerate(AGGS) if op in (O.MIN, O.MAX, O.COUNT)]
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)

@@ -254,3 +254,60 @@ def test_two_real_ranks_share_the_gpu_over_gloo(tmp_path):
         got = cat("join_" + strategy)
         assert got[0].shape[1] == want[0].shape[1], strategy
         assert_groupby_equal(got, want, [O.I64])
+
+
+# ---- the exchange INSIDE the library (pandrs_hip_dist_*: RCCL behind the C ABI), world-size-1 rehearsal -------------
+@pytest.fixture(scope="module")
+def cctx():
+    import pandrs_amd
+    c = pandrs_amd.Context(0)
+    c.comm_init(pandrs_amd.Context.comm_unique_id(), 0, 1)
+    yield c
+    c.close()
+
+
+def test_in_library_exchange_groupby_world1(cctx):
+    """pandrs_hip_dist_groupby_agg: partials -> owner split -> count all-gather -> grouped ncclSend / ncclRecv -> merge,
+    all inside libpandrs_hip.so.  One value column with a null mask, one without, a null-key group."""
+    rng = np.random.default_rng(15)
+    n, g = 2_000_000, 150_000
+    k = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = O.pack_mask(rng.random(n) < 0.001)
+    v, w = rng.normal(100, 10, n), rng.normal(-3, 1, n)
+    wm = O.pack_mask(rng.random(n) < 0.05)
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT), (1, O.MEAN), (1, O.MAX)]
+    for dev in (True, False):
+        cols = ([(_dev(k), _dev(km), O.I64)], [(_dev(v), None, O.F64), (_dev(w), _dev(wm), O.F64)]) if dev else \
+               ([(k, km, O.I64)], [(v, None, O.F64), (w, wm, O.F64)])
+        cctx.dist_groupby_compute(cols[0], n, cols[1], aggs)
+        kc, kn, oa = cctx.groupby_fetch(to_device=False)
+        want = O.groupby_agg([(k, km, O.I64)], n, [(v, None, O.F64), (w, wm, O.F64)], aggs)
+        assert_groupby_equal((kc, kn, oa), want, [O.I64], int_exact_rows=[2, 3, 4, 6])
+    # dist.py is a thin caller of it when the engine holds a communicator
+    from pandrs_amd.dist import DistributedGroupBy
+
+    class _NoDist:                      # the library does the exchange: torch.distributed must not be touched
+        def get_world_size(self): return 1
+        def get_rank(self): return 0
+    d = DistributedGroupBy(cctx, _NoDist(), "cuda:0")
+    kc, kn, oa = d.groupby_agg([(_dev(k), _dev(km), O.I64)], n, [(_dev(v), None, O.F64), (_dev(w), _dev(wm), O.F64)], aggs)
+    assert_groupby_equal((kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy()), want, [O.I64], int_exact_rows=[2, 3, 4, 6])
+    with pytest.raises(Exception):
+        cctx.dist_groupby_compute([(k, None, O.I64)], n, [(v, None, O.F64)], [(0, O.MEDIAN)])
+
+
+def test_in_library_exchange_join_groupby_world1(cctx):
+    """pandrs_hip_dist_join_groupby_sum: build side all-gathered (padding rows are NULL keys), local fused join ->
+    groupby-sum, partial sums through the in-library exchange."""
+    rng = np.random.default_rng(16)
+    nl, nr, g = 1_500_003, 120_001, 700                       # lengths that need padding to a multiple of 8
+    rkeys = (rng.permutation(4 * nr)[:nr].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rgrp = rng.integers(0, g, nr).astype(np.int64)
+    lkeys = np.where(rng.random(nl) < 0.9, rkeys[rng.integers(0, nr, nl)], rng.integers(1, 1 << 40, nl))
+    lval = rng.normal(10, 3, nl)
+    rkm = O.pack_mask(rng.random(nr) < 0.01)
+    kc, kn, oa = cctx.dist_join_groupby_sum((_dev(lkeys), None, O.I64), (_dev(lval), None, O.F64), nl,
+                                            (_dev(rkeys), _dev(rkm), O.I64), (_dev(rgrp), None, O.I64), nr)
+    want = O.join_groupby_sum((lkeys, None, O.I64), (lval, None, O.F64), nl, (rkeys, rkm, O.I64), (rgrp, None, O.I64), nr)
+    got = (kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy())
+    assert_groupby_equal(got, want, [O.I64])
