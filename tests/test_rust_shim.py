@@ -1,0 +1,104 @@
+"""The Rust shim shipped as files (integration/rust/): hip_ffi.rs must declare EXACTLY what include/pandrs_hip.h
+declares — every function (name, arity, parameter names and types, return type), every struct (field names, types,
+order) and every constant — checked mechanically, because this image has no Rust toolchain to compile it (so Rust
+SYNTAX beyond the generated declarations is not verified here).  The three seam patches must still apply to the
+reference tree when it is present (it is not on the GPU box)."""
+import importlib.util
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUST = os.path.join(ROOT, "integration", "rust")
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_ffi", os.path.join(RUST, "gen_ffi.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_hip_ffi_rs_matches_the_header():
+    g = _gen()
+    h_funcs, h_structs, h_consts, h_enums = g.parse_header()
+    r_funcs, r_structs, r_consts = g.parse_rust(os.path.join(RUST, "hip_ffi.rs"))
+    assert len(h_funcs) >= 39
+    assert [f[0] for f in r_funcs] == [f[0] for f in h_funcs], "functions differ or are out of order"
+    for (hn, hp, hr), (rn, rp, rr) in zip(h_funcs, r_funcs):
+        assert len(hp) == len(rp), "%s: arity %d in the header, %d in hip_ffi.rs" % (hn, len(hp), len(rp))
+        assert hp == rp, "%s: parameters differ: %s vs %s" % (hn, hp, rp)
+        assert hr == rr, "%s: return type" % hn
+    for cname, fields in h_structs.items():
+        rname = g.STRUCTS[cname]
+        assert [(n, t) for n, t in r_structs[rname]] == fields, "struct %s" % cname
+    for cname in g.OPAQUE:
+        assert g.STRUCTS[cname] in r_structs or ("pub struct %s { _private: [u8; 0] }" % g.STRUCTS[cname]) in open(os.path.join(RUST, "hip_ffi.rs")).read()
+    merged = dict(h_consts, **h_enums)
+    assert r_consts == merged
+    # the file on disk IS what the generator produces (no hand edits)
+    assert open(os.path.join(RUST, "hip_ffi.rs")).read() == g.generate()
+
+
+def test_ffi_types_match_the_ctypes_binding():
+    """A second, independent reading of the same ABI: pandrs_amd/_lib.py's ctypes table (which the GPU tests
+    exercise) and hip_ffi.rs agree on every function's arity and on pointer-vs-scalar at every position."""
+    import ctypes as C
+    from pandrs_amd import _lib as L
+    g = _gen()
+    r_funcs, _, _ = g.parse_rust(os.path.join(RUST, "hip_ffi.rs"))
+    assert {f[0] for f in r_funcs} == set(L.SYMBOLS)
+    scal = {"i32": C.c_int32, "i64": C.c_int64, "u64": C.c_uint64, "u32": C.c_uint32, "u8": C.c_uint8, "f64": C.c_double}
+    for name, params, ret in r_funcs:
+        res, args = L.SYMBOLS[name]
+        assert len(args) == len(params), name
+        for (pn, pt), a in zip(params, args):
+            if pt.startswith("*"):
+                assert a in (C.c_void_p, C.c_char_p) or hasattr(a, "contents") or issubclass(a, C._Pointer), (name, pn, pt, a)
+            else:
+                assert a is scal[pt], (name, pn, pt, a)
+
+
+def test_shim_uses_only_declared_symbols():
+    import re
+    g = _gen()
+    r_funcs, _, r_consts = g.parse_rust(os.path.join(RUST, "hip_ffi.rs"))
+    declared = {f[0] for f in r_funcs}
+    shim = open(os.path.join(RUST, "hip_shim.rs")).read()
+    used = set(re.findall(r"\b(pandrs_hip_\w+)\s*\(", shim))
+    assert used and used <= declared, used - declared
+    for const in set(re.findall(r"\b(PANDRS_HIP_[A-Z0-9_]+)\b", shim)):
+        assert const in r_consts, const
+    # every call passes as many arguments as the declaration takes
+    arity = {f[0]: len(f[1]) for f in r_funcs}
+    for m in re.finditer(r"\b(pandrs_hip_\w+)\s*\(", shim):
+        depth, i, n_args, any_arg = 1, m.end(), 0, False
+        while depth:
+            ch = shim[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                n_args += 1
+            elif not ch.isspace():
+                any_arg = True
+            i += 1
+        n_args = n_args + 1 if any_arg else 0
+        assert n_args == arity[m.group(1)], "%s called with %d arguments, declared with %d" % (m.group(1), n_args, arity[m.group(1)])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is not on this box")
+def test_seam_patches_apply_to_the_reference():
+    patches = sorted(f for f in os.listdir(os.path.join(RUST, "patches")) if f.endswith(".patch"))
+    assert len(patches) == 3
+    with tempfile.TemporaryDirectory() as d:
+        for rel in ("src/optimized/split_dataframe/group/aggregation.rs", "src/optimized/split_dataframe/join.rs", "src/optimized/lazy.rs"):
+            os.makedirs(os.path.join(d, os.path.dirname(rel)), exist_ok=True)
+            shutil.copy(os.path.join("/root/reference", rel), os.path.join(d, rel))
+        for p in patches:
+            r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(RUST, "patches", p)], cwd=d, capture_output=True, text=True)
+            assert r.returncode == 0, p + "\n" + r.stdout + r.stderr
