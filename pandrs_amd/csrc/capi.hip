@@ -135,6 +135,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "p_max")) c->opt.p_max = value;
     else if (!std::strcmp(name, "slice_rows")) c->opt.slice_rows = value;
     else if (!std::strcmp(name, "agg_v1")) c->opt.agg_v1 = value;
+    else if (!std::strcmp(name, "deterministic")) c->opt.deterministic = value;
     else if (!std::strcmp(name, "sampled_chunked")) c->opt.sampled_chunked = value;
     else if (!std::strcmp(name, "exact_partition")) c->opt.exact_partition = value;
     else if (!std::strcmp(name, "agg_ablate")) c->opt.agg_ablate = value;

@@ -152,6 +152,7 @@ struct Options {
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
     int64_t exact_partition = 0;     // 1 = always run the exact histogram (never the sampled-capacity partition)
     int64_t sampled_chunked = 0;     // experiments: capacity-mode scatter with chunked instead of interleaved tiles
+    int64_t deterministic = 0;       // 1 = f64 Sum / Mean and Std / Var folded in ascending row order per group (bit-identical to the reference's fold)
     int64_t agg_v1 = 0;              // 1 = never use the lean persistent aggregate kernel (aggregate2.hip)
     int64_t agg_depth = 0;           // experiments: register-ring depth of aggregate2 (C2 profile)
     int64_t agg_ablate = 0;          // experiments: 1 no min/max, 2 lookup only, 3 stream only (C2 profile of aggregate2)

@@ -294,6 +294,9 @@ static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_c
     return 0;
 }
 
+static int32_t ordered_fold_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const RowSource &rs, const Plan &pl,
+                                 const pandrs_hip_column *vals, const pandrs_hip_agg_spec *aggs, int n_aggs);
+
 int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *keys,
                       int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
                       const pandrs_hip_agg_spec *aggs, int32_t n_aggs, bool partials,
@@ -366,6 +369,7 @@ int32_t groupby_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_col
         if (is_sorted_pass_op(aggs[a].op))
             ST_TRY(median_pass(c, rs.key, n_rows, med_data[a], med_null[a], pl.fin_kind[a], a,
                                aggs[a].op == PANDRS_HIP_AGG_NUNIQUE ? 1 : 0));
+    if (c->opt.deterministic && !partials) ST_TRY(ordered_fold_pass(c, rs.key, n_rows, rs, pl, vals, aggs, n_aggs));
     if (n_keys > 1 && c->gb.n_groups > 0) {
         hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((c->gb.n_groups + 255) / 256)), dim3(256), 0, c->stream,
                            pd, c->gb.n_groups, (size_t)c->gb.cap, c->gb.keys, c->gb.key_null);
@@ -659,6 +663,135 @@ int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dt
     c->timings.algorithmic_bytes = n_rows * (int64_t)(8 * W) + c->gb.n_groups * (8 + 8 * (int64_t)n_aggs);
     ST_TRY(timings_end(c));
     *out_n_groups = c->gb.n_groups;
+    return 0;
+}
+
+// ---- deterministic mode ("deterministic" = 1): f64 Sum / Mean and Std / Var folded in ASCENDING ROW ORDER ----------
+// The engine's f64 sums re-associate (LDS atomics in arrival order: within 1e-9 of the reference, not bit-identical,
+// and not the same from run to run).  Here every group's rows are put in ascending row order (build_sorted_groups:
+// group_by's own row lists), the values are gathered into that order, and ONE thread per group folds them
+// sequentially — the reference's loop (aggregation.rs:625-648 Sum / Mean, :557-584 + :881-903 Std / Var), so the
+// result is bit-identical to it.  Opt-in: one sort of the rows + one gather and one fold per aggregate
+// (~10 ms per 100 M rows with ~100-row groups; a group of r rows costs r dependent adds on one lane).
+struct OrdEntry { uint64_t key; double value; };
+
+__global__ void group_starts_kernel(const uint32_t *flag, const uint32_t *gid, uint32_t n, uint32_t *goff) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) goff[gid[i]] = i;
+    if (i == 0) goff[gid[n]] = n;
+}
+__global__ void gather_sorted_values_kernel(const uint32_t *prow, uint32_t n, const uint64_t *vdata, const uint8_t *vnull,
+                                            uint64_t *sv, uint8_t *sn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = prow[i];
+    sv[i] = vdata[r];
+    sn[i] = vnull ? (uint8_t)bit_at(vnull, r) : 0;
+}
+__global__ void ordered_fold_kernel(const uint64_t *pk, const uint32_t *goff, uint32_t G, const uint32_t *null_beg,
+                                    const uint64_t *sv, const uint8_t *sn, int kind, int op, OrdEntry *table, uint32_t mask) {
+#pragma clang fp contract(off)      // the reference rounds the product and the sum separately: no fused multiply-add here
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t beg = goff[g], end = goff[g + 1];
+    auto val = [&](uint32_t i) { return kind == 0 ? __longlong_as_double((long long)sv[i]) : (double)(int64_t)sv[i]; };
+    double sum = 0.0;
+    uint64_t cnt = 0;
+    for (uint32_t i = beg; i < end; i++)
+        if (!sn[i]) { sum += val(i); cnt++; }
+    double out;
+    if (op == PANDRS_HIP_AGG_SUM) out = sum;
+    else if (op == PANDRS_HIP_AGG_MEAN) out = cnt ? sum / (double)cnt : 0.0;
+    else {                                               // calculate_variance (aggregation.rs:881-903)
+        double var = 0.0;
+        if (cnt > 0) {
+            const double n = (double)cnt, mean = sum / n;
+            double ssd = 0.0;
+            for (uint32_t i = beg; i < end; i++)
+                if (!sn[i]) { const double d = val(i) - mean; ssd += d * d; }
+            var = cnt > 1 ? ssd / (n - 1.0) : 0.0;
+        }
+        out = op == PANDRS_HIP_AGG_STD ? sqrt(var) : var;
+    }
+    // publish under the group's key (the engine's result rows are in another order)
+    if (beg >= *null_beg) { table[mask + 2].value = out; return; }
+    const uint64_t key = pk[beg];
+    if (key == EMPTY_KEY) { table[mask + 1].value = out; return; }
+    uint32_t slot = hash32(key, 0x2545F491u) & mask;
+    for (uint32_t probes = 0; probes <= mask; probes++) {
+        const uint64_t old = atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, key);
+        if (old == EMPTY_KEY) { table[slot].value = out; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void ordered_lookup_kernel(const uint64_t *gkeys, const uint8_t *gnull, int64_t n_groups, const OrdEntry *table,
+                                      uint32_t mask, double *out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_groups) return;
+    const uint64_t k = gkeys[j];
+    double v = 0.0;
+    if (gnull[j]) v = table[mask + 2].value;
+    else if (k == EMPTY_KEY) v = table[mask + 1].value;
+    else {
+        uint32_t slot = hash32(k, 0x2545F491u) & mask;
+        for (uint32_t probes = 0; probes <= mask; probes++) {
+            const OrdEntry e = table[slot];
+            if (e.key == k) { v = e.value; break; }
+            if (e.key == EMPTY_KEY) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+    out[j] = v;
+}
+
+static bool wants_ordered_fold(const pandrs_hip_agg_spec &a, int dtype) {
+    return ((a.op == PANDRS_HIP_AGG_SUM || a.op == PANDRS_HIP_AGG_MEAN) && dtype == PANDRS_HIP_F64) ||
+           a.op == PANDRS_HIP_AGG_STD || a.op == PANDRS_HIP_AGG_VAR;
+}
+
+// overwrites the order-dependent aggregates of c->gb with their ascending-row-order folds
+static int32_t ordered_fold_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const RowSource &rs, const Plan &pl,
+                                 const pandrs_hip_column *vals, const pandrs_hip_agg_spec *aggs, int n_aggs) {
+    GroupbyResult &res = c->gb;
+    const int64_t G = res.n_groups;
+    if (G <= 0 || n_rows <= 0) return 0;
+    bool any = false;
+    for (int a = 0; a < n_aggs; a++) any = any || wants_ordered_fold(aggs[a], vals[aggs[a].col].dtype);
+    if (!any) return 0;
+    PhaseTimer pt(c, PANDRS_HIP_PHASE_OTHER);
+    c->quiet++;
+    struct Unquiet { pandrs_hip_ctx *c; ~Unquiet() { c->quiet--; } } unq{c};
+    SortedGroups sg;
+    ST_TRY(build_sorted_groups(c, key, n_rows, &sg));
+    if (sg.G != G) return fail(PANDRS_HIP_ERR_COMPUTATION, "deterministic pass found %lld groups, the engine %lld", (long long)sg.G, (long long)G);
+    uint32_t cap = 64;
+    while ((double)cap < 1.5 * (double)G) cap <<= 1;
+    ST_TRY(c->temp.ensure(Arena::padded(size_t(G + 2) * 4) + Arena::padded(size_t(n_rows) * 8) + Arena::padded(size_t(n_rows)) +
+                          Arena::padded(size_t(cap + 4) * 16) + 8192, c->stream));
+    uint32_t *goff = c->temp.take<uint32_t>(G + 2);
+    uint64_t *sv = c->temp.take<uint64_t>(n_rows);
+    uint8_t *sn = c->temp.take<uint8_t>(n_rows);
+    OrdEntry *table = c->temp.take<OrdEntry>((size_t)cap + 4);
+    if (!goff || !sv || !sn || !table) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small (deterministic)");
+    const unsigned nb = (unsigned)((n_rows + 255) / 256);
+    hipLaunchKernelGGL(group_starts_kernel, dim3(nb), dim3(256), 0, c->stream, sg.flag, sg.gid, (uint32_t)n_rows, goff);
+    int gathered_src = -1;
+    for (int a = 0; a < n_aggs; a++) {
+        if (!wants_ordered_fold(aggs[a], vals[aggs[a].col].dtype)) continue;
+        const int s = pl.fin_src[a];
+        if (s != gathered_src) {
+            hipLaunchKernelGGL(gather_sorted_values_kernel, dim3(nb), dim3(256), 0, c->stream, sg.prow, (uint32_t)n_rows,
+                               reinterpret_cast<const uint64_t *>(rs.val_data[s]), rs.val_null_bits[s], sv, sn);
+            gathered_src = s;
+        }
+        HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(cap) * 16, c->stream));
+        HIP_TRY(hipMemsetAsync(&table[cap], 0, 64, c->stream));
+        hipLaunchKernelGGL(ordered_fold_kernel, dim3((unsigned)((G + 127) / 128)), dim3(128), 0, c->stream, sg.pk, goff, (uint32_t)G,
+                           sg.null_beg, sv, sn, (int)pl.src_kind[s], (int)aggs[a].op, table, cap - 1);
+        hipLaunchKernelGGL(ordered_lookup_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream, res.keys, res.key_null, G,
+                           table, cap - 1, res.aggs + (size_t)a * res.cap);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 

@@ -1095,3 +1095,35 @@ def test_k1_stream_rate():
         assert 0.8 / best >= 4.0, "reduce kernel %.3f ms = %.2f TB/s" % (best, 0.8 / best)
     finally:
         c.close()
+
+
+def test_deterministic_mode_is_bit_identical_to_the_sequential_fold(ctx):
+    """"deterministic" = 1: f64 Sum / Mean and Std / Var are folded in ascending row order per group, the reference's
+    own loop (aggregation.rs:625-648, :881-903) — EVERY aggregate then equals the oracle's sequential fold bit for bit
+    (default mode: sums within 1e-9 only, and not the same from run to run)."""
+    rng = np.random.default_rng(31)
+    n, g = 3_000_000, 120_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.05] = 4242                                # a hot key
+    k[rng.random(n) < 0.002] = -1                                 # the table-sentinel value
+    keys = [(k, O.pack_mask(rng.random(n) < 0.01), O.I64)]
+    vals = [(rng.normal(0, 1e6, n) * rng.choice([1e-9, 1.0, 1e9], n), O.pack_mask(rng.random(n) < 0.05), O.F64),
+            (rng.integers(-10**12, 10**12, n).astype(np.int64), None, O.I64),
+            (rng.normal(3, 2, n), None, O.F64)]
+    aggs = [(0, O.SUM), (0, O.MEAN), (0, O.STD), (0, O.VAR), (0, O.MIN), (0, O.MAX), (0, O.COUNT),
+            (1, O.SUM), (1, O.MEAN), (1, O.STD), (1, O.VAR), (2, O.SUM), (2, O.MEAN)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    ctx.set_option("deterministic", 1)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+        assert_groupby_equal(got, want, [O.I64], int_exact_rows=list(range(len(aggs))))
+        got2 = ctx.groupby_agg(keys, n, vals, aggs)                # and reproducible
+        assert_groupby_equal(got2, got, [O.I64], int_exact_rows=list(range(len(aggs))))
+        # two key columns (packed cells) and string-pool codes
+        k2 = rng.integers(0, 7, n).astype(np.uint32)
+        keys2 = [(k, None, O.I64), (k2, None, O.U32CODE)]
+        got3 = ctx.groupby_agg(keys2, n, vals[:1], [(0, O.SUM), (0, O.MEAN)])
+        want3 = O.groupby_agg(keys2, n, vals[:1], [(0, O.SUM), (0, O.MEAN)])
+        assert_groupby_equal(got3, want3, [O.I64, O.U32CODE], int_exact_rows=[0, 1])
+    finally:
+        ctx.set_option("deterministic", 0)
