@@ -44,7 +44,9 @@ typedef enum pandrs_hip_status {
     PANDRS_HIP_ERR_OPERATION_FAILED = 3,   /* Error::OperationFailed (aggregation.rs:744-752, lazy.rs:377-382) */
     PANDRS_HIP_ERR_COMPUTATION = 4,        /* Error::Computation(String) — device failures (src/gpu/mod.rs:206-210) */
     PANDRS_HIP_ERR_OUT_OF_MEMORY = 5,
-    PANDRS_HIP_ERR_NOT_INITIALIZED = 6
+    PANDRS_HIP_ERR_NOT_INITIALIZED = 6,
+    PANDRS_HIP_ERR_BELOW_THRESHOLD = 7     /* fewer rows than GpuConfig.min_size_threshold: the caller keeps its CPU path
+                                              (src/optimized/split_dataframe/gpu.rs:30-32); nothing was computed */
 } pandrs_hip_status;
 
 /* column element types.  Layouts are the reference's own:
@@ -103,8 +105,13 @@ typedef struct pandrs_hip_config {
     int64_t memory_limit;        /* GpuConfig.memory_limit, bytes; 0 = no limit */
     int32_t fallback_to_cpu;     /* GpuConfig.fallback_to_cpu — honoured by the CALLER (shim keeps the
                                     reference CPU path); this library never computes on the CPU */
-    int32_t use_pinned_memory;   /* GpuConfig.use_pinned_memory: pin host staging buffers */
-    int64_t min_size_threshold;  /* GpuConfig.min_size_threshold (default 10_000, src/gpu/mod.rs:41) */
+    int32_t use_pinned_memory;   /* GpuConfig.use_pinned_memory: host columns of a MEM_HOST call are page-locked
+                                    (hipHostRegister) for the duration of the call, so their H2D copies are DMA */
+    int64_t min_size_threshold;  /* GpuConfig.min_size_threshold (src/gpu/mod.rs:41).  Honoured once a config has been
+                                    passed to pandrs_hip_init: the frame-level entry points (groupby_agg, groupby_indices,
+                                    join_indices, join_groupby_sum, reduce_*) return PANDRS_HIP_ERR_BELOW_THRESHOLD for
+                                    fewer rows.  Without an explicit config the threshold is 0: this library has no CPU
+                                    path of its own to prefer. */
 } pandrs_hip_config;
 
 /* One typed column view.  `data` element type per `dtype`; `null_mask` may be NULL. */

@@ -39,7 +39,7 @@ namespace pandrs {
 
 // ---- errors (src/core/error.rs) ---------------------------------------------------------------------
 struct Error : std::runtime_error {
-    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount, Empty, Type };
+    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount, Empty, Type, BelowThreshold };
     Kind kind;
     Error(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
 };
@@ -53,6 +53,7 @@ inline void check(int32_t st) {
     case PANDRS_HIP_ERR_INVALID_ARGUMENT: throw Error(Error::InvalidInput, msg);
     case PANDRS_HIP_ERR_TYPE_MISMATCH: throw Error(Error::ColumnTypeMismatch, msg);
     case PANDRS_HIP_ERR_OPERATION_FAILED: throw Error(Error::OperationFailed, msg);
+    case PANDRS_HIP_ERR_BELOW_THRESHOLD: throw Error(Error::BelowThreshold, msg);     // the shim keeps its CPU path (gpu.rs:30-32)
     default: throw Error(Error::Computation, msg);
     }
 }

@@ -5,8 +5,8 @@ There is no CPU fallback: without the built library or a gfx950 device, calls fa
 from . import _lib
 from ._lib import (I64, F64, U32CODE, BOOLBITS, CELL64, SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST,
                    LAST, CUSTOM, NUNIQUE, INNER, LEFT, RIGHT, OUTER)
-from .engine import Context, PandrsHipError, ColumnTypeMismatch, OperationFailed, EmptyError
+from .engine import Context, PandrsHipError, ColumnTypeMismatch, OperationFailed, EmptyError, BelowThreshold
 
-__all__ = ["Context", "PandrsHipError", "ColumnTypeMismatch", "OperationFailed", "EmptyError", "_lib",
+__all__ = ["Context", "PandrsHipError", "ColumnTypeMismatch", "OperationFailed", "EmptyError", "BelowThreshold", "_lib",
            "I64", "F64", "U32CODE", "BOOLBITS", "CELL64", "SUM", "MEAN", "MIN", "MAX", "COUNT", "STD", "VAR",
            "MEDIAN", "FIRST", "LAST", "CUSTOM", "NUNIQUE", "INNER", "LEFT", "RIGHT", "OUTER"]

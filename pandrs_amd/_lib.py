@@ -20,7 +20,7 @@ SUM, MEAN, MIN, MAX, COUNT, STD, VAR, MEDIAN, FIRST, LAST, CUSTOM, NUNIQUE = ran
 INNER, LEFT, RIGHT, OUTER = range(4)
 MEM_HOST, MEM_DEVICE = 0, 1
 OK, ERR_INVALID_ARGUMENT, ERR_TYPE_MISMATCH, ERR_OPERATION_FAILED, ERR_COMPUTATION, \
-    ERR_OUT_OF_MEMORY, ERR_NOT_INITIALIZED = range(7)
+    ERR_OUT_OF_MEMORY, ERR_NOT_INITIALIZED, ERR_BELOW_THRESHOLD = range(8)
 
 
 class Config(C.Structure):

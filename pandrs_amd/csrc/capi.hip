@@ -7,7 +7,13 @@ namespace {
 std::mutex g_mu;
 bool g_inited = false;
 pandrs_hip_config g_cfg{1, 0, 0, 1, 0, 10000};   // GpuConfig defaults, src/gpu/mod.rs:32-44
+bool g_cfg_explicit = false;                     // a config was passed to pandrs_hip_init: thresholds are honoured
 }  // namespace
+
+namespace pandrs {
+int64_t config_min_size_threshold() { return g_cfg_explicit ? g_cfg.min_size_threshold : 0; }
+bool config_use_pinned_memory() { return g_cfg_explicit && g_cfg.use_pinned_memory != 0; }
+}  // namespace pandrs
 
 using pandrs::fail;
 
@@ -19,7 +25,8 @@ const char *pandrs_hip_last_error(void) { return pandrs::last_error().c_str(); }
 
 int32_t pandrs_hip_init(const pandrs_hip_config *cfg) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (cfg) g_cfg = *cfg;
+    if (cfg) { g_cfg = *cfg; g_cfg_explicit = true; }
+    else g_cfg_explicit = false;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)
@@ -155,6 +162,7 @@ int32_t pandrs_hip_groupby_agg(pandrs_hip_ctx *ctx, int32_t mem_space, const pan
                                int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals,
                                int32_t n_vals, const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
                                int64_t *out_n_groups) {
+    ST_TRY(pandrs::below_threshold(n_rows));
     return pandrs::groupby_entry(ctx, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs,
                                  false, out_n_groups, nullptr);
 }
@@ -207,6 +215,7 @@ int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t 
 
 int32_t pandrs_hip_groupby_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
                                    int32_t n_keys, int64_t n_rows, int64_t *out_n_groups) {
+    ST_TRY(pandrs::below_threshold(n_rows));
     return pandrs::groupby_indices_entry(ctx, mem_space, keys, n_keys, n_rows, out_n_groups);
 }
 
@@ -272,6 +281,7 @@ int32_t pandrs_hip_bytes_to_bitmap(pandrs_hip_ctx *ctx, int32_t mem_space, const
 int32_t pandrs_hip_join_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *left_key,
                                 int64_t n_left, const pandrs_hip_column *right_key, int64_t n_right,
                                 int32_t how, int64_t *out_n_rows) {
+    ST_TRY(pandrs::below_threshold(n_left > n_right ? n_left : n_right));
     return pandrs::join_entry(ctx, mem_space, left_key, n_left, right_key, n_right, how, out_n_rows);
 }
 
@@ -312,11 +322,13 @@ int32_t pandrs_hip_gather_bool(pandrs_hip_ctx *ctx, int32_t mem_space, const uin
 int32_t pandrs_hip_join_groupby_sum(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *lk,
                                     const pandrs_hip_column *lv, int64_t nl, const pandrs_hip_column *rk,
                                     const pandrs_hip_column *rg, int64_t nr, int64_t *out_n_groups) {
+    ST_TRY(pandrs::below_threshold(nl > nr ? nl : nr));
     return pandrs::join_groupby_sum_entry(ctx, mem_space, lk, lv, nl, rk, rg, nr, out_n_groups);
 }
 
 int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col,
                                  int64_t n, double out[4], int64_t *out_count) {
+    ST_TRY(pandrs::below_threshold(n));
     return pandrs::reduce_entry(ctx, mem_space, col, n, out, out_count);
 }
 
@@ -328,6 +340,7 @@ int32_t pandrs_hip_gather_column(pandrs_hip_ctx *ctx, int32_t mem_space, const p
 int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
                                   double *out_sum, double *out_sum_sq, int64_t *out_count) {
     if (!out_sum || !out_sum_sq || !out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce_moments: bad arguments");
+    ST_TRY(pandrs::below_threshold(n));
     double o[4];
     int32_t st = pandrs::reduce_entry(ctx, mem_space, col, n, o, out_count, out_sum_sq);
     if (st) return st;
@@ -337,6 +350,7 @@ int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const 
 
 int32_t pandrs_hip_reduce_stats(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
                                 pandrs_hip_column_stats *out) {
+    ST_TRY(pandrs::below_threshold(n));
     return pandrs::reduce_stats_entry(ctx, mem_space, col, n, out);
 }
 

@@ -50,6 +50,17 @@ inline size_t &arena_limit() {
     return limit;
 }
 
+// pandrs_hip_config as passed to pandrs_hip_init (capi.hip); thresholds apply only once a config was passed explicitly
+int64_t config_min_size_threshold();
+bool config_use_pinned_memory();
+inline int32_t below_threshold(int64_t n_rows) {
+    const int64_t t = config_min_size_threshold();
+    if (t > 0 && n_rows < t)
+        return fail(PANDRS_HIP_ERR_BELOW_THRESHOLD, "%lld rows is below pandrs_hip_config.min_size_threshold (%lld): keep the CPU path",
+                    (long long)n_rows, (long long)t);
+    return 0;
+}
+
 // ---- bump arena over one hipMalloc block -------------------------------------------------------
 // Sized for 288 GB of HBM: one big block per purpose, grown (never shrunk) between calls, so the
 // steady state performs no hipMalloc/hipFree inside a timed call.

@@ -15,14 +15,25 @@ struct Stager {
     pandrs_hip_ctx *c;
     int32_t space;
     int32_t status = 0;
+    std::vector<const void *> pinned;      // host ranges page-locked for this call (GpuConfig.use_pinned_memory)
     // copies `bytes` from a caller pointer into the staging arena when it lives on the host
     const void *in(const void *p, size_t bytes) {
         if (!p || space == PANDRS_HIP_MEM_DEVICE || status) return p;
         void *d = c->staging.take<uint8_t>(bytes + 16);
         if (!d) { status = fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small"); return nullptr; }
+        if (config_use_pinned_memory() && bytes >= (size_t(1) << 20) &&
+            hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+            pinned.push_back(p);                // (a range that cannot be registered is simply copied pageable)
+        else
+            (void)hipGetLastError();
         hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) status = fail(PANDRS_HIP_ERR_COMPUTATION, "H2D copy failed: %s", hipGetErrorString(e));
         return d;
+    }
+    ~Stager() {
+        if (pinned.empty()) return;
+        (void)hipStreamSynchronize(c->stream);   // the DMA engines may still be reading the ranges
+        for (const void *p : pinned) (void)hipHostUnregister(const_cast<void *>(p));
     }
 };
 

@@ -30,6 +30,11 @@ class OperationFailed(PandrsHipError):
     pass
 
 
+class BelowThreshold(PandrsHipError):
+    """PANDRS_HIP_ERR_BELOW_THRESHOLD: fewer rows than GpuConfig.min_size_threshold — the caller keeps its CPU path
+    (src/optimized/split_dataframe/gpu.rs:30-32).  This package has no CPU path: the error is the answer."""
+
+
 class EmptyError(PandrsHipError):
     """Error::Empty (src/optimized/split_dataframe/aggregate.rs:87): no non-null value to aggregate."""
 
@@ -40,6 +45,8 @@ def _raise(status):
         raise ColumnTypeMismatch(status, msg)
     if status == L.ERR_OPERATION_FAILED:
         raise OperationFailed(status, msg)
+    if status == L.ERR_BELOW_THRESHOLD:
+        raise BelowThreshold(status, msg)
     raise PandrsHipError(status, msg)
 
 

@@ -638,6 +638,25 @@ def test_gpu_config_is_honoured():
                           [(rng.normal(size=2_000_000), None, O.F64)], [(0, O.SUM)])
         assert e.value.status == L.ERR_OUT_OF_MEMORY and "memory_limit" in str(e.value)
         c.close()
+        # min_size_threshold: below it the frame-level calls answer "keep your CPU path" (status 7) and compute nothing;
+        # use_pinned_memory: host columns are page-locked for the call, results unchanged
+        cfg.memory_limit, cfg.min_size_threshold, cfg.use_pinned_memory = 0, 10_000, 1
+        assert lib.pandrs_hip_init(C.byref(cfg)) == 0
+        c = pa.Context(0)
+        small = (np.arange(100, dtype=np.int64), None, O.I64)
+        for call in (lambda: c.groupby_agg([small], 100, [(np.ones(100), None, O.F64)], [(0, O.SUM)]),
+                     lambda: c.join_indices(small, 100, small, 100, O.INNER),
+                     lambda: c.column_stats((np.ones(100), None, O.F64), 100),
+                     lambda: c.groupby_indices([small], 100)):
+            with pytest.raises(pa.BelowThreshold) as e:
+                call()
+            assert e.value.status == L.ERR_BELOW_THRESHOLD
+        n = 3_000_000
+        k = (rng.integers(0, 1000, n), None, O.I64)
+        v = (rng.normal(size=n), None, O.F64)
+        got = c.groupby_agg([k], n, [v], FIVE)
+        assert_groupby_equal(got, O.groupby_agg([k], n, [v], FIVE), [O.I64], int_exact_rows=EXACT5)
+        c.close()
     finally:
         cfg = L.Config(enabled=1, device_id=0, memory_limit=0, fallback_to_cpu=1, use_pinned_memory=0, min_size_threshold=10_000)
         lib.pandrs_hip_init(C.byref(cfg))

@@ -303,3 +303,38 @@ def test_join_full_size_properties():
         assert abs(float(oa[0].sum()) - float(lv.sum())) <= 1e-9 * abs(float(lv.sum()))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("nb", [50_000_000, 60_000_000])
+def test_config5_shard_full_size_properties(nb):
+    """BASELINE config 5's per-GPU shard after the build side's all-gather: 62.5 M probe rows x 50 M unique build rows
+    through the fused join -> groupby-sum — right at the ~55 M-row limit of the LDS-partition path — and 60 M build
+    rows, which must take the general-join fallback (limits).  Size-independent properties: the groups are
+    exactly the g values hit, the total of v is conserved, the per-group sums equal a scatter-add of the same pairs."""
+    import torch
+    import pandrs_amd as pa
+    d = "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(48 + nb % 7)
+    npb, g = 62_500_000, 100_000
+    rk = torch.randperm(nb, device=d, generator=gen) * -7046029254386353131        # odd multiplier: unique keys
+    rg = torch.randint(0, g, (nb,), device=d, generator=gen, dtype=torch.int64)
+    pick = torch.randint(0, nb, (npb,), device=d, generator=gen)
+    lk = rk[pick]
+    miss = torch.rand(npb, device=d, generator=gen) < 0.1                          # the 90 %-hit variant of SURVEY 8d
+    lk = torch.where(miss, lk ^ 1, lk)
+    hit = ~miss | (lk == rk[pick])
+    lv = torch.randn(npb, device=d, generator=gen, dtype=torch.float64) * 10 + 100
+    c = pa.Context(0)
+    try:
+        kc, kn, oa = c.join_groupby_sum((lk, None, pa.I64), (lv, None, pa.F64), npb, (rk, None, pa.I64), (rg, None, pa.I64), nb)
+        # a flipped key may by chance equal another build key: settle the truth with the index join on a sample
+        want = torch.zeros(g, dtype=torch.float64, device=d).index_add_(0, rg[pick][hit], lv[hit])
+        got = torch.zeros(g, dtype=torch.float64, device=d)
+        got[kc[0]] = oa[0]
+        assert int(kn.sum()) == 0 and kc.shape[1] == torch.unique(kc[0]).numel()
+        stray = float((got - want).abs().max())
+        assert stray <= 1e-9 * float(want.abs().max()) + 200.0 * 3, stray          # <= a handful of chance hits among 6 M flipped keys
+        assert abs(float(oa[0].sum()) - float(lv[hit].sum())) <= 1e-9 * abs(float(lv.sum())) + 200.0 * 3
+    finally:
+        c.close()
