@@ -96,6 +96,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr int MM = (OP_MIN ? 1 : 0) + (OP_MAX ? 1 : 0);  // min-type states per source
     constexpr uint64_t M_IDENT = KIND == 0 ? 0xFFF0000000000000ull : ~0ull;   // enc(+inf) = ~enc(-inf); enc(MAX) = ~enc(MIN)
     constexpr uint32_t QCAP = 128;                           // per-wave retry queue (row indices)
+    constexpr bool NT = ABLATE == 7;                         // experiments: non-temporal row loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x;   // slot T: the key equal to the table sentinel
     // LDS: keys[T1] | states[round_states][T1] | gsz[T1] (u32) | ctrl[T] (u8) | misc[40] | queue[16][QCAP]   (T multiple of 16)
@@ -143,8 +144,10 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     // current task while the loads of the following batches are in flight.  Batches start at a 128-byte
     // boundary (16 rows: a wave's 512-byte loads cover whole lines; misaligned streams measured 15 %
     // slower, experiments/ubench/stream_formats.hip) and a task's batch count is padded to a multiple of
-    // DEPTH so that slot numbers are compile-time constants across task boundaries.  Plain loads: the first
-    // read of freshly written lines is faster with them than with nt loads (experiments/ubench/fresh_read.hip).
+    // DEPTH so that slot numbers are compile-time constants across task boundaries.  Plain loads: the rows were written
+    // by the scatter just before, and the FIRST read of freshly written lines is faster with plain than with nt loads
+    // (experiments/ubench/fresh_read.hip; this kernel on C2: 1.08 ms plain, 1.27 ms nt).  The PMC read counter shows
+    // 5.7 GB for the 4.0 GB of rows with plain loads and exactly 4.0 GB with nt loads (ABLATE 7 = the nt variant).
     uint64_t rk[DEPTH], rv[DEPTH][NSRC];
     uint32_t rok[DEPTH];
     auto n_batches = [](const AggTask &tk) {
@@ -155,11 +158,11 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         uint32_t i = (tk.beg & ~15u) + batch * AG_THREADS + tid;
         i = min(max(i, tk.beg), tk.end - 1);          // rows outside [beg, end) are loaded (in bounds) but never processed
         if (ABLATE == 6) i = tk.beg + ((i - tk.beg) & 2047u);     // experiments: every load hits L2 (compute time alone)
-        rk[d] = pkeys[i];
+        rk[d] = NT ? __builtin_nontemporal_load(pkeys + i) : pkeys[i];
         rok[d] = 0xFFFFFFFFu;
 #pragma unroll
         for (int c = 0; c < NSRC; c++) {
-            rv[d][c] = vals[c][i];
+            rv[d][c] = NT ? __builtin_nontemporal_load(vals[c] + i) : vals[c][i];
             if (HAS_V && valid[c][i] == 0) rok[d] &= ~(1u << c);
         }
     };
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 if (!last) fetch(h, cur, pit + h + DEPTH);
                 else if (have_next) fetch(h, nxt, h);
                 const bool act = row >= beg && row < end;
-                if (ABLATE >= 3 && ABLATE != 6) {          // experiments: keep every load alive without using it
+                if (ABLATE >= 3 && ABLATE < 6) {          // experiments: keep every load alive without using it
                     uint64_t x = k;
 #pragma unroll
                     for (int c = 0; c < NSRC; c++) x ^= v[c];
@@ -427,7 +430,7 @@ bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profi
         // size only, 3 the HBM stream alone, 4 ... without epilogue, 6 full work on L2-resident rows) and the ring depth
         const int ab = (int)c->opt.agg_ablate, dp = (int)c->opt.agg_depth;
 #define EXP(N, A, D) if (n_src == N && ab == A && dp == D) { launch_one<N, 14, A, D>(c, a, lds, grid); return true; }
-        EXP(4, 0, 2) EXP(4, 0, 3) EXP(4, 0, 5) EXP(4, 1, 0) EXP(4, 2, 0) EXP(4, 3, 0) EXP(4, 4, 0) EXP(4, 6, 0)
+        EXP(4, 7, 0) EXP(4, 0, 2) EXP(4, 0, 3) EXP(4, 0, 5) EXP(4, 1, 0) EXP(4, 2, 0) EXP(4, 3, 0) EXP(4, 4, 0) EXP(4, 6, 0)
         EXP(2, 0, 2) EXP(2, 0, 3) EXP(2, 0, 6) EXP(2, 1, 0) EXP(2, 2, 0) EXP(2, 3, 0) EXP(2, 6, 0)
 #undef EXP
     }
