@@ -365,6 +365,7 @@ class Context:
             records = np.ascontiguousarray(records, np.uint64)
         else:
             records = records.contiguous()
+            self._wait_for_producer()
         n_rows = int(records.shape[0])
         nv = len(val_dtypes)
         vd = (C.c_int32 * max(nv, 1))(*[int(x) for x in val_dtypes])
@@ -405,6 +406,7 @@ class Context:
     def gather(self, src, mask, idx, fill, dtype):
         """Device tensors only.  -> torch tensor (uint8 per row for BOOLBITS sources)."""
         import torch
+        self._wait_for_producer()        # src / mask / idx may still be being written on torch's current stream
         n = idx.numel()
         d = idx.device
         fn, out = {

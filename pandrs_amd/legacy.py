@@ -51,7 +51,8 @@ _ENGINE_OP = {AggFunc.Sum: L.SUM, AggFunc.Mean: L.MEAN, AggFunc.Min: L.MIN, AggF
 # what `str::parse::<f64>` accepts: optional sign, then "inf" / "infinity" / "nan" in any case, or decimal digits
 # with an optional point and exponent (at least one digit before the exponent); nothing else — no blanks,
 # no "_" separators, no hex (Python's float() takes the first two)
-_RUST_F64 = re.compile(r"^[+-]?(?:inf|infinity|nan|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)$", re.IGNORECASE)
+# ASCII digits only and the WHOLE cell (Rust's parse rejects "1.5\n" and Arabic-Indic digits; `$` and `\d` would not)
+_RUST_F64 = re.compile(r"[+-]?(?:inf|infinity|nan|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)", re.IGNORECASE)
 
 
 def parse_f64_cells(cells):
@@ -60,7 +61,7 @@ def parse_f64_cells(cells):
     vals = np.zeros(n, np.float64)
     ok = np.zeros(n, bool)
     for i, s in enumerate(cells):
-        if _RUST_F64.match(s):
+        if _RUST_F64.fullmatch(s):
             vals[i] = float(s)
             ok[i] = True
     return vals, ok
@@ -149,15 +150,15 @@ class DataFrame:
         true / false / 1 / 0 in any case (empty => false), else String."""
         from .frame import BooleanColumn, Float64Column, Int64Column, OptimizedDataFrame, StringColumn
         out = OptimizedDataFrame()
-        rust_i64 = re.compile(r"^[+-]?\d+$")
+        rust_i64 = re.compile(r"[+-]?[0-9]+")
         for name in self.column_names:
             cells = self._cells[name]
 
             def is_i64(s):
-                return bool(rust_i64.match(s)) and -2**63 <= int(s) < 2**63
+                return bool(rust_i64.fullmatch(s)) and -2**63 <= int(s) < 2**63
             if all(s == "" or is_i64(s) for s in cells):
                 out.add_column(name, Int64Column([int(s) if s else 0 for s in cells]))
-            elif all(s == "" or _RUST_F64.match(s) for s in cells):
+            elif all(s == "" or _RUST_F64.fullmatch(s) for s in cells):
                 out.add_column(name, Float64Column([float(s) if s else 0.0 for s in cells]))
             elif all(s.lower() in ("", "true", "false", "1", "0") for s in cells):
                 out.add_column(name, BooleanColumn([s.lower() in ("true", "1") for s in cells]))

@@ -71,6 +71,13 @@ def test_rust_float_grammar_and_type_inference():
     vals, ok = parse_f64_cells(["1", "-2.5", "+3e2", ".5", "7.", "inf", "-Infinity", "NaN", "", " 1", "1_0", "0x10", "abc", "1e", "e5"])
     assert ok.tolist() == [True] * 8 + [False] * 7
     assert vals[:7].tolist() == [1.0, -2.5, 300.0, 0.5, 7.0, math.inf, -math.inf] and math.isnan(vals[7])
+    # str::parse::<f64> takes the WHOLE cell and ASCII digits only: a trailing newline or Arabic-Indic digits fail
+    _, ok2 = parse_f64_cells(["1.5\n", "\u0661\u0662", "\u0663.5", "2.5"])
+    assert ok2.tolist() == [False, False, False, True]
+    d2 = DataFrame()
+    d2.add_column("i", ["1", "2\n"])                   # not i64, not f64, not bool => String
+    d2.add_column("j", ["\u0661", "3"])
+    assert [type(c).__name__ for c in d2.to_optimized().columns] == ["StringColumn", "StringColumn"]
     df = DataFrame()
     df.add_column("i", ["1", "", "-3"])              # src/optimized/convert.rs:31-45: all i64 (empty => 0)
     df.add_column("f", ["1.5", "", "2"])             # :48-61
