@@ -658,8 +658,7 @@ def test_gpu_config_is_honoured():
         assert_groupby_equal(got, O.groupby_agg([k], n, [v], FIVE), [O.I64], int_exact_rows=EXACT5)
         c.close()
     finally:
-        cfg = L.Config(enabled=1, device_id=0, memory_limit=0, fallback_to_cpu=1, use_pinned_memory=0, min_size_threshold=10_000)
-        lib.pandrs_hip_init(C.byref(cfg))
+        lib.pandrs_hip_init(None)    # back to the library defaults (no explicit config: no threshold)
         pa.Context(0).close()        # resets the limit
 
 
