@@ -72,14 +72,18 @@ for case in range(n_cases):
             aggs = [(int(rng.integers(0, nv)), int(rng.choice(ops))) for _ in range(int(rng.integers(1, 9)))]
             opts = {"no_direct": int(rng.random() < 0.3), "slice_rows": int(rng.choice([0, 0, 20_000])),
                     "p_max": int(rng.choice([0, 0, 0, 24])), "generic_aggregate": int(rng.random() < 0.2),
-                    "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9)}
+                    "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9),
+                    "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15)}
             for k, v in opts.items(): ctx.set_option(k, v)
             try:
                 got = ctx.groupby_agg(keys, n, vals, aggs)
             finally:
-                for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1}.items(): ctx.set_option(k, v)
+                for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1,
+                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
+            if opts["deterministic"] and not any(np.isnan(np.asarray(v[0], np.float64)).any() or np.isinf(np.asarray(v[0], np.float64)).any() for v in vals if v[2] == O.F64):
+                exact = list(range(len(aggs)))          # ascending-row-order fold: every aggregate bit for bit
             assert_groupby_equal(got, want, kdts, int_exact_rows=exact, rtol=1e-9)
             if rng.random() < 0.3:      # group_by's own result on the same keys: a complete characterisation
                 cells, nulls, off, rows = ctx.groupby_indices(keys, n)

@@ -33,7 +33,7 @@ __device__ __forceinline__ uint32_t swiss_find(uint64_t k, uint64_t *keys, uint8
     const uint32_t NG = T >> 4;
     const uint32_t h = hash32(k, seed);
     uint32_t g = slot_of(h, NG);
-    const uint32_t tag = 1u + (h & 0xFFu) % 255u;
+    const uint32_t tag = (h & 0xFFu) | 1u;            // never 0 (= empty)
     const uint32_t tag4 = tag * 0x01010101u;
     for (uint32_t probe = 0; probe < NG; probe++) {
         const uint4 cw = *reinterpret_cast<const uint4 *>(ctrl + 16 * g);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 // candidate's key verified (one ds_read_b64)
                 const uint32_t hsh = hash32(k, seed);
                 const uint32_t g = slot_of(hsh, NG);
-                const uint32_t tag4 = (1u + (hsh & 0xFFu) % 255u) * 0x01010101u;
+                const uint32_t tag4 = ((hsh & 0xFFu) | 1u) * 0x01010101u;
                 const uint4 cw = *reinterpret_cast<const uint4 *>(ctrl + 16 * g);
                 const uint32_t x0 = cw.x ^ tag4, x1 = cw.y ^ tag4, x2 = cw.z ^ tag4, x3 = cw.w ^ tag4;
                 const uint32_t c0 = (x0 - 0x01010101u) & ~x0 & 0x80808080u, c1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
