@@ -22,4 +22,6 @@ for optset in sys.argv[1:] or [""]:
     opts = [kv.split("=") for kv in optset.split(",") if kv]
     run("C1 1M/1K [%s]" % optset, 1_000_000, 1_000, opts)
     run("100K rows/100 groups [%s]" % optset, 100_000, 100, opts)
+    run("2M rows/5K groups [%s]" % optset, 2_000_000, 5_000, opts)
+    run("2M rows/12K groups [%s]" % optset, 2_000_000, 12_000, opts)
     run("4M rows/50K groups [%s]" % optset, 4_000_000, 50_000, opts)

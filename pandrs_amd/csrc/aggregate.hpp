@@ -44,6 +44,15 @@ struct AggArgs {
     // device-visible) and sets host_out[4] = 1, so the host polls one word instead of copying and synchronising
     const uint32_t *scatter_flags;
     uint32_t *host_out;
+    // aggregate2's SMALL mode (few rows: no estimate, no partition): workgroup b folds rows [b * s_chunk, ...) of the
+    // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) into its LDS table and flushes the table into
+    // the context's global table with device-scope atomics; small_output_kernel turns that into the result
+    uint32_t s_need_cnt;                      // 0: no output reads a group size (one global atomic less per group and workgroup)
+    uint32_t s_rows, s_chunk, g_slots;        // g_slots: power of two; slot g_slots = sentinel-valued key, g_slots + 1 = NULL key
+    uint64_t *g_keys;                          // [g_slots + 2], EMPTY_KEY when free
+    uint32_t *g_cnt;                           // [g_slots + 2] group sizes
+    uint64_t *g_states;                        // [round_states][g_slots + 2]; sums as they are, min as ~enc, max as enc (all
+                                               // via atomicMax, so an all-zero table is an armed table)
 };
 
 __device__ __forceinline__ uint64_t state_identity(int8_t kind) {
@@ -70,5 +79,10 @@ __device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
 constexpr size_t AGG2_LDS_EXTRA = 16 * 128 * 4 + 64;   // per-wave retry queues of aggregate2_kernel
 bool aggregate2_has(int n_src, int profile);
 bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
+bool aggregate2_small_has(int n_src, int profile);
+// SMALL mode: false when (n_src, profile) has no small instantiation
+bool launch_aggregate2_small(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
+void launch_small_output(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile);
+constexpr uint32_t SMALL_G_SLOTS = 1u << 15;      // global table of the small path: up to 16 K groups
 
 }  // namespace pandrs

@@ -17,6 +17,7 @@
 //     20 + 8 x states => more slots per table => fewer radix partitions for the scatter;
 //   * one block scan for the compaction instead of three; per-source pointers live in SGPRs.
 #include "aggregate.hpp"
+#include <atomic>
 
 namespace pandrs {
 
@@ -29,13 +30,15 @@ namespace {
 // wave and lookup — the dominant cost of the round-1 kernel, instructions and LDS bytes alike).
 // keys[] is the truth (claimed with ds_cmpst_b64); a tag is written after its key and may lag: a
 // lagging tag only sends a lane to the CAS, which answers "already yours" or "taken".
-__device__ __forceinline__ uint32_t swiss_find(uint64_t k, uint64_t *keys, uint8_t *ctrl, uint32_t T, uint32_t seed) {
+// max_groups: SMALL gives up after a few groups (a chain that long means the table is nearly full; the caller falls back)
+__device__ __forceinline__ uint32_t swiss_find(uint64_t k, uint64_t *keys, uint8_t *ctrl, uint32_t T, uint32_t seed, uint32_t max_groups = 0xFFFFFFFFu) {
     const uint32_t NG = T >> 4;
     const uint32_t h = hash32(k, seed);
     uint32_t g = slot_of(h, NG);
     const uint32_t tag = (h & 0xFFu) | 1u;            // never 0 (= empty)
     const uint32_t tag4 = tag * 0x01010101u;
-    for (uint32_t probe = 0; probe < NG; probe++) {
+    const uint32_t n_probe = min(NG, max_groups);
+    for (uint32_t probe = 0; probe < n_probe; probe++) {
         const uint4 cw = *reinterpret_cast<const uint4 *>(ctrl + 16 * g);
         const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
         uint32_t cand[4], emp[4];
@@ -88,7 +91,7 @@ __device__ __forceinline__ uint64_t enc_val(uint64_t bits) {
     return ((uint64_t)(hi ^ (sm | 0x80000000u)) << 32) | (uint32_t)(lo ^ sm);
 }
 
-template <int NSRC, int PROFILE, int ABLATE, int DEPTH>
+template <int NSRC, int PROFILE, int ABLATE, int DEPTH, bool SMALL = false>
 __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr bool HAS_V = (PROFILE & 1) != 0, OP_ADD = ((PROFILE >> 1) & 1) != 0;
     constexpr bool OP_MIN = ((PROFILE >> 2) & 1) != 0, OP_MAX = ((PROFILE >> 3) & 1) != 0;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr uint32_t QCAP = 128;                           // per-wave retry queue (row indices)
     constexpr bool NT = ABLATE == 7;                         // experiments: non-temporal row loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x;   // slot T: the key equal to the table sentinel
+    const uint32_t T = a.T, T1 = T + (SMALL ? 3 : 2), tid = threadIdx.x;   // slot T: the key equal to the table sentinel; T + 1: the NULL key (SMALL)
     // LDS: keys[T1] | states[round_states][T1] | gsz[T1] (u32) | ctrl[T] (u8) | misc[40] | queue[16][QCAP]   (T multiple of 16)
     // state order (fixed by run_engine for this kernel): adds of source 0..n-1, then per source its
     // min-type states (min, ~max), then the non-null counts
@@ -133,12 +136,16 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             }
         }
     };
-    const uint32_t n_tables = a.n_tasks[1];
+    // SMALL: table b = rows [b * s_chunk, (b + 1) * s_chunk) of the original columns; no task list in memory
+    auto small_task = [&](uint32_t b) { return AggTask{0u, (uint32_t)min(b * a.s_chunk, a.s_rows), (uint32_t)min((b + 1) * a.s_chunk, a.s_rows), 0u}; };
+    auto get_table = [&](uint32_t b) { return SMALL ? AggTable{b, 1u, 0u, 0u} : a.tables[b]; };
+    auto get_task = [&](uint32_t i) { return SMALL ? small_task(i) : a.tasks[i]; };
+    const uint32_t n_tables = SMALL ? (a.s_rows + a.s_chunk - 1) / a.s_chunk : a.n_tasks[1];
     uint32_t tb = blockIdx.x;
     if (tb >= n_tables) { finish(); return; }
-    AggTable tab = a.tables[tb];
+    AggTable tab = get_table(tb);
     uint32_t ti = tab.task_beg;
-    AggTask cur = a.tasks[ti];
+    AggTask cur = get_task(ti);
 
     // Register ring of DEPTH row slots per thread (one row per slot): slot d holds batch (pit + d) of the
     // current task while the loads of the following batches are in flight.  Batches start at a 128-byte
@@ -158,12 +165,13 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         uint32_t i = (tk.beg & ~15u) + batch * AG_THREADS + tid;
         i = min(max(i, tk.beg), tk.end - 1);          // rows outside [beg, end) are loaded (in bounds) but never processed
         if (ABLATE == 6) i = tk.beg + ((i - tk.beg) & 2047u);     // experiments: every load hits L2 (compute time alone)
-        rk[d] = NT ? __builtin_nontemporal_load(pkeys + i) : pkeys[i];
-        rok[d] = 0xFFFFFFFFu;
+        rk[d] = SMALL ? key_cell(a.dkey, i) : (NT ? __builtin_nontemporal_load(pkeys + i) : pkeys[i]);
+        rok[d] = 0x7FFFFFFFu;                            // bit c: value c is valid; bit 31: the key is NULL (SMALL)
+        if (SMALL && key_is_null(a.dkey, i)) rok[d] |= 0x80000000u;
 #pragma unroll
         for (int c = 0; c < NSRC; c++) {
             rv[d][c] = NT ? __builtin_nontemporal_load(vals[c] + i) : vals[c][i];
-            if (HAS_V && valid[c][i] == 0) rok[d] &= ~(1u << c);
+            if (HAS_V && (SMALL ? bit_at(valid[c], i) : valid[c][i] == 0)) rok[d] &= ~(1u << c);
         }
     };
 
@@ -224,18 +232,20 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         qn -= n_take;
         if (lane < n_take) {
             const uint32_t i = queue[qn + lane];
-            const uint64_t k = pkeys[i];
+            const uint64_t k = SMALL ? key_cell(a.dkey, i) : pkeys[i];
+            const bool knull = SMALL && key_is_null(a.dkey, i);
             uint64_t v[NSRC];
-            uint32_t okm = 0xFFFFFFFFu;
+            uint32_t okm = 0x7FFFFFFFu;
 #pragma unroll
             for (int c = 0; c < NSRC; c++) {
                 v[c] = vals[c][i];
-                if (HAS_V && valid[c][i] == 0) okm &= ~(1u << c);
+                if (HAS_V && (SMALL ? bit_at(valid[c], i) : valid[c][i] == 0)) okm &= ~(1u << c);
             }
             uint32_t slot = T;
-            if (k == EMPTY_KEY) misc[21] = 1;
-            else slot = swiss_find(k, keys, ctrl, T, seed);
-            if (slot > T) misc[20] = 1;                // table full: host retries with more partitions
+            if (knull) { slot = T + 1; misc[23] = 1; }           // NULL key: its own group (grouping.rs:74)
+            else if (k == EMPTY_KEY) misc[21] = 1;
+            else slot = swiss_find(k, keys, ctrl, T, seed, SMALL ? 8u : 0xFFFFFFFFu);
+            if (slot > T + 1) misc[20] = 1;            // table full: host retries with more partitions
             else update(slot, v, okm);
         }
     };
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     for (;;) {                                         // one LDS table per iteration
         const uint32_t tbn = tb + gridDim.x;
         const bool have_next_tab = tbn < n_tables;
-        const AggTable ntab = a.tables[have_next_tab ? tbn : tb];
+        const AggTable ntab = get_table(have_next_tab ? tbn : tb);
         const bool multi = tab.multi != 0;
         const uint32_t t_end = tab.task_beg + tab.n_tasks;
 
@@ -263,11 +273,14 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
       for (;;) {                                       // the row ranges that feed this table
         const bool more_in_tab = ti + 1 < t_end;
         const bool have_next = more_in_tab || have_next_tab;
-        const AggTask nxt = a.tasks[more_in_tab ? ti + 1 : (have_next_tab ? ntab.task_beg : ti)];
+        const AggTask nxt = get_task(more_in_tab ? ti + 1 : (have_next_tab ? ntab.task_beg : ti));
         const uint32_t beg = cur.beg, end = cur.end, beg0 = cur.beg & ~15u;
         const uint32_t n_it = n_batches(cur);
         for (uint32_t pit = 0; pit < n_it; pit += DEPTH) {
             const bool last = pit + DEPTH >= n_it;
+            // SMALL: a full table is an expected outcome (the caller could not know the group count): stop feeding it,
+            // a probe of a full table walks every group
+            if (SMALL && *reinterpret_cast<volatile uint32_t *>(&misc[20])) { qn = 0; break; }
 #pragma unroll
             for (int h = 0; h < DEPTH; h++) {
                 const uint32_t row = beg0 + (pit + h) * AG_THREADS + tid;
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 sel = c0 ? c0 : sel; off = c0 ? 0u : off;
                 uint32_t idx = 16 * g + off + (((uint32_t)__ffs((int)sel) - 1u) >> 3);
                 idx = sel ? idx : T;                       // no candidate: slot T never holds a real key
-                const bool ok = act && keys[idx] == k && k != EMPTY_KEY;
+                const bool ok = act && keys[idx] == k && k != EMPTY_KEY && !(SMALL && (okm >> 31));
                 const unsigned long long miss = __ballot(act && !ok);
                 if (miss) {                                // wave-uniform
                     if (act && !ok) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(miss >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)miss, 0u))] = row;
@@ -319,6 +332,44 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         __syncthreads();
         if (misc[20]) { if (tid == 0) a.counters[1] = 1; finish(); return; }
         if (ABLATE == 4) { if (!have_next_tab) break; tb = tbn; tab = ntab; ti = tab.task_beg; continue; }   // experiments: no compaction / outputs
+        if (SMALL) {
+            // flush: every group of this table joins the context's global table (device-scope atomics: a few thousand per
+            // workgroup).  Sums add; min states go in as ~enc and max states as enc, both through atomicMax, so an
+            // all-zero global table is an armed one whatever the next call aggregates.
+            const bool sentinel = misc[21] != 0, nullseen = misc[23] != 0;
+            const size_t GS = (size_t)a.g_slots + 2;
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) {
+                const bool occ = s < T ? keys[s] != EMPTY_KEY : (s == T ? sentinel : nullseen);
+                if (!occ) continue;
+                uint32_t gs = s == T ? a.g_slots : a.g_slots + 1;
+                if (s < T) {
+                    const uint64_t k = keys[s];
+                    uint32_t slot = hash32(k, 0x2545F491u) & (a.g_slots - 1), probes = 0;
+                    gs = 0xFFFFFFFFu;
+                    for (; probes < 1024; probes++) {
+                        const uint64_t old = atomicCAS((unsigned long long *)&a.g_keys[slot], EMPTY_KEY, k);
+                        if (old == EMPTY_KEY || old == k) { gs = slot; break; }
+                        slot = (slot + 1) & (a.g_slots - 1);
+                    }
+                    if (gs == 0xFFFFFFFFu) { a.counters[1] = 1; continue; }    // too many groups for the small path: the host falls back
+                }
+                if (a.s_need_cnt || s >= T) atomicAdd(&a.g_cnt[gs], gsz[s]);       // (slots T, T + 1 are occupied iff their size > 0)
+                for (int k = 0; k < a.round_states; k++) {
+                    const uint64_t cell = st[(size_t)k * T1 + s];
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(&a.g_states[(size_t)k * GS + gs]);
+                    if ((uint32_t)k < m_base) {
+                        if (KIND == 0) atomicAdd(reinterpret_cast<double *>(g), __longlong_as_double((long long)cell));
+                        else atomicAdd(g, (unsigned long long)cell);
+                    } else if ((uint32_t)k < m_base + (uint32_t)(NSRC * MM)) {
+                        if (cell != M_IDENT) atomicMax(g, (unsigned long long)~cell);
+                    } else atomicAdd(g, (unsigned long long)cell);
+                }
+            }
+            if (!have_next_tab) break;
+            __syncthreads();
+            tb = tbn; tab = ntab; ti = tab.task_beg;
+            continue;
+        }
 
         // ---- compaction + outputs: every thread owns a contiguous run of slots, ONE block scan ----
         uint64_t *const o_keys = multi ? a.side_keys : a.out_keys;
@@ -413,6 +464,126 @@ bool launch_profile(pandrs_hip_ctx *c, const AggArgs &a, int profile, size_t lds
     }
 }
 
+// ---- the small path's second launch: global table -> result rows (any order), finalised like the compaction above;
+// every visited slot is cleared, so the table is armed again when the kernel ends.  Last workgroup publishes the counters.
+__global__ __launch_bounds__(256) void small_output_kernel(AggArgs a, int n_src, int profile) {
+    const bool op_add = (profile >> 1) & 1, op_min = (profile >> 2) & 1, op_max = (profile >> 3) & 1;
+    const int kind = (profile >> 4) & 1, mm = (op_min ? 1 : 0) + (op_max ? 1 : 0);
+    (void)op_add;
+    const uint32_t S = a.g_slots, s = blockIdx.x * 256 + threadIdx.x;
+    const size_t GS = (size_t)S + 2;
+    if (s < S + 2) {
+        const uint32_t cnt = a.g_cnt[s];
+        const uint64_t key = a.g_keys[s];
+        uint64_t cells[8];                       // all loads first: one memory round trip, not one per dependent step
+#pragma unroll
+        for (int k = 0; k < 8; k++) cells[k] = k < a.round_states ? a.g_states[(size_t)k * GS + s] : 0ull;
+        const bool occ = s < S ? key != EMPTY_KEY : cnt > 0;
+        if (occ) {
+            const uint32_t pos = atomicAdd(&a.counters[0], 1u);
+            if (pos < a.cap) {
+                a.out_keys[pos] = s == S + 1 ? 0ull : (s == S ? EMPTY_KEY : key);
+                a.out_null[pos] = s == S + 1 ? 1 : 0;
+                auto cell = [&](int8_t k) {
+                    uint64_t r = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) r = j == k ? cells[j] : r;
+                    return r;
+                };
+                for (int f = 0; f < a.n_fin; f++) {
+                    const FinDev &fd = a.fin[f];
+                    double r = 0.0;
+                    switch (fd.op) {
+                    case PANDRS_HIP_AGG_COUNT: r = (double)cnt; break;
+                    case PANDRS_HIP_AGG_SUM:
+                        r = kind == 0 ? __longlong_as_double((long long)cell(fd.st_add)) : (double)(int64_t)cell(fd.st_add);
+                        break;
+                    case PANDRS_HIP_AGG_MEAN: {
+                        const uint64_t nn = fd.st_nn >= 0 ? cell(fd.st_nn) : (uint64_t)cnt;
+                        const double sum = kind == 0 ? __longlong_as_double((long long)cell(fd.st_add)) : (double)(int64_t)cell(fd.st_add);
+                        r = nn ? sum / (double)nn : 0.0;
+                        break;
+                    }
+                    case PANDRS_HIP_AGG_MIN: {          // stored as ~enc; 0 = no value; the reference's sentinel rule: +inf / i64::MAX => 0.0
+                        const uint64_t raw = cell(fd.st_min);
+                        if (raw) {
+                            const uint64_t e = ~raw;
+                            if (kind == 0) { const double v = dec_f64(e); r = v == __longlong_as_double(0x7FF0000000000000ll) ? 0.0 : v; }
+                            else { const int64_t v = dec_i64(e); r = v == INT64_MAX ? 0.0 : (double)v; }
+                        }
+                        break;
+                    }
+                    case PANDRS_HIP_AGG_MAX: {          // stored as enc
+                        const uint64_t raw = cell(fd.st_max);
+                        if (raw) {
+                            if (kind == 0) { const double v = dec_f64(raw); r = v == __longlong_as_double((long long)0xFFF0000000000000ull) ? 0.0 : v; }
+                            else { const int64_t v = dec_i64(raw); r = v == INT64_MIN ? 0.0 : (double)v; }
+                        }
+                        break;
+                    }
+                    }
+                    a.out_aggs[(size_t)f * a.cap + pos] = r;
+                }
+            } else a.counters[1] = 1;
+            // re-arm the slot
+            a.g_keys[s] = EMPTY_KEY; a.g_cnt[s] = 0;
+            for (int k = 0; k < a.round_states; k++) a.g_states[(size_t)k * GS + s] = 0ull;
+        }
+    }
+    (void)n_src; (void)mm;
+    __syncthreads();
+    if (threadIdx.x == 0 && a.host_out) {
+        __threadfence();
+        if (atomicAdd(&a.counters[9], 1u) == gridDim.x - 1) {
+            __threadfence();
+            for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.host_out[3] = 0;
+            for (int i = 0; i < 16; i++) a.counters[i] = 0;            // the counter block is armed for the next call too
+            __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <int NSRC, int PROFILE>
+void launch_small_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds, uint32_t grid) {
+    constexpr int D = NSRC <= 2 ? 4 : 2;
+    static std::atomic<uint64_t> attr_done{0};             // per device: the attribute call costs a driver round trip
+    const uint64_t bit = 1ull << (c->device & 63);
+    if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aggregate2_kernel<NSRC, PROFILE, 0, D, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->lds_bytes));
+        attr_done.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((aggregate2_kernel<NSRC, PROFILE, 0, D, true>), dim3(grid), dim3(AG_THREADS), lds, c->stream, a);
+}
+template <int NSRC>
+bool launch_small_profile(pandrs_hip_ctx *c, const AggArgs &a, int profile, size_t lds, uint32_t grid) {
+    switch (profile) {      // the common small-frame shapes: {f64, i64} x {sum, sum+min+max, min+max} (+ null masks for f64)
+#define PROF(K, OPS, V) case ((K) << 4 | (OPS) << 1 | (V)): launch_small_one<NSRC, ((K) << 4 | (OPS) << 1 | (V))>(c, a, lds, grid); return true;
+        PROF(0, 1, 0) PROF(0, 1, 1) PROF(0, 7, 0) PROF(0, 7, 1) PROF(0, 6, 0) PROF(1, 1, 0) PROF(1, 7, 0)
+#undef PROF
+    default: return false;
+    }
+}
+
+}  // namespace
+
+bool aggregate2_small_has(int n_src, int profile) {
+    if (n_src < 1 || n_src > 2) return false;
+    switch (profile) { case 2: case 3: case 14: case 15: case 12: case 18: case 30: return true; default: return false; }
+}
+bool launch_aggregate2_small(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid) {
+    switch (n_src) {
+    case 1: return launch_small_profile<1>(c, a, profile, lds, grid);
+    case 2: return launch_small_profile<2>(c, a, profile, lds, grid);
+    default: return false;
+    }
+}
+void launch_small_output(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile) {
+    hipLaunchKernelGGL(small_output_kernel, dim3((a.g_slots + 2 + 255) / 256), dim3(256), 0, c->stream, a, n_src, profile);
+}
+
+namespace {
 }  // namespace
 
 bool aggregate2_has(int n_src, int profile) {

@@ -103,6 +103,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->est_table) (void)hipFree(c->est_table);
+    if (c->small_table) (void)hipFree(c->small_table);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PANDRS_HIP_OK;
@@ -142,6 +143,8 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "p_max")) c->opt.p_max = value;
     else if (!std::strcmp(name, "slice_rows")) c->opt.slice_rows = value;
     else if (!std::strcmp(name, "agg_v1")) c->opt.agg_v1 = value;
+    else if (!std::strcmp(name, "no_small")) { c->opt.no_small = value; c->small_skip = c->small_backoff = 0; }
+    else if (!std::strcmp(name, "small_chunk")) c->opt.small_chunk = value;
     else if (!std::strcmp(name, "deterministic")) c->opt.deterministic = value;
     else if (!std::strcmp(name, "sampled_chunked")) c->opt.sampled_chunked = value;
     else if (!std::strcmp(name, "exact_partition")) c->opt.exact_partition = value;
@@ -154,6 +157,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
 int32_t pandrs_hip_get_timings(pandrs_hip_ctx *c, pandrs_hip_timings *out) {
     if (!c || !out) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
     std::lock_guard<std::mutex> lock(c->mu);
+    if (c->timings_pending) { (void)hipSetDevice(c->device); (void)pandrs::timings_resolve(c); }
     *out = c->timings;
     return PANDRS_HIP_OK;
 }

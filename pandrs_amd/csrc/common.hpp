@@ -164,6 +164,8 @@ struct Options {
     int64_t exact_partition = 0;     // 1 = always run the exact histogram (never the sampled-capacity partition)
     int64_t sampled_chunked = 0;     // experiments: capacity-mode scatter with chunked instead of interleaved tiles
     int64_t deterministic = 0;       // 1 = f64 Sum / Mean and Std / Var folded in ascending row order per group (bit-identical to the reference's fold)
+    int64_t small_chunk = 0;         // experiments: rows per workgroup of the small path (0 = auto)
+    int64_t no_small = 0;            // 1 = never take the two-launch small-call path (groupby.hip run_small)
     int64_t agg_v1 = 0;              // 1 = never use the lean persistent aggregate kernel (aggregate2.hip)
     int64_t agg_depth = 0;           // experiments: register-ring depth of aggregate2 (C2 profile)
     int64_t agg_ablate = 0;          // experiments: 1 no min/max, 2 lookup only, 3 stream only (C2 profile of aggregate2)
@@ -191,6 +193,9 @@ struct pandrs_hip_ctx {
     bool ev_used[PANDRS_HIP_MAX_PHASES]{};
     hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
     void *pinned = nullptr;      // small pinned host block for readbacks
+    bool timings_lazy = false, timings_pending = false;   // see timings_resolve
+    int small_skip = 0, small_backoff = 0;     // run_small's back-off after a call that did not fit
+    void *small_table = nullptr;      // the small path's armed global table (groupby.hip run_small)
     uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)
     bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)
     bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
@@ -217,10 +222,13 @@ struct PhaseTimer {
 inline void timings_begin(pandrs_hip_ctx *c) {
     std::memset(&c->timings, 0, sizeof c->timings);
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) c->ev_used[i] = false;
+    c->timings_lazy = c->timings_pending = false;
     (void)hipEventRecord(c->ev_call_begin, c->stream);
 }
-inline int32_t timings_end(pandrs_hip_ctx *c) {
-    HIP_TRY(hipEventRecord(c->ev_call_end, c->stream));
+// Small calls have already seen their completion record in pinned memory: their event times are resolved only when
+// somebody asks (pandrs_hip_get_timings), which saves the call a second host-device round trip.
+inline int32_t timings_resolve(pandrs_hip_ctx *c) {
+    c->timings_pending = false;
     HIP_TRY(hipEventSynchronize(c->ev_call_end));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_call_begin, c->ev_call_end));
@@ -231,6 +239,11 @@ inline int32_t timings_end(pandrs_hip_ctx *c) {
         c->timings.phase_ms[i] = ms;
     }
     return 0;
+}
+inline int32_t timings_end(pandrs_hip_ctx *c) {
+    HIP_TRY(hipEventRecord(c->ev_call_end, c->stream));
+    if (c->timings_lazy) { c->timings_lazy = false; c->timings_pending = true; return 0; }
+    return timings_resolve(c);
 }
 
 // entry points implemented across the .hip files

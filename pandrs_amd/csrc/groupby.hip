@@ -758,6 +758,135 @@ struct EngSrc {
     int n_states() const { return (st_add >= 0) + (st_min >= 0) + (st_max >= 0) + (st_nn >= 0) + (st_fadd >= 0) + (st_ssq >= 0); }
 };
 
+constexpr int32_t SMALL_NOT_TAKEN = -1000;
+constexpr int64_t SMALL_MAX_ROWS = int64_t(1) << 21;
+constexpr int SMALL_MAX_STATES = 8;
+
+// Small calls: aggregate2's SMALL mode folds row chunks of the ORIGINAL columns into LDS tables and flushes their
+// groups into a context-owned global table (<= 16 K groups); small_output_kernel turns that table into result rows and
+// re-arms it.  Returns SMALL_NOT_TAKEN when the call does not qualify or the table overflowed (the caller goes on with
+// the general path; nothing is left behind).
+int32_t run_small(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, const std::vector<EngSrc> &srcs, int n_aggs,
+                  int n_keys_out, GroupbyResult &res, Arena &rarena) {
+    const int64_t N = rs.n_rows;
+    const int n_src = (int)srcs.size();
+    // a call that outgrew the tables paid for the attempt: sit out a growing number of the following calls
+    if (c->small_skip > 0) { c->small_skip--; return SMALL_NOT_TAKEN; }
+    if (c->opt.no_small || N > SMALL_MAX_ROWS || n_src < 1 || !pl.mergeable || pl.needs_second_pass || c->opt.generic_aggregate ||
+        c->opt.agg_v1 || c->opt.deterministic)
+        return SMALL_NOT_TAKEN;
+    auto prof_of = [](const EngSrc &e) {
+        int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
+        return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
+    };
+    const int profile = prof_of(srcs[0]);
+    int round_states = 0;
+    for (auto &e : srcs) {
+        if (e.rowidx || e.valid_bytes || !e.data || prof_of(e) != profile) return SMALL_NOT_TAKEN;
+        round_states += e.n_states();
+    }
+    if (!aggregate2_small_has(n_src, profile) || round_states > SMALL_MAX_STATES) return SMALL_NOT_TAKEN;
+
+    const uint32_t S = SMALL_G_SLOTS;
+    const size_t GS = (size_t)S + 2;
+    if (!c->small_table) {
+        const size_t bytes = GS * 8 + GS * 8 * SMALL_MAX_STATES + GS * 4 + 64 * 4;
+        HIP_TRY(hipMalloc(&c->small_table, bytes));
+        HIP_TRY(hipMemsetAsync(c->small_table, 0, bytes, c->stream));
+        HIP_TRY(hipMemsetAsync(c->small_table, 0xFF, GS * 8, c->stream));       // keys: EMPTY_KEY
+    }
+    uint64_t *g_keys = reinterpret_cast<uint64_t *>(c->small_table);
+    uint64_t *g_states = g_keys + GS;
+    uint32_t *g_cnt = reinterpret_cast<uint32_t *>(g_states + GS * SMALL_MAX_STATES);
+    uint32_t *counters = g_cnt + GS;
+
+    const size_t slot_bytes = 13 + 8 * (size_t)round_states;
+    int64_t T = (int64_t)(((size_t)c->lds_bytes - 512 - 192 - AGG2_LDS_EXTRA) / slot_bytes) - 3;
+    T = std::min<int64_t>(T, 32768) & ~int64_t(15);
+    if (T < 64) return SMALL_NOT_TAKEN;
+
+    const size_t cap = (size_t)std::min<int64_t>(N, (int64_t)GS);
+    ST_TRY(rarena.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) +
+                         std::max<size_t>(n_aggs, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
+    res.cap = (int64_t)cap;
+    res.keys = rarena.take<uint64_t>(cap * n_keys_out);
+    res.key_null = rarena.take<uint8_t>(cap * n_keys_out);
+    res.aggs = rarena.take<double>(cap * std::max<size_t>(n_aggs, 1) + 32);
+    if (!res.keys || !res.key_null || !res.aggs) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "result arena too small");
+
+    AggArgs aa{};
+    int8_t st_lds[MAX_STATES];
+    for (int k = 0; k < MAX_STATES; k++) st_lds[k] = -1;
+    const int mm = ((profile >> 2) & 1) + ((profile >> 3) & 1);
+    const int mbase = ((profile >> 1) & 1) ? n_src : 0;
+    int next_nn = mbase + n_src * mm;
+    for (int s = 0; s < n_src; s++) {
+        const EngSrc &e = srcs[s];
+        SrcDev &sd = aa.src[s];
+        sd = SrcDev{static_cast<const uint64_t *>(e.data), e.null_bits, e.kind, -1, -1, -1, -1, -1, -1, {0}};     // SMALL: valid = the column's null bitmap
+        auto put = [&](int8_t abs_id, int8_t &lds_id, int at) {
+            if (abs_id < 0) return;
+            st_lds[abs_id] = (int8_t)at; lds_id = (int8_t)at;
+        };
+        put(e.st_add, sd.st_add, s);
+        put(e.st_min, sd.st_min, mbase + s * mm);
+        put(e.st_max, sd.st_max, mbase + s * mm + mm - 1);
+        if (e.st_nn >= 0) put(e.st_nn, sd.st_nn, next_nn++);
+    }
+    aa.dkey = rs.key; aa.s_rows = (uint32_t)N;
+    // rows per workgroup: every workgroup flushes its groups with global atomics, so more than ~64 of them cost more in
+    // the flush than they gain in the stream (experiments/c1_chunks.py: 1 M rows / 1 K groups 59 us at 16 K rows per
+    // workgroup, 79 us at 4 K; 100 K rows / 100 groups 40 us at 4 K, 46 us at 16 K)
+    const int64_t chunk = c->opt.small_chunk > 0 ? c->opt.small_chunk : std::max<int64_t>(4096, (N + 63) / 64);
+    aa.s_chunk = (uint32_t)((chunk + 1023) / 1024 * 1024);
+    aa.g_slots = S; aa.g_keys = g_keys; aa.g_cnt = g_cnt; aa.g_states = g_states;
+    aa.T = (uint32_t)T; aa.seed = 0x9E3779B9u; aa.n_src = n_src; aa.n_states = pl.n_states;
+    aa.n_fin = n_aggs; aa.partials = 0; aa.n_rounds = 1; aa.round_states = round_states; aa.second_pass = 0;
+    std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
+    for (int f = 0; f < n_aggs; f++) {
+        FinDev &fd = aa.fin[f];
+        fd = FinDev{};
+        fd.op = pl.fin_op[f]; fd.kind = pl.fin_kind[f];
+        fd.st_add = fd.st_nn = fd.st_min = fd.st_max = fd.st_ssq = fd.st_fadd = fd.rowsrc_min = fd.rowsrc_max = -1;
+        const int s = pl.fin_src[f];
+        if (s < 0) { aa.s_need_cnt = 1; continue; }
+        auto lds_of = [&](int8_t abs_id) -> int8_t { return abs_id < 0 ? (int8_t)-1 : st_lds[abs_id]; };
+        fd.st_add = lds_of(pl.st_add[s]); fd.st_nn = lds_of(pl.st_nn[s]);
+        fd.st_min = lds_of(pl.st_min[s]); fd.st_max = lds_of(pl.st_max[s]);
+        if (fd.op == PANDRS_HIP_AGG_COUNT || (fd.op == PANDRS_HIP_AGG_MEAN && fd.st_nn < 0)) aa.s_need_cnt = 1;
+        if (fd.op != PANDRS_HIP_AGG_COUNT && fd.op != PANDRS_HIP_AGG_SUM && fd.op != PANDRS_HIP_AGG_MEAN &&
+            fd.op != PANDRS_HIP_AGG_MIN && fd.op != PANDRS_HIP_AGG_MAX)
+            return SMALL_NOT_TAKEN;
+    }
+    aa.out_keys = res.keys; aa.out_null = res.key_null; aa.out_aggs = res.aggs; aa.cap = cap; aa.counters = counters;
+    volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;
+    hp[4] = 0;
+    aa.host_out = nullptr;                       // the fold publishes nothing: the output kernel does
+    const uint32_t n_tables = (aa.s_rows + aa.s_chunk - 1) / aa.s_chunk;
+    aa.launch_grid = n_tables;
+    const size_t lds = (size_t)(T + 3) * slot_bytes + 192 + AGG2_LDS_EXTRA;
+    // (no phase events: each one is a barrier packet between two 10-30 us kernels)
+    if (!launch_aggregate2_small(c, aa, n_src, profile, lds, std::min<uint32_t>((uint32_t)c->n_cu, n_tables)))
+        return SMALL_NOT_TAKEN;
+    aa.host_out = const_cast<uint32_t *>(hp);
+    launch_small_output(c, aa, n_src, profile);
+    HIP_TRY(hipGetLastError());
+    for (int spin = 0; spin < 4000000 && hp[4] != 1; spin++) __builtin_ia32_pause();
+    if (hp[4] != 1) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hp[4] != 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "small path: no completion record");
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    c->timings.n_partitions = 0; c->timings.table_slots = T; c->timings.retries = 0; c->timings.estimated_groups = hp[0];
+    if (hp[1]) {                                // more groups than the tables hold: the global table is armed again, nothing kept
+        c->small_backoff = std::min(c->small_backoff ? c->small_backoff * 2 : 4, 256);
+        c->small_skip = c->small_backoff;
+        return SMALL_NOT_TAKEN;
+    }
+    c->small_backoff = 0;
+    res.n_groups = hp[0]; res.valid = true;
+    c->timings_lazy = true;
+    return 0;
+}
+
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
                           bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
@@ -808,6 +937,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                     "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
     const int n_src = (int)srcs.size();
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
+
+    // ---- small calls (launch-bound: the reference's 1 M-row case): two launches, no estimate, no partition
+    if (!merge && !partials && res_slot == 0 && !c->quiet && c->opt.groups_hint <= 0) {
+        int32_t st = run_small(c, rs, pl, srcs, n_aggs, n_keys_out, res, rarena);
+        if (st != SMALL_NOT_TAKEN) return st;
+    }
 
     // ---- workspace upper bound so that one ensure() covers the whole call (incl. retries)
     // the capacity layout of radix_partition_sampled over-allocates the partitioned columns by <= 25 %

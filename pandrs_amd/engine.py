@@ -85,7 +85,7 @@ class Context:
             pass
 
     # -- helpers ---------------------------------------------------------------------------------
-    def _cols(self, cols, keep):
+    def _cols(self, cols, keep, wait=True):
         arr = (L.Column * max(len(cols), 1))()
         space = None
         for i, (data, mask, dt) in enumerate(cols):
@@ -108,7 +108,7 @@ class Context:
             arr[i].data = _ptr(data)
             arr[i].null_mask = _ptr(mask)
             arr[i].dtype = int(dt)
-        if space == L.MEM_DEVICE:
+        if space == L.MEM_DEVICE and wait:
             self._wait_for_producer()
         return arr, (space if space is not None else L.MEM_HOST)
 
@@ -154,7 +154,7 @@ class Context:
     def groupby_compute(self, keys, n_rows, vals, aggs):
         """Runs the device pipeline and keeps the result in the context.  -> n_groups."""
         keep = []
-        kc, sp1 = self._cols(keys, keep)
+        kc, sp1 = self._cols(keys, keep, wait=not vals)       # one wait covers both column lists
         vc, sp2 = self._cols(vals, keep) if vals else ((L.Column * 1)(), sp1)
         if vals and sp1 != sp2:
             raise ValueError("keys and values must live in the same memory space")

@@ -1145,3 +1145,55 @@ def test_deterministic_mode_is_bit_identical_to_the_sequential_fold(ctx):
         assert_groupby_equal(got3, want3, [O.I64, O.U32CODE], int_exact_rows=[0, 1])
     finally:
         ctx.set_option("deterministic", 0)
+
+
+@pytest.mark.parametrize("shape", ["c1", "nulls", "i64", "two_cols", "tiny"])
+def test_small_call_path_matches_oracle_and_general_path(ctx, shape):
+    """calls of <= 2 M rows take two launches (fold into LDS tables + a context-owned global table,
+    then the output kernel).  Same results as the oracle and as the general path; n_partitions == 0 proves it ran."""
+    rng = np.random.default_rng(77)
+    n, g = (1_000_000, 1_000) if shape != "tiny" else (777, 13)
+    kv = sparse_keys(rng, n, g)
+    kv[rng.integers(0, n, 5)] = -1                      # the table sentinel's bit pattern as a key
+    km = O.pack_mask(rng.random(n) < 0.01) if shape in ("nulls", "tiny") else None
+    keys = [(kv, km, O.I64)]
+    if shape == "i64":
+        vals = [(rng.integers(-10**9, 10**9, n).astype(np.int64), None, O.I64)]
+        aggs, exact = FIVE, range(5)
+    elif shape == "two_cols":
+        vals = [(rng.normal(100, 10, n), None, O.F64), (rng.normal(-5, 1, n), None, O.F64)]
+        aggs = [(c, op) for c in (0, 1) for op in (O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT)]
+        exact = [i for i, (_, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT)]
+    elif shape in ("nulls", "tiny"):
+        vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.2), O.F64)]
+        aggs, exact = FIVE, EXACT5
+    else:
+        vals = [(rng.normal(100, 10, n), None, O.F64)]
+        aggs, exact = [(0, O.SUM)], []
+    ctx.set_option("no_small", 0)           # (also clears the back-off an earlier test's oversized call may have left)
+    got = check(ctx, keys, n, vals, aggs, [O.I64], exact=exact)
+    assert ctx.timings()["n_partitions"] == 0, "the small path did not run"
+    ctx.set_option("no_small", 1)
+    try:
+        ref = check(ctx, keys, n, vals, aggs, [O.I64], exact=exact)
+        assert ctx.timings()["n_partitions"] > 0 or n < 5000
+    finally:
+        ctx.set_option("no_small", 0)
+    assert got[0].shape == ref[0].shape
+
+
+def test_small_call_path_falls_back_when_groups_outgrow_its_tables(ctx):
+    rng = np.random.default_rng(78)
+    n = 1_500_000
+    vals = [(rng.normal(100, 10, n), None, O.F64)]
+    for g in (12_000, 200_000):          # 12 K: fits the global table but overflows an LDS table; 200 K: outgrows both
+        ctx.set_option("no_small", 0)
+        check(ctx, [(sparse_keys(rng, n, g), None, O.I64)], n, vals, FIVE, [O.I64], exact=EXACT5)
+        assert ctx.timings()["n_partitions"] > 0
+    # a call that did not fit makes the next ones skip the attempt ...
+    check(ctx, [(sparse_keys(rng, 50_000, 10), None, O.I64)], 50_000, [(vals[0][0][:50_000], None, O.F64)], FIVE, [O.I64], exact=EXACT5)
+    assert ctx.timings()["n_partitions"] > 0
+    # ... and the armed global table is clean afterwards
+    ctx.set_option("no_small", 0)
+    check(ctx, [(sparse_keys(rng, 50_000, 10), None, O.I64)], 50_000, [(vals[0][0][:50_000], None, O.F64)], FIVE, [O.I64], exact=EXACT5)
+    assert ctx.timings()["n_partitions"] == 0
