@@ -146,7 +146,6 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_small")) { c->opt.no_small = value; c->small_skip = c->small_backoff = 0; }
     else if (!std::strcmp(name, "small_chunk")) c->opt.small_chunk = value;
     else if (!std::strcmp(name, "deterministic")) c->opt.deterministic = value;
-    else if (!std::strcmp(name, "sampled_chunked")) c->opt.sampled_chunked = value;
     else if (!std::strcmp(name, "exact_partition")) c->opt.exact_partition = value;
     else if (!std::strcmp(name, "agg_ablate")) c->opt.agg_ablate = value;
     else if (!std::strcmp(name, "agg_depth")) c->opt.agg_depth = value;

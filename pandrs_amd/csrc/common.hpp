@@ -162,7 +162,6 @@ struct Options {
     int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
     int64_t exact_partition = 0;     // 1 = always run the exact histogram (never the sampled-capacity partition)
-    int64_t sampled_chunked = 0;     // experiments: capacity-mode scatter with chunked instead of interleaved tiles
     int64_t deterministic = 0;       // 1 = f64 Sum / Mean and Std / Var folded in ascending row order per group (bit-identical to the reference's fold)
     int64_t small_chunk = 0;         // experiments: rows per workgroup of the small path (0 = auto)
     int64_t no_small = 0;            // 1 = never take the two-launch small-call path (groupby.hip run_small)

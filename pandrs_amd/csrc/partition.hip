@@ -189,33 +189,33 @@ __device__ __forceinline__ uint32_t tile_idx(uint32_t tid, int r, uint32_t tile_
     return min((uint32_t)(r * THREADS) + tid, tile_last);
 }
 
-template <int THREADS>
+template <int THREADS, int RPT = SC_RPT>
 __device__ __forceinline__ void load_column8(const void *col, int64_t tbase, uint32_t tid, uint32_t tile_last,
-                                             uint64_t (&out)[SC_RPT]) {
+                                             uint64_t (&out)[RPT]) {
     // streamed once: non-temporal, so the input does not evict the partially written output lines
     // that the XCD's L2 is completing (shared-cursor write frontier)
     const uint64_t *src = reinterpret_cast<const uint64_t *>(col) + tbase;
 #pragma unroll
-    for (int r = 0; r < SC_RPT; r++) out[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
+    for (int r = 0; r < RPT; r++) out[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
 }
 
 // key cells + null flags (bit r of *nulls) for the thread's SC_RPT rows; the dtype switch is
 // wave-uniform and sits outside the unrolled loads.  tbase is a multiple of 8 (tile aligned), so
 // bitmaps are addressed from a byte base.
-template <int THREADS>
+template <int THREADS, int RPT = SC_RPT>
 __device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, uint32_t tid, uint32_t tile_last,
-                                               uint64_t (&kc)[SC_RPT], uint32_t *nulls) {
+                                               uint64_t (&kc)[RPT], uint32_t *nulls) {
     switch (k.dtype) {
     case PANDRS_HIP_U32CODE: {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(k.data) + tbase;
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
+        for (int r = 0; r < RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
         break;
     }
     case PANDRS_HIP_BOOLBITS: {
         const uint8_t *src = reinterpret_cast<const uint8_t *>(k.data) + (tbase >> 3);
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) {
+        for (int r = 0; r < RPT; r++) {
             uint32_t j = tile_idx<THREADS>(tid, r, tile_last);
             kc[r] = (src[j >> 3] >> (j & 7)) & 1;
         }
@@ -224,10 +224,10 @@ __device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, 
     default: {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(k.data) + tbase;
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
+        for (int r = 0; r < RPT; r++) kc[r] = __builtin_nontemporal_load(src + tile_idx<THREADS>(tid, r, tile_last));
         if (k.dtype == PANDRS_HIP_F64) {
 #pragma unroll
-            for (int r = 0; r < SC_RPT; r++)
+            for (int r = 0; r < RPT; r++)
                 if ((kc[r] & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) kc[r] = CANON_NAN;
         }
     }
@@ -236,14 +236,14 @@ __device__ __forceinline__ void load_key_cells(const KeyDesc &k, int64_t tbase, 
     if (k.null_bits) {
         const uint8_t *src = k.null_bits + (tbase >> 3);
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) {
+        for (int r = 0; r < RPT; r++) {
             uint32_t j = tile_idx<THREADS>(tid, r, tile_last);
             nm |= ((src[j >> 3] >> (j & 7)) & 1u) << r;
         }
     } else if (k.null_bytes) {
         const uint8_t *src = k.null_bytes + tbase;
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) nm |= (src[tile_idx<THREADS>(tid, r, tile_last)] ? 1u : 0u) << r;
+        for (int r = 0; r < RPT; r++) nm |= (src[tile_idx<THREADS>(tid, r, tile_last)] ? 1u : 0u) << r;
     }
     *nulls = nm;
 }
@@ -302,11 +302,11 @@ __global__ void init_group_cursors_kernel(const uint32_t *offsets, uint32_t NB, 
 
 // One tile of the scatter.  FULL = the tile has all TILE rows (every tile but the input's last):
 // no per-row predicates anywhere on that path.
-template <int THREADS, bool STAGED, bool FULL, bool CAPPED>
+template <int THREADS, bool STAGED, bool FULL, bool CAPPED, int RPT = SC_RPT>
 __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase, uint32_t tile_n,
                                              uint32_t *cursor, uint32_t *cnt, uint32_t *delta,
                                              uint32_t *wave_tot, uint16_t *pid, uint64_t *stage) {
-    constexpr uint32_t SPM = (1u << 13) - 1;
+    constexpr uint32_t SPM = (1u << SC_POS_BITS) - 1;
     const uint32_t P1 = a.P + 1, tid = threadIdx.x;
     const uint32_t ipt = (P1 + THREADS - 1) / THREADS;   // partition counters each thread scans
     const uint32_t tile_last = tile_n - 1;
@@ -314,16 +314,16 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 
     for (uint32_t p = tid; p < P1; p += THREADS) cnt[p] = 0;
     block_sync_lds();
-    // per row: key cell + packed (partition << 13 | position)
-    uint64_t kc[SC_RPT];
-    uint32_t ps[SC_RPT], nulls;
-    load_key_cells<THREADS>(a.key, tbase, tid, tile_last, kc, &nulls);
+    // per row: key cell + packed (partition << SC_POS_BITS | position)
+    uint64_t kc[RPT];
+    uint32_t ps[RPT], nulls;
+    load_key_cells<THREADS, RPT>(a.key, tbase, tid, tile_last, kc, &nulls);
 #pragma unroll
-    for (int r = 0; r < SC_RPT; r++) {
+    for (int r = 0; r < RPT; r++) {
         bool nul = (nulls >> r) & 1;
         if (nul) kc[r] = 0ull;
         uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
-        ps[r] = p << 13;
+        ps[r] = p << SC_POS_BITS;
         if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
     }
     block_sync_lds();
@@ -337,7 +337,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
     }
     block_sync_lds();
 #pragma unroll
-    for (int r = 0; r < SC_RPT; r++) ps[r] += delta[ps[r] >> 13];
+    for (int r = 0; r < RPT; r++) ps[r] += delta[ps[r] >> SC_POS_BITS];
     block_sync_lds();
     // delta[p] := global cursor - tile-local start, so dst = delta[p] + sorted position.
     // Shared cursors: the 32 CUs of an XCD append to the SAME region of each partition, so a
@@ -350,7 +350,8 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
             uint32_t c = n ? atomicAdd(&a.gcur[p * 8 + g], n) : 0u;
             if (CAPPED && n && c + n > a.gend[p * 8 + g]) {          // the sampled capacity was too small: drop the run
                 a.flags[0] = 1;
-                delta[p] = a.total_cap;                                // dst >= total_cap: no store below is issued
+                delta[p] = a.total_cap;                                // dst in [total_cap, total_cap + TILE): the trash tile every
+                                                                       // partitioned column carries behind its regions (no guards below)
             } else
             delta[p] = c - delta[p];
         }
@@ -365,68 +366,66 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 
     if constexpr (STAGED) {
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++)
-            if (live(r)) { stage[ps[r] & SPM] = kc[r]; pid[ps[r] & SPM] = (uint16_t)(ps[r] >> 13); }
+        for (int r = 0; r < RPT; r++)
+            if (live(r)) { stage[ps[r] & SPM] = kc[r]; pid[ps[r] & SPM] = (uint16_t)(ps[r] >> SC_POS_BITS); }
         // from here kc[] is dead: the first value column's loads go out before the barrier.
         // mv[0 .. n_move8) are 8-byte columns (software-pipelined), the rest byte-wide.
-        uint64_t vnext[SC_RPT];
-        if (a.n_move8 > 0) load_column8<THREADS>(a.mv[0].src, tbase, tid, tile_last, vnext);
+        // one register buffer for the value columns (a second one spilled: 128 VGPRs at 1024 threads): column m + 1's
+        // loads are issued right after column m went to LDS and fly under its barrier, linear reads and global stores
+        uint64_t v[RPT];
+        if (a.n_move8 > 0) load_column8<THREADS, RPT>(a.mv[0].src, tbase, tid, tile_last, v);
         block_sync_lds();
-        uint32_t dst[SC_RPT];
+        uint32_t dst[RPT];
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++) {
+        for (int r = 0; r < RPT; r++) {
             uint32_t j = r * THREADS + tid;
-            if (live(r)) { dst[r] = delta[pid[j]] + j; if (!CAPPED || dst[r] < a.total_cap) a.pkeys[dst[r]] = stage[j]; }
+            if (live(r)) { dst[r] = delta[pid[j]] + j; a.pkeys[dst[r]] = stage[j]; }
         }
         for (int m = 0; m < a.n_move8; m++) {
             uint64_t *out = reinterpret_cast<uint64_t *>(a.mv[m].dst);
-            uint64_t v[SC_RPT];
-#pragma unroll
-            for (int r = 0; r < SC_RPT; r++) v[r] = vnext[r];
-            // next column's loads fly under this column's staging
-            if (m + 1 < a.n_move8) load_column8<THREADS>(a.mv[m + 1].src, tbase, tid, tile_last, vnext);
             block_sync_lds();   // previous column's linear reads done
 #pragma unroll
-            for (int r = 0; r < SC_RPT; r++) if (live(r)) stage[ps[r] & SPM] = v[r];
+            for (int r = 0; r < RPT; r++) if (live(r)) stage[ps[r] & SPM] = v[r];
+            if (m + 1 < a.n_move8) load_column8<THREADS, RPT>(a.mv[m + 1].src, tbase, tid, tile_last, v);
             block_sync_lds();
 #pragma unroll
-            for (int r = 0; r < SC_RPT; r++) {
+            for (int r = 0; r < RPT; r++) {
                 uint32_t j = r * THREADS + tid;
-                if (live(r) && (!CAPPED || dst[r] < a.total_cap)) out[dst[r]] = stage[j];
+                if (live(r)) out[dst[r]] = stage[j];
             }
         }
         for (int m = a.n_move8; m < a.n_move; m++) {      // validity bytes / byte columns
             const MoveDesc mv = a.mv[m];
             block_sync_lds();
 #pragma unroll
-            for (int r = 0; r < SC_RPT; r++)
+            for (int r = 0; r < RPT; r++)
                 if (live(r)) stage[ps[r] & SPM] = move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last));
             block_sync_lds();
 #pragma unroll
-            for (int r = 0; r < SC_RPT; r++) {
+            for (int r = 0; r < RPT; r++) {
                 uint32_t j = r * THREADS + tid;
-                if (live(r) && (!CAPPED || dst[r] < a.total_cap)) move_store(mv, dst[r], stage[j]);
+                if (live(r)) move_store(mv, dst[r], stage[j]);
             }
         }
         block_sync_lds();
     } else {
-        uint32_t dst[SC_RPT];
+        uint32_t dst[RPT];
 #pragma unroll
-        for (int r = 0; r < SC_RPT; r++)
-            if (live(r)) { dst[r] = delta[ps[r] >> 13] + (ps[r] & SPM); if (!CAPPED || dst[r] < a.total_cap) a.pkeys[dst[r]] = kc[r]; }
+        for (int r = 0; r < RPT; r++)
+            if (live(r)) { dst[r] = delta[ps[r] >> SC_POS_BITS] + (ps[r] & SPM); a.pkeys[dst[r]] = kc[r]; }
         for (int m = 0; m < a.n_move; m++) {
             const MoveDesc mv = a.mv[m];
 #pragma unroll
-            for (int r = 0; r < SC_RPT; r++)
-                if (live(r) && (!CAPPED || dst[r] < a.total_cap)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
+            for (int r = 0; r < RPT; r++)
+                if (live(r)) move_store(mv, dst[r], move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last)));
         }
         block_sync_lds();
     }
 }
 
-template <int THREADS, bool STAGED, bool CAPPED = false>
+template <int THREADS, bool STAGED, bool CAPPED = false, int RPT = SC_RPT>
 __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
-    constexpr int TILE = THREADS * SC_RPT;
+    constexpr int TILE = THREADS * RPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t P1 = a.P + 1;
     // LDS: [cursor[P1] only with private cursors] | cnt[P1] | delta[P1] | wave_tot[32] | pid[TILE] | stage[TILE]
@@ -440,26 +439,15 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
 
     const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
     if (!a.gcur) for (uint32_t p = tid; p < P1; p += THREADS) cursor[p] = a.offsets[(size_t)p * NB + group_slot(b, NB)];
-    if (CAPPED && a.chunk == 0) {
+    if (CAPPED) {
         // capacity mode: tiles are dealt round-robin, so group g = b % 8 takes every 8th tile of the input and
         // its share of a partition is 1/8 whenever the key distribution is stationary over 8 tiles (64 K rows)
         for (int64_t tbase = (int64_t)b * TILE; tbase < a.n_rows; tbase += (int64_t)NB * TILE) {
             const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, a.n_rows - tbase);
             if (tile_n == TILE)
-                scatter_tile<THREADS, STAGED, true, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+                scatter_tile<THREADS, STAGED, true, true, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
             else
-                scatter_tile<THREADS, STAGED, false, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
-        }
-        return;
-    }
-    if (CAPPED) {
-        const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
-        for (int64_t tbase = beg; tbase < end; tbase += TILE) {
-            const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
-            if (tile_n == TILE)
-                scatter_tile<THREADS, STAGED, true, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
-            else
-                scatter_tile<THREADS, STAGED, false, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+                scatter_tile<THREADS, STAGED, false, true, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
         }
         return;
     }
@@ -467,9 +455,9 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     for (int64_t tbase = beg; tbase < end; tbase += TILE) {
         const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
         if (tile_n == TILE)
-            scatter_tile<THREADS, STAGED, true, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+            scatter_tile<THREADS, STAGED, true, false, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
         else
-            scatter_tile<THREADS, STAGED, false, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
+            scatter_tile<THREADS, STAGED, false, false, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
     }
 }
 
@@ -702,7 +690,7 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
 
 uint32_t sampled_partition_rows(int64_t n_rows, int64_t P) {
     // budget: the sampled shares + 6 sigma twice (<= ~19 % at the sizes sampled_partition_ok admits) + per-region constants
-    const double rows = (double)n_rows * 1.22 + (double)(P + 1) * 8.0 * 96.0 + 65536.0;
+    const double rows = (double)n_rows * 1.22 + (double)(P + 1) * 8.0 * 96.0 + 65536.0 + (double)SC_TILE_MAX;
     return rows >= 4.2e9 ? 0u : (uint32_t)rows;
 }
 bool sampled_partition_ok(int64_t n_rows, int64_t P) {
@@ -724,7 +712,7 @@ int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *ou
     uint32_t *gend = c->work.take<uint32_t>((size_t)P1 * 8);
     uint32_t *flags = hist ? hist + (size_t)SAMPLE_REPL * (P1 + 1) : nullptr;
     if (!hist || !gbeg || !gcur || !gend || !flags) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (partition)");
-    const uint32_t total_cap = sampled_partition_rows(N, sa.P);
+    const uint32_t total_cap = sampled_partition_rows(N, sa.P) - SC_TILE_MAX;      // the last tile of every column: trash
     {
         PhaseTimer pt(c, phase_hist);
         HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)SAMPLE_REPL * (P1 + 1) + 64) * 4, c->stream));
@@ -735,7 +723,7 @@ int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *ou
                            gbeg, gcur, gend, flags);
         HIP_TRY(hipGetLastError());
     }
-    sa.offsets = nullptr; sa.chunk = c->opt.sampled_chunked ? ((n_tiles + NB - 1) / NB) * SC_TILE : 0; sa.gcur = gcur; sa.gend = gend; sa.flags = flags; sa.total_cap = total_cap;
+    sa.offsets = nullptr; sa.chunk = 0; sa.gcur = gcur; sa.gend = gend; sa.flags = flags; sa.total_cap = total_cap;
     std::stable_sort(sa.mv, sa.mv + sa.n_move, [](const MoveDesc &x, const MoveDesc &y) { return (x.kind != 0) < (y.kind != 0); });
     sa.n_move8 = 0;
     while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
