@@ -160,6 +160,7 @@ struct Options {
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
     int64_t no_runs = 0;             // 1 = never use the run-folding aggregate kernels
     int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit
+    int64_t join_no_l2 = 0;          // 1 = the fused join never takes the L2-resident-table path; -1 = always tries it (testing)
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
     int64_t exact_partition = 0;     // 1 = always run the exact histogram (never the sampled-capacity partition)
     int64_t deterministic = 0;       // 1 = f64 Sum / Mean and Std / Var folded in ascending row order per group (bit-identical to the reference's fold)

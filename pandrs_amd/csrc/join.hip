@@ -925,6 +925,243 @@ __global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
     }
 }
 
+// ================================================================================================
+// The fused path for LARGE build sides (more than ~1024 LDS-sized partitions, C5: 50 M build rows).
+// The LDS multimap above needs the PROBE side partitioned as finely as the build side, and at 8192
+// partitions an 8192-row scatter tile leaves as 1-row runs (500 M probe rows: 12.4 ms for 16 GB moved).
+// Here only the build side is partitioned finely (P_f).  One workgroup per fine partition assembles
+// an open-addressing region of 16-byte {key, g} entries in LDS and stores it whole (no global
+// atomics); 8 consecutive regions (1 MiB) belong to one COARSE partition c = f / 8.  The probe side
+// is partitioned by c only (P_c = P_f / 8 <= 1024: 8-row runs, capacity mode without a histogram
+// pass), and coarse partition c is probed by the workgroups of ONE XCD group (blockIdx % 8), whose L2
+// then holds c's regions: random 16-byte lookups out of a 1-3 MiB region run at 130-155 G/s, out of
+// MALL / HBM at 40-57 G/s (experiments/ubench/l2_probe.hip).  The XCD mapping is a matter of speed,
+// never of correctness.  Unique build keys only (the primary-key side of a PK-FK join): the build
+// raises a flag on a duplicate and the caller takes the LDS-multimap path instead.
+// ================================================================================================
+struct __attribute__((aligned(16))) L2Entry { uint64_t key, g; };
+constexpr uint32_t L2_REG = 8192;                    // entries per fine region (128 KB: what one workgroup can assemble in LDS)
+constexpr uint32_t L2_MAXROWS = L2_REG / 8 * 7;
+constexpr uint32_t L2_SEED = 0x3C6EF372u;
+constexpr int L2_FINE_PER_COARSE = 8;
+
+struct L2BuildArgs {
+    const uint64_t *rkeys, *rpay;                    // partitioned build side
+    const uint32_t *roff; uint32_t rNB;
+    L2Entry *table;                                  // [P_f * sub * L2_REG] + 1 entry for the sentinel-valued key
+    uint32_t P_f, sub;                               // sub = 1 or 2 regions per fine partition (by one more hash bit): load <= ~0.4,
+                                                     // linear-probe chains stay short (at 0.75 a wave waits for 30+ dependent reads)
+    uint32_t *flags;                                 // [0] a partition does not fit, [1] duplicate build key, [4] sentinel-valued key present
+};
+
+__global__ __launch_bounds__(JN_THREADS) void fused_l2_build_kernel(L2BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t rbeg = a.roff[(size_t)p * a.rNB], rend = a.roff[(size_t)(p + 1) * a.rNB];
+    const uint32_t nR = rend - rbeg;
+    L2Entry *reg = a.table + (size_t)p * a.sub * L2_REG;
+    if (nR == 0 || nR > L2_MAXROWS) {
+        for (uint32_t s = tid; s < a.sub * L2_REG; s += JN_THREADS) reg[s] = L2Entry{EMPTY_KEY, 0ull};
+        if (nR != 0 && tid == 0) a.flags[0] = 1;
+        return;
+    }
+    uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *sg = sk + L2_REG;
+    for (uint32_t sub = 0; sub < a.sub; sub++) {
+        for (uint32_t s = tid; s < L2_REG; s += JN_THREADS) sk[s] = EMPTY_KEY;
+        __syncthreads();
+        for (uint32_t i = tid; i < nR; i += JN_THREADS) {
+            const uint64_t k = a.rkeys[rbeg + i], g = a.rpay[rbeg + i];
+            if (k == EMPTY_KEY) {                         // the sentinel-valued key lives behind the last region
+                if (sub == 0) {
+                    if (atomicExch(&a.flags[4], 1u)) a.flags[1] = 1;
+                    else a.table[(size_t)a.P_f * a.sub * L2_REG].g = g;
+                }
+                continue;
+            }
+            const uint32_t h = hash32(k, L2_SEED);
+            if (((h >> 13) & (a.sub - 1)) != sub) continue;
+            uint32_t s = h & (L2_REG - 1);
+            for (;;) {
+                const uint64_t old = atomicCAS((unsigned long long *)&sk[s], EMPTY_KEY, k);
+                if (old == EMPTY_KEY) { sg[s] = g; break; }
+                if (old == k) { a.flags[1] = 1; break; }             // duplicate build key: not this path
+                s = (s + 1) & (L2_REG - 1);
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = tid; s < L2_REG; s += JN_THREADS) reg[(size_t)sub * L2_REG + s] = L2Entry{sk[s], sg[s]};
+        __syncthreads();
+    }
+}
+
+constexpr int L2_BATCH = 1;      // (4 tiles per ticket measured slower: the group spreads over more partitions, 7.0 -> 7.8 ms)
+constexpr int L2_THREADS = 512, L2_RPT = 8, L2_TILE = L2_THREADS * L2_RPT;      // 4 workgroups per CU: the tile is a chain of dependent
+                                                                                   // round trips (rows, entries, walk, cursor), other tiles fill the gaps
+struct L2ProbeArgs {
+    const uint64_t *lkeys, *lpay;                    // probe side, partitioned by COARSE partition
+    const uint32_t *loff; uint32_t lNB;              // exact layout, or (gbeg != nullptr) the capacity layout's 8 ranges per partition
+    const uint32_t *gbeg, *gcur, *gend;
+    uint32_t P_c, P_f, sub;
+    uint32_t *ticket;                                // [8] zeroed: next tile of XCD group g
+    uint32_t ablate;                                 // experiments: 1 = no pair output, 2 = no walk either
+    const L2Entry *table;
+    const uint32_t *flags;
+    unsigned long long *cursor; uint64_t cap;
+    uint64_t *out_g, *out_v;
+};
+
+__global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeArgs a) {
+    constexpr int NW = L2_THREADS / 64;
+    __shared__ uint32_t wsum[L2_RPT * NW];
+    __shared__ uint32_t s_tot;
+    __shared__ unsigned long long s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t grp = blockIdx.x & 7;
+    const bool have_sentinel = a.flags[4] != 0;
+    const uint64_t sentinel_g = a.table[(size_t)a.P_f * a.sub * L2_REG].g;
+    // The group's tiles, in the order (partition c0: tile 0, 1, ..), (c0 + 8: ..), ..., are handed out by a ticket per group:
+    // every workgroup always takes the NEXT tile, so the group as a whole works on one or two partitions at a time whatever
+    // the speed of its members (a static deal lets slow workgroups fall partitions behind and the L2 holds none of them).
+    uint32_t c = grp, acc = 0;                         // acc = tiles of the group's partitions before c
+    uint32_t sb[8], nt[8], se[8], total = 0;
+    auto load_partition = [&]() {                      // the row ranges of coarse partition c and their tiles (wave-uniform)
+        total = 0;
+        if (c >= a.P_c) return;
+        uint32_t n_seg;
+        if (a.gbeg) {
+            n_seg = 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                sb[j] = a.gbeg[c * 8 + j];
+                se[j] = max(min(a.gcur[c * 8 + j], a.gend[c * 8 + j]), sb[j]);
+            }
+        } else {
+            n_seg = 1;
+            sb[0] = a.loff[(size_t)c * a.lNB]; se[0] = a.loff[(size_t)(c + 1) * a.lNB];
+#pragma unroll
+            for (int j = 1; j < 8; j++) { sb[j] = 0; se[j] = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { nt[j] = (uint32_t)j < n_seg ? (se[j] - sb[j] + L2_TILE - 1) / L2_TILE : 0u; total += nt[j]; }
+    };
+    load_partition();
+    uint32_t next_tile = 0, batch_left = 0;
+    for (;;) {
+        {
+            // one ticket = L2_BATCH consecutive tiles (a returning device-scope atomic is a ~2 us round trip)
+            if (batch_left == 0) {
+                if (tid == 0) s_tot = atomicAdd(&a.ticket[grp], (uint32_t)L2_BATCH);
+                __syncthreads();
+                next_tile = s_tot;
+                __syncthreads();
+                batch_left = L2_BATCH;
+            }
+            const uint32_t ticket = next_tile++;
+            batch_left--;
+            while (c < a.P_c && ticket >= acc + total) { acc += total; c += 8; load_partition(); }
+            if (c >= a.P_c) break;
+            const uint32_t tau = ticket - acc;
+            uint32_t t = tau, beg = 0, end = 0;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (!found && t < nt[j]) { beg = sb[j] + t * L2_TILE; end = se[j]; found = true; }
+                if (!found) t -= nt[j];
+            }
+            const uint32_t i0 = beg + tid;
+            uint64_t k[L2_RPT], v[L2_RPT];
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) {
+                const uint32_t i = min(i0 + (uint32_t)r * L2_THREADS, end - 1);
+                k[r] = __builtin_nontemporal_load(&a.lkeys[i]);
+                v[r] = __builtin_nontemporal_load(&a.lpay[i]);
+            }
+            uint32_t slot[L2_RPT], rb[L2_RPT];
+            L2Entry e[L2_RPT];
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) {
+                const uint32_t h = hash32(k[r], L2_SEED);
+                rb[r] = (part_of(hash32(k[r], JN_SEED), a.P_f) * a.sub + ((h >> 13) & (a.sub - 1))) * L2_REG;
+                slot[r] = h & (L2_REG - 1);
+            }
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) e[r] = a.table[(size_t)rb[r] + slot[r]];
+            uint32_t m[L2_RPT], walk = 0;              // walk bit r: slice r has seen neither its key nor an empty entry yet
+            uint64_t gv[L2_RPT];
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) {
+                const bool live = i0 + (uint32_t)r * L2_THREADS < end;
+                const bool is_sentinel = k[r] == EMPTY_KEY;
+                const bool hit = live && (is_sentinel ? have_sentinel : e[r].key == k[r]);
+                m[r] = hit ? 1u : 0u;
+                gv[r] = is_sentinel ? sentinel_g : e[r].g;
+                if (live && !is_sentinel && !hit && e[r].key != EMPTY_KEY) walk |= 1u << r;
+            }
+            // the walk, all slices in step (wave-uniform loop: the next entries of every walking slice are in flight together).
+            // (A per-slice `for (; e.key != k && e.key != EMPTY; ) e = next` walk in front of the ballots below lost every row it
+            // found past its home slot with hipcc 7.2 -O3; with two atomics added behind it, it did not.  This form has no divergent loop.)
+            for (uint32_t probes = 0; a.ablate < 2 && __any(walk != 0) && probes < L2_REG; probes++) {
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++)
+                    if ((walk >> r) & 1u) {
+                        slot[r] = (slot[r] + 1) & (L2_REG - 1);
+                        e[r] = a.table[(size_t)rb[r] + slot[r]];
+                    }
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++)
+                    if ((walk >> r) & 1u) {
+                        if (e[r].key == k[r]) { m[r] = 1; gv[r] = e[r].g; walk &= ~(1u << r); }
+                        else if (e[r].key == EMPTY_KEY) walk &= ~(1u << r);
+                    }
+            }
+            if (a.ablate) {
+                uint64_t x = 0;
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) x += m[r] ? gv[r] ^ v[r] : 0ull;
+                if (x == 0x123456789ull) a.out_g[0] = x;
+                continue;
+            }
+            // compaction of the tile's pairs, row-slice major (as in fused_probe_kernel): one global atomic per tile
+            uint32_t inc[L2_RPT];
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) {
+                const unsigned long long bal = __ballot(m[r] != 0);
+                inc[r] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));           // exclusive inside the wave
+                if (lane == 0) wsum[r * NW + wave] = (uint32_t)__popcll(bal);
+            }
+            __syncthreads();
+            if (tid < 64) {                            // exclusive scan of the L2_RPT x NW (<= 64) wave totals
+                const uint32_t a0 = lane < L2_RPT * NW ? wsum[lane] : 0u;
+                uint32_t x = a0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t tt = __shfl_up(x, d, 64);
+                    if (lane >= (uint32_t)d) x += tt;
+                }
+                const uint32_t tot = __shfl(x, 63, 64);
+                if (lane < L2_RPT * NW) wsum[lane] = x - a0;
+                if (lane == 0) { s_tot = tot; s_base = tot ? atomicAdd(a.cursor, (unsigned long long)tot) : 0ull; }
+            }
+            __syncthreads();
+            const uint32_t tot = s_tot;
+            const unsigned long long base = s_base;
+            uint32_t before[L2_RPT];
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) before[r] = wsum[r * NW + wave];
+            __syncthreads();
+            if (tot == 0 || base + tot > a.cap) continue;
+#pragma unroll
+            for (int r = 0; r < L2_RPT; r++) {
+                if (!m[r]) continue;
+                const uint64_t pos = base + before[r] + inc[r];
+                // streamed out: must not evict the table regions this XCD's L2 is holding
+                __builtin_nontemporal_store(gv[r], &a.out_g[pos]); __builtin_nontemporal_store(v[r], &a.out_v[pos]);
+            }
+        }
+    }
+}
+
 // General fallback of the fused path: (g, v) pairs from materialised join indices, with the
 // reference's gather fill (null => 0, join.rs:304-307, :319-322); u32 group codes widened.
 __global__ void pairs_from_indices_kernel(const int64_t *li, const int64_t *ri, int64_t n, KeyDesc g, int g_is_u32,
@@ -943,6 +1180,79 @@ __global__ void clean_payload_kernel(const void *src, const uint8_t *null_bits, 
     if (i >= n) return;
     uint64_t v = is_u32 ? (uint64_t)reinterpret_cast<const uint32_t *>(src)[i] : reinterpret_cast<const uint64_t *>(src)[i];
     out[i] = (null_bits && bit_at(null_bits, i)) ? 0ull : v;
+}
+
+constexpr int32_t FUSED_L2_NOT_TAKEN = -1001;
+// The large-build fused path (see fused_l2_build_kernel).  Leaves the (g, v) pairs in c->pairs.
+static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void *vsrc, int64_t nl, const KeyDesc &rkey,
+                             const void *gsrc, int64_t nr, uint32_t *flags, uint64_t **out_g_p, uint64_t **out_v_p, int64_t *M_p) {
+    int64_t P_f = (int64_t)std::ceil((double)nr / (L2_REG * 0.75));       // two sub-regions per fine partition: load ~0.38
+    P_f = std::min<int64_t>((P_f + 7) / 8 * 8, P_MAX);
+    const int64_t P_c = P_f / L2_FINE_PER_COARSE;
+    if ((double)nr / (double)P_f > L2_MAXROWS * 0.92) return FUSED_L2_NOT_TAKEN;
+    const uint32_t sub = (double)nr / (double)P_f > L2_REG * 0.4 ? 2u : 1u;
+    uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+    uint64_t *prk = c->work.take<uint64_t>(nr + 1), *prg = c->work.take<uint64_t>(nr + 1);
+    L2Entry *table = reinterpret_cast<L2Entry *>(c->work.take<uint64_t>(((size_t)P_f * sub * L2_REG + 1) * 2));
+    if (!prk || !prg || !table) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join, table)");
+    PartInfo rpart{};
+    ScatterArgs rs{};
+    rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P_f; rs.seed = JN_SEED;
+    rs.mv[rs.n_move++] = MoveDesc{gsrc, prg, 0, 0};
+    ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
+    {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_BUILD);
+        L2BuildArgs ba{prk, prg, rpart.offsets, rpart.NB, table, (uint32_t)P_f, sub, flags};
+        const size_t lds = (size_t)L2_REG * 16;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_l2_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fused_l2_build_kernel, dim3((unsigned)P_f), dim3(JN_THREADS), lds, c->stream, ba);
+        HIP_TRY(hipGetLastError());
+    }
+    // the probe side, by coarse partition: capacity mode when the sizes allow it (no histogram pass), else exact
+    const bool sampled = sampled_partition_ok(nl, P_c) && !c->opt.exact_partition;
+    PartInfo lpart{};
+    uint64_t *plk = nullptr, *plv = nullptr;
+    for (int pass = sampled ? 0 : 1; pass < 2; pass++) {
+        const size_t NP = pass == 0 ? (size_t)sampled_partition_rows(nl, P_c) : (size_t)nl + 1;
+        const size_t mark = c->work.off;
+        plk = c->work.take<uint64_t>(NP); plv = c->work.take<uint64_t>(NP);
+        if (!plk || !plv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join, probe side)");
+        ScatterArgs ls{};
+        ls.key = lkey; ls.pkeys = plk; ls.n_rows = nl; ls.P = (uint32_t)P_c; ls.seed = JN_SEED;
+        ls.mv[ls.n_move++] = MoveDesc{vsrc, plv, 0, 0};
+        lpart = PartInfo{};
+        if (pass == 0) ST_TRY(radix_partition_sampled(c, ls, &lpart, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCATTER));
+        else ST_TRY(radix_partition(c, ls, &lpart, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
+        // one read-back: build flags (+ the capacity-mode overflow flag)
+        if (pass == 0) HIP_TRY(hipMemcpyAsync(flags + 5, lpart.flags, 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(h, flags, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[0] || h[1]) return FUSED_L2_NOT_TAKEN;       // a fine partition too large, or a duplicate build key
+        if (pass == 0 && h[5]) { c->work.off = mark; HIP_TRY(hipMemsetAsync(flags + 5, 0, 4, c->stream)); continue; }
+        break;
+    }
+    const uint64_t cap_pairs = (uint64_t)std::max<int64_t>(nl, 1);            // unique build keys: at most one pair per probe row
+    ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(cap_pairs + 1) * 8) + 4096, c->stream));
+    uint64_t *out_g = c->pairs.take<uint64_t>(cap_pairs + 1), *out_v = c->pairs.take<uint64_t>(cap_pairs + 1);
+    if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
+    {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+        L2ProbeArgs pa{};
+        pa.lkeys = plk; pa.lpay = plv; pa.loff = lpart.offsets; pa.lNB = lpart.NB;
+        pa.gbeg = lpart.gbeg; pa.gcur = lpart.gcur; pa.gend = lpart.gend;
+        pa.ablate = (uint32_t)c->opt.agg_ablate; pa.ticket = flags + 8;
+        pa.P_c = (uint32_t)P_c; pa.P_f = (uint32_t)P_f; pa.sub = sub; pa.table = table; pa.flags = flags;
+        pa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); pa.cap = cap_pairs; pa.out_g = out_g; pa.out_v = out_v;
+        hipLaunchKernelGGL(fused_l2_probe_kernel, dim3((unsigned)(8 * 2 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS), 0, c->stream, pa);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+    if (total > cap_pairs) return fail(PANDRS_HIP_ERR_COMPUTATION, "fused join: more pairs than probe rows with unique build keys");
+    c->timings.n_partitions = P_f;
+    *out_g_p = out_g; *out_v_p = out_v; *M_p = (int64_t)total;
+    return 0;
 }
 
 int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk,
@@ -979,10 +1289,17 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         ST_TRY(stage_key(c, mem_space, lv, nl, &lval));
         ST_TRY(stage_key(c, mem_space, rg, nr, &rgrp));
     }
-    size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + 3 * Arena::padded(size_t(nl + 1) * 8) + 3 * Arena::padded(size_t(nr + 1) * 8) + (1 << 20);
-    ST_TRY(c->work.ensure(ws, c->stream));
     int64_t P = c->opt.partitions > 0 ? c->opt.partitions
                                      : std::max<int64_t>(1, (int64_t)std::ceil((double)nr / (JN_RCAP * 0.6)));
+    // beyond ~1024 LDS-sized build partitions the probe side's scatter degrades (short runs): table regions in L2 instead
+    // (and only when the probe side is at least twice the build side: the regions cost a 2 GB table store per 50 M build rows and
+    // every entry must be looked up a few times for the L2 to matter.  Measured, 50 M build rows: 500 M probe rows 24.2 -> 19.6 ms,
+    // 62.5 M probe rows 4.65 -> 4.9 ms)
+    bool l2_path = c->opt.partitions <= 0 && !c->opt.join_generic && c->opt.join_no_l2 <= 0 && nl > 0 &&
+                   ((P > 1024 && nl >= 2 * nr) || c->opt.join_no_l2 < 0);
+    size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + 3 * Arena::padded(size_t(nl + 1) * 8) + 3 * Arena::padded(size_t(nr + 1) * 8) + (1 << 20);
+    if (l2_path) ws += Arena::padded(((size_t)P_MAX * 2 * L2_REG + 1) * 16) + Arena::padded(size_t(nl) * 4 + (size_t(1) << 25)) + (1 << 20);
+    ST_TRY(c->work.ensure(ws, c->stream));
     P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, (nl + nr) / 32768)), P_MAX);
     P = std::max<int64_t>(P, 1);
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
@@ -1013,10 +1330,7 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.retries = attempt;
         uint32_t *flags = c->work.take<uint32_t>(64);               // [0] partition overflow, [2..3] pair cursor
-        uint64_t *prk = c->work.take<uint64_t>(nr + 1), *prg = c->work.take<uint64_t>(nr + 1);
-        uint64_t *plk = c->work.take<uint64_t>(nl + 1), *plv = c->work.take<uint64_t>(nl + 1);
-        if (!flags || !prk || !prg || !plk || !plv)
-            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
+        if (!flags) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
         HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
         // payload columns: plain 8-byte columns move as they are; masked / 4-byte ones are cleaned first
         const void *gsrc = rgrp.data, *vsrc = lval.data;
@@ -1034,6 +1348,19 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
                                lval.data, lval.null_bits, 0, nl, t);
             vsrc = t;
         }
+        if (l2_path) {
+            l2_path = false;                        // one try; whatever it declines goes down the LDS-multimap path below
+            const size_t mark = c->work.off;
+            int32_t st = fused_l2_path(c, lkey, vsrc, nl, rkey, gsrc, nr, flags, &out_g, &out_v, &M);
+            if (st == 0) break;
+            if (st != FUSED_L2_NOT_TAKEN) return st;
+            c->work.off = mark;
+            HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
+        }
+        uint64_t *prk = c->work.take<uint64_t>(nr + 1), *prg = c->work.take<uint64_t>(nr + 1);
+        uint64_t *plk = c->work.take<uint64_t>(nl + 1), *plv = c->work.take<uint64_t>(nl + 1);
+        if (!prk || !prg || !plk || !plv)
+            return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
         PartInfo rpart{}, lpart{};
         ScatterArgs rs{}, ls{};
         rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P; rs.seed = JN_SEED;
@@ -1091,7 +1418,9 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     rsrc.key = KeyDesc{out_g, nullptr, nullptr, rg->dtype == PANDRS_HIP_U32CODE ? DT_CELL : rg->dtype};
     rsrc.val_data[0] = out_v;
     rsrc.val_null_bits[0] = nullptr;
+    const int64_t join_fanout = general ? 0 : c->timings.n_partitions;
     ST_TRY(run_engine(c, rsrc, pl, /*merge=*/false, /*partials=*/false, 1, rg->dtype));
+    c->timings.n_partitions = join_fanout;          // the join's build-side fan-out (0: general path), not the pair groupby's
     {
         int64_t K = lk->dtype == PANDRS_HIP_U32CODE ? 4 : 8;
         c->timings.algorithmic_bytes = nl * (K + 8) + nr * (K + 8) + c->gb.n_groups * 16;   // SURVEY.md §8d, fused form

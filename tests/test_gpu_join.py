@@ -338,3 +338,83 @@ def test_config5_shard_full_size_properties(nb):
         assert abs(float(oa[0].sum()) - float(lv[hit].sum())) <= 1e-9 * abs(float(lv.sum())) + 200.0 * 3
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("case", ["unique", "sentinel_nulls_u32", "duplicates_decline", "sampled_probe_side"])
+def test_fused_join_large_build_path_with_l2_resident_table_regions(ctx, case):
+    """build sides beyond ~1024 LDS partitions keep their hash-table regions in global memory
+    (8 fine regions = one coarse partition, probed by one XCD group out of its L2) and partition the probe side only
+    coarsely.  Forced here at sizes the oracle finishes in seconds (join_no_l2 = -1); unique build keys only — a
+    duplicate build key makes the path decline and the LDS-multimap path answers."""
+    rng = np.random.default_rng(900 + len(case))
+    nb, npb = (400_000, 3_000_000) if case != "sampled_probe_side" else (300_000, 9_000_000)
+    rkeys = sparse(rng.permutation(nb * 3)[:nb])
+    gdt = O.U32CODE if case == "sentinel_nulls_u32" else O.I64
+    rg = rng.integers(0, 5000, nb)
+    rg = rg.astype(np.uint32) if gdt == O.U32CODE else rg.astype(np.int64)
+    rmask = lmask = vmask = gmask = None
+    if case == "sentinel_nulls_u32":
+        rkeys[7] = -1                                               # the table sentinel's bit pattern as a build key
+        rmask = O.pack_mask(rng.random(nb) < 0.01)
+        gmask = O.pack_mask(rng.random(nb) < 0.01)
+    if case == "duplicates_decline":
+        rkeys[1000:1010] = rkeys[5]
+    lkeys = rkeys[rng.integers(0, nb, npb)].copy()
+    lkeys[rng.random(npb) < 0.1] = -7                               # 10 % misses
+    if case == "sentinel_nulls_u32":
+        lkeys[rng.random(npb) < 0.001] = -1
+        lmask = O.pack_mask(rng.random(npb) < 0.01)
+        vmask = O.pack_mask(rng.random(npb) < 0.05)
+    lv = rng.integers(-1000, 1000, npb).astype(np.int64) if case != "sampled_probe_side" else rng.normal(100, 10, npb)
+    vdt = O.I64 if case != "sampled_probe_side" else O.F64
+    args = ((lkeys, lmask, O.I64), (lv, vmask, vdt), npb, (rkeys, rmask, O.I64), (rg, gmask, gdt), nb)
+    want = O.join_groupby_sum(*args)
+    ctx.set_option("join_no_l2", -1)
+    try:
+        got = ctx.join_groupby_sum(*args)
+        parts = ctx.timings()["n_partitions"]
+    finally:
+        ctx.set_option("join_no_l2", 0)
+    assert_groupby_equal(got, want, [gdt], int_exact_rows=[0] if vdt == O.I64 else [])
+    # the L2 path reports its fine fan-out (a multiple of 8 chosen from the build size); a declined call reports the LDS path's
+    if case == "duplicates_decline":
+        assert parts % 8 != 0
+    else:
+        assert parts % 8 == 0 and parts >= nb // 6144
+
+
+def test_config5_full_size_on_one_gpu_takes_the_l2_path():
+    """BASELINE config 5 whole on ONE GPU (500 M probe rows x 50 M unique build rows -> 100 K groups): the probe side is
+    ten times the build side, so the fused join takes the L2-resident-region path.  Properties: exactly the g values hit
+    are groups, the per-group sums equal a scatter-add of the same pairs (f64 sums in another order: 1e-9 relative), and
+    the LDS-multimap path gives the same answer."""
+    import torch
+    import pandrs_amd as pa
+    d = "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(4848)
+    nb, npb, g = 50_000_000, 500_000_000, 100_000
+    rk = torch.randperm(nb, device=d, generator=gen) * -7046029254386353131
+    rg = torch.randint(0, g, (nb,), device=d, generator=gen, dtype=torch.int64)
+    pick = torch.randint(0, nb, (npb,), device=d, generator=gen)
+    lk = rk[pick]
+    lv = torch.randn(npb, device=d, generator=gen, dtype=torch.float64) * 10 + 100
+    want = torch.zeros(g, dtype=torch.float64, device=d).index_add_(0, rg[pick], lv)
+    del pick
+    c = pa.Context(0)
+    try:
+        res = {}
+        for mode in (0, 1):
+            c.set_option("join_no_l2", mode)
+            kc, kn, oa = c.join_groupby_sum((lk, None, pa.I64), (lv, None, pa.F64), npb, (rk, None, pa.I64), (rg, None, pa.I64), nb)
+            t = c.timings()
+            assert int(kn.sum()) == 0 and kc.shape[1] == g == torch.unique(kc[0]).numel()
+            got = torch.zeros(g, dtype=torch.float64, device=d)
+            got[kc[0]] = oa[0]
+            assert float((got - want).abs().max()) <= 1e-9 * float(want.abs().max())
+            res[mode] = (got, t["n_partitions"], t["total_ms"])
+        assert res[0][1] % 8 == 0 and res[0][1] != res[1][1]           # the L2 path's fine fan-out vs the LDS path's
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-9 * float(want.abs().max())
+        print("C5 on one GPU: L2 path %.2f ms, LDS-multimap path %.2f ms" % (res[0][2], res[1][2]))
+    finally:
+        c.close()
