@@ -161,6 +161,31 @@ def extra_configs(torch, pa, ctx, device, steps=5):
     timed("c5_shard", nl, "C5 per-GPU shard: inner join 62.5M probe x 50M build (unique i64 keys), then groupby(g in [0,100000)).sum(v), fused",
           lambda: ctx.join_groupby_sum((lkey, None, pa.I64), (lval, None, pa.F64), nl, (rkey, None, pa.I64), (rgrp, None, pa.I64), nr),
           bytes_alg=nl * 16 + nr * 16 + g * 16)
+    del lkey, lval
+    # C5 whole on one GPU: 500 M probe rows x the same build side (the probe side dominates: L2-resident table regions)
+    nl = 500_000_000
+    lkey = torch.randint(0, nr, (nl,), device=device, generator=gen, dtype=torch.int64) * MIX
+    lval = torch.randn(nl, device=device, generator=gen, dtype=torch.float64)
+    timed("c5_one_gpu", nl, "C5 on one GPU: inner join 500M probe x 50M build (unique i64 keys), then groupby(g in [0,100000)).sum(v), fused",
+          lambda: ctx.join_groupby_sum((lkey, None, pa.I64), (lval, None, pa.F64), nl, (rkey, None, pa.I64), (rgrp, None, pa.I64), nr),
+          bytes_alg=nl * 16 + nr * 16 + g * 16)
+    del lkey, lval, rkey, rgrp
+    # C1 (the reference's own CPU-runnable case): 1 M rows, 1 K groups, one f64 sum — wall time per call, launch-bound
+    n, g = 1_000_000, 1_000
+    k = torch.randint(0, g, (n,), device=device, generator=gen, dtype=torch.int64)
+    v = torch.randn(n, device=device, generator=gen, dtype=torch.float64)
+    f = lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.SUM)])
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        f()
+    wall_ms = (time.perf_counter() - t0) / 100 * 1e3
+    b = n * 16 + g * 16
+    out["c1"] = {"ms": wall_ms, "algorithmic_bytes": b, "frac": b / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "Mrows_per_s": n / wall_ms / 1e3, "config": "C1: 1M rows, i64 key (1K groups), sum of one f64 column; HOST WALL time per call "
+                 "(Python + C ABI + two launches + completion poll), mean of 100"}
     return out
 
 
