@@ -996,7 +996,7 @@ __global__ __launch_bounds__(JN_THREADS) void fused_l2_build_kernel(L2BuildArgs 
 }
 
 constexpr int L2_BATCH = 1;      // (4 tiles per ticket measured slower: the group spreads over more partitions, 7.0 -> 7.8 ms)
-constexpr int L2_THREADS = 512, L2_RPT = 8, L2_TILE = L2_THREADS * L2_RPT;      // 4 workgroups per CU: the tile is a chain of dependent
+constexpr int L2_THREADS = 256, L2_RPT = 8, L2_TILE = L2_THREADS * L2_RPT;      // 4 workgroups per CU: the tile is a chain of dependent
                                                                                    // round trips (rows, entries, walk, cursor), other tiles fill the gaps
 struct L2ProbeArgs {
     const uint64_t *lkeys, *lpay;                    // probe side, partitioned by COARSE partition
@@ -1243,7 +1243,7 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
         pa.ablate = (uint32_t)c->opt.agg_ablate; pa.ticket = flags + 8;
         pa.P_c = (uint32_t)P_c; pa.P_f = (uint32_t)P_f; pa.sub = sub; pa.table = table; pa.flags = flags;
         pa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); pa.cap = cap_pairs; pa.out_g = out_g; pa.out_v = out_v;
-        hipLaunchKernelGGL(fused_l2_probe_kernel, dim3((unsigned)(8 * 2 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS), 0, c->stream, pa);
+        hipLaunchKernelGGL(fused_l2_probe_kernel, dim3((unsigned)(8 * 4 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS), 0, c->stream, pa);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
