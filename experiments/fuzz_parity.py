@@ -73,13 +73,14 @@ for case in range(n_cases):
             opts = {"no_direct": int(rng.random() < 0.3), "slice_rows": int(rng.choice([0, 0, 20_000])),
                     "p_max": int(rng.choice([0, 0, 0, 24])), "generic_aggregate": int(rng.random() < 0.2),
                     "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9),
-                    "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15)}
+                    "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15),
+                    "no_small": int(rng.random() < 0.4)}
             for k, v in opts.items(): ctx.set_option(k, v)
             try:
                 got = ctx.groupby_agg(keys, n, vals, aggs)
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1,
-                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0}.items(): ctx.set_option(k, v)
+                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
             if opts["deterministic"] and not any(np.isnan(np.asarray(v[0], np.float64)).any() or np.isinf(np.asarray(v[0], np.float64)).any() for v in vals if v[2] == O.F64):
@@ -99,6 +100,29 @@ for case in range(n_cases):
                     np.testing.assert_array_equal(np.where(nulls[kk][gid] == 1, 0, cells[kk][gid]), cell[rows])
                 assert gcount == want[0].shape[1]
             desc = "groupby n=%d kd=%d g=%d %s %s nk=%d aggs=%s opts=%s" % (n, kd, g, skew, layout, nk, aggs, opts)
+        elif rng.random() < 0.35:   # ---------------- fused join -> groupby-sum (LDS multimap / L2 regions / general)
+            nl = int(rng.choice([0, 7, 4000, 300_000, 2_000_000])) * (SCALE if rng.random() < 0.5 else 1); nr = int(rng.choice([0, 5, 3000, 120_000, 700_000]))
+            unique = rng.random() < 0.6
+            space = max(nr * 3, 8)
+            rcells = (rng.permutation(space)[:nr] if unique else rng.integers(0, max(nr // 2, 3), nr)).astype(np.int64) * 7919 - 5
+            if nr and rng.random() < 0.3: rcells[rng.integers(0, nr)] = -1                    # the table sentinel's bit pattern
+            lcells = (rcells[rng.integers(0, nr, nl)] if nr else rng.integers(0, 9, nl).astype(np.int64)).copy()
+            if nl: lcells[rng.random(nl) < 0.15] = 123456789                                 # misses
+            gdt = int(rng.choice([O.I64, O.U32CODE])); vdt = int(rng.choice([O.I64, O.F64]))
+            rg = rng.integers(0, int(rng.choice([3, 400, 60_000])), nr)
+            rg = rg.astype(np.uint32) if gdt == O.U32CODE else rg.astype(np.int64) - 7
+            lv = rng.integers(-1000, 1000, nl).astype(np.int64) if vdt == O.I64 else rng.normal(10, 5, nl)
+            args = ((lcells, mask(rng, nl, rng.choice([0, 0.02])), O.I64), (lv, mask(rng, nl, rng.choice([0, 0.05])), vdt), nl,
+                    (rcells, mask(rng, nr, rng.choice([0, 0.02])), O.I64), (rg, mask(rng, nr, rng.choice([0, 0.02])), gdt), nr)
+            l2 = int(rng.choice([-1, -1, 0, 1]))
+            ctx.set_option("join_no_l2", l2)
+            try:
+                got = ctx.join_groupby_sum(*args)
+            finally:
+                ctx.set_option("join_no_l2", 0)
+            want = O.join_groupby_sum(*args)
+            assert_groupby_equal(got, want, [gdt], int_exact_rows=[0] if vdt == O.I64 else [], rtol=1e-9)
+            desc = "fused join nl=%d nr=%d unique=%d g=%d v=%d l2=%d -> %d groups" % (nl, nr, unique, gdt, vdt, l2, want[0].shape[1])
         else:                       # ---------------- join
             nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])) * (SCALE if rng.random() < 0.5 else 1); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000])) * (SCALE if rng.random() < 0.5 else 1)
             kd = int(rng.choice([O.I64, O.I64, O.U32CODE, O.F64]))

@@ -1187,7 +1187,7 @@ constexpr int32_t FUSED_L2_NOT_TAKEN = -1001;
 static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void *vsrc, int64_t nl, const KeyDesc &rkey,
                              const void *gsrc, int64_t nr, uint32_t *flags, uint64_t **out_g_p, uint64_t **out_v_p, int64_t *M_p) {
     int64_t P_f = (int64_t)std::ceil((double)nr / (L2_REG * 0.75));       // two sub-regions per fine partition: load ~0.38
-    P_f = std::min<int64_t>((P_f + 7) / 8 * 8, P_MAX);
+    P_f = std::min<int64_t>(std::max<int64_t>((P_f + 7) / 8 * 8, 8), P_MAX);
     const int64_t P_c = P_f / L2_FINE_PER_COARSE;
     if ((double)nr / (double)P_f > L2_MAXROWS * 0.92) return FUSED_L2_NOT_TAKEN;
     const uint32_t sub = (double)nr / (double)P_f > L2_REG * 0.4 ? 2u : 1u;
@@ -1295,7 +1295,7 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     // (and only when the probe side is at least twice the build side: the regions cost a 2 GB table store per 50 M build rows and
     // every entry must be looked up a few times for the L2 to matter.  Measured, 50 M build rows: 500 M probe rows 24.2 -> 19.6 ms,
     // 62.5 M probe rows 4.65 -> 4.9 ms)
-    bool l2_path = c->opt.partitions <= 0 && !c->opt.join_generic && c->opt.join_no_l2 <= 0 && nl > 0 &&
+    bool l2_path = c->opt.partitions <= 0 && !c->opt.join_generic && c->opt.join_no_l2 <= 0 && nl > 0 && nr > 0 &&
                    ((P > 1024 && nl >= 2 * nr) || c->opt.join_no_l2 < 0);
     size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + 3 * Arena::padded(size_t(nl + 1) * 8) + 3 * Arena::padded(size_t(nr + 1) * 8) + (1 << 20);
     if (l2_path) ws += Arena::padded(((size_t)P_MAX * 2 * L2_REG + 1) * 16) + Arena::padded(size_t(nl) * 4 + (size_t(1) << 25)) + (1 << 20);
