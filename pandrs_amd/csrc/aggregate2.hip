@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t swiss_find(uint64_t k, uint64_t *keys, uint8
     const uint32_t NG = T >> 4;
     const uint32_t h = hash32(k, seed);
     uint32_t g = slot_of(h, NG);
-    const uint32_t tag = (h & 0xFFu) | 1u;            // never 0 (= empty)
+    const uint32_t tag = max(h & 0xFFu, 1u);          // never 0 (= empty); 255 values: half the false candidates of `| 1`
     const uint32_t tag4 = tag * 0x01010101u;
     const uint32_t n_probe = min(NG, max_groups);
     for (uint32_t probe = 0; probe < n_probe; probe++) {
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             if (atomicAdd(&a.counters[8], 1u) == gridDim.x - 1) {
                 __threadfence();
                 for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ABLATE == 8) a.host_out[5] = __hip_atomic_load(&a.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.host_out[3] = a.scatter_flags ? __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     uint32_t qn = 0;                                   // wave-uniform
     auto drain = [&](uint32_t n_take) {                // n_take <= 64 entries from the top of the wave's queue
         qn -= n_take;
+        if (ABLATE == 8 && lane == 0) atomicAdd(&a.counters[5], n_take);       // experiments: rows that took the retry queue
         if (lane < n_take) {
             const uint32_t i = queue[qn + lane];
             const uint64_t k = SMALL ? key_cell(a.dkey, i) : pkeys[i];
@@ -238,7 +240,10 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             uint32_t okm = 0x7FFFFFFFu;
 #pragma unroll
             for (int c = 0; c < NSRC; c++) {
-                v[c] = vals[c][i];
+                // the queued rows' values are re-read 64+ rows after the ring loaded them: a third of these lines have left L2 by then
+                // (C2: 7.5 % of the rows take the queue; PMC 5.7 GB fetched for 4.0 GB of rows; ABLATE 9 = no re-read: 1.14 -> 0.99 ms).
+                // Carrying the values in a per-wave global ring instead cost the same time in stores (5 per batch) as it saved in gathers.
+                v[c] = ABLATE == 9 ? k : vals[c][i];
                 if (HAS_V && (SMALL ? bit_at(valid[c], i) : valid[c][i] == 0)) okm &= ~(1u << c);
             }
             uint32_t slot = T;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 // candidate's key verified (one ds_read_b64)
                 const uint32_t hsh = hash32(k, seed);
                 const uint32_t g = slot_of(hsh, NG);
-                const uint32_t tag4 = ((hsh & 0xFFu) | 1u) * 0x01010101u;
+                const uint32_t tag4 = max(hsh & 0xFFu, 1u) * 0x01010101u;
                 const uint4 cw = *reinterpret_cast<const uint4 *>(ctrl + 16 * g);
                 const uint32_t x0 = cw.x ^ tag4, x1 = cw.y ^ tag4, x2 = cw.z ^ tag4, x3 = cw.w ^ tag4;
                 const uint32_t c0 = (x0 - 0x01010101u) & ~x0 & 0x80808080u, c1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
@@ -601,7 +606,7 @@ bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profi
         // size only, 3 the HBM stream alone, 4 ... without epilogue, 6 full work on L2-resident rows) and the ring depth
         const int ab = (int)c->opt.agg_ablate, dp = (int)c->opt.agg_depth;
 #define EXP(N, A, D) if (n_src == N && ab == A && dp == D) { launch_one<N, 14, A, D>(c, a, lds, grid); return true; }
-        EXP(4, 7, 0) EXP(4, 0, 2) EXP(4, 0, 3) EXP(4, 0, 5) EXP(4, 1, 0) EXP(4, 2, 0) EXP(4, 3, 0) EXP(4, 4, 0) EXP(4, 6, 0)
+        EXP(4, 7, 0) EXP(4, 0, 2) EXP(4, 0, 3) EXP(4, 0, 5) EXP(4, 1, 0) EXP(4, 2, 0) EXP(4, 3, 0) EXP(4, 4, 0) EXP(4, 6, 0) EXP(4, 8, 0) EXP(4, 9, 0)
         EXP(2, 0, 2) EXP(2, 0, 3) EXP(2, 0, 6) EXP(2, 1, 0) EXP(2, 2, 0) EXP(2, 3, 0) EXP(2, 6, 0)
 #undef EXP
     }

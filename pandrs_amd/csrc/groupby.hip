@@ -1283,6 +1283,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (hp[4] == 1) {
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 for (int i = 0; i < 4; i++) h[i] = hp[i];
+                if (c->opt.agg_ablate == 8) fprintf(stderr, "aggregate2: %u rows took the retry queue\n", hp[5]);
                 have = true;
             }
         }
