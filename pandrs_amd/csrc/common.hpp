@@ -160,6 +160,7 @@ struct Options {
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
     int64_t no_runs = 0;             // 1 = never use the run-folding aggregate kernels
     int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit
+    int64_t join_no_pairpart = 0;    // 1 = the L2-region path emits its pairs at one cursor and lets the engine partition them; 2 = tests: undersized regions
     int64_t join_no_l2 = 0;          // 1 = the fused join never takes the L2-resident-table path; -1 = always tries it (testing)
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
     int64_t exact_partition = 0;     // 1 = always run the exact histogram (never the sampled-capacity partition)
@@ -194,6 +195,7 @@ struct pandrs_hip_ctx {
     hipEvent_t ev_call_begin = nullptr, ev_call_end = nullptr;
     void *pinned = nullptr;      // small pinned host block for readbacks
     bool timings_lazy = false, timings_pending = false;   // see timings_resolve
+    bool pair_fallback = false;       // fused join: the partitioned pair output overflowed a region, the plain emission answered
     int small_skip = 0, small_backoff = 0;     // run_small's back-off after a call that did not fit
     void *small_table = nullptr;      // the small path's armed global table (groupby.hip run_small)
     uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)

@@ -83,9 +83,11 @@ struct Plan {
 
 
 // Row source handed to the engine: device pointers only.
+struct PrePartitioned;
 struct RowSource {
     KeyDesc key;
     int64_t n_rows = 0;
+    const PrePartitioned *pre = nullptr;        // rows that a producer already wrote in the capacity layout (see below)
     // raw mode: per plan source, the value column and its null bitmap
     const void *val_data[MAX_SRC]{};
     const uint8_t *val_null_bits[MAX_SRC]{};
@@ -113,6 +115,17 @@ struct PartInfo {
     uint32_t total_cap = 0;
 };
 
+// Rows that arrive already radix-partitioned in the capacity layout (the fused join's probe writes its (g, v) pairs
+// straight into their partitions): run_engine skips estimate and partition and aggregates `part`'s regions.
+// The producer must have placed every row of a key in ONE partition; which function it used does not matter.
+// key / val_data of the RowSource are ignored; n_rows = rows actually written (for sizing).
+struct PrePartitioned {
+    PartInfo part;                     // gbeg / gcur / gend / flags, P
+    const uint64_t *pkeys = nullptr;   // [total_cap + trash tile] key cells
+    const uint64_t *pvals[MAX_SRC]{};  // per plan source, 8-byte values, same layout
+    int64_t est_groups = 0;            // an upper bound on the number of groups (sizes nothing but the retry decision)
+};
+
 // histogram -> scan -> scatter.  The caller fills sa.key, sa.pkeys, sa.mv[0..n_move), sa.n_rows,
 // sa.P, sa.seed; workspace comes from c->work (not reset here).
 int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
@@ -123,6 +136,13 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
 // sampled_partition_rows(n_rows, P) rows.
 int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scatter);
 uint32_t sampled_partition_rows(int64_t n_rows, int64_t P);
+constexpr uint32_t SAMPLE_REPL = 16;        // replicas of a sampled partition histogram (same-address global atomics serialise)
+// (clump = how many rows travel together on average: 1 for independent rows; widens the 6-sigma margin of the split)
+// regions of the capacity layout from a sampled histogram hist[SAMPLE_REPL][P1 + 1] ([..][P1] = rows sampled) that stands for n_rows rows
+void plan_sampled_regions(pandrs_hip_ctx *c, const uint32_t *hist, int64_t n_rows, uint32_t P1, uint32_t total_cap, uint32_t *gbeg,
+                          uint32_t *gcur, uint32_t *gend, uint32_t *flags, double clump);
+// LDS table slots of the lean aggregate kernel for a plan with `round_states` 8-byte states per group (what run_engine will use)
+int64_t lean_table_slots(const pandrs_hip_ctx *c, int round_states);
 bool sampled_partition_ok(int64_t n_rows, int64_t P);
 int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint32_t *out, uint32_t *seg);
 size_t scan_seg_count(size_t n);     // entries the `seg` scratch of exclusive_scan_u32 needs

@@ -758,6 +758,12 @@ struct EngSrc {
     int n_states() const { return (st_add >= 0) + (st_min >= 0) + (st_max >= 0) + (st_nn >= 0) + (st_fadd >= 0) + (st_ssq >= 0); }
 };
 
+int64_t lean_table_slots(const pandrs_hip_ctx *c, int round_states) {
+    const size_t slot_bytes = 13 + 8 * (size_t)round_states;
+    int64_t T = (int64_t)(((size_t)c->lds_bytes - 512 - 192 - AGG2_LDS_EXTRA) / slot_bytes) - 3;
+    return std::min<int64_t>(T, 32768) & ~int64_t(15);
+}
+
 constexpr int32_t SMALL_NOT_TAKEN = -1000;
 constexpr int64_t SMALL_MAX_ROWS = int64_t(1) << 21;
 constexpr int SMALL_MAX_STATES = 8;
@@ -939,16 +945,17 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
     // ---- small calls (launch-bound: the reference's 1 M-row case): two launches, no estimate, no partition
-    if (!merge && !partials && res_slot == 0 && !c->quiet && c->opt.groups_hint <= 0) {
+    if (!merge && !partials && res_slot == 0 && !c->quiet && c->opt.groups_hint <= 0 && !rs.pre) {
         int32_t st = run_small(c, rs, pl, srcs, n_aggs, n_keys_out, res, rarena);
         if (st != SMALL_NOT_TAKEN) return st;
     }
 
     // ---- workspace upper bound so that one ensure() covers the whole call (incl. retries)
     // the capacity layout of radix_partition_sampled over-allocates the partitioned columns by <= 25 %
-    size_t ws = engine_workspace_bytes(N + N / 4 + 131072, 1 + n_src + (merge ? 1 : 0), n_src);
+    size_t ws = rs.pre ? engine_workspace_bytes(0, 0, 0) + (size_t(64) << 20)            // the partitioned columns are the producer's
+                       : engine_workspace_bytes(N + N / 4 + 131072, 1 + n_src + (merge ? 1 : 0), n_src);
     ST_TRY(c->work.ensure(ws, c->stream));
-    int64_t est = c->opt.groups_hint;
+    int64_t est = rs.pre ? std::max<int64_t>(rs.pre->est_groups, 1) : c->opt.groups_hint;
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
     else c->clustered_rows = false;          // no sample taken: nothing known about the row order
     c->timings.estimated_groups = est;
@@ -961,7 +968,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // (below a few million rows the whole call is launch-bound and the two-stage direct path loses)
     bool has_valid_bytes = false;
     for (auto &e : srcs) has_valid_bytes |= e.valid_bytes != nullptr;
-    if (!merge && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
+    if (!merge && !rs.pre && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
         int total_states = 0;
         for (auto &e : srcs) total_states += e.n_states();
         const size_t sb = 20 + 8 * (size_t)total_states;
@@ -1087,7 +1094,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     }
     if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
     const size_t slot_bytes = (use_v2 ? 13 : 20) + 8 * (size_t)round_states;
-    if (c->opt.partitions > 0) P = c->opt.partitions;
+    if (rs.pre) {
+        P = rs.pre->part.P;
+        // few large partitions: cut them into ~512 row slices for the chip's workgroups (partial records merged below)
+        if (P < 256) auto_slice_rows = std::max<int64_t>(N / 512, 65536);
+    } else if (c->opt.partitions > 0) P = c->opt.partitions;
     else {
         // enough workgroups to fill 256 CUs (a partial record carries every state: fewer per workgroup)
         int64_t p_par = std::min<int64_t>(512, N / (merge ? 2048 : 16384));
@@ -1111,6 +1122,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         } else if (P > 256) P = (P + 127) / 128 * 128;
     }
     const int64_t P_LIMIT = c->opt.p_max > 0 ? std::min<int64_t>(c->opt.p_max, P_MAX) : P_MAX;
+    if (rs.pre && (P > P_LIMIT || !v2_ok)) return fail(PANDRS_HIP_ERR_COMPUTATION, "pre-partitioned rows: unsupported plan or fan-out");
     if (P > P_LIMIT && c->opt.partitions <= 0 && res_slot == 0 && !c->quiet)
         // more groups than one radix level can hold (P_LIMIT tables of T slots): split by an
         // independent hash into super-partitions and run the engine on each
@@ -1126,11 +1138,14 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
         const uint32_t P1 = (uint32_t)P + 1;
         // capacity mode (no histogram pass): aggregate2 only (it walks a partition's 8 row ranges), unclustered rows
-        const bool sampled = use_v2 && !sampled_failed && !c->opt.exact_partition && c->opt.shared_cursors &&
+        const bool sampled = rs.pre ? true
+                           : use_v2 && !sampled_failed && !c->opt.exact_partition && c->opt.shared_cursors &&
                              c->opt.scatter_threads != 512 && c->opt.scatter_staged && sampled_partition_ok(N, P);
-        const size_t NP = sampled ? (size_t)sampled_partition_rows(N, P) : (size_t)N;     // rows of the partitioned columns
+        if (rs.pre && (!use_v2 || sampled_failed || attempt > 0))      // a full table or a dropped run: the producer must start over
+            return fail(PANDRS_HIP_ERR_COMPUTATION, "pre-partitioned rows: a partition did not fit");
+        const size_t NP = rs.pre ? 0 : sampled ? (size_t)sampled_partition_rows(N, P) : (size_t)N;     // rows of the partitioned columns
         uint32_t *counters = c->work.take<uint32_t>(64);
-        uint64_t *pkeys = c->work.take<uint64_t>(NP);
+        uint64_t *pkeys = rs.pre ? const_cast<uint64_t *>(rs.pre->pkeys) : c->work.take<uint64_t>(NP);
         if (!counters || !pkeys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
         HIP_TRY(hipMemsetAsync(counters, 0, 64 * 4, c->stream));
 
@@ -1155,7 +1170,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             int next = 0;
             for (int s = round_begin[r]; s < round_begin[r + 1]; s++) {
                 EngSrc &e = srcs[s];
-                uint64_t *pv = c->work.take<uint64_t>(NP);
+                uint64_t *pv = rs.pre ? const_cast<uint64_t *>(rs.pre->pvals[s]) : c->work.take<uint64_t>(NP);
                 if (!pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small");
                 sa.mv[sa.n_move++] = MoveDesc{e.data, pv, (e.rowidx && !e.data) ? 5 : 0, 0};
                 uint8_t *pvalid = nullptr;
@@ -1186,7 +1201,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             }
         }
         PartInfo part;
-        if (sampled) ST_TRY(radix_partition_sampled(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCATTER));
+        if (rs.pre) part = rs.pre->part;
+        else if (sampled) ST_TRY(radix_partition_sampled(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCATTER));
         else ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
         const uint32_t NB = part.NB;
         uint32_t *offsets = part.offsets;

@@ -996,8 +996,9 @@ __global__ __launch_bounds__(JN_THREADS) void fused_l2_build_kernel(L2BuildArgs 
 }
 
 constexpr int L2_BATCH = 1;      // (4 tiles per ticket measured slower: the group spreads over more partitions, 7.0 -> 7.8 ms)
-constexpr int L2_THREADS = 256, L2_RPT = 8, L2_TILE = L2_THREADS * L2_RPT;      // 4 workgroups per CU: the tile is a chain of dependent
-                                                                                   // round trips (rows, entries, walk, cursor), other tiles fill the gaps
+// 256-thread workgroups, four per CU: the tile is a chain of dependent round trips (rows, entries, walk, cursor), other tiles fill
+// the gaps.  MODE 2 takes 512 threads (4096-row tiles, two per CU): half the reservations and barriers per row.
+constexpr int L2_THREADS = 256, L2_THREADS_PART = 512, L2_RPT = 8;
 struct L2ProbeArgs {
     const uint64_t *lkeys, *lpay;                    // probe side, partitioned by COARSE partition
     const uint32_t *loff; uint32_t lNB;              // exact layout, or (gbeg != nullptr) the capacity layout's 8 ranges per partition
@@ -1009,15 +1010,38 @@ struct L2ProbeArgs {
     const uint32_t *flags;
     unsigned long long *cursor; uint64_t cap;
     uint64_t *out_g, *out_v;
+    // MODE 1 (sample) / MODE 2 (pairs written straight into the groupby engine's capacity layout, partitioned by g)
+    uint32_t pair_P, pair_seed;                      // pair partition = part_of(hash32(g, pair_seed), pair_P), <= L2_PAIR_PMAX
+    uint32_t sample_stride;                          // MODE 1 looks at the first tile of every sample_stride
+    uint32_t *pair_hist;                             // MODE 1: [SAMPLE_REPL][pair_P + 2] like sample_histogram_kernel's
+    uint32_t *pair_cur; const uint32_t *pair_end;    // MODE 2: the plan's cursors / region ends, [pair_P + 1][8]
+    uint32_t pair_cap;                               // rows of the regions; [pair_cap, pair_cap + tile) is the trash tile
+    uint32_t *pair_flags;                            // [0] a region overflowed
 };
+constexpr uint32_t L2_PAIR_PMAX = 512;
 
-__global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeArgs a) {
-    constexpr int NW = L2_THREADS / 64;
+// MODE 0: pairs appended at one global cursor (any order).  MODE 1: no output — a histogram of the pair partitions over 1 tile in
+// 64, from which plan_regions_kernel sizes the regions.  MODE 2: every tile's pairs are ranked by pair partition in LDS and
+// appended as contiguous runs to region (partition, XCD group) — the capacity layout aggregate2 reads — so the pairs are
+// written once, already partitioned (MODE 0 + the engine's own scatter writes, reads, writes and reads them).
+template <int MODE, int TH>
+__global__ __launch_bounds__(TH, 4) void fused_l2_probe_kernel(L2ProbeArgs a) {
+    constexpr int TILE = TH * L2_RPT;
+    constexpr int NW = TH / 64;
     __shared__ uint32_t wsum[L2_RPT * NW];
     __shared__ uint32_t s_tot;
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t grp = blockIdx.x & 7;
+    __shared__ uint32_t pcnt[MODE ? L2_PAIR_PMAX + 1 : 1], pdelta[MODE == 2 ? L2_PAIR_PMAX + 1 : 1], pwt[17];
+    __shared__ uint16_t ppid[MODE == 2 ? TILE : 1];
+    __shared__ uint64_t pstage[MODE == 2 ? TILE : 1];
+    uint32_t rows_seen = 0;                            // MODE 1
+    unsigned long long pairs_mine = 0;                 // MODE 2 (thread 0): pairs this workgroup wrote
+    if (MODE == 1) {
+        for (uint32_t p = tid; p <= a.pair_P; p += TH) pcnt[p] = 0;
+        __syncthreads();
+    }
     const bool have_sentinel = a.flags[4] != 0;
     const uint64_t sentinel_g = a.table[(size_t)a.P_f * a.sub * L2_REG].g;
     // The group's tiles, in the order (partition c0: tile 0, 1, ..), (c0 + 8: ..), ..., are handed out by a ticket per group:
@@ -1043,7 +1067,7 @@ __global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeAr
             for (int j = 1; j < 8; j++) { sb[j] = 0; se[j] = 0; }
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) { nt[j] = (uint32_t)j < n_seg ? (se[j] - sb[j] + L2_TILE - 1) / L2_TILE : 0u; total += nt[j]; }
+        for (int j = 0; j < 8; j++) { nt[j] = (uint32_t)j < n_seg ? (se[j] - sb[j] + TILE - 1) / TILE : 0u; total += nt[j]; }
     };
     load_partition();
     uint32_t next_tile = 0, batch_left = 0;
@@ -1051,7 +1075,7 @@ __global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeAr
         {
             // one ticket = L2_BATCH consecutive tiles (a returning device-scope atomic is a ~2 us round trip)
             if (batch_left == 0) {
-                if (tid == 0) s_tot = atomicAdd(&a.ticket[grp], (uint32_t)L2_BATCH);
+                if (tid == 0) s_tot = atomicAdd(&a.ticket[grp], MODE == 1 ? a.sample_stride : (uint32_t)L2_BATCH);
                 __syncthreads();
                 next_tile = s_tot;
                 __syncthreads();
@@ -1066,14 +1090,14 @@ __global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeAr
             bool found = false;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if (!found && t < nt[j]) { beg = sb[j] + t * L2_TILE; end = se[j]; found = true; }
+                if (!found && t < nt[j]) { beg = sb[j] + t * TILE; end = se[j]; found = true; }
                 if (!found) t -= nt[j];
             }
             const uint32_t i0 = beg + tid;
             uint64_t k[L2_RPT], v[L2_RPT];
 #pragma unroll
             for (int r = 0; r < L2_RPT; r++) {
-                const uint32_t i = min(i0 + (uint32_t)r * L2_THREADS, end - 1);
+                const uint32_t i = min(i0 + (uint32_t)r * TH, end - 1);
                 k[r] = __builtin_nontemporal_load(&a.lkeys[i]);
                 v[r] = __builtin_nontemporal_load(&a.lpay[i]);
             }
@@ -1091,7 +1115,7 @@ __global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeAr
             uint64_t gv[L2_RPT];
 #pragma unroll
             for (int r = 0; r < L2_RPT; r++) {
-                const bool live = i0 + (uint32_t)r * L2_THREADS < end;
+                const bool live = i0 + (uint32_t)r * TH < end;
                 const bool is_sentinel = k[r] == EMPTY_KEY;
                 const bool hit = live && (is_sentinel ? have_sentinel : e[r].key == k[r]);
                 m[r] = hit ? 1u : 0u;
@@ -1120,6 +1144,71 @@ __global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeAr
 #pragma unroll
                 for (int r = 0; r < L2_RPT; r++) x += m[r] ? gv[r] ^ v[r] : 0ull;
                 if (x == 0x123456789ull) a.out_g[0] = x;
+                continue;
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) {
+                    if (i0 + (uint32_t)r * TH < end) rows_seen++;
+                    if (m[r]) atomicAdd(&pcnt[part_of(hash32(gv[r], a.pair_seed), a.pair_P)], 1u);
+                }
+                continue;
+            }
+            if (MODE == 2) {
+                const uint32_t PP1 = a.pair_P + 1;
+                for (uint32_t p = tid; p < PP1; p += TH) pcnt[p] = 0;
+                __syncthreads();
+                uint32_t ps[L2_RPT], mm = 0;               // (pair partition << 16 | position in the tile's sorted order); match bits
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) {
+                    const uint32_t pp = part_of(hash32(gv[r], a.pair_seed), a.pair_P);
+                    ps[r] = pp << 16;
+                    if (m[r]) { mm |= 1u << r; ps[r] |= atomicAdd(&pcnt[pp], 1u); }
+                }
+                __syncthreads();
+                {                                          // exclusive scan of pcnt -> pdelta (tile-local partition starts)
+                    constexpr uint32_t IPT = (L2_PAIR_PMAX + 1 + TH - 1) / TH;
+                    const uint32_t first = tid * IPT;
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < IPT; q++) if (first + q < PP1) sum += pcnt[first + q];
+                    uint32_t tot;
+                    uint32_t ex = block_exclusive_scan<TH>(sum, pwt, &tot);
+#pragma unroll
+                    for (uint32_t q = 0; q < IPT; q++) if (first + q < PP1) { pdelta[first + q] = ex; ex += pcnt[first + q]; }
+                    if (tid == 0) { s_tot = tot; pairs_mine += tot; }
+                }
+                __syncthreads();
+                const uint32_t tot = s_tot;
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) ps[r] += pdelta[ps[r] >> 16];
+                __syncthreads();
+                // region reservation: one device-scope atomic per partition with pairs in this tile (<= pair_P + 1 per tile)
+                for (uint32_t p = tid; p < PP1; p += TH) {
+                    const uint32_t n = pcnt[p];
+                    uint32_t c0 = n ? atomicAdd(&a.pair_cur[p * 8 + grp], n) : 0u;
+                    if (n && c0 + n > a.pair_end[p * 8 + grp]) { a.pair_flags[0] = 1; c0 = a.pair_cap + pdelta[p]; }   // the trash tile
+                    pdelta[p] = c0 - pdelta[p];            // destination = pdelta[partition] + sorted position
+                }
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++)
+                    if ((mm >> r) & 1u) { pstage[ps[r] & 0xFFFFu] = gv[r]; ppid[ps[r] & 0xFFFFu] = (uint16_t)(ps[r] >> 16); }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) {
+                    const uint32_t j = (uint32_t)r * TH + tid;
+                    if (j < tot) __builtin_nontemporal_store(pstage[j], &a.out_g[pdelta[ppid[j]] + j]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) if ((mm >> r) & 1u) pstage[ps[r] & 0xFFFFu] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < L2_RPT; r++) {
+                    const uint32_t j = (uint32_t)r * TH + tid;
+                    if (j < tot) __builtin_nontemporal_store(pstage[j], &a.out_v[pdelta[ppid[j]] + j]);
+                }
+                __syncthreads();
                 continue;
             }
             // compaction of the tile's pairs, row-slice major (as in fused_probe_kernel): one global atomic per tile
@@ -1160,6 +1249,16 @@ __global__ __launch_bounds__(L2_THREADS, 4) void fused_l2_probe_kernel(L2ProbeAr
             }
         }
     }
+    if (MODE == 1) {
+        __syncthreads();
+        uint32_t *myhist = a.pair_hist + (size_t)(blockIdx.x % SAMPLE_REPL) * (a.pair_P + 2);
+        for (uint32_t p = tid; p <= a.pair_P; p += TH) if (pcnt[p]) atomicAdd(&myhist[p], pcnt[p]);
+        uint32_t w = rows_seen;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) w += __shfl_down(w, d, 64);
+        if (lane == 0 && w) atomicAdd(&myhist[a.pair_P + 1], w);
+    }
+    if (MODE == 2 && tid == 0 && pairs_mine) atomicAdd(a.cursor, pairs_mine);
 }
 
 // General fallback of the fused path: (g, v) pairs from materialised join indices, with the
@@ -1185,9 +1284,11 @@ __global__ void clean_payload_kernel(const void *src, const uint8_t *null_bits, 
 constexpr int32_t FUSED_L2_NOT_TAKEN = -1001;
 // The large-build fused path (see fused_l2_build_kernel).  Leaves the (g, v) pairs in c->pairs.
 static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void *vsrc, int64_t nl, const KeyDesc &rkey,
-                             const void *gsrc, int64_t nr, uint32_t *flags, uint64_t **out_g_p, uint64_t **out_v_p, int64_t *M_p) {
+                             const void *gsrc, int64_t nr, uint32_t *flags, uint64_t **out_g_p, uint64_t **out_v_p, int64_t *M_p,
+                             PrePartitioned *pre, bool *use_pre) {
     int64_t P_f = (int64_t)std::ceil((double)nr / (L2_REG * 0.75));       // two sub-regions per fine partition: load ~0.38
-    P_f = std::min<int64_t>(std::max<int64_t>((P_f + 7) / 8 * 8, 8), P_MAX);
+    // a multiple of 64: every XCD group then owns the same number of coarse partitions (the pair regions assume an even 1/8 split)
+    P_f = std::min<int64_t>(std::max<int64_t>((P_f + 63) / 64 * 64, 64), P_MAX);
     const int64_t P_c = P_f / L2_FINE_PER_COARSE;
     if ((double)nr / (double)P_f > L2_MAXROWS * 0.92) return FUSED_L2_NOT_TAKEN;
     const uint32_t sub = (double)nr / (double)P_f > L2_REG * 0.4 ? 2u : 1u;
@@ -1232,18 +1333,81 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
         break;
     }
     const uint64_t cap_pairs = (uint64_t)std::max<int64_t>(nl, 1);            // unique build keys: at most one pair per probe row
+    L2ProbeArgs pa{};
+    pa.lkeys = plk; pa.lpay = plv; pa.loff = lpart.offsets; pa.lNB = lpart.NB;
+    pa.gbeg = lpart.gbeg; pa.gcur = lpart.gcur; pa.gend = lpart.gend;
+    pa.ablate = (uint32_t)c->opt.agg_ablate; pa.ticket = flags + 8;
+    pa.P_c = (uint32_t)P_c; pa.P_f = (uint32_t)P_f; pa.sub = sub; pa.table = table; pa.flags = flags;
+    pa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); pa.cap = cap_pairs;
+    const dim3 grid((unsigned)(8 * 4 * ((c->n_cu + 7) / 8)));
+
+    // ---- pairs straight into the groupby engine's partitions (MODE 2) when the group count allows a fan-out the probe's LDS
+    // holds: the group count is bounded by the distinct g of the build side (one estimate over n_right rows), the regions are
+    // sized from the pair partitions of 1 tile in 64 at C5's size (MODE 1: a 1.6 % probe).  An overflowing region (a group the sample
+    // under-weighted) raises a flag and the plain emission below runs instead.
+    if (c->opt.join_no_pairpart != 1 && !pa.ablate) {
+        int64_t est_g = 0;
+        ST_TRY(estimate_groups(c, KeyDesc{gsrc, nullptr, nullptr, DT_CELL}, nr, &est_g));
+        const int64_t T = lean_table_slots(c, 1);
+        int64_t pair_P = std::max<int64_t>(256, (int64_t)std::ceil((double)std::max<int64_t>(est_g, 1) / ((double)T * 0.70)));
+        if (pair_P <= (int64_t)L2_PAIR_PMAX && sampled_partition_ok(nl, pair_P) && (double)nl * 1.5 < 4.0e9) {
+            const uint32_t PP1 = (uint32_t)pair_P + 1;
+            // 1.5 rows of capacity per probe row: the pairs of one build row (n_left / n_right of them on average) land in ONE region,
+            // so the regions' margins are wider than for independent rows
+            const size_t NPp = (size_t)((double)nl * 1.5) + (size_t)(pair_P + 1) * 8 * 96 + 65536 + SC_TILE_MAX;
+            const size_t mark = c->work.off;
+            uint32_t *hist = c->work.take<uint32_t>((size_t)SAMPLE_REPL * (PP1 + 1) + 64);
+            uint32_t *gb = c->work.take<uint32_t>((size_t)PP1 * 8), *gc = c->work.take<uint32_t>((size_t)PP1 * 8), *ge = c->work.take<uint32_t>((size_t)PP1 * 8);
+            ST_TRY(c->pairs.ensure(2 * Arena::padded(std::max(NPp, size_t(cap_pairs + 1)) * 8) + 4096, c->stream));
+            uint64_t *pg = c->pairs.take<uint64_t>(NPp), *pv = c->pairs.take<uint64_t>(NPp);
+            if (!hist || !gb || !gc || !ge || !pg || !pv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join, pair partitions)");
+            uint32_t *pflags = hist + (size_t)SAMPLE_REPL * (PP1 + 1);
+            pa.pair_P = (uint32_t)pair_P; pa.pair_seed = 0x9E3779B9u; pa.pair_hist = hist; pa.pair_cur = gc; pa.pair_end = ge;
+            pa.pair_cap = (uint32_t)(NPp - SC_TILE_MAX); pa.pair_flags = pflags; pa.out_g = pg; pa.out_v = pv;
+            // >= ~4 K sampled rows per pair partition (the budget of sampled_partition_rows assumes that much), at most 1 tile in 64
+            pa.sample_stride = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, nl / (pair_P * 4096)));
+            {
+                PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
+                HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)SAMPLE_REPL * (PP1 + 1) + 64) * 4, c->stream));
+                HIP_TRY(hipMemsetAsync(flags + 8, 0, 32, c->stream));
+                hipLaunchKernelGGL((fused_l2_probe_kernel<1, L2_THREADS>), grid, dim3(L2_THREADS), 0, c->stream, pa);
+                // (join_no_pairpart = 2, tests: regions planned for an eighth of the rows, so that they overflow and the fallback runs)
+                plan_sampled_regions(c, hist, c->opt.join_no_pairpart == 2 ? nl / 8 : nl, PP1, pa.pair_cap, gb, gc, ge, pflags,
+                                     1.0 + (double)nl / (double)nr);
+                HIP_TRY(hipMemsetAsync(flags + 8, 0, 32, c->stream));
+                hipLaunchKernelGGL((fused_l2_probe_kernel<2, L2_THREADS_PART>), dim3((unsigned)(8 * 2 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS_PART), 0, c->stream, pa);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipMemcpyAsync(flags + 6, pflags, 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(h, flags, 32, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint64_t total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+            if (getenv("PANDRS_DEBUG_PAIRS")) fprintf(stderr, "pairpart: est_g %lld pair_P %lld stride %u NPp %zu flag %u total %llu cap %llu\n", (long long)est_g, (long long)pair_P, pa.sample_stride, NPp, h[6], (unsigned long long)total, (unsigned long long)cap_pairs);
+            if (!h[6] && total <= cap_pairs) {
+                pre->part = PartInfo{};
+                pre->part.P = (uint32_t)pair_P; pre->part.gbeg = gb; pre->part.gcur = gc; pre->part.gend = ge; pre->part.flags = pflags;
+                pre->part.total_cap = pa.pair_cap;
+                pre->pkeys = pg; pre->pvals[0] = pv; pre->est_groups = est_g;
+                *use_pre = true;
+                c->timings.n_partitions = P_f;
+                *out_g_p = pg; *out_v_p = pv; *M_p = (int64_t)total;
+                return 0;
+            }
+            // a region overflowed: plain emission
+            c->pair_fallback = true;
+            c->work.off = mark;
+            c->pairs.off = 0;
+            HIP_TRY(hipMemsetAsync(flags + 2, 0, 8, c->stream));
+            HIP_TRY(hipMemsetAsync(flags + 8, 0, 32, c->stream));
+        }
+    }
     ST_TRY(c->pairs.ensure(2 * Arena::padded(size_t(cap_pairs + 1) * 8) + 4096, c->stream));
     uint64_t *out_g = c->pairs.take<uint64_t>(cap_pairs + 1), *out_v = c->pairs.take<uint64_t>(cap_pairs + 1);
     if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
+    pa.out_g = out_g; pa.out_v = out_v;
     {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
-        L2ProbeArgs pa{};
-        pa.lkeys = plk; pa.lpay = plv; pa.loff = lpart.offsets; pa.lNB = lpart.NB;
-        pa.gbeg = lpart.gbeg; pa.gcur = lpart.gcur; pa.gend = lpart.gend;
-        pa.ablate = (uint32_t)c->opt.agg_ablate; pa.ticket = flags + 8;
-        pa.P_c = (uint32_t)P_c; pa.P_f = (uint32_t)P_f; pa.sub = sub; pa.table = table; pa.flags = flags;
-        pa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); pa.cap = cap_pairs; pa.out_g = out_g; pa.out_v = out_v;
-        hipLaunchKernelGGL(fused_l2_probe_kernel, dim3((unsigned)(8 * 4 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS), 0, c->stream, pa);
+        hipLaunchKernelGGL((fused_l2_probe_kernel<0, L2_THREADS>), grid, dim3(L2_THREADS), 0, c->stream, pa);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
@@ -1306,6 +1470,9 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     int64_t M = 0;
     uint64_t *out_g = nullptr, *out_v = nullptr;
     uint64_t cap_pairs = (uint64_t)std::max<int64_t>(nl, 1);    // exact bound for unique build keys
+    PrePartitioned pre{};
+    bool use_pre = false;
+    c->pair_fallback = false;
     // the LDS multimaps cannot hold the build side when even the maximum fan-out leaves partitions too large
     bool general = c->opt.join_generic != 0 || (double)nr / (double)P > FJ_MAXROWS * 0.95;
     for (int attempt = 0;; attempt++) {
@@ -1351,7 +1518,7 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         if (l2_path) {
             l2_path = false;                        // one try; whatever it declines goes down the LDS-multimap path below
             const size_t mark = c->work.off;
-            int32_t st = fused_l2_path(c, lkey, vsrc, nl, rkey, gsrc, nr, flags, &out_g, &out_v, &M);
+            int32_t st = fused_l2_path(c, lkey, vsrc, nl, rkey, gsrc, nr, flags, &out_g, &out_v, &M, &pre, &use_pre);
             if (st == 0) break;
             if (st != FUSED_L2_NOT_TAKEN) return st;
             c->work.off = mark;
@@ -1418,9 +1585,11 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     rsrc.key = KeyDesc{out_g, nullptr, nullptr, rg->dtype == PANDRS_HIP_U32CODE ? DT_CELL : rg->dtype};
     rsrc.val_data[0] = out_v;
     rsrc.val_null_bits[0] = nullptr;
+    if (use_pre) rsrc.pre = &pre;
     const int64_t join_fanout = general ? 0 : c->timings.n_partitions;
     ST_TRY(run_engine(c, rsrc, pl, /*merge=*/false, /*partials=*/false, 1, rg->dtype));
     c->timings.n_partitions = join_fanout;          // the join's build-side fan-out (0: general path), not the pair groupby's
+    c->timings.retries = c->pair_fallback ? 1 : 0;  // 1: the partitioned pair output overflowed a region and the plain emission answered
     {
         int64_t K = lk->dtype == PANDRS_HIP_U32CODE ? 4 : 8;
         c->timings.algorithmic_bytes = nl * (K + 8) + nr * (K + 8) + c->gb.n_groups * 16;   // SURVEY.md §8d, fused form

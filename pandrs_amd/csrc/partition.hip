@@ -463,7 +463,6 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
 
 // ---- capacity mode: regions from a sample instead of the exact histogram ---------------------------
 constexpr uint32_t SAMPLE_BLOCK = 1024, SAMPLE_PERIOD = 8;     // rows of every 8th 1024-row block are counted
-constexpr uint32_t SAMPLE_REPL = 16;        // replicas of the global histogram (same-address global atomics serialise)
 __global__ __launch_bounds__(1024) void sample_histogram_kernel(KeyDesc key, int64_t n_rows, uint32_t P, uint32_t seed,
                                                                 uint32_t *hist /* [SAMPLE_REPL][P + 2]; [P + 1] = rows sampled */) {
     extern __shared__ uint32_t cnt[];  // P + 1
@@ -505,9 +504,10 @@ __global__ __launch_bounds__(1024) void sample_histogram_kernel(KeyDesc key, int
 
 // one workgroup: region (p, g) = [gbeg, gend), 16-row aligned (128-byte lines), capacity = the partition's sampled
 // share scaled up + 6 sigma of the sampling noise + 6 sigma of the split over the 8 groups + a constant
+// `clump`: rows that travel together (the fused join's pairs: all pairs of one build row land in one region) widen the split's noise
 __global__ __launch_bounds__(1024) void plan_regions_kernel(const uint32_t *hist, int64_t n_rows,
                                                             uint32_t P1, uint32_t total_cap, uint32_t *gbeg, uint32_t *gcur,
-                                                            uint32_t *gend, uint32_t *flags) {
+                                                            uint32_t *gend, uint32_t *flags, double clump) {
     __shared__ uint32_t wt[17];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(1024) void plan_regions_kernel(const uint32_t *hist
             for (uint32_t r = 0; r < SAMPLE_REPL; r++) ci += hist[(size_t)r * (P1 + 1) + p];
             const double c = (double)ci;
             const double share = (c + 6.0 * sqrt(c) + 4.0) * scale * 0.125;
-            const double want = share + 6.0 * sqrt(share) + 32.0;
+            const double want = share + 6.0 * sqrt(share * clump) + 32.0;
             cap = want >= 4.0e9 ? 0xFFFFFFF0u : ((uint32_t)want + 15u) & ~15u;
         }
         uint32_t tot;
@@ -688,6 +688,11 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
     return 0;
 }
 
+void plan_sampled_regions(pandrs_hip_ctx *c, const uint32_t *hist, int64_t n_rows, uint32_t P1, uint32_t total_cap, uint32_t *gbeg,
+                          uint32_t *gcur, uint32_t *gend, uint32_t *flags, double clump) {
+    hipLaunchKernelGGL(plan_regions_kernel, dim3(1), dim3(1024), 0, c->stream, hist, n_rows, P1, total_cap, gbeg, gcur, gend, flags, clump);
+}
+
 uint32_t sampled_partition_rows(int64_t n_rows, int64_t P) {
     // budget: the sampled shares + 6 sigma twice (<= ~19 % at the sizes sampled_partition_ok admits) + per-region constants
     const double rows = (double)n_rows * 1.22 + (double)(P + 1) * 8.0 * 96.0 + 65536.0 + (double)SC_TILE_MAX;
@@ -720,7 +725,7 @@ int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *ou
         hipLaunchKernelGGL(sample_histogram_kernel, dim3((unsigned)std::min<int64_t>((n_sb + 3) / 4, 256)), dim3(1024), P1 * 4, c->stream,
                            sa.key, N, sa.P, sa.seed, hist);
         hipLaunchKernelGGL(plan_regions_kernel, dim3(1), dim3(1024), 0, c->stream, hist, N, P1, total_cap,
-                           gbeg, gcur, gend, flags);
+                           gbeg, gcur, gend, flags, 1.0);
         HIP_TRY(hipGetLastError());
     }
     sa.offsets = nullptr; sa.chunk = 0; sa.gcur = gcur; sa.gend = gend; sa.flags = flags; sa.total_cap = total_cap;

@@ -340,14 +340,17 @@ def test_config5_shard_full_size_properties(nb):
         c.close()
 
 
-@pytest.mark.parametrize("case", ["unique", "sentinel_nulls_u32", "duplicates_decline", "sampled_probe_side"])
+@pytest.mark.parametrize("case", ["unique", "sentinel_nulls_u32", "duplicates_decline", "sampled_probe_side", "pair_partitions", "pair_regions_overflow"])
 def test_fused_join_large_build_path_with_l2_resident_table_regions(ctx, case):
     """build sides beyond ~1024 LDS partitions keep their hash-table regions in global memory
     (8 fine regions = one coarse partition, probed by one XCD group out of its L2) and partition the probe side only
     coarsely.  Forced here at sizes the oracle finishes in seconds (join_no_l2 = -1); unique build keys only — a
     duplicate build key makes the path decline and the LDS-multimap path answers."""
     rng = np.random.default_rng(900 + len(case))
-    nb, npb = (400_000, 3_000_000) if case != "sampled_probe_side" else (300_000, 9_000_000)
+    big = case in ("sampled_probe_side", "pair_partitions", "pair_regions_overflow")
+    nb, npb = (300_000, 9_000_000) if big else (400_000, 3_000_000)
+    if case in ("pair_partitions", "pair_regions_overflow"):
+        nb = 1_500_000                      # enough build rows per (pair partition, XCD group) region for the sampled plan to hold
     rkeys = sparse(rng.permutation(nb * 3)[:nb])
     gdt = O.U32CODE if case == "sentinel_nulls_u32" else O.I64
     rg = rng.integers(0, 5000, nb)
@@ -367,20 +370,26 @@ def test_fused_join_large_build_path_with_l2_resident_table_regions(ctx, case):
         vmask = O.pack_mask(rng.random(npb) < 0.05)
     lv = rng.integers(-1000, 1000, npb).astype(np.int64) if case != "sampled_probe_side" else rng.normal(100, 10, npb)
     vdt = O.I64 if case != "sampled_probe_side" else O.F64
+    # from 8.4 M probe rows on, the probe writes its (g, v) pairs straight into the groupby engine's partitions (regions sized from
+    # a 1-in-64 sample); "pair_regions_overflow" plans them for an eighth of the rows: they overflow and the plain emission answers
+    pairpart = {"pair_partitions": 0, "pair_regions_overflow": 2}.get(case, 1 if case == "sampled_probe_side" else 0)
     args = ((lkeys, lmask, O.I64), (lv, vmask, vdt), npb, (rkeys, rmask, O.I64), (rg, gmask, gdt), nb)
     want = O.join_groupby_sum(*args)
     ctx.set_option("join_no_l2", -1)
+    ctx.set_option("join_no_pairpart", pairpart)
     try:
         got = ctx.join_groupby_sum(*args)
         parts = ctx.timings()["n_partitions"]
+        assert ctx.timings()["retries"] == (1 if case == "pair_regions_overflow" else 0)
     finally:
         ctx.set_option("join_no_l2", 0)
+        ctx.set_option("join_no_pairpart", 0)
     assert_groupby_equal(got, want, [gdt], int_exact_rows=[0] if vdt == O.I64 else [])
     # the L2 path reports its fine fan-out (a multiple of 8 chosen from the build size); a declined call reports the LDS path's
     if case == "duplicates_decline":
-        assert parts % 8 != 0
+        assert parts % 64 != 0
     else:
-        assert parts % 8 == 0 and parts >= nb // 6144
+        assert parts % 64 == 0 and parts >= nb // 6144
 
 
 def test_config5_full_size_on_one_gpu_takes_the_l2_path():
