@@ -1389,7 +1389,7 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
                 pre->part.total_cap = pa.pair_cap;
                 pre->pkeys = pg; pre->pvals[0] = pv; pre->est_groups = est_g;
                 *use_pre = true;
-                c->timings.n_partitions = P_f;
+                c->timings.n_partitions = P_c;        // the probe side's (coarse) fan-out
                 *out_g_p = pg; *out_v_p = pv; *M_p = (int64_t)total;
                 return 0;
             }
@@ -1414,7 +1414,7 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
     if (total > cap_pairs) return fail(PANDRS_HIP_ERR_COMPUTATION, "fused join: more pairs than probe rows with unique build keys");
-    c->timings.n_partitions = P_f;
+    c->timings.n_partitions = P_c;        // the probe side's (coarse) fan-out
     *out_g_p = out_g; *out_v_p = out_v; *M_p = (int64_t)total;
     return 0;
 }

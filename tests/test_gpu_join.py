@@ -385,11 +385,11 @@ def test_fused_join_large_build_path_with_l2_resident_table_regions(ctx, case):
         ctx.set_option("join_no_l2", 0)
         ctx.set_option("join_no_pairpart", 0)
     assert_groupby_equal(got, want, [gdt], int_exact_rows=[0] if vdt == O.I64 else [])
-    # the L2 path reports its fine fan-out (a multiple of 8 chosen from the build size); a declined call reports the LDS path's
+    # the L2 path reports the probe side's coarse fan-out (a multiple of 8); a declined call reports the LDS path's fan-out
     if case == "duplicates_decline":
-        assert parts % 64 != 0
+        assert parts % 8 != 0
     else:
-        assert parts % 64 == 0 and parts >= nb // 6144
+        assert parts % 8 == 0 and parts >= nb // 6144 // 8
 
 
 def test_config5_full_size_on_one_gpu_takes_the_l2_path():
@@ -422,7 +422,7 @@ def test_config5_full_size_on_one_gpu_takes_the_l2_path():
             got[kc[0]] = oa[0]
             assert float((got - want).abs().max()) <= 1e-9 * float(want.abs().max())
             res[mode] = (got, t["n_partitions"], t["total_ms"])
-        assert res[0][1] % 8 == 0 and res[0][1] != res[1][1]           # the L2 path's fine fan-out vs the LDS path's
+        assert res[0][1] == 1024 and res[1][1] == 8192                 # the L2 path's coarse probe-side fan-out vs the LDS path's
         assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-9 * float(want.abs().max())
         print("C5 on one GPU: L2 path %.2f ms, LDS-multimap path %.2f ms" % (res[0][2], res[1][2]))
     finally:
