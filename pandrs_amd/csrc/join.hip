@@ -1382,7 +1382,6 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
             HIP_TRY(hipMemcpyAsync(h, flags, 32, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             const uint64_t total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
-            if (getenv("PANDRS_DEBUG_PAIRS")) fprintf(stderr, "pairpart: est_g %lld pair_P %lld stride %u NPp %zu flag %u total %llu cap %llu\n", (long long)est_g, (long long)pair_P, pa.sample_stride, NPp, h[6], (unsigned long long)total, (unsigned long long)cap_pairs);
             if (!h[6] && total <= cap_pairs) {
                 pre->part = PartInfo{};
                 pre->part.P = (uint32_t)pair_P; pre->part.gbeg = gb; pre->part.gcur = gc; pre->part.gend = ge; pre->part.flags = pflags;
