@@ -134,11 +134,14 @@ typedef struct pandrs_hip_agg_spec {
 #define PANDRS_HIP_MAX_PHASES 12
 typedef struct pandrs_hip_timings {
     double total_ms;                          /* hipEvent time, whole call on the ctx stream */
-    double phase_ms[PANDRS_HIP_MAX_PHASES];   /* per phase, see PANDRS_HIP_PHASE_* */
+    double phase_ms[PANDRS_HIP_MAX_PHASES];   /* per phase, see PANDRS_HIP_PHASE_*: from the phase's first launch to its last (phases
+                                                 of one call may overlap); small calls (the two-launch path) record none */
     int64_t algorithmic_bytes;                /* SURVEY.md §8d formula for this call */
-    int64_t n_partitions;                     /* radix fan-out chosen */
+    int64_t n_partitions;                     /* radix fan-out chosen (0: the small-call path; fused join: the probe side's fan-out,
+                                                 0 = general fallback) */
     int64_t table_slots;                      /* LDS hash-table slots per partition */
-    int64_t retries;                          /* overflow retries taken */
+    int64_t retries;                          /* overflow retries taken (fused join: 1 = the partitioned pair output overflowed a
+                                                 region and the one-cursor emission answered) */
     int64_t estimated_groups;
 } pandrs_hip_timings;
 

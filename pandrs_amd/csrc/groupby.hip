@@ -73,7 +73,11 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32
         if (p < P1) {
             if (ss.gbeg) {
                 n_seg = 8;
-                for (int g = 0; g < 8; g++) { sb[g] = ss.gbeg[p * 8 + g]; se[g] = max(min(ss.gcur[p * 8 + g], ss.gend[p * 8 + g]), sb[g]); }
+                uint32_t cu[8], en[8];
+#pragma unroll
+                for (int g = 0; g < 8; g++) { sb[g] = ss.gbeg[p * 8 + g]; cu[g] = ss.gcur[p * 8 + g]; en[g] = ss.gend[p * 8 + g]; }      // 24 loads in flight
+#pragma unroll
+                for (int g = 0; g < 8; g++) se[g] = max(min(cu[g], en[g]), sb[g]);
             } else {
                 n_seg = 1;
                 sb[0] = ss.offsets[(size_t)p * ss.NB]; se[0] = ss.offsets[(size_t)(p + 1) * ss.NB];
