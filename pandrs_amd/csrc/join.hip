@@ -1343,7 +1343,7 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
 
     // ---- pairs straight into the groupby engine's partitions (MODE 2) when the group count allows a fan-out the probe's LDS
     // holds: the group count is bounded by the distinct g of the build side (one estimate over n_right rows), the regions are
-    // sized from the pair partitions of 1 tile in 64 at C5's size (MODE 1: a 1.6 % probe).  An overflowing region (a group the sample
+    // sized from the pair partitions of 1 tile in 256 at C5's size (MODE 1: a 0.4 % probe).  An overflowing region (a group the sample
     // under-weighted) raises a flag and the plain emission below runs instead.
     if (c->opt.join_no_pairpart != 1 && !pa.ablate) {
         int64_t est_g = 0;
@@ -1364,8 +1364,8 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
             uint32_t *pflags = hist + (size_t)SAMPLE_REPL * (PP1 + 1);
             pa.pair_P = (uint32_t)pair_P; pa.pair_seed = 0x9E3779B9u; pa.pair_hist = hist; pa.pair_cur = gc; pa.pair_end = ge;
             pa.pair_cap = (uint32_t)(NPp - SC_TILE_MAX); pa.pair_flags = pflags; pa.out_g = pg; pa.out_v = pv;
-            // >= ~4 K sampled rows per pair partition (the budget of sampled_partition_rows assumes that much), at most 1 tile in 64
-            pa.sample_stride = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, nl / (pair_P * 4096)));
+            // >= ~4 K sampled rows per pair partition (the budget of sampled_partition_rows assumes that much), at most 1 tile in 256
+            pa.sample_stride = (uint32_t)std::min<int64_t>(256, std::max<int64_t>(1, nl / (pair_P * 4096)));
             {
                 PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
                 HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)SAMPLE_REPL * (PP1 + 1) + 64) * 4, c->stream));
