@@ -332,6 +332,198 @@ class DataFrameGroupBy:
 
 
 # ------------------------------------------------------------------------------------------------- merge
+class PandasGroupBy:
+    """pandas_compat::DataFrameGroupBy (src/dataframe/pandas_compat/groupby.rs:11-455, `groupby_multi` :467-475) on the device.
+
+    The reference groups the rows on the key cells joined with "|||" (:63) — so two key tuples whose joined strings
+    coincide are ONE group, labelled with the tuple seen first (:68) — and folds every numeric column (a column whose
+    every cell is a number, `get_column_numeric_values`) per group with NaN meaning "missing":
+    sum of the non-NaN values (0.0 for none), mean / std / var NaN for none (n <= 1 for std / var, n - 1 divisor), min / max
+    the fold's +inf / -inf for none, count = size = rows of the group, first / last the group's first / last ROW (NaN and
+    string columns included), `agg` with "{col}_{agg}" columns where count is the number of non-NaN values and an unknown
+    aggregate name gives NaN (:333-409).  Here: the joined strings become pool codes, every numeric column goes to the
+    device with its NaN cells as nulls (one groupby for all columns and aggregates, plus a sum of 0/1 flags for the
+    non-NaN counts), and the few cases where the engine's null rules differ from this file's NaN rules are patched from
+    those counts.  Group order: the device's (the reference's is HashMap order)."""
+
+    def __init__(self, df, by):
+        by = list(by)
+        if not by:
+            raise InvalidValue("GroupBy requires at least one column")                         # :23-27
+        for c in by:
+            if not df.contains_column(c):
+                raise InvalidValue("Column '%s' not found in DataFrame" % c)                 # :30-37
+        self.df, self.group_columns = df, by
+        n = df.row_count()
+        cols = [df.get_column_string_values(c) for c in by]
+        joined = ["|||".join(parts) for parts in zip(*cols)] if n else []
+        self._codes = np.fromiter((GLOBAL_STRING_POOL.get_or_insert(s) for s in joined), dtype=np.uint32, count=n)
+        self._labels = {}                                                                      # joined key -> parts of its first row
+        for parts, j in zip(zip(*cols), joined):
+            self._labels.setdefault(j, parts)
+        self._rows = None
+
+    def _key(self):
+        return [(self._codes, None, L.U32CODE)]
+
+    def _row_lists(self):
+        if self._rows is None:
+            n = self.df.row_count()
+            if n:
+                cells, _, off, rows = get_context().groupby_indices(self._key(), n)
+                self._rows = (cells[0].astype(np.uint32), np.asarray(off), np.asarray(rows))
+            else:
+                self._rows = (np.zeros(0, np.uint32), np.zeros(1, np.int64), np.zeros(0, np.int64))
+        return self._rows
+
+    def ngroups(self):                                                                         # :83-85
+        return len(self._labels)
+
+    def _numeric_columns(self):
+        out = []
+        for c in self.df.column_names:
+            if c not in self.group_columns:
+                v = _numeric_column(self.df, c)
+                if v is not None:
+                    out.append((c, v))
+        return out
+
+    def _group_frame(self, codes):
+        out = DataFrame()
+        labels = [self._labels[GLOBAL_STRING_POOL.get(int(c))] for c in codes]
+        for i, name in enumerate(self.group_columns):
+            out.add_column(name, [lab[i] for lab in labels])
+        return out
+
+    def _fold(self, requests):
+        """requests: [(values f64[n], op name)] -> (group codes, [f64[G] per request]) with this file's NaN rules."""
+        n = self.df.row_count()
+        if n == 0:
+            return np.zeros(0, np.uint32), [np.zeros(0) for _ in requests]
+        ops = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "std": L.STD, "var": L.VAR}
+        cols, col_of, aggs, slots = [], {}, [], []
+        for vals, op in requests:
+            if id(vals) not in col_of:
+                nan = np.isnan(vals)
+                col_of[id(vals)] = len(cols)
+                cols.append((np.where(nan, 0.0, vals), np.packbits(nan, bitorder="little") if nan.any() else None, L.F64))
+                cols.append(((~nan).astype(np.float64), None, L.F64))                          # non-NaN flags: their sum is the count
+            c = col_of[id(vals)]
+            slots.append((len(aggs) if op in ops else -1, len(aggs) + (1 if op in ops else 0)))
+            if op in ops:
+                aggs.append((c, ops[op]))
+            aggs.append((c + 1, L.SUM))
+        kc, _, oa = get_context().groupby_agg(self._key(), n, cols, aggs)
+        out = []
+        for (vals, op), (a, cnt_slot) in zip(requests, slots):
+            nn = oa[cnt_slot]
+            if op == "count":
+                r = nn.copy()
+            elif op == "sum":
+                r = oa[a].copy()
+            elif op == "mean":
+                r = np.where(nn > 0, oa[a], np.nan)
+            elif op == "min":
+                r = np.where(nn > 0, oa[a], np.inf)
+            elif op == "max":
+                r = np.where(nn > 0, oa[a], -np.inf)
+            elif op in ("std", "var"):
+                r = np.where(nn > 1, oa[a], np.nan)
+            else:
+                r = np.full(kc.shape[1], np.nan)                                               # unknown aggregate name (:405)
+            out.append(r)
+        return kc[0].astype(np.uint32), out
+
+    def _aggregate(self, op):                                                                  # aggregate (:203-262): "{col}" columns
+        numeric = self._numeric_columns()
+        if not numeric:
+            codes, _ = self._sizes()
+            return self._group_frame(codes)
+        codes, res = self._fold([(v, op) for _, v in numeric])
+        out = self._group_frame(codes)
+        for (name, _), r in zip(numeric, res):
+            out.add_column(name, [float(x) for x in r])
+        return out
+
+    def _sizes(self):
+        n = self.df.row_count()
+        if n == 0:
+            return np.zeros(0, np.uint32), np.zeros(0)
+        kc, _, oa = get_context().groupby_agg(self._key(), n, [self._key()[0]], [(0, L.COUNT)])
+        return kc[0].astype(np.uint32), oa[0]
+
+    def size(self):                                                                            # :88-117
+        codes, sizes = self._sizes()
+        out = self._group_frame(codes)
+        out.add_column("size", [float(x) for x in sizes])
+        return out
+
+    def count(self):                                                                           # :120-122
+        return self.size()
+
+    def sum(self):
+        return self._aggregate("sum")
+
+    def mean(self):
+        return self._aggregate("mean")
+
+    def min(self):
+        return self._aggregate("min")
+
+    def max(self):
+        return self._aggregate("max")
+
+    def std(self):
+        return self._aggregate("std")
+
+    def var(self):
+        return self._aggregate("var")
+
+    def _first_last(self, first):                                                              # aggregate_first_last (:264-330)
+        codes, off, rows = self._row_lists()
+        pick = rows[off[:-1]] if first else rows[off[1:] - 1]
+        out = self._group_frame(codes)
+        for c in self.df.column_names:
+            if c not in self.group_columns:
+                cells = self.df.get_column_string_values(c)
+                num = _numeric_column(self.df, c)
+                out.add_column(c, [float(num[i]) for i in pick] if num is not None else [cells[i] for i in pick])
+        return out
+
+    def first(self):
+        return self._first_last(True)
+
+    def last(self):
+        return self._first_last(False)
+
+    def agg(self, aggs):                                                                       # :333-455
+        aggs = [(c, a) for c, a in aggs if self.df.contains_column(c)]
+        numeric = {c: _numeric_column(self.df, c) for c, _ in aggs}
+        todo = [(c, a) for c, a in aggs if numeric[c] is not None]
+        fl = [(c, a) for c, a in todo if a in ("first", "last")]
+        fold = [(c, a) for c, a in todo if a not in ("first", "last")]
+        codes, res = self._fold([(numeric[c], a) for c, a in fold]) if fold else (self._sizes()[0], [])
+        by_name = {"%s_%s" % (c, a): r for (c, a), r in zip(fold, res)}
+        if fl:
+            gcodes, off, rows = self._row_lists()
+            order = {int(k): i for i, k in enumerate(gcodes)}
+            at = np.array([order[int(k)] for k in codes], np.int64)
+            for c, a in fl:
+                pick = rows[off[:-1]] if a == "first" else rows[off[1:] - 1]
+                by_name["%s_%s" % (c, a)] = numeric[c][pick][at]
+        out = self._group_frame(codes)
+        for c, a in todo:
+            name = "%s_%s" % (c, a)
+            if not out.contains_column(name):
+                out.add_column(name, [float(x) for x in by_name[name]])
+        return out
+
+
+def groupby_multi(df, by):
+    """PandasGroupByExt::groupby_multi (src/dataframe/pandas_compat/groupby.rs:467-475)."""
+    return PandasGroupBy(df, by)
+
+
 class JoinType(IntEnum):             # src/dataframe/pandas_compat/merge.rs:11-20 (same order as the engine's)
     Inner = 0
     Left = 1
