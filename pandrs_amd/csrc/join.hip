@@ -78,7 +78,10 @@ struct TableRef {
     __device__ __forceinline__ uint32_t base_of(uint64_t k) const {
         return regions > 1 ? part_of(hash32(k, JN_SEED), regions) * (rmask + 1) : 0u;
     }
-    __device__ __forceinline__ uint32_t home_of(uint64_t k) const { return hash32(k, BH_SEED) & rmask; }
+    // home slots are multiples of 4: a key sits in its 64-byte home BUCKET (4 entries) unless that overflowed, so a lookup that
+    // reads the bucket whole needs ~1.1 line reads where entry-by-entry probing at load 0.6 needs 1.75 (the probe is bound by
+    // random line reads out of MALL: 50 M x 5 M lookup kernel 1.43 -> see DESIGN §7)
+    __device__ __forceinline__ uint32_t home_of(uint64_t k) const { return (hash32(k, BH_SEED) & (rmask >> 2)) << 2; }
     // claims the first free entry of the key's probe sequence (distinct keys only)
     __device__ __forceinline__ void insert(uint32_t base, uint64_t k, uint32_t start, uint32_t count) const {
         uint32_t o = home_of(k);
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(JN_THREADS) void join_build_kernel(BuildArgs a) {
         if (i >= nR) continue;
         uint32_t s = BH_SLOTS;                       // the sentinel-valued key counts in the extra entry
         if (k[r] != EMPTY_KEY) {
-            s = hash32(k[r], BH_SEED) & (BH_SLOTS - 1);
+            s = (hash32(k[r], BH_SEED) & (BH_SLOTS / 4 - 1)) << 2;       // = TableRef::home_of: the home bucket's first slot
             for (;;) {
                 const uint64_t old = atomicCAS((unsigned long long *)&sk[s], EMPTY_KEY, k[r]);
                 if (old == EMPTY_KEY || old == k[r]) break;
@@ -247,6 +250,46 @@ __global__ void publish_runs_kernel(const uint64_t *rkeys, const uint32_t *rrows
     tab.insert(tab.base_of(k), k, e_start, e_count);
 }
 
+// Lookup of 4 keys per thread: the 4 home buckets (4 x 4 entries of 16 B) are in flight together; a key that is not in its home
+// bucket and saw no empty entry there walks on entry by entry (its bucket overflowed: ~10 % at load 0.6).
+// skip[r]: no lookup (null key / row past the end); k == EMPTY_KEY: the sentinel-valued key's dedicated entry.
+__device__ __forceinline__ void bucket_lookup4(const TableRef &tab, const uint64_t (&k)[4], const bool (&skip)[4],
+                                               uint32_t (&slot)[4], JoinEntry (&e)[4], bool (&found)[4]) {
+    const JoinEntry *table = tab.t;
+    uint32_t tb[4];
+    JoinEntry b[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        tb[r] = tab.base_of(k[r]);
+        slot[r] = k[r] == EMPTY_KEY ? tab.sentinel() : tb[r] + tab.home_of(k[r]);     // (the table carries 8 spare entries behind sentinel())
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[r][j] = table[slot[r] + j];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        found[r] = false;
+        e[r] = b[r][0];
+        if (skip[r]) continue;
+        if (k[r] == EMPTY_KEY) { found[r] = b[r][0].count != 0; continue; }
+        bool open = true;                                   // neither the key nor an empty entry seen yet
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool hit = open && b[r][j].key == k[r];
+            if (hit) { found[r] = true; e[r] = b[r][j]; slot[r] += j; }
+            open = open && !hit && b[r][j].key != EMPTY_KEY;
+        }
+        if (open) {                                         // the home bucket is full of other keys: walk on
+            uint32_t sl = slot[r] - tb[r] + 3;
+            JoinEntry x = b[r][3];
+            for (uint32_t probes = 0; x.key != k[r] && x.key != EMPTY_KEY && probes < tab.rmask; probes++) {
+                sl = (sl + 1) & tab.rmask;
+                x = table[tb[r] + sl];
+            }
+            if (x.key == k[r]) { found[r] = true; e[r] = x; slot[r] = tb[r] + sl; }
+        }
+    }
+}
+
 // Probe pass over the left rows in ORIGINAL order.  LK_RPT rows per thread: all key loads, then all
 // first-probe table reads (16-byte entries, cache resident for typical builds) are in flight together;
 // only rows whose first entry is neither their key nor empty walk on.
@@ -255,46 +298,34 @@ __global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, i
                                                                  int keep_left, int flag_right,
                                                                  uint2 *match, uint32_t *cnt, uint8_t *hit) {
     const int64_t base = (int64_t)blockIdx.x * (LK_THREADS * LK_RPT) + threadIdx.x;
-    const JoinEntry *table = tab.t;
-    uint64_t k[LK_RPT];
-    uint32_t slot[LK_RPT], tb[LK_RPT];
-    bool nul[LK_RPT];
 #pragma unroll
-    for (int r = 0; r < LK_RPT; r++) {
-        const int64_t l = min(base + (int64_t)r * LK_THREADS, n_left - 1);
-        nul[r] = key_is_null(lkey, l);
-        k[r] = key_cell(lkey, l);
-        tb[r] = tab.base_of(k[r]);
-        slot[r] = k[r] == EMPTY_KEY ? tab.sentinel() : tb[r] + tab.home_of(k[r]);
-    }
-    JoinEntry e[LK_RPT];
+    for (int h = 0; h < LK_RPT; h += 4) {
+        uint64_t k[4];
+        bool skip[4], live[4], found[4];
+        uint32_t slot[4];
+        JoinEntry e[4];
 #pragma unroll
-    for (int r = 0; r < LK_RPT; r++) e[r] = table[slot[r]];
+        for (int r = 0; r < 4; r++) {
+            const int64_t l0 = base + (int64_t)(h + r) * LK_THREADS, l = min(l0, n_left - 1);
+            live[r] = l0 < n_left;
+            skip[r] = !live[r] || key_is_null(lkey, l);     // null left keys are dropped even for left/outer (join.rs:152)
+            k[r] = key_cell(lkey, l);
+        }
+        bucket_lookup4(tab, k, skip, slot, e, found);
 #pragma unroll
-    for (int r = 0; r < LK_RPT; r++) {
-        const int64_t l = base + (int64_t)r * LK_THREADS;
-        if (l >= n_left) continue;
-        uint2 out = make_uint2(NO_MATCH, 0u);           // null left keys are dropped even for left/outer (join.rs:152)
-        if (!nul[r]) {
-            bool found;
-            if (k[r] == EMPTY_KEY) {
-                found = e[r].count != 0;                // the sentinel-valued key's dedicated entry
-            } else {
-                for (uint32_t probes = 0; e[r].key != k[r] && e[r].key != EMPTY_KEY && probes < tab.rmask; probes++) {
-                    slot[r] = tb[r] + ((slot[r] - tb[r] + 1) & tab.rmask);      // bounded: never spin on a full region
-                    e[r] = table[slot[r]];
-                }
-                found = e[r].key == k[r];
-            }
-            if (found) {
+        for (int r = 0; r < 4; r++) {
+            if (!live[r]) continue;
+            const int64_t l = base + (int64_t)(h + r) * LK_THREADS;
+            uint2 out = make_uint2(NO_MATCH, 0u);
+            if (found[r]) {
                 out = make_uint2(e[r].start, e[r].count);
                 if (flag_right) hit[slot[r]] = 1;
-            } else if (keep_left) {
+            } else if (keep_left && !key_is_null(lkey, l)) {
                 out.y = 1;
             }
+            match[l] = out;
+            cnt[l] = out.y & ~JN_DIRECT;    // dense per-row output counts for the scan
         }
-        match[l] = out;
-        cnt[l] = out.y & ~JN_DIRECT;    // dense per-row output counts for the scan
     }
 }
 
@@ -331,43 +362,34 @@ __global__ __launch_bounds__(OP_THREADS) void join_probe_onepass_kernel(OnePassA
     // row slice r of the tile = rows tile * OP_TILE + r * OP_THREADS + tid: coalesced key loads and,
     // for a unique-key build side, coalesced output stores (consecutive lanes, consecutive rows)
     const int64_t base = (int64_t)tile * OP_TILE + tid;
-    uint64_t k[OP_RPT];
-    uint32_t slot[OP_RPT], tb[OP_RPT];
-    bool nul[OP_RPT];
-#pragma unroll
-    for (int r = 0; r < OP_RPT; r++) {
-        const int64_t l = min(base + (int64_t)r * OP_THREADS, a.n_left - 1);
-        nul[r] = key_is_null(a.lkey, l) || base + (int64_t)r * OP_THREADS >= a.n_left;
-        k[r] = key_cell(a.lkey, l);
-        tb[r] = a.tab.base_of(k[r]);
-        slot[r] = k[r] == EMPTY_KEY ? a.tab.sentinel() : tb[r] + a.tab.home_of(k[r]);
-    }
-    JoinEntry e[OP_RPT];
-#pragma unroll
-    for (int r = 0; r < OP_RPT; r++) e[r] = a.tab.t[slot[r]];
     uint32_t start[OP_RPT], cnt[OP_RPT], inc[OP_RPT];
     bool direct[OP_RPT];
 #pragma unroll
-    for (int r = 0; r < OP_RPT; r++) {
-        start[r] = NO_MATCH; cnt[r] = 0; direct[r] = false;
-        if (!nul[r]) {                                  // null left keys are dropped even for left/outer (join.rs:152)
-            bool found;
-            if (k[r] == EMPTY_KEY) {
-                found = e[r].count != 0;
-            } else {
-                for (uint32_t probes = 0; e[r].key != k[r] && e[r].key != EMPTY_KEY && probes < a.tab.rmask; probes++) {
-                    slot[r] = tb[r] + ((slot[r] - tb[r] + 1) & a.tab.rmask);
-                    e[r] = a.tab.t[slot[r]];
-                }
-                found = e[r].key == k[r];
-            }
-            if (found) {
-                start[r] = e[r].start; cnt[r] = e[r].count & ~JN_DIRECT; direct[r] = (e[r].count & JN_DIRECT) != 0;
-                if (a.flag_right) a.hit[slot[r]] = 1;
-            } else if (a.keep_left) {
-                cnt[r] = 1;
+    for (int h = 0; h < OP_RPT; h += 4) {
+        uint64_t k4[4];
+        bool skip[4], found[4];
+        uint32_t slot4[4];
+        JoinEntry e4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t l0 = base + (int64_t)(h + r) * OP_THREADS, l = min(l0, a.n_left - 1);
+            skip[r] = key_is_null(a.lkey, l) || l0 >= a.n_left;       // null left keys are dropped even for left/outer (join.rs:152)
+            k4[r] = key_cell(a.lkey, l);
+        }
+        bucket_lookup4(a.tab, k4, skip, slot4, e4, found);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            start[h + r] = NO_MATCH; cnt[h + r] = 0; direct[h + r] = false;
+            if (found[r]) {
+                start[h + r] = e4[r].start; cnt[h + r] = e4[r].count & ~JN_DIRECT; direct[h + r] = (e4[r].count & JN_DIRECT) != 0;
+                if (a.flag_right) a.hit[slot4[r]] = 1;
+            } else if (a.keep_left && !skip[r]) {
+                cnt[h + r] = 1;
             }
         }
+    }
+#pragma unroll
+    for (int r = 0; r < OP_RPT; r++) {
         uint32_t v = cnt[r];                            // inclusive scan over the wave's lanes
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -570,7 +592,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
     P = std::max<int64_t>(P, 1);
     const uint32_t cap_tab = (uint32_t)std::max<uint64_t>(cap_glob, (uint64_t)partitions_for(P) * BH_SLOTS);
     size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nr + 1) * 8) + Arena::padded(size_t(nr + 1) * 4)
-              + Arena::padded(size_t(cap_tab + 2) * 16) + Arena::padded(size_t(cap_tab) + 16)
+              + Arena::padded(size_t(cap_tab + 8) * 16) + Arena::padded(size_t(cap_tab) + 16)
               + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded(size_t(nl + 2) * 4)
               + 2 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
               + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16)
@@ -588,7 +610,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
         uint32_t *flags = c->work.take<uint32_t>(64);
         uint64_t *prk = c->work.take<uint64_t>(nr + 1);
         uint32_t *prr = c->work.take<uint32_t>(nr + 1);
-        JoinEntry *table = c->work.take<JoinEntry>((size_t)cap_tab + 2);
+        JoinEntry *table = c->work.take<JoinEntry>((size_t)cap_tab + 8);       // + the sentinel-valued key's entry and the rest of its "bucket"
         uint8_t *hit = c->work.take<uint8_t>((size_t)cap_tab + 16);
         uint2 *match = c->work.take<uint2>(nl + 2);
         uint32_t *cnt = c->work.take<uint32_t>(nl + 2);
@@ -605,7 +627,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
         const uint32_t n_entries = tab.regions * (tab.rmask + 1);
         if ((uint64_t)tab.regions * (tab.rmask + 1) > cap_tab) return fail(PANDRS_HIP_ERR_COMPUTATION, "join: table geometry exceeds its allocation");
         if (generic) HIP_TRY(hipMemsetAsync(table, 0xFF, size_t(n_entries) * 16, c->stream));   // keys = EMPTY, filled with atomics
-        HIP_TRY(hipMemsetAsync(&table[n_entries], 0, 32, c->stream));                   // the key ~0's own entry: count 0
+        HIP_TRY(hipMemsetAsync(&table[n_entries], 0, 8 * 16, c->stream));              // the key ~0's own entry: count 0 (+ 7 spare entries)
         if (keep_right) HIP_TRY(hipMemsetAsync(hit, 0, size_t(n_entries) + 16, c->stream));
 
         // ---- build side: radix partition (null keys -> their own partition, never built), sort, publish
