@@ -362,6 +362,8 @@ def test_fused_join_large_build_path_with_l2_resident_table_regions(ctx, case):
         gmask = O.pack_mask(rng.random(nb) < 0.01)
     if case == "duplicates_decline":
         rkeys[1000:1010] = rkeys[5]
+    if case == "pair_partitions":
+        rg[::1000] = -1                                             # a GROUP key with the table sentinel's bit pattern, through the partitioned pair output
     lkeys = rkeys[rng.integers(0, nb, npb)].copy()
     lkeys[rng.random(npb) < 0.1] = -7                               # 10 % misses
     if case == "sentinel_nulls_u32":
