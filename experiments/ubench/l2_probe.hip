@@ -89,7 +89,60 @@ int visits_main() {
     return 0;
 }
 
+
+// third experiment (argv: "bucket"): a lookup that needs its whole 64-byte bucket (4 entries of 16 B) out of a 128 MB table:
+// (a) every lane loads its own bucket with four 16-byte loads (four L2 requests per lookup);
+// (b) a QUAD of lanes serves its four lookups one after the other, lane j loading entry j (one coalesced 64-byte request per lookup).
+template <bool QUAD>
+__global__ __launch_bounds__(256) void bucket_kernel(const uint4 *table, uint32_t n_buckets, uint32_t lookups, u64 *out) {
+    u64 acc = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t s = mix(blockIdx.x * 256u + threadIdx.x + 1u);
+    for (uint32_t i = 0; i < lookups; i += 4) {
+        uint32_t b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { s = s * 1664525u + 1013904223u; b[u] = mix(s) % n_buckets; }
+        uint4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (QUAD) {
+                    const uint32_t bq = __shfl(b[u], (lane & ~3u) + q, 64);      // the bucket of lane q of this quad
+                    v[u][q] = table[(size_t)bq * 4 + (lane & 3u)];
+                } else v[u][q] = table[(size_t)b[u] * 4 + q];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc += v[u][q].x + v[u][q].z;
+    }
+    if (acc == 0x123456789ull) out[0] = acc;
+}
+int bucket_main() {
+    u64 *out; CK(hipMalloc(&out, 64));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const uint32_t n_buckets = 2u << 20;                      // 128 MB
+    uint4 *table; CK(hipMalloc(&table, (size_t)n_buckets * 64));
+    CK(hipMemset(table, 1, (size_t)n_buckets * 64));
+    const uint32_t grid = 256 * 8, lookups = 96;
+    for (int mode = 0; mode < 2; mode++) {
+        float best = 1e9;
+        for (int it = 0; it < 3; it++) {
+            CK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL((bucket_kernel<false>), dim3(grid), dim3(256), 0, 0, table, n_buckets, lookups, out);
+            else hipLaunchKernelGGL((bucket_kernel<true>), dim3(grid), dim3(256), 0, 0, table, n_buckets, lookups, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        printf("64-byte buckets out of 128 MB, %s: %.3f ms  %.1f G lookups/s\n", mode == 0 ? "4 loads per lane      " : "quad of lanes per lookup",
+               best, (double)grid * 256 * lookups / best / 1e6);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'b') return bucket_main();
     if (argc > 1) return visits_main();
     const uint32_t P = 1024;
     u64 *out; CK(hipMalloc(&out, 64));
