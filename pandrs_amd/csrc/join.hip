@@ -1056,8 +1056,10 @@ __global__ __launch_bounds__(TH, 4) void fused_l2_probe_kernel(L2ProbeArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t grp = blockIdx.x & 7;
     __shared__ uint32_t pcnt[MODE ? L2_PAIR_PMAX + 1 : 1], pdelta[MODE == 2 ? L2_PAIR_PMAX + 1 : 1], pwt[17];
-    __shared__ uint16_t ppid[MODE == 2 ? TILE : 1];
-    __shared__ uint64_t pstage[MODE == 2 ? TILE : 1];
+    // MODE 2: dynamic LDS = (g, v) records of the tile in sorted order [TILE] x 16 B | their pair partitions [TILE] x u16
+    extern __shared__ __attribute__((aligned(16))) unsigned char l2_dyn[];
+    ulonglong2 *pstage = reinterpret_cast<ulonglong2 *>(l2_dyn);
+    uint16_t *ppid = reinterpret_cast<uint16_t *>(l2_dyn + (MODE == 2 ? (size_t)TILE * 16 : 0));
     uint32_t rows_seen = 0;                            // MODE 1
     unsigned long long pairs_mine = 0;                 // MODE 2 (thread 0): pairs this workgroup wrote
     if (MODE == 1) {
@@ -1214,21 +1216,16 @@ __global__ __launch_bounds__(TH, 4) void fused_l2_probe_kernel(L2ProbeArgs a) {
                 }
 #pragma unroll
                 for (int r = 0; r < L2_RPT; r++)
-                    if ((mm >> r) & 1u) { pstage[ps[r] & 0xFFFFu] = gv[r]; ppid[ps[r] & 0xFFFFu] = (uint16_t)(ps[r] >> 16); }
+                    if ((mm >> r) & 1u) { pstage[ps[r] & 0xFFFFu] = make_ulonglong2(gv[r], v[r]); ppid[ps[r] & 0xFFFFu] = (uint16_t)(ps[r] >> 16); }
                 __syncthreads();
 #pragma unroll
-                for (int r = 0; r < L2_RPT; r++) {
+                for (int r = 0; r < L2_RPT; r++) {          // one staging round for both columns (16-byte records)
                     const uint32_t j = (uint32_t)r * TH + tid;
-                    if (j < tot) __builtin_nontemporal_store(pstage[j], &a.out_g[pdelta[ppid[j]] + j]);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < L2_RPT; r++) if ((mm >> r) & 1u) pstage[ps[r] & 0xFFFFu] = v[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < L2_RPT; r++) {
-                    const uint32_t j = (uint32_t)r * TH + tid;
-                    if (j < tot) __builtin_nontemporal_store(pstage[j], &a.out_v[pdelta[ppid[j]] + j]);
+                    if (j < tot) {
+                        const ulonglong2 rec = pstage[j];
+                        const uint32_t dst = pdelta[ppid[j]] + j;
+                        __builtin_nontemporal_store(rec.x, &a.out_g[dst]); __builtin_nontemporal_store(rec.y, &a.out_v[dst]);
+                    }
                 }
                 __syncthreads();
                 continue;
@@ -1397,7 +1394,11 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
                 plan_sampled_regions(c, hist, c->opt.join_no_pairpart == 2 ? nl / 8 : nl, PP1, pa.pair_cap, gb, gc, ge, pflags,
                                      1.0 + (double)nl / (double)nr);
                 HIP_TRY(hipMemsetAsync(flags + 8, 0, 32, c->stream));
-                hipLaunchKernelGGL((fused_l2_probe_kernel<2, L2_THREADS_PART>), dim3((unsigned)(8 * 2 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS_PART), 0, c->stream, pa);
+                const size_t part_lds = (size_t)L2_THREADS_PART * L2_RPT * 18;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_l2_probe_kernel<2, L2_THREADS_PART>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+                hipLaunchKernelGGL((fused_l2_probe_kernel<2, L2_THREADS_PART>), dim3((unsigned)(8 * 2 * ((c->n_cu + 7) / 8))), dim3(L2_THREADS_PART),
+                                   part_lds, c->stream, pa);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipMemcpyAsync(flags + 6, pflags, 4, hipMemcpyDeviceToDevice, c->stream));
