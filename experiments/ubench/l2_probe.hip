@@ -141,7 +141,60 @@ int bucket_main() {
     return 0;
 }
 
+// fourth experiment (argv: "lbucket"): the same two bucket forms against L2-sized regions (the XCD group walks the regions together)
+template <bool QUAD>
+__global__ __launch_bounds__(256) void local_bucket_kernel(const uint4 *table, uint32_t P, uint32_t buckets_per_region, uint32_t lookups, u64 *out) {
+    const uint32_t g = blockIdx.x & 7, lane = threadIdx.x & 63;
+    u64 acc = 0;
+    for (uint32_t p = g; p < P; p += 8) {
+        const uint4 *reg = table + (size_t)p * buckets_per_region * 4;
+        uint32_t s = mix(p * 7919u + (blockIdx.x >> 3) * 256u + threadIdx.x + 1u);
+        for (uint32_t i = 0; i < lookups; i += 4) {
+            uint32_t b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { s = s * 1664525u + 1013904223u; b[u] = mix(s) % buckets_per_region; }
+            uint4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (QUAD) {
+                        const uint32_t bq = __shfl(b[u], (lane & ~3u) + q, 64);
+                        v[u][q] = reg[(size_t)bq * 4 + (lane & 3u)];
+                    } else v[u][q] = reg[(size_t)b[u] * 4 + q];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc += v[u][q].x + v[u][q].z;
+        }
+    }
+    if (acc == 0x123456789ull) out[0] = acc;
+}
+int local_bucket_main() {
+    u64 *out; CK(hipMalloc(&out, 64));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const uint32_t P = 1024, bpr = 1024 * 1024 / 64;          // 1 MB regions
+    uint4 *table; CK(hipMalloc(&table, (size_t)P * bpr * 64));
+    CK(hipMemset(table, 1, (size_t)P * bpr * 64));
+    const uint32_t grid = 256 * 4, lookups = 16;
+    for (int mode = 0; mode < 2; mode++) {
+        float best = 1e9;
+        for (int it = 0; it < 3; it++) {
+            CK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL((local_bucket_kernel<false>), dim3(grid), dim3(256), 0, 0, table, P, bpr, lookups, out);
+            else hipLaunchKernelGGL((local_bucket_kernel<true>), dim3(grid), dim3(256), 0, 0, table, P, bpr, lookups, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        printf("64-byte buckets out of 1 MB regions (L2), %s: %.3f ms  %.1f G lookups/s\n", mode == 0 ? "4 loads per lane      " : "quad of lanes per lookup",
+               best, (double)(P / 8) * grid * 256 * lookups / best / 1e6);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'l') return local_bucket_main();
     if (argc > 1 && argv[1][0] == 'b') return bucket_main();
     if (argc > 1) return visits_main();
     const uint32_t P = 1024;
