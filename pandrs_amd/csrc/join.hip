@@ -14,12 +14,14 @@
 //      partition's region of the global table of 16-byte {key, start, count} entries and is stored
 //      whole, without global atomics.  Partitions with a long run fall back to an LDS bitonic sort,
 //      partitions beyond LDS to the general segmented sort (segsort.hip);
-//   3. probe pass over the LEFT rows in their ORIGINAL order (never partitioned): one table lookup
-//      per row -> {first match, output rows}; null left keys emit nothing (join.rs:152);
-//   4. exclusive scan of the per-left-row counts = output offsets in reference order
+//   3. probe pass over the LEFT rows in their ORIGINAL order (never partitioned): one lookup per row — its 64-byte
+//      home bucket of the table, read whole — -> {first match, output rows}, and the output rows of every
+//      2048-row tile; null left keys emit nothing (join.rs:152);
+//   4. exclusive scan of the TILE sums (64-bit) = output offset of every tile in reference order
 //      (left rows ascending, join.rs:151);
-//   5. emit pass in original left order: coalesced index-pair writes, the only gather is from the
-//      sorted right-row array; left/outer misses write (left, -1) (join.rs:159-162);
+//   5. emit pass, tile by tile in original left order: a row's position = its tile's offset + the in-tile prefix
+//      of the match records it re-reads (no per-row count / offset arrays); coalesced index-pair writes, the
+//      only gather is from the sorted right-row array; left/outer misses write (left, -1) (join.rs:159-162);
 //   6. right/outer: runs hit by the probe mark their right rows; unmatched right rows (null keys
 //      included) are compacted ascending behind the probe output (join.rs:211-224).
 // All of it is HBM-bound integer work: no MFMA.
@@ -296,8 +298,9 @@ __device__ __forceinline__ void bucket_lookup4(const TableRef &tab, const uint64
 constexpr int LK_THREADS = 256, LK_RPT = 8;
 __global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, int64_t n_left, TableRef tab,
                                                                  int keep_left, int flag_right,
-                                                                 uint2 *match, uint32_t *cnt, uint8_t *hit) {
+                                                                 uint2 *match, unsigned long long *tile_sum, uint8_t *hit) {
     const int64_t base = (int64_t)blockIdx.x * (LK_THREADS * LK_RPT) + threadIdx.x;
+    unsigned long long mine = 0;                   // output rows of this thread's left rows
 #pragma unroll
     for (int h = 0; h < LK_RPT; h += 4) {
         uint64_t k[4];
@@ -324,9 +327,51 @@ __global__ __launch_bounds__(LK_THREADS) void join_lookup_kernel(KeyDesc lkey, i
                 out.y = 1;
             }
             match[l] = out;
-            cnt[l] = out.y & ~JN_DIRECT;    // dense per-row output counts for the scan
+            mine += out.y & ~JN_DIRECT;
         }
     }
+    // the tile's output rows: the emit pass re-derives every row's position from the scanned tile sums and the tile's own
+    // match records, so no per-row count / offset arrays travel through HBM (16 B per left row less)
+    __shared__ unsigned long long wsum[LK_THREADS / 64];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < LK_THREADS / 64; w++) t += wsum[w];
+        tile_sum[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the tile sums (one workgroup; 64-bit: the total is checked against the 2^32-row limit), total -> *total
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const unsigned long long *tile_sum, uint32_t n_tiles, unsigned long long *tile_off,
+                                                         unsigned long long *total) {
+    __shared__ unsigned long long wtot[16];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + tid;
+        const unsigned long long v = i < n_tiles ? tile_sum[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += t;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t w = 0; w < wave; w++) before += wtot[w];
+        if (i < n_tiles) tile_off[i] = before + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
 }
 
 // ---- single-pass probe (opt-in, option join_one_pass): lookup + scan + emit in ONE kernel -----------
@@ -473,29 +518,59 @@ __global__ void mark_matched_kernel(const JoinEntry *table, const uint8_t *hit, 
 // Emit pass, in ORIGINAL left order: coalesced reads of (match, offset), coalesced index-pair writes;
 // the only gather is from the sorted right-row array (n_right x 4 B, cache resident for typical builds).
 // EM_RPT rows per thread so the gathers of several rows are in flight together.
-constexpr int EM_THREADS = 256, EM_RPT = 4;
-__global__ __launch_bounds__(EM_THREADS) void join_emit_kernel(const uint2 *match, const uint32_t *out_off,
+constexpr int EM_THREADS = LK_THREADS, EM_RPT = LK_RPT;      // the emit tile IS the lookup tile
+__global__ __launch_bounds__(EM_THREADS) void join_emit_kernel(const uint2 *match, const unsigned long long *tile_off,
                                                                const uint32_t *rrows_sorted, int64_t n_left,
                                                                int64_t *out_left, int64_t *out_right) {
-    const int64_t base = (int64_t)blockIdx.x * (EM_THREADS * EM_RPT) + threadIdx.x;
+    constexpr int NW = EM_THREADS / 64;
+    __shared__ uint32_t wsum[EM_RPT][NW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * (EM_THREADS * EM_RPT) + tid;
     uint2 mt[EM_RPT];
-    uint32_t o[EM_RPT], first[EM_RPT];
-#pragma unroll
-    for (int r = 0; r < EM_RPT; r++) {
-        const int64_t l = min(base + (int64_t)r * EM_THREADS, n_left - 1);
-        mt[r] = match[l];
-        o[r] = out_off[l];
-    }
-#pragma unroll
-    for (int r = 0; r < EM_RPT; r++)
-        first[r] = (mt[r].y & JN_DIRECT) ? mt[r].x : ((mt[r].y != 0 && mt[r].x != NO_MATCH) ? rrows_sorted[mt[r].x] : 0u);
+    uint32_t cntr[EM_RPT], inc[EM_RPT], first[EM_RPT];
 #pragma unroll
     for (int r = 0; r < EM_RPT; r++) {
         const int64_t l = base + (int64_t)r * EM_THREADS;
-        if (l >= n_left || mt[r].y == 0) continue;
-        if (mt[r].x == NO_MATCH) { out_left[o[r]] = l; out_right[o[r]] = -1; continue; }
-        out_left[o[r]] = l; out_right[o[r]] = first[r];
-        for (uint32_t q = 1; q < (mt[r].y & ~JN_DIRECT); q++) { out_left[(size_t)o[r] + q] = l; out_right[(size_t)o[r] + q] = rrows_sorted[mt[r].x + q]; }
+        mt[r] = match[min(l, n_left - 1)];
+        cntr[r] = l < n_left ? (mt[r].y & ~JN_DIRECT) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++)
+        first[r] = (mt[r].y & JN_DIRECT) ? mt[r].x : ((cntr[r] != 0 && mt[r].x != NO_MATCH) ? rrows_sorted[mt[r].x] : 0u);
+    // positions in left-row order: row slice r (rows base + r * EM_THREADS) before slice r + 1, lanes in order inside a slice.
+    // (a tile's output can exceed 2^32 only if the whole join does, which the host has already refused)
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++) {
+        uint32_t v = cntr[r];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += t;
+        }
+        inc[r] = v;
+        if (lane == 63) wsum[r][wave] = v;
+    }
+    __syncthreads();
+    uint64_t pos0 = tile_off[blockIdx.x];
+    uint32_t before[EM_RPT], run = 0;
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++) {
+        before[r] = run;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t x = wsum[r][w];
+            if (w < (int)wave) before[r] += x;
+            run += x;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < EM_RPT; r++) {
+        if (cntr[r] == 0) continue;
+        const int64_t l = base + (int64_t)r * EM_THREADS;
+        const uint64_t o = pos0 + before[r] + inc[r] - cntr[r];
+        if (mt[r].x == NO_MATCH) { out_left[o] = l; out_right[o] = -1; continue; }
+        out_left[o] = l; out_right[o] = first[r];
+        for (uint32_t q = 1; q < cntr[r]; q++) { out_left[o + q] = l; out_right[o + q] = rrows_sorted[mt[r].x + q]; }
     }
 }
 
@@ -509,16 +584,6 @@ __global__ void append_unmatched_kernel(const uint8_t *rmatched, const uint32_t 
     if (i < n && !rmatched[i]) { out_left[base + off[i]] = -1; out_right[base + off[i]] = i; }
 }
 
-// 64-bit total of the per-left-row output counts: the u32 scan would wrap silently past 2^32 rows
-__global__ __launch_bounds__(256) void sum_counts_kernel(const uint32_t *cnt, int64_t n, unsigned long long *out) {
-    unsigned long long s = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += cnt[i];
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_down(s, o, 64);
-    __shared__ unsigned long long ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
-}
 
 static int32_t stage_key(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n, KeyDesc *out) {
     const void *d = col->data; const uint8_t *m = col->null_mask;
@@ -593,7 +658,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
     const uint32_t cap_tab = (uint32_t)std::max<uint64_t>(cap_glob, (uint64_t)partitions_for(P) * BH_SLOTS);
     size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + Arena::padded(size_t(nr + 1) * 8) + Arena::padded(size_t(nr + 1) * 4)
               + Arena::padded(size_t(cap_tab + 8) * 16) + Arena::padded(size_t(cap_tab) + 16)
-              + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded(size_t(nl + 2) * 4)
+              + Arena::padded(size_t(nl + 2) * 8) + 2 * Arena::padded((size_t(nl) / (LK_THREADS * LK_RPT) + 4) * 8)
               + 2 * Arena::padded(size_t(nr + 2) * 4) + Arena::padded(size_t(nr) + 8)
               + Arena::padded(scan_seg_count((size_t)nl + 1) * 4) + Arena::padded(scan_seg_count((size_t)nr + 1) * 4) + (1 << 16)
               + segsort_workspace_bytes(nr, P_MAX + 1, 4) + Arena::padded((size_t(nl) / OP_TILE + 2) * 8) + 4096;
@@ -613,14 +678,13 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
         JoinEntry *table = c->work.take<JoinEntry>((size_t)cap_tab + 8);       // + the sentinel-valued key's entry and the rest of its "bucket"
         uint8_t *hit = c->work.take<uint8_t>((size_t)cap_tab + 16);
         uint2 *match = c->work.take<uint2>(nl + 2);
-        uint32_t *cnt = c->work.take<uint32_t>(nl + 2);
-        uint32_t *off = c->work.take<uint32_t>(nl + 2);
-        uint32_t *seg = c->work.take<uint32_t>(scan_seg_count((size_t)nl + 1));
+        const uint32_t n_tiles = (uint32_t)((nl + LK_THREADS * LK_RPT - 1) / (LK_THREADS * LK_RPT));
+        unsigned long long *tile_sum = c->work.take<unsigned long long>((size_t)n_tiles + 2);
+        unsigned long long *tile_off = c->work.take<unsigned long long>((size_t)n_tiles + 2);
         uint8_t *rmatched = c->work.take<uint8_t>(nr + 8);
-        if (!flags || !prk || !prr || !table || !hit || !match || !cnt || !off || !seg || !rmatched)
+        if (!flags || !prk || !prr || !table || !hit || !match || !tile_sum || !tile_off || !rmatched)
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (join)");
         HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
-        HIP_TRY(hipMemsetAsync(cnt, 0, size_t(nl + 2) * 4, c->stream));
         HIP_TRY(hipMemsetAsync(rmatched, 0, size_t(nr) + 8, c->stream));
         TableRef tab{table, 1u, cap_glob - 1};
         if (!generic) { tab.regions = (uint32_t)P; tab.rmask = BH_SLOTS - 1; }          // regions are written whole by their build workgroups
@@ -731,17 +795,14 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
             if (nl > 0) {
                 hipLaunchKernelGGL(join_lookup_kernel, dim3((unsigned)((nl + LK_THREADS * LK_RPT - 1) / (LK_THREADS * LK_RPT))), dim3(LK_THREADS), 0, c->stream,
-                                   lkey, nl, tab, keep_left ? 1 : 0, keep_right ? 1 : 0, match, cnt, hit);
+                                   lkey, nl, tab, keep_left ? 1 : 0, keep_right ? 1 : 0, match, tile_sum, hit);
             }
+            // output position of every tile (64-bit: flags[2..3] = rows from the probe, checked against the 2^32-row limit below)
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tile_sum, n_tiles, tile_off,
+                               reinterpret_cast<unsigned long long *>(flags + 2));
             HIP_TRY(hipGetLastError());
-            ST_TRY(exclusive_scan_u32(c, cnt, (size_t)nl + 1, off, seg));    // off[nl] = rows from the probe
-            if (nl > 0)
-                hipLaunchKernelGGL(sum_counts_kernel, dim3((unsigned)std::min<int64_t>(1024, (nl + 255) / 256)), dim3(256), 0, c->stream,
-                                   cnt, nl, reinterpret_cast<unsigned long long *>(flags + 2));
         }
-        HIP_TRY(hipMemcpyAsync(h + 2, flags + 2, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h + 1, off + nl, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (h[0]) {
             // first overflow: more partitions (unlucky hashing); second: the general sort handles any size
@@ -749,9 +810,9 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             else generic = true;
             continue;
         }
-        M1 = h[1];
         if (((uint64_t)h[2] | ((uint64_t)h[3] << 32)) + (uint64_t)nr >= (1ull << 32) - 16384)
             return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join: the output exceeds the 2^32-row per-call limit");
+        M1 = (int64_t)((uint64_t)h[2] | ((uint64_t)h[3] << 32));
         // ---- right / outer: unmatched right rows, ascending
         uint32_t *roff2 = nullptr;
         if (keep_right && nr > 0) {
@@ -777,7 +838,7 @@ static int32_t join_core(pandrs_hip_ctx *c, const KeyDesc &lkey, int64_t nl, con
             PhaseTimer pt(c, PANDRS_HIP_PHASE_PROBE);
             if (M1 > 0)
                 hipLaunchKernelGGL(join_emit_kernel, dim3((unsigned)((nl + EM_THREADS * EM_RPT - 1) / (EM_THREADS * EM_RPT))), dim3(EM_THREADS), 0, c->stream,
-                                   match, off, prr, nl, c->jn.left_idx, c->jn.right_idx);
+                                   match, tile_off, prr, nl, c->jn.left_idx, c->jn.right_idx);
             if (M2 > 0)
                 hipLaunchKernelGGL(append_unmatched_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream,
                                    rmatched, roff2, nr, M1, c->jn.left_idx, c->jn.right_idx);
