@@ -39,7 +39,8 @@ def mask(rng, n, p):
 
 SCALE = int(os.environ.get("FUZZ_SCALE", "1"))
 fails = 0
-for case in range(n_cases):
+first_case = int(os.environ.get("FUZZ_FIRST", "0"))          # replay: FUZZ_FIRST=781 fuzz_parity.py 782 77001 runs case 781 alone
+for case in range(first_case, n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     try:
         if rng.random() < float(os.environ.get("FUZZ_GROUPBY_FRAC", "0.7")):      # ---------------- groupby

@@ -621,6 +621,10 @@ template <int THREADS>
 static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t NB, bool staged) {
     constexpr int TILE = THREADS * SC_RPT;
     size_t lds = (size_t)(sa.P + 1) * (sa.gcur ? 8 : 12) + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
+    if (lds > 160 * 1024 && staged && !sa.gend) {          // private cursors at the widest fan-outs: no room for the staging tile,
+        staged = false;                                     // the rows go out unstaged (slower, same result)
+        lds -= (size_t)TILE * 8;
+    }
     if (lds > 160 * 1024) return fail(PANDRS_HIP_ERR_COMPUTATION, "radix fan-out %u does not fit the scatter's LDS", sa.P);
     if (sa.gend) {
         ST_TRY(set_max_lds(scatter_kernel<THREADS, true, true>, (int)lds));
