@@ -335,6 +335,54 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (argc > 1 && argv[1][0] == '5') {
+        // launch-per-chunk, phases separated: produce-only, consume-only, both; ring vs fresh; 128 / 64 MB chunks
+        constexpr int TILE = 8192, NP = 256;
+        for (int ring_mb : {64, 128})
+        for (int what = 0; what < 3; what++)
+        for (int fresh = 0; fresh < 2; fresh++)
+        for (int read_input = 0; read_input < 2; read_input++) {
+            if (what == 1 && read_input) continue;
+            const size_t chunk_rows = (size_t)ring_mb << 20 >> 4;
+            const int tiles = chunk_rows / TILE; const u32 cap = chunk_rows / NP;
+            const int n_chunks = N / chunk_rows;
+            const size_t span = fresh ? big_bytes / ((size_t)ring_mb << 20) : 1;
+            float best = 1e9;
+            for (int rep = 0; rep < 4; rep++) {
+                CK(hipEventRecord(e0));
+                for (int c = 0; c < n_chunks; c++) {
+                    char *dst = big + (size_t)(c % span) * ((size_t)ring_mb << 20);
+                    if (what != 1) produce_kernel<1024, TILE, false><<<tiles, 1024>>>(keys, vals, c * chunk_rows, NP, cap, dst, (u32)(chunk_rows * 16), read_input);
+                    if (what != 0) consume_kernel<1024, false><<<4 * NP, 1024>>>(dst, (u32)(chunk_rows * 16), cap / 4, cap / 4, out);
+                }
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                best = std::min(best, time_ms(e0, e1));
+            }
+            printf("T5 chunk %3d MB x %2d, %s, %s, %s: %.3f ms  (%.1f us per chunk)\n", ring_mb, n_chunks, what == 0 ? "produce only" : what == 1 ? "consume only" : "produce+consume",
+                   fresh ? "FRESH" : "RING ", read_input ? "input from HBM" : "no input read ", best, best * 1000 / n_chunks);
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == '6') {
+        const size_t total = (size_t)2 << 30;
+        for (int mb : {64, 128, 192, 2048}) {
+            const size_t region = (size_t)mb << 20; const int sweeps = total / region;
+            for (int mode = 0; mode < 4; mode++) {
+                float best = 1e9;
+                for (int rep = 0; rep < 3; rep++) {
+                    CK(hipEventRecord(e0));
+                    if (mode == 0) sweep_write_kernel<false><<<1024, 1024>>>(big, region, sweeps);
+                    else if (mode == 1) for (int s2 = 0; s2 < sweeps; s2++) sweep_write_kernel<false><<<1024, 1024>>>(big, region, 1);
+                    else if (mode == 2) sweep_read_kernel<<<1024, 1024>>>(big, region, sweeps, out);
+                    else for (int s2 = 0; s2 < sweeps; s2++) sweep_read_kernel<<<1024, 1024>>>(big, region, 1, out);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    best = std::min(best, time_ms(e0, e1));
+                }
+                printf("T6 %s 2 GB as %4d MB region x %3d sweeps: %.3f ms  %.2f TB/s\n", mode == 0 ? "stores, one launch      " : mode == 1 ? "stores, launch per sweep" : mode == 2 ? "loads, one launch       " : "loads, launch per sweep ", mb, sweeps, best, 2.147 / best);
+            }
+        }
+        return 0;
+    }
     // ---- T0a: read floor
     for (int rep = 0; rep < 3; rep++) {
         CK(hipMemset(out, 0, 4096 * 8));

@@ -174,17 +174,63 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *ctx);
 int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *ctx);
 /* Pre-size the workspace arena (bytes) so the first timed call does not pay hipMalloc. */
 int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *ctx, int64_t workspace_bytes);
-/* Tuning / testing knobs (all default to 0 = automatic unless noted):
- *   "groups_hint"   expected number of groups (skips the sampled estimate)
- *   "partitions"    force the radix fan-out; "p_max" lower the fan-out cap (forces the two-level path)
- *   "load_pct"      LDS table load factor in percent (default 70); "p_target", "src_per_round" rounds heuristic
- *   "scatter_staged" (default 1), "scatter_threads" (1024 / 512), "shared_cursors" (default 1)
- *   "no_direct", "no_slice", "slice_rows", "no_runs", "generic_aggregate"  switch individual code paths off / on
- *   "join_generic"  always build the join with the general segmented sort; "join_one_pass" single-pass probe
- *   "median_generic" Median / Nunique: always the general segmented-sort pass, never the LDS group-sort path
+/* Tuning / testing knobs — EVERY name the library accepts (all default to 0 = automatic unless noted; the tests and
+ * experiments/ use them to force individual code paths; tests/test_abi.py checks this list against capi.hip):
+ *  planning
+ *   "groups_hint"       expected number of groups (skips the sampled estimate)
+ *   "partitions"        force the radix fan-out P
+ *   "p_max"             lower the fan-out cap (forces the two-level path above it)
+ *   "p_target"          rounds heuristic: take several aggregate rounds only above this fan-out (default 3072)
+ *   "src_per_round"     force the number of value columns folded per aggregate round
+ *   "load_pct"          LDS table load factor in percent (default 70)
+ *  partition (scatter) pass
+ *   "scatter_staged"    1 (default) = stage columns through LDS and write contiguous per-partition runs; 0 = direct stores
+ *   "scatter_threads"   1024 (default) or 512 threads per scatter workgroup
+ *   "shared_cursors"    1 (default) = one write cursor per (partition, XCD group); 0 = private cursors per workgroup
+ *   "exact_partition"   1 = always the exact histogram + scan layout, never the sampled-capacity layout
+ *  aggregate pass
+ *   "agg_v1"            1 = never the lean persistent aggregate (aggregate2.hip); the round-1 kernel answers
+ *   "generic_aggregate" 1 = the descriptor-driven generic instantiation of the round-1 kernel
+ *   "agg_depth"         register-ring depth of the lean aggregate (2..4; default 3)
+ *   "agg_ablate"        experiments only: switch parts of the lean aggregate off (see experiments/agg2_ablate.py)
+ *   "no_runs"           1 = never the clustered-rows (RUNS) instantiation
+ *   "no_direct"         1 = never the few-groups direct path (-1 = allow it below 4 M rows too)
+ *   "no_absorb"         1 = never the hot-key absorb-and-spill pass in front of the radix path
+ *   "no_slice"          1 = never cut oversized partitions into row slices; "slice_rows" forces the slice length
+ *   "no_small"          1 = never the two-launch path for calls of <= 2 M rows; "small_chunk" rows per workgroup there
+ *   "deterministic"     1 = f64 Sum / Mean / Std / Var re-folded in ascending row order (bit-identical to the
+ *                       reference's sequential fold; about 3 x the default time)
+ *  join
+ *   "join_generic"      1 = always build the join with the general segmented sort
+ *   "join_one_pass"     1 = single-pass probe (decoupled look-back) instead of count + emit
+ *   "join_no_l2"        1 = fused join->groupby never takes the L2-region path for large build sides
+ *   "join_no_pairpart"  1 = the L2-region probe emits its pairs through one cursor instead of pre-partitioned
+ *  Median / Nunique
+ *   "median_generic"    1 = always the general segmented-sort pass, never the LDS group-sort path
  * Unknown names are rejected with PANDRS_HIP_ERR_INVALID_ARGUMENT. */
 int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *ctx, const char *name, int64_t value);
 int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
+
+/* ---- resident columns --------------------------------------------------------------------------
+ * The reference's columns are immutable Arc<[T]> buffers (src/column/int64_column.rs:10, float64_column.rs:9,
+ * string_column.rs:26) that every operator of the public frame Arc-clones into the split frame
+ * (src/optimized/dataframe/transformations.rs:524-577 aggregate, :628-694 join): nothing ever writes to them.  A shim
+ * therefore uploads a column ONCE and serves every later aggregate / join on it from HBM:
+ *   pandrs_hip_column_upload copies the host column (data + null bitmap, if any) into one device allocation owned by
+ *     the context and fills *out_device_col with the device pointers (same dtype); returns after the copy has
+ *     completed, so the host buffers may be dropped.  Use the descriptor with PANDRS_HIP_MEM_DEVICE in any entry
+ *     point, as often as wanted.
+ *   pandrs_hip_column_release frees it (waits for work in flight on the context's stream first); columns still
+ *     resident when the context is destroyed are freed with it.  Releasing a descriptor twice, or one that did not
+ *     come from column_upload on this context, is PANDRS_HIP_ERR_INVALID_ARGUMENT.
+ *   pandrs_hip_resident_bytes reports what the context currently holds (counted against
+ *     pandrs_hip_config.memory_limit).
+ * The Rust shim keys its handles by the Arc's data pointer and keeps a Weak beside each (integration/rust/
+ * hip_shim.rs `ResidentCache`): a dropped column can neither be served stale nor have its address reused while cached. */
+int32_t pandrs_hip_column_upload(pandrs_hip_ctx *ctx, const pandrs_hip_column *host_col, int64_t n_rows,
+                                 pandrs_hip_column *out_device_col);
+int32_t pandrs_hip_column_release(pandrs_hip_ctx *ctx, const pandrs_hip_column *device_col);
+int32_t pandrs_hip_resident_bytes(pandrs_hip_ctx *ctx, int64_t *out_bytes, int64_t *out_columns);
 
 /* ---- groupby-aggregate ------------------------------------------------------------------
  * Replaces OptimizedDataFrame::group_by(..)?.aggregate(..)

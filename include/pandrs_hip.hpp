@@ -175,6 +175,16 @@ inline pandrs_hip_column view(const Column &c) {
     }, c);
     return v;
 }
+// Columns uploaded once (pandrs_hip_column_upload) and shared by every copy of the frame: the stand-in for the Rust
+// shim's ResidentCache over the reference's immutable Arc<[T]> columns (src/column/int64_column.rs:10), which the
+// public frame's operators Arc-clone on every call (src/optimized/dataframe/transformations.rs:524-577, :628-694).
+struct ResidentSet {
+    std::vector<pandrs_hip_column> cols;
+    ResidentSet() = default;
+    ResidentSet(const ResidentSet &) = delete;
+    ResidentSet &operator=(const ResidentSet &) = delete;
+    ~ResidentSet() { for (auto &c : cols) (void)pandrs_hip_column_release(context(), &c); }
+};
 // group-key cell -> the string the reference's result frame holds (grouping.rs:69-98)
 inline std::string key_string(int32_t dtype, uint64_t cell, bool is_null, const char *null_string = "NULL") {
     if (is_null) return null_string;
@@ -208,8 +218,31 @@ public:
         column_indices[name] = columns.size();
         column_names.push_back(name);
         columns.push_back(std::move(column));
+        resident_.reset();                       // the device copies describe the frame as it was
         return *this;
     }
+    // Uploads every column to HBM once; group_by(..).aggregate(..), groups(), joins, gathers and the whole-column
+    // reductions of this frame AND its copies then read the device copies (PANDRS_HIP_MEM_DEVICE) instead of staging
+    // the host vectors on every call.  The columns must not be modified afterwards (the reference's are immutable).
+    OptimizedDataFrame &make_resident() {
+        auto rs = std::make_shared<detail::ResidentSet>();
+        rs->cols.reserve(columns.size());
+        for (auto &c : columns) {
+            pandrs_hip_column host = detail::view(c), dev{};
+            detail::check(pandrs_hip_column_upload(detail::context(), &host, (int64_t)detail::col_len(c), &dev));
+            rs->cols.push_back(dev);
+        }
+        resident_ = std::move(rs);
+        return *this;
+    }
+    bool is_resident() const { return resident_ != nullptr; }
+    // the column's view for a library call, and the memory space it lives in
+    pandrs_hip_column view_of(const std::string &name) const {
+        auto it = column_indices.find(name);
+        if (it == column_indices.end()) throw Error(Error::ColumnNotFound, name);
+        return resident_ ? resident_->cols[it->second] : detail::view(columns[it->second]);
+    }
+    int32_t mem_space() const { return resident_ ? PANDRS_HIP_MEM_DEVICE : PANDRS_HIP_MEM_HOST; }
     const Column &column(const std::string &name) const {
         auto it = column_indices.find(name);
         if (it == column_indices.end()) throw Error(Error::ColumnNotFound, name);
@@ -245,13 +278,14 @@ public:
 
 private:
     size_t row_count_ = 0;
+    std::shared_ptr<detail::ResidentSet> resident_;
 
     pandrs_hip_column_stats stats(const std::string &name) const {
         const Column &c = column(name);
         if (c.index() > 1) throw Error(Error::Type, "Column '" + name + "' is not a numeric type");      // aggregate.rs:57
-        pandrs_hip_column v = detail::view(c);
+        pandrs_hip_column v = view_of(name);
         pandrs_hip_column_stats st{};
-        detail::check(pandrs_hip_reduce_stats(detail::context(), PANDRS_HIP_MEM_HOST, &v, (int64_t)detail::col_len(c), &st));
+        detail::check(pandrs_hip_reduce_stats(detail::context(), mem_space(), &v, (int64_t)detail::col_len(c), &st));
         return st;
     }
     pandrs_hip_column_stats non_empty(const std::string &name) const {
@@ -284,9 +318,10 @@ private:
         if (!contains_column(left_on)) throw Error(Error::ColumnNotFound, left_on);              // :84-87
         if (!other.contains_column(right_on)) throw Error(Error::ColumnNotFound, right_on);      // :89-92
         const Column &lc = column(left_on), &rc = other.column(right_on);
-        pandrs_hip_column lv = detail::view(lc), rv = detail::view(rc);
+        const bool dev = is_resident() && other.is_resident();      // one memory space per call
+        pandrs_hip_column lv = dev ? view_of(left_on) : detail::view(lc), rv = dev ? other.view_of(right_on) : detail::view(rc);
         int64_t n = 0;      // a key-type mismatch surfaces as ColumnTypeMismatch from the library (:98-104)
-        detail::check(pandrs_hip_join_indices(detail::context(), PANDRS_HIP_MEM_HOST, &lv, (int64_t)detail::col_len(lc), &rv,
+        detail::check(pandrs_hip_join_indices(detail::context(), dev ? PANDRS_HIP_MEM_DEVICE : PANDRS_HIP_MEM_HOST, &lv, (int64_t)detail::col_len(lc), &rv,
                                               (int64_t)detail::col_len(rc), (int32_t)how, &n));
         std::vector<int64_t> li(n), ri(n);
         detail::check(pandrs_hip_join_fetch(detail::context(), PANDRS_HIP_MEM_HOST, li.data(), ri.data()));
@@ -337,16 +372,16 @@ public:
             if (!df.contains_column(std::get<0>(a))) throw Error(Error::ColumnNotFound, std::get<0>(a));       // :770-774
         std::vector<pandrs_hip_column> keys, vals;
         std::vector<std::string> val_names;
-        for (auto &k : group_by_columns) keys.push_back(detail::view(df.column(k)));
+        for (auto &k : group_by_columns) keys.push_back(df.view_of(k));
         std::vector<pandrs_hip_agg_spec> specs;
         for (auto &a : aggregations) {
             size_t vi = 0;
             while (vi < val_names.size() && val_names[vi] != std::get<0>(a)) vi++;
-            if (vi == val_names.size()) { val_names.push_back(std::get<0>(a)); vals.push_back(detail::view(df.column(std::get<0>(a)))); }
+            if (vi == val_names.size()) { val_names.push_back(std::get<0>(a)); vals.push_back(df.view_of(std::get<0>(a))); }
             specs.push_back(pandrs_hip_agg_spec{(int32_t)vi, (int32_t)std::get<1>(a)});
         }
         int64_t g = 0;
-        detail::check(pandrs_hip_groupby_agg(detail::context(), PANDRS_HIP_MEM_HOST, keys.data(), (int32_t)keys.size(), (int64_t)df.row_count(),
+        detail::check(pandrs_hip_groupby_agg(detail::context(), df.mem_space(), keys.data(), (int32_t)keys.size(), (int64_t)df.row_count(),
                                              vals.data(), (int32_t)vals.size(), specs.data(), (int32_t)specs.size(), &g));
         const size_t nk = keys.size(), na = specs.size();
         std::vector<std::vector<uint64_t>> kc(nk, std::vector<uint64_t>(g));
@@ -387,10 +422,10 @@ public:
     // the pub field `groups` (types.rs:52): HashMap<Vec<String>, Vec<usize>>, every list ascending
     std::map<std::vector<std::string>, std::vector<size_t>> groups(const char *null_string = "NULL") const {
         std::vector<pandrs_hip_column> keys;
-        for (auto &k : group_by_columns) keys.push_back(detail::view(df.column(k)));
+        for (auto &k : group_by_columns) keys.push_back(df.view_of(k));
         int64_t g = 0;
         const int64_t n = (int64_t)df.row_count();
-        detail::check(pandrs_hip_groupby_indices(detail::context(), PANDRS_HIP_MEM_HOST, keys.data(), (int32_t)keys.size(), n, &g));
+        detail::check(pandrs_hip_groupby_indices(detail::context(), df.mem_space(), keys.data(), (int32_t)keys.size(), n, &g));
         const size_t nk = keys.size();
         std::vector<std::vector<uint64_t>> kc(nk, std::vector<uint64_t>(g));
         std::vector<std::vector<uint8_t>> kn(nk, std::vector<uint8_t>(g));

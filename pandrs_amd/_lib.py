@@ -64,6 +64,9 @@ SYMBOLS = {
     "pandrs_hip_ctx_reserve": (C.c_int32, [_P, C.c_int64]),
     "pandrs_hip_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "pandrs_hip_get_timings": (C.c_int32, [_P, C.POINTER(Timings)]),
+    "pandrs_hip_column_upload": (C.c_int32, [_P, C.POINTER(Column), C.c_int64, C.POINTER(Column)]),
+    "pandrs_hip_column_release": (C.c_int32, [_P, C.POINTER(Column)]),
+    "pandrs_hip_resident_bytes": (C.c_int32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pandrs_hip_groupby_agg": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64,
                                            C.POINTER(Column), C.c_int32, C.POINTER(AggSpec), C.c_int32,
                                            C.POINTER(C.c_int64)]),

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *st = keys + T1;
     uint32_t *gsz = reinterpret_cast<uint32_t *>(st + (size_t)a.round_states * T1);
-    uint8_t *ctrl = reinterpret_cast<uint8_t *>(gsz + ((T1 + 3) & ~3u));      // [T] slot tags, 16-byte groups
+    // [T] slot tags, read as 16-byte groups (ds_read_b128): the start is rounded up to 16 bytes — in SMALL mode (T1 = T + 3)
+    // an odd 1 + round_states leaves gsz 8 bytes off (the LDS budget keeps ~90 spare bytes for this)
+    uint8_t *ctrl = smem + ((static_cast<uint32_t>(reinterpret_cast<unsigned char *>(gsz + ((T1 + 3) & ~3u)) - smem) + 15u) & ~15u);
     uint32_t *misc = reinterpret_cast<uint32_t *>(ctrl + T);
     uint32_t *queue = misc + 40 + (tid >> 6) * QCAP;
     // misc[0..16] scan scratch, [20] overflow, [21] sentinel-key-present, [22] output base

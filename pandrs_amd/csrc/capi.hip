@@ -104,6 +104,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->est_table) (void)hipFree(c->est_table);
     if (c->small_table) (void)hipFree(c->small_table);
+    for (auto &kv : c->resident) (void)hipFree(kv.second.base);      // columns the caller never released
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PANDRS_HIP_OK;
@@ -120,6 +121,56 @@ int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *c, int64_t workspace_bytes) {
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     return c->work.ensure((size_t)workspace_bytes, c->stream);
+}
+
+// ---- resident columns -------------------------------------------------------------------------------------------
+// The reference's columns are immutable Arc<[T]> (src/column/int64_column.rs:10) that every operator Arc-clones
+// (src/optimized/dataframe/transformations.rs:524-577): uploaded ONCE, a column serves every later aggregate / join
+// from HBM.  One hipMalloc per column: data, then the null bitmap on a 256-byte boundary.
+int32_t pandrs_hip_column_upload(pandrs_hip_ctx *c, const pandrs_hip_column *host, int64_t n_rows, pandrs_hip_column *out) {
+    if (!c || !host || !out || n_rows < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (host->dtype < PANDRS_HIP_I64 || host->dtype > PANDRS_HIP_CELL64) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad dtype %d", host->dtype);
+    if (!host->data && n_rows > 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null data pointer");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t db = pandrs::dtype_bytes(host->dtype, n_rows), mb = host->null_mask ? (size_t)((n_rows + 7) / 8) : 0;
+    const size_t dpad = (db + 255) & ~size_t(255);
+    const size_t total = dpad + ((mb + 255) & ~size_t(255)) + 256;     // (+256: the kernels' 16-byte tail loads stay inside)
+    if (pandrs::arena_limit() && c->resident_bytes + total > pandrs::arena_limit())
+        return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "resident columns (%zu + %zu bytes) exceed pandrs_hip_config.memory_limit (%zu)",
+                    c->resident_bytes, total, pandrs::arena_limit());
+    char *base = nullptr;
+    HIP_TRY(hipMalloc((void **)&base, total));
+    hipError_t e = db ? hipMemcpyAsync(base, host->data, db, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    if (e == hipSuccess && mb) e = hipMemcpyAsync(base + dpad, host->null_mask, mb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the host buffers may be dropped as soon as we return
+    if (e != hipSuccess) { (void)hipFree(base); return fail(PANDRS_HIP_ERR_COMPUTATION, "column upload failed: %s", hipGetErrorString(e)); }
+    c->resident[base] = pandrs_hip_ctx::Resident{base, total};
+    c->resident_bytes += total;
+    out->data = base; out->null_mask = mb ? reinterpret_cast<const uint8_t *>(base + dpad) : nullptr;
+    out->dtype = host->dtype; out->reserved = 0;
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_column_release(pandrs_hip_ctx *c, const pandrs_hip_column *col) {
+    if (!c || !col) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->resident.find(col->data);
+    if (it == c->resident.end()) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "not a column of pandrs_hip_column_upload on this context (or released twice)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));     // a call that reads the column may still be in flight
+    HIP_TRY(hipFree(it->second.base));
+    c->resident_bytes -= it->second.bytes;
+    c->resident.erase(it);
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_resident_bytes(pandrs_hip_ctx *c, int64_t *out_bytes, int64_t *out_columns) {
+    if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (out_bytes) *out_bytes = (int64_t)c->resident_bytes;
+    if (out_columns) *out_columns = (int64_t)c->resident.size();
+    return PANDRS_HIP_OK;
 }
 
 int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t value) {

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pandrs_hip.h"
@@ -201,6 +202,10 @@ struct pandrs_hip_ctx {
     uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)
     bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)
     bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
+    // resident columns (pandrs_hip_column_upload): device data pointer -> {allocation, bytes}; freed by _release / ctx_destroy
+    struct Resident { void *base; size_t bytes; };
+    std::unordered_map<const void *, Resident> resident;
+    size_t resident_bytes = 0;
     int quiet = 0;               // > 0: nested engine runs (slice / direct merges) do not record phase events
     int lds_bytes = 0;           // usable LDS per workgroup
     int n_cu = 0;

@@ -62,6 +62,27 @@ def _ptr(x):
     return x.ctypes.data
 
 
+class ResidentColumn:
+    """A column uploaded ONCE with `Context.upload_column` (pandrs_hip_column_upload): usable wherever a
+    (data, null_mask, dtype) triple is, any number of times, until `release()` / the context is closed.  The
+    reference's columns are immutable Arc<[T]> (src/column/int64_column.rs:10), so a shim can keep them in HBM
+    across aggregate / join calls (src/optimized/dataframe/transformations.rs:524-577)."""
+
+    def __init__(self, ctx, desc, n_rows):
+        self.ctx, self.desc, self.n_rows, self.dtype = ctx, desc, n_rows, desc.dtype
+
+    def release(self):
+        if self.desc is not None and getattr(self.ctx, "h", None):
+            st = self.ctx.lib.pandrs_hip_column_release(self.ctx.h, C.byref(self.desc))
+            self.desc = None
+            if st:
+                _raise(st)
+        self.desc = None
+
+    def __iter__(self):        # unpacks like a triple: (self, None, dtype)
+        return iter((self, None, self.dtype))
+
+
 class Context:
     def __init__(self, device=0):
         self.lib = L.load()
@@ -89,6 +110,15 @@ class Context:
         arr = (L.Column * max(len(cols), 1))()
         space = None
         for i, (data, mask, dt) in enumerate(cols):
+            if isinstance(data, ResidentColumn):
+                if data.desc is None or data.ctx is not self:
+                    raise ValueError("resident column released, or uploaded through another context")
+                if space not in (None, L.MEM_DEVICE):
+                    raise ValueError("columns of one call must all be host or all device")
+                space = L.MEM_DEVICE
+                keep.append(data)
+                arr[i].data, arr[i].null_mask, arr[i].dtype = data.desc.data, data.desc.null_mask, data.desc.dtype
+                continue
             if _is_torch(data):
                 sp = L.MEM_DEVICE
                 if not data.is_contiguous():
@@ -108,7 +138,7 @@ class Context:
             arr[i].data = _ptr(data)
             arr[i].null_mask = _ptr(mask)
             arr[i].dtype = int(dt)
-        if space == L.MEM_DEVICE and wait:
+        if space == L.MEM_DEVICE and wait and any(_is_torch(c[0]) for c in cols):
             self._wait_for_producer()
         return arr, (space if space is not None else L.MEM_HOST)
 
@@ -125,6 +155,32 @@ class Context:
         for i, (c, op) in enumerate(aggs):
             arr[i].col, arr[i].op = int(c), int(op)
         return arr
+
+    # -- resident columns -------------------------------------------------------------------------
+    def upload_column(self, data, mask, dtype):
+        """Host column -> HBM, once (pandrs_hip_column_upload).  -> ResidentColumn."""
+        data = np.ascontiguousarray(data, dtype=_NP_OF[dtype])
+        n = int(data.shape[0]) * (8 if dtype == L.BOOLBITS else 1)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            if dtype != L.BOOLBITS:
+                assert mask.shape[0] >= (n + 7) // 8
+        return self.upload_column_n(data, mask, dtype, n)
+
+    def upload_column_n(self, data, mask, dtype, n_rows):
+        host = L.Column(_ptr(data), _ptr(mask), int(dtype), 0)
+        dev = L.Column()
+        st = self.lib.pandrs_hip_column_upload(self.h, C.byref(host), int(n_rows), C.byref(dev))
+        if st:
+            _raise(st)
+        return ResidentColumn(self, dev, int(n_rows))
+
+    def resident_bytes(self):
+        b, n = C.c_int64(0), C.c_int64(0)
+        st = self.lib.pandrs_hip_resident_bytes(self.h, C.byref(b), C.byref(n))
+        if st:
+            _raise(st)
+        return b.value, n.value
 
     def set_option(self, name, value):
         st = self.lib.pandrs_hip_ctx_set_option(self.h, name.encode(), int(value))

@@ -283,6 +283,80 @@ static void test_random_frame_matches_the_oracle() {
     oracle_free(ok); oracle_free(on); oracle_free(oa);
 }
 
+// Resident columns: the reference's frames Arc-clone their immutable columns into every operator
+// (src/optimized/dataframe/transformations.rs:524-577, :628-694); uploaded once (make_resident), a C2-shaped frame's
+// second aggregate no longer stages anything and runs at the device-resident rate.  Results are the host path's.
+static void test_resident_frame_skips_the_staging() {
+    const size_t n = 20'000'000, g = 200'000;
+    std::vector<int64_t> keys(n);
+    std::vector<std::vector<double>> vals(4, std::vector<double>(n));
+    uint64_t x = 88172645463325252ull;
+    auto next = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (size_t i = 0; i < n; i++) {
+        keys[i] = (int64_t)((next() % g) * 0x9E3779B97F4A7C15ull);
+        for (auto &v : vals) v[i] = (double)(next() % 2000001) / 1000.0 - 1000.0;
+    }
+    OptimizedDataFrame df;
+    df.add_column("k", Int64Column(keys));
+    const char *names[4] = {"a", "b", "c", "d"};
+    for (int c = 0; c < 4; c++) df.add_column(names[c], Float64Column(vals[c]));
+    std::vector<GroupBy::Aggregation> req;
+    for (int c = 0; c < 4; c++)
+        for (auto op : {AggregateOp::Sum, AggregateOp::Mean, AggregateOp::Min, AggregateOp::Max})
+            req.emplace_back(names[c], op, std::string(names[c]) + "_" + std::to_string((int)op));
+    auto timings = [] { pandrs_hip_timings t{}; detail::check(pandrs_hip_get_timings(detail::context(), &t)); return t; };
+    auto host = df.group_by({"k"}).aggregate(req);
+    host = df.group_by({"k"}).aggregate(req);                 // steady state (arenas sized)
+    const pandrs_hip_timings th = timings();
+    CHECK(th.phase_ms[PANDRS_HIP_PHASE_STAGE_IN] > 0.0);
+    OptimizedDataFrame copy = df;                             // a copy made BEFORE the upload stays on the host path
+    df.make_resident();
+    OptimizedDataFrame shared = df;                           // copies made after it share the device columns
+    CHECK(df.is_resident() && shared.is_resident() && !copy.is_resident());
+    int64_t rb = 0, rc = 0;
+    detail::check(pandrs_hip_resident_bytes(detail::context(), &rb, &rc));
+    CHECK(rc == 5 && rb >= (int64_t)(n * 40));
+    auto dev = shared.group_by({"k"}).aggregate(req);
+    dev = shared.group_by({"k"}).aggregate(req);
+    const pandrs_hip_timings td = timings();
+    CHECK(td.phase_ms[PANDRS_HIP_PHASE_STAGE_IN] == 0.0);
+    const double compute_host = th.total_ms - th.phase_ms[PANDRS_HIP_PHASE_STAGE_IN];
+    std::printf("    20 M rows x 5 columns: host call %.2f ms (staging %.2f), resident call %.2f ms\n", th.total_ms, th.phase_ms[PANDRS_HIP_PHASE_STAGE_IN], td.total_ms);
+    CHECK(td.total_ms <= 1.2 * compute_host + 0.05);
+    CHECK(td.total_ms * 3 < th.total_ms);
+    CHECK(dev.row_count() == g && host.row_count() == g);
+    for (auto &a : req) {                                     // same numbers as the host path (group order may differ)
+        auto mh = by_key(host, "k", std::get<2>(a)), md = by_key(dev, "k", std::get<2>(a));
+        size_t bad = 0;
+        for (auto &kv : mh) {
+            const double w = kv.second, got = md[kv.first];
+            const bool exact = std::get<1>(a) == AggregateOp::Min || std::get<1>(a) == AggregateOp::Max;
+            if (exact ? got != w : std::fabs(got - w) > 1e-9 * std::max(1.0, std::fabs(w))) bad++;
+        }
+        CHECK(bad == 0);
+    }
+    CHECK(std::fabs(shared.sum("a") - copy.sum("a")) <= 1e-9 * std::fabs(copy.sum("a")));     // K1 on the resident column
+    // a join between two resident frames
+    OptimizedDataFrame right;
+    std::vector<int64_t> rk(1000);
+    for (size_t i = 0; i < rk.size(); i++) rk[i] = (int64_t)(i * 0x9E3779B97F4A7C15ull);
+    right.add_column("k", Int64Column(rk));
+    right.add_column("w", Int64Column(std::vector<int64_t>(rk.size(), 7)));
+    auto jh = copy.inner_join(right, "k", "k");
+    right.make_resident();
+    auto jd = shared.inner_join(right, "k", "k");
+    CHECK(jh.row_count() == jd.row_count() && jd.row_count() > 0);
+    CHECK(std::get<Int64Column>(jh.column("k")).data == std::get<Int64Column>(jd.column("k")).data);
+    CHECK(std::get<Float64Column>(jh.column("a")).data == std::get<Float64Column>(jd.column("a")).data);
+    // adding a column invalidates the device copies of THAT frame object only; dropping every sharer frees them
+    df.add_column("e", Float64Column(vals[0]));
+    CHECK(!df.is_resident() && shared.is_resident());
+    shared = OptimizedDataFrame();
+    right = OptimizedDataFrame();
+    detail::check(pandrs_hip_resident_bytes(detail::context(), &rb, &rc));
+    CHECK(rc == 0 && rb == 0);
+}
+
 int main() {
     int32_t n_dev = 0;
     if (pandrs_hip_init(nullptr) != PANDRS_HIP_OK || pandrs_hip_device_count(&n_dev) != PANDRS_HIP_OK || n_dev == 0) {
@@ -301,6 +375,7 @@ int main() {
     RUN(test_key_strings_and_errors);
     RUN(test_concurrent_callers_share_one_frame);
     RUN(test_random_frame_matches_the_oracle);
+    RUN(test_resident_frame_skips_the_staging);
     std::printf("%d tests, %d failed checks\n", g_run, g_failed);
     return g_failed ? 2 : 0;
 }
