@@ -161,7 +161,7 @@ def test_every_reference_member_the_shim_touches_exists():
     used = set(re.findall(r"(?<![.\d])\.([A-Za-z_]\w*)\b", code)) - _STD_MEMBERS - own
     missing = sorted(n for n in used if n not in declared)
     assert not missing, "hip_shim.rs uses members the reference does not declare: %s" % missing
-    for needed in ("indices", "optimization_mode", "columns", "column_indices", "filter_by_indices", "memory_limit"):
+    for needed in ("indices", "optimization_mode", "columns", "column_indices", "filter_by_indices"):
         assert needed in used, needed
     # crate paths: modules re-export what the shim imports
     for path, src, pat in [
