@@ -138,7 +138,7 @@ class Context:
             arr[i].data = _ptr(data)
             arr[i].null_mask = _ptr(mask)
             arr[i].dtype = int(dt)
-        if space == L.MEM_DEVICE and wait and any(_is_torch(c[0]) for c in cols):
+        if space == L.MEM_DEVICE and wait and any(_is_torch(next(iter(c))) for c in cols):
             self._wait_for_producer()
         return arr, (space if space is not None else L.MEM_HOST)
 
@@ -181,6 +181,11 @@ class Context:
         if st:
             _raise(st)
         return b.value, n.value
+
+    def synchronize(self):
+        st = self.lib.pandrs_hip_ctx_synchronize(self.h)
+        if st:
+            _raise(st)
 
     def set_option(self, name, value):
         st = self.lib.pandrs_hip_ctx_set_option(self.h, name.encode(), int(value))

@@ -55,3 +55,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.lower(), "%s mentions the oracle" % os.path.join(dirpath, f)
+
+
+def test_every_set_option_name_is_documented_in_the_header():
+    """pandrs_hip.h documented a third of the option names the tests use.  The header's list and the
+    strcmp chain of pandrs_hip_ctx_set_option must name the same options."""
+    import re
+    capi = open(os.path.join(ROOT, "pandrs_amd", "csrc", "capi.hip")).read()
+    body = capi[capi.index("int32_t pandrs_hip_ctx_set_option("):]
+    body = body[:body.index("return PANDRS_HIP_OK;")]
+    accepted = set(re.findall(r'std::strcmp\(name, "(\w+)"\)', body))
+    header = open(os.path.join(ROOT, "include", "pandrs_hip.h")).read()
+    doc = header[header.index("Tuning / testing knobs"):header.index("int32_t pandrs_hip_ctx_set_option(")]
+    documented = set(re.findall(r'"(\w+)"', doc))
+    assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
