@@ -38,16 +38,18 @@ def make_shard(torch, n_rows, n_groups, n_cols, seed, device):
 
 def pmc_traffic(n, g, ncol):
     """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/): counters cannot be read
-    from inside the process, so the corrected per-launch figure is loaded when it was collected on
-    this exact workload; otherwise null."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            t = json.load(f)
-        if t["config"] == {"rows": n, "groups": g, "value_cols": ncol}:
-            return t["pipeline_hbm_bytes_per_step"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    from inside the process, so the corrected per-launch figure is loaded — a STATIC number measured in a
+    separate `rocprofv3 --pmc` run of this command, not in this run — when it was collected on this exact
+    workload; otherwise null.  -> (bytes or None, source)"""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if t["config"] == {"rows": n, "groups": g, "value_cols": ncol}:
+                return t["pipeline_hbm_bytes_per_step"], "profiles/%s (static: separate rocprofv3 --pmc passes, not this run)" % name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def cpu_baseline(n_sample, n_groups, n_cols, aggs):
@@ -104,6 +106,26 @@ def cpu_baseline_typed(n_sample, n_groups, n_cols):
     dt = time.perf_counter() - t0
     return {"value": n_sample / dt / 1e6, "unit": "Mrows/s", "cores": cores, "kind": "typed-hash (not the reference's algorithm)",
             "sample": "%d rows, %d-group key space, %d f64 cols, count/sum/min/max per column, %.2f s" % (n_sample, n_groups, n_cols, dt)}
+
+
+def cpu_baseline_join(n_left, n_right):
+    """join_impl's index build in the reference's own shape — HashMap<String, Vec<usize>> over
+    the right side, one formatted String + SipHash-1-3 per probed left row (join.rs:107-224), serial like the
+    reference — on a bounded sample of the C5 shape (probe : build = 10 : 1, unique build keys, every probe row hits)."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(45)
+    mix = np.uint64(0x9E3779B97F4A7C15)
+    rk = (rng.permutation(n_right).astype(np.uint64) * mix).view(np.int64)
+    lk = (rng.integers(0, n_right, n_left).astype(np.uint64) * mix).view(np.int64)
+    O.lib()
+    t0 = time.perf_counter()
+    li, _ = O.join_indices((lk, None, O.I64), n_left, (rk, None, O.I64), n_right, O.INNER, faithful=True)
+    dt = time.perf_counter() - t0
+    assert len(li) == n_left
+    return {"value": n_left / dt / 1e6, "unit": "Mrows/s (probe rows)", "cores": 1, "kind": "port",
+            "sample": "inner join %d probe x %d build rows (unique i64 keys, every probe row matches); string-keyed HashMap "
+                      "restatement of join.rs:107-224 (oracle_join_indices_ref), serial, %.1f s" % (n_left, n_right, dt)}
 
 
 def extra_configs(torch, pa, ctx, device, steps=5):
@@ -170,6 +192,24 @@ def extra_configs(torch, pa, ctx, device, steps=5):
           lambda: ctx.join_groupby_sum((lkey, None, pa.I64), (lval, None, pa.F64), nl, (rkey, None, pa.I64), (rgrp, None, pa.I64), nr),
           bytes_alg=nl * 16 + nr * 16 + g * 16)
     del lkey, lval, rkey, rgrp
+    # join_indices (join_impl's index build, all pairs materialised in the reference's order): 50 M probe x 5 M build
+    nl, nr = 50_000_000, 5_000_000
+    rkey = torch.randperm(nr, device=device, generator=gen) * MIX
+    lkey = torch.randint(0, nr, (nl,), device=device, generator=gen, dtype=torch.int64) * MIX
+    timed("join_indices_50m_5m", nl, "inner join_indices 50M probe x 5M build (unique i64 keys, every probe row matches): (left row, right row) pairs in the reference's order",
+          lambda: ctx.join_indices_compute((lkey, None, pa.I64), nl, (rkey, None, pa.I64), nr, pa.INNER),
+          bytes_alg=nl * 8 + nr * 8 + nl * 16)
+    del lkey, rkey
+    torch.cuda.empty_cache()
+    # C4 WHOLE on one GPU (1 B rows, 10 M groups, sum + count) — one call, N < 2^32
+    n, g = 1_000_000_000, 10_000_000
+    k = torch.randint(0, g, (n,), device=device, generator=gen, dtype=torch.int64)
+    k.mul_(MIX)
+    v = torch.randn(n, device=device, generator=gen, dtype=torch.float64)
+    timed("c4_one_gpu", n, "C4 on one GPU: 1B rows, i64 key (10M groups), sum + count, one call",
+          lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.SUM), (0, pa.COUNT)]))
+    del k, v
+    torch.cuda.empty_cache()
     # C1 (the reference's own CPU-runnable case): 1 M rows, 1 K groups, one f64 sum — wall time per call, launch-bound
     n, g = 1_000_000, 1_000
     k = torch.randint(0, g, (n,), device=device, generator=gen, dtype=torch.int64)
@@ -380,7 +420,8 @@ def main():
                        "rows_per_gpu": n, "groups": g, "value_cols": ncol, "aggregates": len(aggs),
                        "parallelism": "row-range shards + 1 RCCL all-to-all of partial records inside the library (pandrs_hip_dist_groupby_agg)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(n, g, ncol) if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(n, g, ncol)[0] if world == 1 else None,
+                         "traffic_source": pmc_traffic(n, g, ncol)[1] if world == 1 else None,
                          "algorithmic_bytes": bytes_alg, "device_ms": dev_ms, "phase_ms": phases,
                          "note": "whole groupby pipeline (estimate+histogram+scan+scatter+aggregate) "
                                  "timed with hipEvents on the library stream; B = N(K+8C)+G(K+8A)"},
@@ -403,6 +444,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
             out["cpu_baseline_parallel"] = cpu_baseline_parallel(min(n, 2 * args.cpu_sample), g, ncol, aggs)
             out["cpu_baseline_typed"] = cpu_baseline_typed(min(n, 3 * args.cpu_sample), g, ncol)
+            if not args.no_extras:
+                out["cpu_baseline_join"] = cpu_baseline_join(10_000_000, 1_000_000)      # beside c5_* / join_indices_50m_5m
         emit(out)
     if dist is not None:
         dist.barrier()
@@ -483,6 +526,8 @@ def bench_join(args, torch, pa, dist, rank, local_rank, world, device):
                             "phase_ms": {p: v / k for p, v in sorted(phases.items())}}}
         if djg is not None:
             res["roofline"]["wall_ms_last_step"] = djg.last_wall_ms
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_join(10_000_000, 1_000_000)
         emit(res)
     if dist is not None:
         dist.barrier()

@@ -145,12 +145,15 @@ def groupby_agg(keys, n_rows, vals, aggs, faithful=False, pools=None, threads=1)
             _take(pa.value, (len(aggs), g), np.float64))
 
 
-def join_indices(lkey, n_left, rkey, n_right, how):
+def join_indices(lkey, n_left, rkey, n_right, how, faithful=False):
+    """faithful=True: the reference's own shape (HashMap<String, Vec<usize>> over the right side, one formatted
+    String + SipHash per probed left row, join.rs:107-224); same pairs, same order."""
     keep = []
     lc, rc_ = _cols([lkey], keep), _cols([rkey], keep)
     n = C.c_int64(0)
     pl, pr = C.c_void_p(), C.c_void_p()
-    rc = lib().oracle_join_indices(lc, C.c_int64(n_left), rc_, C.c_int64(n_right), C.c_int(how),
+    fn = lib().oracle_join_indices_ref if faithful else lib().oracle_join_indices
+    rc = fn(lc, C.c_int64(n_left), rc_, C.c_int64(n_right), C.c_int(how),
                                    C.byref(n), C.byref(pl), C.byref(pr))
     if rc:
         raise OracleError(rc)

@@ -588,6 +588,81 @@ int oracle_join_indices(const ocol *lkey, int64_t n_left, const ocol *rkey, int6
     return 0;
 }
 
+/* The same pairs in the reference's own SHAPE (join.rs:107-224): the right side goes into a
+ * HashMap<String, Vec<usize>> — per non-null row one heap String (val.to_string()), one SipHash-1-3 of its bytes
+ * (+ 0xFF, <str as Hash>), a probe and a Vec::push (:107-142) — then every non-null left row formats ITS key,
+ * hashes it and looks it up (:146-208); unmatched right rows are appended by a scan over a matched-set (:211-224,
+ * a HashSet<usize> there, a byte map here).  Serial, like the reference.  This is what bench.py times as the join's
+ * cpu_baseline; tests/test_oracle_golden.py checks it pair for pair against oracle_join_indices. */
+int oracle_join_indices_ref(const ocol *lkey, int64_t n_left, const ocol *rkey, int64_t n_right,
+                            int how, int64_t *out_n, int64_t **out_left, int64_t **out_right) {
+    *out_n = 0; *out_left = NULL; *out_right = NULL;
+    if (lkey->dtype != rkey->dtype) return PANDRS_HIP_ERR_TYPE_MISMATCH;     /* join.rs:98-104 */
+    stable t;
+    t.n_groups = 0; t.cap_groups = 1024; t.n_slots = 2048;
+    t.groups = (sgroup *)malloc(sizeof(sgroup) * (size_t)t.cap_groups);
+    t.slots = (int64_t *)malloc(sizeof(int64_t) * (size_t)t.n_slots);
+    for (int64_t i = 0; i < t.n_slots; i++) t.slots[i] = -1;
+    char buf[96];
+    for (int64_t row = 0; row < n_right; row++) {
+        if (is_null(rkey->null_mask, row)) continue;                        /* :112 `if let Ok(Some(val))` */
+        char *part = (char *)malloc(64);                                     /* val.to_string() */
+        int w = format_key_part(part, 64, rkey, row, NULL);
+        memcpy(buf, part, (size_t)w); buf[w] = (char)0xFF; free(part);
+        const size_t len = (size_t)w + 1;
+        uint64_t h = siphash13((const uint8_t *)buf, len);
+        int64_t p = (int64_t)(h & (uint64_t)(t.n_slots - 1)), g = -1;
+        while (t.slots[p] >= 0) {
+            sgroup *c = &t.groups[t.slots[p]];
+            if (c->hash == h && c->key_len == len && memcmp(c->key, buf, len) == 0) { g = t.slots[p]; break; }
+            p = (p + 1) & (t.n_slots - 1);
+        }
+        if (g < 0) {
+            if (t.n_groups == t.cap_groups) { t.cap_groups *= 2; t.groups = (sgroup *)realloc(t.groups, sizeof(sgroup) * (size_t)t.cap_groups); }
+            g = t.n_groups++;
+            sgroup *c = &t.groups[g];
+            c->key = (char *)malloc(len); memcpy(c->key, buf, len); c->key_len = (uint32_t)len;
+            c->hash = h; c->rows = NULL; c->n = 0; c->cap = 0; c->first_row = row;
+            t.slots[p] = g;
+            if (t.n_groups * 2 > t.n_slots) stable_grow(&t);
+        }
+        sgroup *c = &t.groups[g];
+        if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 4; c->rows = (int64_t *)realloc(c->rows, sizeof(int64_t) * (size_t)c->cap); }
+        c->rows[c->n++] = row;
+    }
+    int64_t cap = n_left + n_right + 16, n = 0;
+    int64_t *ol = (int64_t *)malloc(8 * (size_t)cap), *orr = (int64_t *)malloc(8 * (size_t)cap);
+    uint8_t *matched = (uint8_t *)calloc((size_t)(n_right ? n_right : 1), 1);
+#define PUSH(L, R) do { if (n == cap) { cap *= 2; ol = (int64_t *)realloc(ol, 8 * (size_t)cap); \
+        orr = (int64_t *)realloc(orr, 8 * (size_t)cap); } ol[n] = (L); orr[n] = (R); n++; } while (0)
+    for (int64_t row = 0; row < n_left; row++) {
+        if (is_null(lkey->null_mask, row)) continue;                        /* :152 */
+        char *part = (char *)malloc(64);
+        int w = format_key_part(part, 64, lkey, row, NULL);
+        memcpy(buf, part, (size_t)w); buf[w] = (char)0xFF; free(part);
+        const size_t len = (size_t)w + 1;
+        uint64_t h = siphash13((const uint8_t *)buf, len);
+        int64_t p = (int64_t)(h & (uint64_t)(t.n_slots - 1)), g = -1;
+        while (t.slots[p] >= 0) {
+            sgroup *c = &t.groups[t.slots[p]];
+            if (c->hash == h && c->key_len == len && memcmp(c->key, buf, len) == 0) { g = t.slots[p]; break; }
+            p = (p + 1) & (t.n_slots - 1);
+        }
+        if (g >= 0) {
+            const sgroup *c = &t.groups[g];
+            for (int64_t j = 0; j < c->n; j++) { PUSH(row, c->rows[j]); matched[c->rows[j]] = 1; }   /* :156-158 */
+        } else if (how == PANDRS_HIP_JOIN_LEFT || how == PANDRS_HIP_JOIN_OUTER) {
+            PUSH(row, -1);                                                   /* :159-162 */
+        }
+    }
+    if (how == PANDRS_HIP_JOIN_RIGHT || how == PANDRS_HIP_JOIN_OUTER)
+        for (int64_t i = 0; i < n_right; i++) if (!matched[i]) PUSH(-1, i);  /* :211-224 */
+#undef PUSH
+    free(matched); free_string_groups(&t);
+    *out_n = n; *out_left = ol; *out_right = orr;
+    return 0;
+}
+
 /* join.rs:296-357 gathers: None index or null source => fill */
 void oracle_gather_i64(const int64_t *src, const uint8_t *mask, const int64_t *idx, int64_t n,
                        int64_t fill, int64_t *out) {

@@ -441,7 +441,8 @@ class Context:
         return ng.value
 
     # -- join --------------------------------------------------------------------------------------------
-    def join_indices(self, lkey, n_left, rkey, n_right, how):
+    def join_indices_compute(self, lkey, n_left, rkey, n_right, how):
+        """Runs the join and keeps the pairs in the context (pandrs_hip_join_indices).  -> (n_pairs, memory space)"""
         keep = []
         lc, sp1 = self._cols([lkey], keep)
         rc, sp2 = self._cols([rkey], keep)
@@ -451,7 +452,10 @@ class Context:
         st = self.lib.pandrs_hip_join_indices(self.h, sp1, lc, int(n_left), rc, int(n_right), int(how), C.byref(n))
         if st:
             _raise(st)
-        n = n.value
+        return n.value, sp1
+
+    def join_indices(self, lkey, n_left, rkey, n_right, how):
+        n, sp1 = self.join_indices_compute(lkey, n_left, rkey, n_right, how)
         if sp1 == L.MEM_DEVICE:
             import torch
             d = "cuda:%d" % self.device

@@ -1014,6 +1014,55 @@ def test_config4_shard_full_size_properties_and_scaled_oracle():
         c.close()
 
 
+
+def test_config4_full_size_on_one_gpu():
+    """BASELINE C4 WHOLE (1 B rows, sparse i64 key, 10 M groups, sum + count) on one MI355X: 16 GB of input fits the
+    288 GB several times over.  Once through ONE call (N < 2^32) and once through groupby_agg_chunked (4 x 250 M rows:
+    partial states per chunk + one merge), both checked through size-independent properties and against each other."""
+    import torch
+    import pandrs_amd as pa
+    n, g, d = 1_000_000_000, 10_000_000, "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(48)
+    ids = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64)
+    keys = ids * -7046029254386353131 ^ 0x5555AAAA5555AAAA
+    v = torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100
+    c = pa.Context(0)
+    try:
+        aggs = [(0, O.SUM), (0, O.COUNT)]
+        ng = c.groupby_compute([(keys, None, O.I64)], n, [(v, None, O.F64)], aggs)
+        t = c.timings()
+        print("C4 on one GPU: %.2f ms, %d partitions, %d groups" % (t["total_ms"], t["n_partitions"], ng))
+        kc, kn, oa = c.groupby_fetch()
+        assert ng == g                                   # 100 rows per group on average: every id is drawn
+        assert torch.unique(kc[0]).numel() == ng and int(kn.sum()) == 0
+        assert float(oa[1].sum()) == n
+        tot = float(v.sum())
+        assert abs(float(oa[0].sum()) - tot) <= 1e-9 * abs(tot)
+        # a handful of groups against a direct masked reduction over the 1 B rows
+        order = torch.argsort(kc[0])
+        skeys, ssum, scnt = kc[0][order], oa[0][order], oa[1][order]
+        for gid in (0, 1, 4_999_999, 9_999_999, 1234567):
+            key = gid * -7046029254386353131 ^ 0x5555AAAA5555AAAA
+            key = (key + 2**63) % 2**64 - 2**63
+            m = ids == gid
+            want_n, want_s = int(m.sum()), float(v[m].sum())
+            pos = int(torch.searchsorted(skeys, torch.tensor([key], device=d, dtype=torch.int64))[0])
+            assert int(skeys[pos]) == key and float(scnt[pos]) == want_n
+            assert abs(float(ssum[pos]) - want_s) <= 1e-9 * max(1.0, abs(want_s))
+        del ids, m, kc, kn, oa, order
+        torch.cuda.empty_cache()
+        kc2, kn2, oa2 = c.groupby_agg_chunked([(keys, None, O.I64)], n, [(v, None, O.F64)], aggs, 250_000_000)
+        assert kc2.shape[1] == g and int(kn2.sum()) == 0
+        order2 = torch.argsort(kc2[0])
+        assert torch.equal(kc2[0][order2], skeys)
+        assert torch.equal(oa2[1][order2], scnt)                                   # counts exact
+        rel = ((oa2[0][order2] - ssum).abs() / ssum.abs().clamp_min(1.0)).max()
+        assert float(rel) <= 1e-9
+    finally:
+        c.close()
+
+
 # ---- K1: the three reference families from one device pass (pandrs_hip_reduce_stats) -----------------------
 def _k1_check(ctx, col, n):
     st = ctx.column_stats(col, n)

@@ -256,6 +256,28 @@ def test_join_random_vs_twin():
         assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
 
 
+def test_join_faithful_string_keyed_shape_gives_the_same_pairs(golden):
+    """oracle_join_indices_ref (HashMap<String, Vec<usize>> build + per-row formatted probe, join.rs:107-224) — the shape
+    bench.py times as the join's cpu_baseline — pair for pair against the typed restatement and the reference's vectors."""
+    rng = np.random.default_rng(11)
+    cases = [((rng.integers(0, 50, 400).astype(np.int64), O.pack_mask(rng.random(400) < 0.05), O.I64),
+              (rng.integers(0, 60, 300).astype(np.int64), O.pack_mask(rng.random(300) < 0.05), O.I64)),
+             ((rng.integers(-3, 4, 500).astype(np.float64) / 2, None, O.F64), (np.array([0.0, -0.0, 0.5, np.nan, -1.5, 0.5]), None, O.F64)),
+             ((np.array([np.nan, 0.5, np.nan]), None, O.F64), (np.array([np.nan, 2.0]), None, O.F64)),
+             ((rng.integers(0, 9, 200).astype(np.uint32), None, O.U32CODE), (rng.integers(0, 12, 50).astype(np.uint32), O.pack_mask(rng.random(50) < 0.1), O.U32CODE)),
+             ((np.zeros(0, np.int64), None, O.I64), (np.arange(4, dtype=np.int64), None, O.I64))]
+    for lk, rk in cases:
+        for how in (O.INNER, O.LEFT, O.RIGHT, O.OUTER):
+            a = O.join_indices(lk, len(lk[0]), rk, len(rk[0]), how)
+            b = O.join_indices(lk, len(lk[0]), rk, len(rk[0]), how, faithful=True)
+            assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist(), how
+    case = golden["join_optimized"]          # tests/optimized_join_test.rs:6-164: ids [1,2,3,4] x [1,2,5,6]
+    lk = (np.array(case["left_ids"], np.int64), None, O.I64)
+    rk = (np.array(case["right_ids"], np.int64), None, O.I64)
+    for how, rows in ((O.INNER, case["rows"]["inner"]), (O.LEFT, case["rows"]["left"]), (O.RIGHT, case["rows"]["right"]), (O.OUTER, case["rows"]["outer"])):
+        assert len(O.join_indices(lk, 4, rk, 4, how, faithful=True)[0]) == rows
+
+
 def test_fused_join_groupby_matches_composition():
     rng = np.random.default_rng(5)
     nb, npb = 200, 2000
