@@ -174,6 +174,9 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *ctx);
 int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *ctx);
 /* Pre-size the workspace arena (bytes) so the first timed call does not pay hipMalloc. */
 int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *ctx, int64_t workspace_bytes);
+/* Number of device allocations (hipMalloc) the library has made in this process: workspace arenas grow but never
+ * shrink, so a repeated call of the same shape adds none — tests assert that on the steady state. */
+int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
 /* Tuning / testing knobs — EVERY name the library accepts (all default to 0 = automatic unless noted; the tests and
  * experiments/ use them to force individual code paths; tests/test_abi.py checks this list against capi.hip):
  *  planning
@@ -425,12 +428,29 @@ typedef struct pandrs_hip_comm pandrs_hip_comm;
 int32_t pandrs_hip_comm_unique_id(char out_id[128]);
 int32_t pandrs_hip_comm_init(pandrs_hip_ctx *ctx, const char id[128], int32_t rank, int32_t world, pandrs_hip_comm **out_comm);
 int32_t pandrs_hip_comm_adopt(void *nccl_comm, int32_t rank, int32_t world, pandrs_hip_comm **out_comm);
+/* Any other fabric (and the multi-rank tests on one GPU): the collectives the exchange needs, as host callbacks over
+ * HOST buffers — the library stages its device buffers through them.  Every callback returns 0 on success and is
+ * called by every rank in the same order:
+ *   all_gather          every rank contributes `bytes` bytes; recv holds world * bytes, rank-major
+ *   all_reduce_max_i64  element-wise maximum over the ranks of n int64 values, in place
+ *   all_to_all_v        send_bytes[p] bytes at send + send_off[p] go to rank p; recv_bytes[p] bytes from rank p land at
+ *                       recv + recv_off[p] (the counts were agreed by an all_gather before) */
+typedef struct pandrs_hip_transport {
+    void *user;
+    int32_t (*all_gather)(void *user, const void *send, void *recv, int64_t bytes);
+    int32_t (*all_reduce_max_i64)(void *user, int64_t *vals, int32_t n);
+    int32_t (*all_to_all_v)(void *user, const void *send, const int64_t *send_bytes, const int64_t *send_off,
+                            void *recv, const int64_t *recv_bytes, const int64_t *recv_off);
+} pandrs_hip_transport;
+int32_t pandrs_hip_comm_adopt_transport(const pandrs_hip_transport *transport, int32_t rank, int32_t world, pandrs_hip_comm **out_comm);
 int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *comm);
 
 /* Row-range-sharded group_by(..).aggregate(..) (aggregation.rs:763) over all ranks' rows: local partial states ->
  * owner split -> count exchange -> ONE grouped ncclSend / ncclRecv all-to-all of packed records on the context's
  * stream -> merge.  The result (fetch with groupby_fetch) holds the groups this rank owns; the ranks' key sets are
- * disjoint.  Sum / Mean / Min / Max / Count, one key column; null-mask presence may differ between ranks. */
+ * disjoint.  Sum / Mean / Min / Max / Count, one key column; null-mask presence may differ between ranks.  A rank whose
+ * local phase fails still joins the count exchange with its status: EVERY rank then returns an error (nobody is left
+ * blocked in a collective).  The exchange buffers live in the communicator and are only ever grown. */
 int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, int32_t mem_space,
                                     const pandrs_hip_column *keys, int32_t n_keys, int64_t n_rows,
                                     const pandrs_hip_column *vals, int32_t n_vals,

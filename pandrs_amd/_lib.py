@@ -50,6 +50,18 @@ class Timings(C.Structure):
                 ("table_slots", C.c_int64), ("retries", C.c_int64), ("estimated_groups", C.c_int64)]
 
 
+# pandrs_hip_transport: the exchange's collectives as host callbacks (pandrs_hip_comm_adopt_transport)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+ALL_REDUCE_MAX_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_int32)
+ALL_TO_ALL_V_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                              C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_reduce_max_i64", ALL_REDUCE_MAX_FN),
+                ("all_to_all_v", ALL_TO_ALL_V_FN)]
+
+
 # every symbol include/pandrs_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -62,6 +74,7 @@ SYMBOLS = {
     "pandrs_hip_ctx_destroy": (C.c_int32, [_P]),
     "pandrs_hip_ctx_synchronize": (C.c_int32, [_P]),
     "pandrs_hip_ctx_reserve": (C.c_int32, [_P, C.c_int64]),
+    "pandrs_hip_alloc_events": (C.c_int32, [C.POINTER(C.c_int64)]),
     "pandrs_hip_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "pandrs_hip_get_timings": (C.c_int32, [_P, C.POINTER(Timings)]),
     "pandrs_hip_column_upload": (C.c_int32, [_P, C.POINTER(Column), C.c_int64, C.POINTER(Column)]),
@@ -104,6 +117,7 @@ SYMBOLS = {
     "pandrs_hip_comm_unique_id": (C.c_int32, [C.c_char_p]),
     "pandrs_hip_comm_init": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "pandrs_hip_comm_adopt": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "pandrs_hip_comm_adopt_transport": (C.c_int32, [C.POINTER(Transport), C.c_int32, C.c_int32, C.POINTER(_P)]),
     "pandrs_hip_comm_destroy": (C.c_int32, [_P]),
     "pandrs_hip_dist_groupby_agg": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64,
                                                 C.POINTER(Column), C.c_int32, C.POINTER(AggSpec), C.c_int32,

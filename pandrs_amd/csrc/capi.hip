@@ -141,6 +141,7 @@ int32_t pandrs_hip_column_upload(pandrs_hip_ctx *c, const pandrs_hip_column *hos
                     c->resident_bytes, total, pandrs::arena_limit());
     char *base = nullptr;
     HIP_TRY(hipMalloc((void **)&base, total));
+    pandrs::alloc_events()++;
     hipError_t e = db ? hipMemcpyAsync(base, host->data, db, hipMemcpyHostToDevice, c->stream) : hipSuccess;
     if (e == hipSuccess && mb) e = hipMemcpyAsync(base + dpad, host->null_mask, mb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the host buffers may be dropped as soon as we return
@@ -162,6 +163,12 @@ int32_t pandrs_hip_column_release(pandrs_hip_ctx *c, const pandrs_hip_column *co
     HIP_TRY(hipFree(it->second.base));
     c->resident_bytes -= it->second.bytes;
     c->resident.erase(it);
+    return PANDRS_HIP_OK;
+}
+
+int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations) {
+    if (!out_device_allocations) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null output");
+    *out_device_allocations = pandrs::alloc_events().load();
     return PANDRS_HIP_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -62,6 +63,13 @@ inline int32_t below_threshold(int64_t n_rows) {
     return 0;
 }
 
+// device allocations made by the library since it was loaded (arena growths, resident columns, one-off tables):
+// a steady-state call makes none — pandrs_hip_alloc_events lets tests assert it
+inline std::atomic<int64_t> &alloc_events() {
+    static std::atomic<int64_t> n{0};
+    return n;
+}
+
 // ---- bump arena over one hipMalloc block -------------------------------------------------------
 // Sized for 288 GB of HBM: one big block per purpose, grown (never shrunk) between calls, so the
 // steady state performs no hipMalloc/hipFree inside a timed call.
@@ -83,6 +91,7 @@ struct Arena {
             return ::pandrs::fail(PANDRS_HIP_ERR_OUT_OF_MEMORY,
                                   "workspace of %zu bytes exceeds pandrs_hip_config.memory_limit (%zu)", want, arena_limit());
         HIP_TRY(hipMalloc((void **)&base, want));
+        alloc_events()++;
         cap = want;
         return 0;
     }

@@ -75,18 +75,29 @@ int32_t export_result_columns(pandrs_hip_ctx *c, uint64_t *cells, uint8_t *nulls
 }  // namespace pandrs
 
 struct pandrs_hip_comm {
-    void *nccl = nullptr;
+    void *nccl = nullptr;                    // RCCL transport (the default)
+    pandrs_hip_transport host{};             // host-callback transport (pandrs_hip_comm_adopt_transport); used when nccl == nullptr
     int rank = 0, world = 1;
     bool owned = false;
-    pandrs::Arena send, recv, small;         // exchange buffers: grown, never shrunk
-    std::vector<int64_t> counts;             // world x world matrix of the last count exchange
+    // exchange buffers: grown, never shrunk, never released between calls (no hipMalloc in a steady-state step).
+    // send / recv: packed records; small: counts and flags; zeros: an all-valid null bitmap (written once per growth);
+    // stage: the join's exported (g, sum) columns, which must outlive the nested groupby exchange
+    pandrs::Arena send, recv, small, zeros, stage;
+    size_t zeros_valid = 0;                  // bytes of `zeros` known to be zero
+    std::vector<int64_t> counts;             // world x (world + 1) matrix of the last count exchange (last column: status)
+    std::vector<uint8_t> hsend, hrecv;       // host staging of the callback transport
 };
 
 namespace pandrs {
 
+// ---- the collectives, behind one small table: RCCL on device buffers (default), or host callbacks (tests, other fabrics)
 // all-reduce (max) of a few host integers: layout agreement before planning (a rank-local decision such as "this
 // column has a null mask" must not change the partial-record width on one rank only)
 static int32_t agree_max(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t *vals, int n) {
+    if (!cm->nccl) {
+        const int32_t st = cm->host.all_reduce_max_i64(cm->host.user, vals, n);
+        return st ? fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_reduce_max_i64 failed (%d)", st) : 0;
+    }
     ST_TRY(cm->small.ensure(4096 + (size_t)n * 16, c->stream));
     int64_t *d = cm->small.take<int64_t>(n);
     HIP_TRY(hipMemcpyAsync(d, vals, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
@@ -96,52 +107,103 @@ static int32_t agree_max(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t *vals, 
     return 0;
 }
 
+// all-gather of `bytes` bytes per rank between DEVICE buffers (recv: world * bytes, rank-major), stream-ordered
+static int32_t all_gather_dev(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const void *send, void *recv, size_t bytes) {
+    if (cm->nccl) {
+        if (bytes % 8 == 0) RCCL_TRY(rccl().AllGather(send, recv, bytes / 8, RCCL_INT64, cm->nccl, c->stream));
+        else RCCL_TRY(rccl().AllGather(send, recv, bytes, RCCL_INT8, cm->nccl, c->stream));
+        return 0;
+    }
+    cm->hsend.resize(bytes + 8); cm->hrecv.resize(bytes * (size_t)cm->world + 8);
+    HIP_TRY(hipMemcpyAsync(cm->hsend.data(), send, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int32_t st = cm->host.all_gather(cm->host.user, cm->hsend.data(), cm->hrecv.data(), (int64_t)bytes);
+    if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_gather failed (%d)", st);
+    HIP_TRY(hipMemcpyAsync(recv, cm->hrecv.data(), bytes * (size_t)cm->world, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));            // hrecv is reused by the next collective
+    return 0;
+}
+
 // The exchange proper.  `send`: device records, rank-contiguous by owner, `send_counts[p]` records of W words for rank p.
+// `local_status`: this rank's status so far; it rides on the count exchange, and when ANY rank reports a failure every
+// rank returns an error together instead of leaving its peers blocked in the all-to-all.
 // -> *out_recv (device, cm->recv arena), *out_n_recv.
 static int32_t exchange_records(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const uint64_t *send, const int64_t *send_counts,
-                                size_t W, uint64_t **out_recv, int64_t *out_n_recv) {
-    const int world = cm->world, me = cm->rank;
-    // 1. counts: every rank learns the whole world x world matrix with one all-gather
-    ST_TRY(cm->small.ensure(4096 + (size_t)world * (size_t)world * 8 + (size_t)world * 8, c->stream));
-    int64_t *d_mine = cm->small.take<int64_t>(world);
-    int64_t *d_all = cm->small.take<int64_t>((size_t)world * world);
-    HIP_TRY(hipMemcpyAsync(d_mine, send_counts, (size_t)world * 8, hipMemcpyHostToDevice, c->stream));
-    RCCL_TRY(rccl().AllGather(d_mine, d_all, (size_t)world, RCCL_INT64, cm->nccl, c->stream));
-    cm->counts.assign((size_t)world * world, 0);
-    HIP_TRY(hipMemcpyAsync(cm->counts.data(), d_all, (size_t)world * world * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+                                size_t W, int32_t local_status, uint64_t **out_recv, int64_t *out_n_recv) {
+    const int world = cm->world, me = cm->rank, row = world + 1;
+    // 1. counts (+ status): every rank learns the whole world x (world + 1) matrix with one all-gather
+    std::vector<int64_t> mine((size_t)row, 0);
+    for (int p = 0; p < world; p++) mine[p] = local_status ? 0 : send_counts[p];
+    mine[world] = local_status;
+    cm->counts.assign((size_t)world * row, 0);
+    if (cm->nccl) {
+        ST_TRY(cm->small.ensure(4096 + (size_t)world * row * 8 + (size_t)row * 8, c->stream));
+        int64_t *d_mine = cm->small.take<int64_t>(row);
+        int64_t *d_all = cm->small.take<int64_t>((size_t)world * row);
+        HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), (size_t)row * 8, hipMemcpyHostToDevice, c->stream));
+        RCCL_TRY(rccl().AllGather(d_mine, d_all, (size_t)row, RCCL_INT64, cm->nccl, c->stream));
+        HIP_TRY(hipMemcpyAsync(cm->counts.data(), d_all, (size_t)world * row * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        const int32_t st = cm->host.all_gather(cm->host.user, mine.data(), cm->counts.data(), (int64_t)row * 8);
+        if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_gather failed (%d)", st);
+    }
+    for (int r = 0; r < world; r++)
+        if (cm->counts[(size_t)r * row + world] != 0) {
+            if (r == me && local_status) return local_status;           // this rank's own error text is already set
+            return fail(PANDRS_HIP_ERR_COMPUTATION, "rank %d failed in its local phase (status %lld): the exchange is abandoned on every rank",
+                        r, (long long)cm->counts[(size_t)r * row + world]);
+        }
     int64_t n_recv = 0;
     for (int r = 0; r < world; r++) {
-        const int64_t v = cm->counts[(size_t)r * world + me];          // what rank r sends to this rank
+        const int64_t v = cm->counts[(size_t)r * row + me];          // what rank r sends to this rank
         if (v < 0) return fail(PANDRS_HIP_ERR_COMPUTATION, "negative record count from rank %d", r);
         n_recv += v;
     }
     for (int p = 0; p < world; p++)
-        if (cm->counts[(size_t)me * world + p] != send_counts[p])
+        if (cm->counts[(size_t)me * row + p] != send_counts[p])
             return fail(PANDRS_HIP_ERR_COMPUTATION, "count exchange returned a different row for this rank");
     // 2. ONE grouped all-to-all of the packed records (every xGMI link busy at once; no ring)
     ST_TRY(cm->recv.ensure((size_t)std::max<int64_t>(n_recv, 1) * W * 8 + 4096, c->stream));
     uint64_t *recv = cm->recv.take<uint64_t>((size_t)std::max<int64_t>(n_recv, 1) * W);
     if (!recv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small");
-    RCCL_TRY(rccl().GroupStart());
-    int64_t soff = 0, roff = 0;
-    int rc = 0;
-    for (int p = 0; p < world && rc == 0; p++) {
-        const int64_t ns = send_counts[p], nr = cm->counts[(size_t)p * world + me];
-        if (ns > 0) rc = rccl().Send(send + (size_t)soff * W, (size_t)ns * W, RCCL_INT64, p, cm->nccl, c->stream);
-        if (nr > 0 && rc == 0) rc = rccl().Recv(recv + (size_t)roff * W, (size_t)nr * W, RCCL_INT64, p, cm->nccl, c->stream);
-        soff += ns; roff += nr;
+    if (cm->nccl) {
+        RCCL_TRY(rccl().GroupStart());
+        int64_t soff = 0, roff = 0;
+        int rc = 0;
+        for (int p = 0; p < world && rc == 0; p++) {
+            const int64_t ns = send_counts[p], nr = cm->counts[(size_t)p * row + me];
+            if (ns > 0) rc = rccl().Send(send + (size_t)soff * W, (size_t)ns * W, RCCL_INT64, p, cm->nccl, c->stream);
+            if (nr > 0 && rc == 0) rc = rccl().Recv(recv + (size_t)roff * W, (size_t)nr * W, RCCL_INT64, p, cm->nccl, c->stream);
+            soff += ns; roff += nr;
+        }
+        const int rc_end = rccl().GroupEnd();
+        if (rc != 0) return fail(PANDRS_HIP_ERR_COMPUTATION, "ncclSend / ncclRecv failed: %s", rccl().GetErrorString(rc));
+        RCCL_TRY(rc_end);
+    } else {
+        std::vector<int64_t> sb((size_t)world), so((size_t)world), rb((size_t)world), ro((size_t)world);
+        int64_t soff = 0, roff = 0;
+        for (int p = 0; p < world; p++) {
+            sb[p] = send_counts[p] * (int64_t)W * 8; so[p] = soff; soff += sb[p];
+            rb[p] = cm->counts[(size_t)p * row + me] * (int64_t)W * 8; ro[p] = roff; roff += rb[p];
+        }
+        cm->hsend.resize((size_t)soff + 8); cm->hrecv.resize((size_t)roff + 8);
+        if (soff) HIP_TRY(hipMemcpyAsync(cm->hsend.data(), send, (size_t)soff, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int32_t st = cm->host.all_to_all_v(cm->host.user, cm->hsend.data(), sb.data(), so.data(), cm->hrecv.data(), rb.data(), ro.data());
+        if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_to_all_v failed (%d)", st);
+        if (roff) HIP_TRY(hipMemcpyAsync(recv, cm->hrecv.data(), (size_t)roff, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    const int rc_end = rccl().GroupEnd();
-    if (rc != 0) return fail(PANDRS_HIP_ERR_COMPUTATION, "ncclSend / ncclRecv failed: %s", rccl().GetErrorString(rc));
-    RCCL_TRY(rc_end);
     *out_recv = recv; *out_n_recv = n_recv;
     return 0;
 }
 
+// `prior_status`: a failure of the caller's local phase (the join's fused pass): this rank still takes part in every
+// collective below, contributes nothing, and all ranks return an error together.
 static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t mem_space, const pandrs_hip_column *key,
                                  int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals, const pandrs_hip_agg_spec *aggs,
-                                 int32_t n_aggs, int64_t *out_n_groups) {
+                                 int32_t n_aggs, int64_t *out_n_groups, int32_t prior_status = 0) {
     if (n_vals > 64) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: more than 64 value columns");
     for (int a = 0; a < n_aggs; a++)
         if (aggs[a].op > PANDRS_HIP_AGG_COUNT)
@@ -149,47 +211,55 @@ static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t
                                                          "(the row shuffle for the rest is pandrs_hip_shuffle_split + the host's all-to-all)");
     // 0. one layout on every rank: a value column has an nn state iff SOME rank passes a null mask for it
     int64_t flags[65] = {0};
-    for (int i = 0; i < n_vals; i++) flags[i] = vals[i].null_mask ? 1 : 0;
+    for (int i = 0; i < n_vals; i++) flags[i] = (!prior_status && vals[i].null_mask) ? 1 : 0;
     flags[n_vals] = n_rows > 0 ? 1 : 0;
     ST_TRY(agree_max(c, cm, flags, n_vals + 1));
-    std::vector<pandrs_hip_column> v2(vals, vals + n_vals);
-    std::vector<uint8_t> has_nulls((size_t)std::max(n_vals, 1), 0);
-    std::vector<int32_t> dtypes((size_t)std::max(n_vals, 1), 0);
-    std::vector<uint8_t> zero_host;
-    uint8_t *zero_dev = nullptr;
-    for (int i = 0; i < n_vals; i++) {
-        has_nulls[i] = (uint8_t)flags[i];
-        dtypes[i] = vals[i].dtype;
-        if (flags[i] && !vals[i].null_mask) {           // another rank has nulls here: an all-valid bitmap keeps the plan identical
-            const size_t nb = (size_t)(n_rows + 7) / 8 + 8;
-            if (mem_space == PANDRS_HIP_MEM_HOST) {
-                if (zero_host.size() < nb) zero_host.assign(nb, 0);
-                v2[i].null_mask = zero_host.data();
-            } else {
-                if (!zero_dev) {
-                    ST_TRY(cm->send.ensure(nb + 4096, c->stream));      // (the send arena is re-sized below, after the local pass)
-                    HIP_TRY(hipMalloc((void **)&zero_dev, nb));
-                    HIP_TRY(hipMemsetAsync(zero_dev, 0, nb, c->stream));
-                }
-                v2[i].null_mask = zero_dev;
-            }
-        }
-    }
-    struct Free { uint8_t *p; hipStream_t s; ~Free() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } } } free_zero{zero_dev, c->stream};
-    // 1. local partial aggregation (states retained in the context)
+    int32_t status = prior_status;
     int64_t ng = 0;
     int32_t n_state = 0;
-    ST_TRY(groupby_entry(c, mem_space, key, 1, n_rows, v2.data(), n_vals, aggs, n_aggs, /*partials=*/true, &ng, &n_state));
-    const size_t W = 2 + (size_t)n_state;
-    // 2. owner split: packed records, rank-contiguous
-    ST_TRY(cm->send.ensure((size_t)std::max<int64_t>(ng, 1) * W * 8 + 4096, c->stream));
-    uint64_t *send = cm->send.take<uint64_t>((size_t)std::max<int64_t>(ng, 1) * W);
+    uint64_t *send = nullptr;
     std::vector<int64_t> send_counts((size_t)cm->world, 0);
-    ST_TRY(partials_split_entry(c, PANDRS_HIP_MEM_DEVICE, cm->world, send, send_counts.data()));
-    // 3. count exchange + ONE all-to-all
+    std::vector<uint8_t> has_nulls((size_t)std::max(n_vals, 1), 0);
+    std::vector<int32_t> dtypes((size_t)std::max(n_vals, 1), 0);
+    for (int i = 0; i < n_vals; i++) { has_nulls[i] = (uint8_t)flags[i]; dtypes[i] = vals[i].dtype; }
+    // the local phase: a failure here must not return before the count exchange (the peers are waiting in it)
+    auto local_phase = [&]() -> int32_t {
+        std::vector<pandrs_hip_column> v2(vals, vals + n_vals);
+        std::vector<uint8_t> zero_host;
+        for (int i = 0; i < n_vals; i++) {
+            if (flags[i] && !vals[i].null_mask) {           // another rank has nulls here: an all-valid bitmap keeps the plan identical
+                const size_t nb = (size_t)(n_rows + 7) / 8 + 8;
+                if (mem_space == PANDRS_HIP_MEM_HOST) {
+                    if (zero_host.size() < nb) zero_host.assign(nb, 0);
+                    v2[i].null_mask = zero_host.data();
+                } else {
+                    if (cm->zeros.cap < nb + 256 || cm->zeros_valid < nb) {       // kept in the communicator: zeroed once per growth
+                        ST_TRY(cm->zeros.ensure(nb + 256, c->stream));
+                        HIP_TRY(hipMemsetAsync(cm->zeros.base, 0, cm->zeros.cap, c->stream));
+                        cm->zeros_valid = cm->zeros.cap;
+                    }
+                    v2[i].null_mask = reinterpret_cast<const uint8_t *>(cm->zeros.base);
+                }
+            }
+        }
+        // 1. local partial aggregation (states retained in the context)
+        ST_TRY(groupby_entry(c, mem_space, key, 1, n_rows, v2.data(), n_vals, aggs, n_aggs, /*partials=*/true, &ng, &n_state));
+        // 2. owner split: packed records, rank-contiguous
+        const size_t W = 2 + (size_t)n_state;
+        ST_TRY(cm->send.ensure((size_t)std::max<int64_t>(ng, 1) * W * 8 + 4096, c->stream));
+        send = cm->send.take<uint64_t>((size_t)std::max<int64_t>(ng, 1) * W);
+        ST_TRY(partials_split_entry(c, PANDRS_HIP_MEM_DEVICE, cm->world, send, send_counts.data()));
+        return 0;
+    };
+    if (!status) status = local_phase();
+    if (status) std::fill(send_counts.begin(), send_counts.end(), 0);
+    // the record width is a function of (dtypes, agreed null flags, aggs) alone: identical on every rank, also on one whose local
+    // phase failed (it sends nothing, but it must still size what it would receive — it receives nothing either: all abort)
+    const size_t W = 2 + (size_t)n_state;
+    // 3. count exchange (+ status agreement) + ONE all-to-all
     uint64_t *recv = nullptr;
     int64_t n_recv = 0;
-    ST_TRY(exchange_records(c, cm, send, send_counts.data(), W, &recv, &n_recv));
+    ST_TRY(exchange_records(c, cm, send, send_counts.data(), W, status, &recv, &n_recv));
     // 4. merge what this rank owns (cardinality bounded by the records received: no sampling pass)
     const int64_t hint_saved = c->opt.groups_hint;
     c->opt.groups_hint = std::max<int64_t>(n_recv, 1);
@@ -237,9 +307,18 @@ int32_t pandrs_hip_comm_adopt(void *nccl_comm, int32_t rank, int32_t world, pand
     return PANDRS_HIP_OK;
 }
 
+int32_t pandrs_hip_comm_adopt_transport(const pandrs_hip_transport *t, int32_t rank, int32_t world, pandrs_hip_comm **out) {
+    if (!t || !out || world < 1 || rank < 0 || rank >= world || !t->all_gather || !t->all_reduce_max_i64 || !t->all_to_all_v)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "comm_adopt_transport: bad arguments (all three callbacks are required)");
+    auto *cm = new pandrs_hip_comm();
+    cm->host = *t; cm->rank = rank; cm->world = world; cm->owned = false;
+    *out = cm;
+    return PANDRS_HIP_OK;
+}
+
 int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *cm) {
     if (!cm) return PANDRS_HIP_OK;
-    cm->send.release(); cm->recv.release(); cm->small.release();
+    cm->send.release(); cm->recv.release(); cm->small.release(); cm->zeros.release(); cm->stage.release();
     if (cm->owned && cm->nccl) (void)pandrs::rccl().CommDestroy(cm->nccl);
     delete cm;
     return PANDRS_HIP_OK;
@@ -308,32 +387,32 @@ int32_t pandrs_hip_dist_join_groupby_sum(pandrs_hip_ctx *ctx, pandrs_hip_comm *c
         HIP_TRY(hipMemsetAsync(sgm, 0, mb, c->stream));
         if (right_group->null_mask) HIP_TRY(hipMemcpyAsync(sgm, right_group->null_mask, (size_t)(n_right + 7) / 8, hipMemcpyDeviceToDevice, c->stream));
     }
-    RCCL_TRY(rccl().AllGather(sk, ak, (size_t)n_pad, RCCL_INT64, cm->nccl, c->stream));
-    RCCL_TRY(rccl().AllGather(sg, ag, (size_t)n_pad, RCCL_INT64, cm->nccl, c->stream));
-    if (key_mask) RCCL_TRY(rccl().AllGather(skm, akm, mb, RCCL_INT8, cm->nccl, c->stream));
-    if (grp_mask) RCCL_TRY(rccl().AllGather(sgm, agm, mb, RCCL_INT8, cm->nccl, c->stream));
-    // 2. local fused join -> groupby-sum against the whole build side
+    ST_TRY(all_gather_dev(c, cm, sk, ak, (size_t)n_pad * 8));
+    ST_TRY(all_gather_dev(c, cm, sg, ag, (size_t)n_pad * 8));
+    if (key_mask) ST_TRY(all_gather_dev(c, cm, skm, akm, mb));
+    if (grp_mask) ST_TRY(all_gather_dev(c, cm, sgm, agm, mb));
+    // 2. local fused join -> groupby-sum against the whole build side.  From here to the groupby exchange's count
+    // all-gather nothing may return early: a rank-local failure travels as `status` and every rank aborts together.
     pandrs_hip_column rk{ak, key_mask ? akm : nullptr, right_key->dtype, 0}, rg{ag, grp_mask ? agm : nullptr, right_group->dtype, 0};
-    int64_t g_local = 0;
-    ST_TRY(join_groupby_sum_entry(c, PANDRS_HIP_MEM_DEVICE, left_key, left_val, n_left, &rk, &rg, n_all, &g_local));
-    // 3. the <= G local sums go through the groupby exchange, keyed on g's cell
-    ST_TRY(cm->recv.ensure((size_t)std::max<int64_t>(g_local, 1) * 17 + ((size_t)g_local + 7) / 8 + (1 << 16), c->stream));
-    uint64_t *cells = cm->recv.take<uint64_t>((size_t)std::max<int64_t>(g_local, 1));
-    double *sums = cm->recv.take<double>((size_t)std::max<int64_t>(g_local, 1));
-    uint8_t *nb = cm->recv.take<uint8_t>((size_t)std::max<int64_t>(g_local, 1)), *nbits = cm->recv.take<uint8_t>(((size_t)g_local + 7) / 8 + 16);
-    int64_t got = 0;
-    ST_TRY(export_result_columns(c, cells, nb, sums, &got));
-    ST_TRY(bytes_to_bitmap_entry(c, PANDRS_HIP_MEM_DEVICE, nb, got, nbits));
-    pandrs_hip_column gk{cells, nbits, PANDRS_HIP_CELL64, 0}, gv{sums, nullptr, PANDRS_HIP_F64, 0};
+    int64_t g_local = 0, got = 0;
+    pandrs_hip_column gk{nullptr, nullptr, PANDRS_HIP_CELL64, 0}, gv{nullptr, nullptr, PANDRS_HIP_F64, 0};
+    auto local_phase = [&]() -> int32_t {
+        ST_TRY(join_groupby_sum_entry(c, PANDRS_HIP_MEM_DEVICE, left_key, left_val, n_left, &rk, &rg, n_all, &g_local));
+        // 3. the <= G local sums go through the groupby exchange, keyed on g's cell; they live in the communicator's own
+        // `stage` arena (grown, never released): the nested exchange re-takes send / recv
+        ST_TRY(cm->stage.ensure((size_t)std::max<int64_t>(g_local, 1) * 17 + ((size_t)g_local + 7) / 8 + (1 << 16), c->stream));
+        uint64_t *cells = cm->stage.take<uint64_t>((size_t)std::max<int64_t>(g_local, 1));
+        double *sums = cm->stage.take<double>((size_t)std::max<int64_t>(g_local, 1));
+        uint8_t *nb = cm->stage.take<uint8_t>((size_t)std::max<int64_t>(g_local, 1)), *nbits = cm->stage.take<uint8_t>(((size_t)g_local + 7) / 8 + 16);
+        if (!cells || !sums || !nb || !nbits) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "stage arena too small");
+        ST_TRY(export_result_columns(c, cells, nb, sums, &got));
+        ST_TRY(bytes_to_bitmap_entry(c, PANDRS_HIP_MEM_DEVICE, nb, got, nbits));
+        gk.data = cells; gk.null_mask = nbits; gv.data = sums;
+        return 0;
+    };
+    const int32_t local_status = local_phase();
     const pandrs_hip_agg_spec sum_spec{0, PANDRS_HIP_AGG_SUM};
-    // (exchange_records re-takes cm->recv: the columns above must outlive the local partial pass only, which reads them
-    // before the exchange allocates — keep them in their own arena to be safe)
-    pandrs::Arena keep;
-    std::swap(keep, cm->recv);
-    const int32_t st = dist_groupby_impl(c, cm, PANDRS_HIP_MEM_DEVICE, &gk, got, &gv, 1, &sum_spec, 1, out_n_groups);
-    (void)hipStreamSynchronize(c->stream);
-    keep.release();
-    return st;
+    return dist_groupby_impl(c, cm, PANDRS_HIP_MEM_DEVICE, &gk, local_status ? 0 : got, &gv, 1, &sum_spec, 1, out_n_groups, local_status);
 }
 
 }  // extern "C"

@@ -536,6 +536,62 @@ class Context:
         self.comm_world = world
         return h
 
+    def comm_adopt_transport(self, all_gather, all_reduce_max, all_to_all_v, rank, world):
+        """pandrs_hip_comm_adopt_transport: the in-library exchange over host callbacks instead of RCCL.
+        all_gather(send: bytes) -> list of world bytes objects; all_reduce_max(list of int) -> list of int;
+        all_to_all_v(list of world bytes objects) -> list of world bytes objects (what each rank sent to this one)."""
+        def _ag(_user, send, recv, nbytes):
+            try:
+                parts = all_gather(C.string_at(send, nbytes))
+                for r, part in enumerate(parts):
+                    assert len(part) == nbytes
+                    C.memmove(recv + r * nbytes, part, nbytes)
+                return 0
+            except Exception:        # noqa: BLE001 — the library turns a non-zero status into an error on every rank
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ar(_user, vals, n):
+            try:
+                out = all_reduce_max([int(vals[i]) for i in range(n)])
+                for i in range(n):
+                    vals[i] = int(out[i])
+                return 0
+            except Exception:        # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _a2a(_user, send, sb, so, recv, rb, ro):
+            try:
+                parts = all_to_all_v([C.string_at(send + so[p], sb[p]) if sb[p] else b"" for p in range(world)])
+                for p in range(world):
+                    assert len(parts[p]) == rb[p], (p, len(parts[p]), rb[p])
+                    if rb[p]:
+                        C.memmove(recv + ro[p], parts[p], rb[p])
+                return 0
+            except Exception:        # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        t = L.Transport(None, L.ALL_GATHER_FN(_ag), L.ALL_REDUCE_MAX_FN(_ar), L.ALL_TO_ALL_V_FN(_a2a))
+        h = C.c_void_p()
+        st = self.lib.pandrs_hip_comm_adopt_transport(C.byref(t), int(rank), int(world), C.byref(h))
+        if st:
+            _raise(st)
+        self._transport = t            # the callbacks must outlive the communicator
+        self.comm = h
+        self.comm_world = world
+        return h
+
+    @staticmethod
+    def alloc_events():
+        n = C.c_int64(0)
+        L.load().pandrs_hip_alloc_events(C.byref(n))
+        return n.value
+
     def comm_destroy(self):
         if getattr(self, "comm", None):
             self.lib.pandrs_hip_comm_destroy(self.comm)

@@ -311,3 +311,145 @@ def test_in_library_exchange_join_groupby_world1(cctx):
     want = O.join_groupby_sum((lkeys, None, O.I64), (lval, None, O.F64), nl, (rkeys, rkm, O.I64), (rgrp, None, O.I64), nr)
     got = (kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy())
     assert_groupby_equal(got, want, [O.I64])
+
+
+# ---- the in-library exchange at world 2 and 3 on ONE GPU: host-callback transport (gloo underneath) ------------------
+# exchange_records / dist_groupby_impl / dist_join_groupby_sum had only ever run with world = 1, where a
+# rank sends to itself.  pandrs_hip_comm_adopt_transport puts the same C++ code over any fabric; here every rank is a fresh
+# process with its own HIP context on cuda:0 and the collectives travel over a gloo process group.
+def _shard_bounds(n, world, uneven):
+    if not uneven:
+        return [n * r // world for r in range(world + 1)]
+    cuts = [0]
+    for r in range(world):
+        share = 0 if (uneven == "empty" and r == 1) else (r + 1) * 3 + 1
+        cuts.append(cuts[-1] + share)
+    total = cuts[-1]
+    return [n * c // total for c in cuts]
+
+
+def _gen_case(seed):
+    rng = np.random.default_rng(seed)
+    n, g = 700_001, 30_000
+    k = (rng.integers(0, g, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    km = rng.random(n) < 0.002
+    v0 = np.round(rng.normal(100, 10, n), 1)
+    v1 = rng.integers(-1000, 1000, n).astype(np.int64)
+    m1 = rng.random(n) < 0.1
+    m1[: int(0.4 * n)] = False              # rank 0's shard has no null here: it passes NO mask while the other ranks do
+    nr = 60_003
+    rk = (rng.permutation(4 * nr)[:nr].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rg = rng.integers(0, 900, nr).astype(np.int64)
+    rgm = rng.random(nr) < 0.01
+    rgm[: int(0.4 * nr)] = False            # likewise: rank 0's build shard carries no group mask
+    lk = np.where(rng.random(n) < 0.9, rk[rng.integers(0, nr, n)], rng.integers(1, 1 << 40, n))
+    return dict(n=n, k=k, km=km, v0=v0, v1=v1, m1=m1, nr=nr, rk=rk, rg=rg, rgm=rgm, lk=lk)
+
+
+def _transport_worker(rank, world, port, outdir, uneven):
+    import datetime
+    import pickle
+    import torch
+    import torch.distributed as dist
+    import pandrs_amd as pa
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    torch.cuda.set_device(0)
+    ctx = pa.Context(0)
+
+    def all_gather(b):
+        parts = [None] * world
+        dist.all_gather_object(parts, b)
+        return parts
+
+    def all_reduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def all_to_all_v(parts):
+        everyone = [None] * world
+        dist.all_gather_object(everyone, parts)          # test-sized payloads: the whole matrix travels
+        return [everyone[src][rank] for src in range(world)]
+
+    ctx.comm_adopt_transport(all_gather, all_reduce_max, all_to_all_v, rank, world)
+    c = _gen_case(77)
+    b = _shard_bounds(c["n"], world, uneven)
+    lo, hi = b[rank], b[rank + 1]
+    dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bits = lambda m, lo, hi: O.pack_mask(m[lo:hi])
+    out = {}
+    # groupby: rank 0 passes NO null mask for v1 although others do (layout agreement), device and host shards
+    keys = [(dev(c["k"][lo:hi]), dev(bits(c["km"], lo, hi)), O.I64)]
+    assert rank != 0 or not c["m1"][lo:hi].any()
+    m1 = None if rank == 0 else dev(bits(c["m1"], lo, hi))
+    vals = [(dev(c["v0"][lo:hi]), None, O.F64), (dev(c["v1"][lo:hi]), m1, O.I64)]
+    aggs = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 4)]
+    ctx.dist_groupby_compute(keys, hi - lo, vals, aggs)
+    kc, kn, oa = ctx.groupby_fetch(to_device=False)
+    out.update(gb_kc=kc, gb_kn=kn, gb_oa=oa)
+    # steady state: the same call again allocates nothing on the device
+    ctx.dist_groupby_compute(keys, hi - lo, vals, aggs)
+    a0 = pa.Context.alloc_events()
+    ctx.dist_groupby_compute(keys, hi - lo, vals, aggs)
+    out["gb_allocs_in_steady_state"] = np.array([pa.Context.alloc_events() - a0])
+    # host shards through the same exchange
+    hk = [(c["k"][lo:hi], bits(c["km"], lo, hi), O.I64)]
+    hv = [(c["v0"][lo:hi], None, O.F64), (c["v1"][lo:hi], bits(c["m1"], lo, hi), O.I64)]
+    ctx.dist_groupby_compute(hk, hi - lo, hv, aggs)
+    kc, kn, oa = ctx.groupby_fetch(to_device=False)
+    out.update(gbh_kc=kc, gbh_kn=kn, gbh_oa=oa)
+    # join: uneven build shards (padding rows with NULL keys in the all-gather), one possibly empty
+    rb = _shard_bounds(c["nr"], world, uneven)
+    rlo, rhi = rb[rank], rb[rank + 1]
+    assert rank != 0 or not c["rgm"][rlo:rhi].any()
+    rgm = dev(O.pack_mask(c["rgm"][rlo:rhi])) if rank != 0 else None
+    for rep in range(3):
+        if rep == 2:
+            a0 = pa.Context.alloc_events()
+        kc, kn, oa = ctx.dist_join_groupby_sum((dev(c["lk"][lo:hi]), None, O.I64), (dev(c["v0"][lo:hi]), None, O.F64), hi - lo,
+                                               (dev(c["rk"][rlo:rhi]), None, O.I64), (dev(c["rg"][rlo:rhi]), rgm, O.I64), rhi - rlo)
+    out["join_allocs_in_steady_state"] = np.array([pa.Context.alloc_events() - a0])
+    out.update(jn_kc=kc.cpu().numpy().view(np.uint64), jn_kn=kn.cpu().numpy(), jn_oa=oa.cpu().numpy())
+    # a rank-local failure between collectives: rank `world - 1` passes a value column nothing can sum; EVERY rank must
+    # come back with an error instead of waiting in the count exchange
+    bad = [(dev(c["v1"][lo:hi].astype(np.uint32)), None, O.U32CODE)] if rank == world - 1 else [(dev(c["v0"][lo:hi]), None, O.F64)]
+    try:
+        ctx.dist_groupby_compute(keys, hi - lo, bad, [(0, 0)])
+        out["failure_status"] = np.array([0])
+    except pa.engine.PandrsHipError as e:
+        out["failure_status"] = np.array([e.status])
+    # ... and the communicator still works afterwards
+    ctx.dist_groupby_compute(keys, hi - lo, vals[:1], [(0, 0)])
+    out["after_failure_groups"] = np.array([ctx.groupby_fetch(to_device=False)[0].shape[1]])
+    np.savez(os.path.join(outdir, "x%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,uneven", [(2, "uneven"), (3, "empty")])
+def test_in_library_exchange_with_real_ranks_over_a_host_transport(tmp_path, world, uneven):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_transport_worker, args=(world, port, str(tmp_path), uneven), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, "x%d.npz" % r)) for r in range(world)]
+    cat = lambda name: tuple(np.concatenate([p[name + s_] for p in parts], axis=1) for s_ in ("_kc", "_kn", "_oa"))
+    c = _gen_case(77)
+    keys = [(c["k"], O.pack_mask(c["km"]), O.I64)]
+    vals = [(c["v0"], None, O.F64), (c["v1"], O.pack_mask(c["m1"]), O.I64)]
+    aggs = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 4)]
+    want = O.groupby_agg(keys, c["n"], vals, aggs)
+    for name in ("gb", "gbh"):
+        got = cat(name)
+        assert got[0].shape[1] == want[0].shape[1], name            # owners are disjoint: no key on two ranks
+        assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 6])
+    wantj = O.join_groupby_sum((c["lk"], None, O.I64), (c["v0"], None, O.F64), c["n"], (c["rk"], None, O.I64),
+                               (c["rg"], O.pack_mask(c["rgm"]), O.I64), c["nr"])
+    gotj = cat("jn")
+    assert gotj[0].shape[1] == wantj[0].shape[1]
+    assert_groupby_equal(gotj, wantj, [O.I64])
+    for p in parts:
+        assert int(p["gb_allocs_in_steady_state"][0]) == 0 and int(p["join_allocs_in_steady_state"][0]) == 0
+        assert int(p["failure_status"][0]) != 0                     # every rank, not only the failing one
+    assert sum(int(p["after_failure_groups"][0]) for p in parts) == want[0].shape[1]
