@@ -141,7 +141,9 @@ typedef struct pandrs_hip_timings {
                                                  0 = general fallback) */
     int64_t table_slots;                      /* LDS hash-table slots per partition */
     int64_t retries;                          /* overflow retries taken (fused join: 1 = the partitioned pair output overflowed a
-                                                 region and the one-cursor emission answered) */
+                                                 region and the one-cursor emission answered; 2 = the groupby engine refused the
+                                                 pre-partitioned pairs — a full LDS table — and the whole call was repeated with
+                                                 the one-cursor emission) */
     int64_t estimated_groups;
 } pandrs_hip_timings;
 

@@ -1430,7 +1430,8 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
         ST_TRY(estimate_groups(c, KeyDesc{gsrc, nullptr, nullptr, DT_CELL}, nr, &est_g));
         const int64_t T = lean_table_slots(c, 1);
         int64_t pair_P = std::max<int64_t>(256, (int64_t)std::ceil((double)std::max<int64_t>(est_g, 1) / ((double)T * 0.70)));
-        if (pair_P <= (int64_t)L2_PAIR_PMAX && sampled_partition_ok(nl, pair_P) && (double)nl * 1.5 < 4.0e9) {
+        const bool lean_ok = !c->opt.agg_v1 && !c->opt.generic_aggregate && (c->opt.p_max <= 0 || pair_P <= c->opt.p_max);
+        if (lean_ok && pair_P <= (int64_t)L2_PAIR_PMAX && sampled_partition_ok(nl, pair_P) && (double)nl * 1.5 < 4.0e9) {
             const uint32_t PP1 = (uint32_t)pair_P + 1;
             // 1.5 rows of capacity per probe row: the pairs of one build row (n_left / n_right of them on average) land in ONE region,
             // so the regions' margins are wider than for independent rows
@@ -1523,6 +1524,11 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
 
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    // the whole call as one attempt: when the pairs went pre-partitioned into the groupby engine (MODE 2 of the L2-region probe)
+    // and the engine could not take them as they were — a full LDS table (cardinality under-estimated under skew), or a plan
+    // that rules the lean aggregate out — the attempt is repeated with the plain pair emission, which the engine partitions itself
+    bool pre_failed = false;
+    auto attempt_call = [&]() -> int32_t {
     timings_begin(c);
     c->jn.valid = false;
     KeyDesc lkey{}, rkey{}, lval{}, rgrp{};
@@ -1670,7 +1676,11 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     rsrc.val_null_bits[0] = nullptr;
     if (use_pre) rsrc.pre = &pre;
     const int64_t join_fanout = general ? 0 : c->timings.n_partitions;
-    ST_TRY(run_engine(c, rsrc, pl, /*merge=*/false, /*partials=*/false, 1, rg->dtype));
+    {
+        const int32_t est = run_engine(c, rsrc, pl, /*merge=*/false, /*partials=*/false, 1, rg->dtype);
+        if (est && use_pre) pre_failed = true;
+        ST_TRY(est);
+    }
     c->timings.n_partitions = join_fanout;          // the join's build-side fan-out (0: general path), not the pair groupby's
     c->timings.retries = c->pair_fallback ? 1 : 0;  // 1: the partitioned pair output overflowed a region and the plain emission answered
     {
@@ -1680,6 +1690,17 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     ST_TRY(timings_end(c));
     *out_n_groups = c->gb.n_groups;
     return 0;
+    };
+    int32_t st = attempt_call();
+    if (st && pre_failed) {
+        const int64_t saved = c->opt.join_no_pairpart;
+        c->opt.join_no_pairpart = 1;
+        pre_failed = false;
+        st = attempt_call();
+        c->opt.join_no_pairpart = saved;
+        if (!st) c->timings.retries = 2;            // 2: the pre-partitioned pairs were refused by the engine, the plain emission answered
+    }
+    return st;
 }
 
 }  // namespace pandrs

@@ -304,10 +304,8 @@ class DistributedJoinGroupBy:
         "shuffle": both sides go to the owner of their join key (SURVEY.md 8e's radix all-to-all) —
         every GPU then builds only 1/world of the build side, at the price of moving the probe rows."""
         t0 = time.perf_counter()
-        if getattr(self.engine, "comm", None) and strategy in ("auto", "allgather"):
-            out = self.engine.dist_join_groupby_sum(lkey, lval, n_left, rkey, rgroup, n_right)
-            self.last_wall_ms = {"in_library": (time.perf_counter() - t0) * 1e3}
-            return out
+        if strategy == "auto" and getattr(self.engine, "comm", None) and not hasattr(self.dist, "all_reduce"):
+            strategy = "allgather"          # the library owns the fabric: no host collective to take the size vote with
         if strategy == "auto":
             # replicating the build side makes EVERY rank build all of it; shuffling moves the probe rows once.
             # By the single-GPU numbers (DESIGN.md 8e) the shuffle wins from 4 ranks up once the build side is large.
@@ -315,6 +313,13 @@ class DistributedJoinGroupBy:
             tot = torch.tensor([int(n_right)], dtype=torch.int64, device=self.device if str(self.device) != "cpu" else "cpu")
             self.dist.all_reduce(tot)
             strategy = "shuffle" if self.world >= 4 and int(tot.item()) >= 8_000_000 else "allgather"
+        # the in-library exchange (pandrs_hip_dist_join_groupby_sum) replicates the build side and takes 8-byte build-side
+        # columns on the device: string-code keys / groups and host shards keep the path below
+        if strategy == "allgather" and getattr(self.engine, "comm", None) and rkey[2] in (0, 1, 4) and rgroup[2] in (0, 1, 4) and \
+                all(hasattr(c[0], "is_cuda") or type(c[0]).__name__ == "ResidentColumn" for c in (lkey, lval, rkey, rgroup)):
+            out = self.engine.dist_join_groupby_sum(lkey, lval, n_left, rkey, rgroup, n_right)
+            self.last_wall_ms = {"in_library": (time.perf_counter() - t0) * 1e3}
+            return out
         if strategy == "shuffle":
             lk2, lv2, nl2 = self._shuffled_side(lkey, lval, n_left)
             rk2, rg2, nr2 = self._shuffled_side(rkey, rgroup, n_right)

@@ -429,3 +429,37 @@ def test_config5_full_size_on_one_gpu_takes_the_l2_path():
         print("C5 on one GPU: L2 path %.2f ms, LDS-multimap path %.2f ms" % (res[0][2], res[1][2]))
     finally:
         c.close()
+
+
+def test_fused_join_prepartitioned_pairs_fall_back_when_the_group_estimate_is_far_too_low():
+    """with pairs written straight into the groupby engine's partitions, a full LDS table used to
+    surface as PANDRS_HIP_ERR_COMPUTATION.  Build side: 60 % of the rows in 16 hot groups, the rest one group EACH
+    (3.2 M groups) — the strided sample sees mostly repeats and estimates ~0.1 M groups, the pair fan-out stays at 256,
+    every table overflows.  The call must answer (through the plain pair emission), exactly."""
+    import torch
+    import pandrs_amd as pa
+    d = "cuda:0"
+    nr, nl = 8_000_000, 17_000_000
+    rng = np.random.default_rng(31)
+    rk = (rng.permutation(nr).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    hot = rng.random(nr) < 0.6
+    rg = np.where(hot, rng.integers(0, 16, nr), 1_000 + np.arange(nr)).astype(np.int64)
+    pick = rng.integers(0, nr, nl)
+    lk = rk[pick]
+    lv = rng.integers(-8, 9, nl).astype(np.float64)          # small integers: the sums are exact in any order
+    dev = lambda a: torch.from_numpy(a).to(d)
+    c = pa.Context(0)
+    try:
+        kc, kn, oa = c.join_groupby_sum((dev(lk), None, pa.I64), (dev(lv), None, pa.F64), nl, (dev(rk), None, pa.I64), (dev(rg), None, pa.I64), nr)
+        t = c.timings()
+        assert t["n_partitions"] > 0                          # the L2-region path (not the general fallback)
+        assert t["retries"] == 2, t                           # ... whose pre-partitioned pairs the engine refused
+        groups, inv = np.unique(rg[pick], return_inverse=True)
+        want = np.bincount(inv, weights=lv, minlength=len(groups))
+        got_k = kc[0].cpu().numpy().view(np.int64)
+        order = np.argsort(got_k)
+        np.testing.assert_array_equal(got_k[order], groups)
+        np.testing.assert_array_equal(oa[0].cpu().numpy()[order], want)
+        assert int(kn.sum()) == 0
+    finally:
+        c.close()
