@@ -145,6 +145,7 @@ typedef struct pandrs_hip_timings {
                                                  pre-partitioned pairs — a full LDS table — and the whole call was repeated with
                                                  the one-cursor emission) */
     int64_t estimated_groups;
+    int64_t absorbed_rows;                    /* rows folded by the hot-key absorb pass in front of the radix path (0: it did not run) */
 } pandrs_hip_timings;
 
 enum {

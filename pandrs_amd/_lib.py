@@ -47,7 +47,8 @@ class ColumnStats(C.Structure):            # pandrs_hip_column_stats
 class Timings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("phase_ms", C.c_double * MAX_PHASES),
                 ("algorithmic_bytes", C.c_int64), ("n_partitions", C.c_int64),
-                ("table_slots", C.c_int64), ("retries", C.c_int64), ("estimated_groups", C.c_int64)]
+                ("table_slots", C.c_int64), ("retries", C.c_int64), ("estimated_groups", C.c_int64),
+                ("absorbed_rows", C.c_int64)]
 
 
 # pandrs_hip_transport: the exchange's collectives as host callbacks (pandrs_hip_comm_adopt_transport)

@@ -74,6 +74,30 @@ __device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
 }
 
 
+// absorb.hip: hot-key absorb-and-spill pass in front of the radix path (uniform profiles, <= 4 value columns)
+constexpr int MAX_ABS_SRC = 4;
+struct AbsorbArgs {
+    KeyDesc key;                                  // the ORIGINAL key column (any dtype, null bitmap in place)
+    uint32_t n_rows, chunk, T, seed;              // workgroup w owns rows [w * chunk, (w + 1) * chunk)
+    int n_src, n_lds_states;
+    const uint64_t *vals[MAX_ABS_SRC];
+    const uint8_t *null_bits[MAX_ABS_SRC];
+    int8_t st_add[MAX_ABS_SRC], st_min[MAX_ABS_SRC], st_max[MAX_ABS_SRC], st_nn[MAX_ABS_SRC];   // LDS state index, -1 = none
+    int8_t lds_kind[MAX_STATES];                  // StateKind of LDS state k
+    int8_t lds_abs[MAX_STATES];                   // its absolute (ABI / partial) state index
+    uint64_t *out_keys; uint8_t *out_null; uint64_t *out_states; size_t cap;      // partial records ([1 + n_states][cap])
+    uint32_t *counters;                           // [1] a spill region overflowed, [2] partial records (shared with the lean aggregate's
+                                                  // side records), [3] rows spilled
+    // spill: row of partition p from workgroup w -> region (w * spill_P + p), spill_cap rows each, in the spill columns
+    uint32_t spill_P, spill_cap;
+    uint64_t *sp_keys; uint64_t *sp_vals[MAX_ABS_SRC]; uint8_t *sp_valid[MAX_ABS_SRC];
+    uint32_t *sp_count;                           // [grid * spill_P] rows in each region
+};
+bool absorb_has(int n_src, int profile);
+bool launch_absorb(pandrs_hip_ctx *c, const AbsorbArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
+void launch_build_spill_tables(pandrs_hip_ctx *c, const uint32_t *sp_count, uint32_t n_wg, uint32_t PS, uint32_t cap_wp, uint32_t wpt,
+                               AggTask *tasks, AggTable *tables, uint32_t *counts);
+
 // aggregate2.hip: lean persistent aggregate for uniform profiles on raw partitioned rows (one round).
 // Returns false when (n_src, profile) has no instantiation: the caller falls back to aggregate_kernel.
 constexpr size_t AGG2_LDS_EXTRA = 16 * 128 * 4 + 64;   // per-wave retry queues of aggregate2_kernel

@@ -98,7 +98,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     if (!c) return PANDRS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release(); c->shuf.release();
+    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release(); c->shuf.release(); c->absorb.release();
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);

@@ -193,7 +193,7 @@ struct pandrs_hip_ctx {
     // arena with what that run allocates (work: per-run scratch; temp: direct-path records;
     // side: slice records; super: two-level columns; packed: multi-key cells and dictionaries;
     // pairs: fused-join pairs; groups: retained group index (CSR); shuf: retained shuffle buckets)
-    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups, shuf;
+    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups, shuf, absorb;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
     pandrs::GroupbyResult gb, gb2, gb3;   // gb2 / gb3: nested results (slice merges, two-level sub-runs)
@@ -210,6 +210,7 @@ struct pandrs_hip_ctx {
     int small_skip = 0, small_backoff = 0;     // run_small's back-off after a call that did not fit
     void *small_table = nullptr;      // the small path's armed global table (groupby.hip run_small)
     uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)
+    bool est_kept = false;            // the table still holds the last estimate's keys (estimate_coverage / estimate_release pending)
     bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)
     bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
     // resident columns (pandrs_hip_column_upload): device data pointer -> {allocation, bytes}; freed by _release / ctx_destroy

@@ -898,6 +898,147 @@ int32_t run_small(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, const 
 }
 
 // Core: groups rs by key and reduces the plan's states.  Result retained in c->gb.
+// ---- hot-key absorb-and-spill (kernels: absorb.hip) ------------------------------------------------------------------
+// One pass over the ORIGINAL columns folds the rows of the keys that found a slot in a workgroup's LDS table; the other
+// rows are spilled straight into P_s radix partitions (per-workgroup regions), the lean aggregate folds those regions
+// and appends its groups as partial records behind the absorbed ones, and one merge finishes.  No host round trip
+// between the absorb pass and the spill aggregate.  ABSORB_NOT_TAKEN: the caller continues with the ordinary path.
+constexpr int32_t ABSORB_NOT_TAKEN = -1001;
+static int64_t absorb_table_slots(const pandrs_hip_ctx *c, int lds_states) {
+    return ((int64_t)(((size_t)c->lds_bytes - 512 - 640) / (12 + 8 * (size_t)lds_states)) - 2) & ~int64_t(3);
+}
+static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, const std::vector<EngSrc> &srcs, int profile, int64_t T,
+                          int64_t est, bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
+    const int64_t N = rs.n_rows;
+    const int n_src = (int)srcs.size();
+    const bool has_v = (profile & 1) != 0;
+    const uint32_t n_wg = (uint32_t)std::max(c->n_cu, 1);
+    const uint32_t chunk = (uint32_t)(((N + n_wg - 1) / n_wg + 15) & ~int64_t(15));
+    // the spill side: the lean aggregate's table geometry decides the fan-out of the spilled rows
+    int round_states = 0;
+    for (auto &e : srcs) round_states += (e.st_add >= 0) + (e.st_min >= 0) + (e.st_max >= 0) + (e.st_nn >= 0);
+    const int64_t T2 = lean_table_slots(c, round_states);
+    if (T2 < 64) return ABSORB_NOT_TAKEN;
+    int64_t PS = 1;
+    while ((double)est / (double)PS > (double)T2 * 0.60 && PS < 64) PS *= 2;
+    if ((double)est / (double)PS > (double)T2 * 0.80) return ABSORB_NOT_TAKEN;
+    const uint32_t cap_wp = (uint32_t)((((int64_t)chunk / PS) * 2 + 256 + 15) & ~int64_t(15));
+    const size_t region_rows = (size_t)n_wg * (size_t)PS * cap_wp;
+    if (region_rows >= (size_t(1) << 32) - (size_t(1) << 20)) return ABSORB_NOT_TAKEN;
+    // tables over the regions: ~2 per CU, each fed by `wpt` consecutive workgroups' regions of one partition
+    uint32_t tpp = std::max<uint32_t>(1, std::min<uint32_t>(n_wg, (2 * n_wg) / (uint32_t)PS));
+    while ((uint64_t)tpp * (uint64_t)PS > 1024) tpp--;
+    const uint32_t wpt = (n_wg + tpp - 1) / tpp;
+    const uint32_t max_tables = (uint32_t)PS * ((n_wg + wpt - 1) / wpt), max_tasks = (uint32_t)PS * n_wg;
+    const size_t n_state = 1 + (size_t)pl.n_states;
+    const size_t dcap = (size_t)n_wg * (size_t)(T + 2) + (size_t)max_tables * (size_t)(T2 + 2);
+    ST_TRY(c->temp.ensure(Arena::padded(dcap * 8) + Arena::padded(dcap) + n_state * Arena::padded(dcap * 8 + 256) + Arena::padded((size_t)max_tasks * 16 + 256) +
+                          Arena::padded((size_t)max_tables * 16 + 256) + Arena::padded((size_t)n_wg * PS * 4 + 256) + 65536, c->stream));
+    uint64_t *rk = c->temp.take<uint64_t>(dcap);
+    uint8_t *rn = c->temp.take<uint8_t>(dcap);
+    uint64_t *rst = c->temp.take<uint64_t>(dcap * n_state + 32);
+    uint32_t *counters = c->temp.take<uint32_t>(64);
+    uint32_t *sp_count = c->temp.take<uint32_t>((size_t)n_wg * PS + 16);
+    AggTask *tasks = c->temp.take<AggTask>(max_tasks + 8);
+    AggTable *tables = c->temp.take<AggTable>(max_tables + 8);
+    uint32_t *n_tasks = c->temp.take<uint32_t>(64);
+    if (!rk || !rn || !rst || !counters || !sp_count || !tasks || !tables || !n_tasks) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small (absorb)");
+    ST_TRY(c->absorb.ensure((1 + (size_t)n_src) * Arena::padded(region_rows * 8 + 256) + (has_v ? (size_t)n_src * Arena::padded(region_rows + 256) : 0) + (1 << 20), c->stream));
+    AbsorbArgs a{};
+    a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = 0x9E3779B9u; a.n_src = n_src;
+    a.spill_P = (uint32_t)PS; a.spill_cap = cap_wp;
+    a.sp_keys = c->absorb.take<uint64_t>(region_rows + 16);
+    AggArgs aa{};
+    int next = 0;
+    // the lean aggregate's fixed LDS state order (run_engine): adds of source 0..n-1, per source its min-type states, then the counts
+    const int v2_mm = ((profile >> 2) & 1) + ((profile >> 3) & 1), v2_mbase = ((profile >> 1) & 1) ? n_src : 0;
+    int v2_next_nn = v2_mbase + n_src * v2_mm;
+    for (int k = 0; k < MAX_STATES; k++) { aa.st_round[k] = -1; aa.st_lds[k] = -1; }
+    for (int s = 0; s < n_src; s++) {
+        const EngSrc &e = srcs[s];
+        a.vals[s] = reinterpret_cast<const uint64_t *>(e.data);
+        a.null_bits[s] = e.null_bits;
+        a.sp_vals[s] = c->absorb.take<uint64_t>(region_rows + 16);
+        a.sp_valid[s] = has_v ? c->absorb.take<uint8_t>(region_rows + 16) : nullptr;
+        if (!a.sp_vals[s] || (has_v && !a.sp_valid[s])) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "absorb arena too small");
+        auto place = [&](int8_t abs_id, int8_t &lds_id) {
+            lds_id = -1;
+            if (abs_id < 0) return;
+            lds_id = (int8_t)next; a.lds_abs[next] = abs_id; a.lds_kind[next] = pl.kinds[abs_id]; next++;
+        };
+        place(e.st_add, a.st_add[s]); place(e.st_min, a.st_min[s]); place(e.st_max, a.st_max[s]); place(e.st_nn, a.st_nn[s]);
+        SrcDev &sd = aa.src[s];
+        sd = SrcDev{a.sp_vals[s], a.sp_valid[s], e.kind, -1, -1, -1, -1, -1, -1, {0}};
+        auto put = [&](int8_t abs_id, int8_t &lds_id, int at) {
+            if (abs_id < 0) return;
+            aa.st_round[abs_id] = 0; aa.st_lds[abs_id] = (int8_t)at; lds_id = (int8_t)at;
+        };
+        put(e.st_add, sd.st_add, s);
+        put(e.st_min, sd.st_min, v2_mbase + s * v2_mm);
+        put(e.st_max, sd.st_max, v2_mbase + s * v2_mm + v2_mm - 1);
+        if (e.st_nn >= 0) put(e.st_nn, sd.st_nn, v2_next_nn++);
+    }
+    if (!a.sp_keys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "absorb arena too small");
+    a.n_lds_states = next;
+    a.out_keys = rk; a.out_null = rn; a.out_states = rst; a.cap = dcap;
+    a.counters = counters; a.sp_count = sp_count;
+    HIP_TRY(hipMemsetAsync(counters, 0, 256, c->stream));
+    const size_t lds = (size_t)(T + 2) * (12 + 8 * (size_t)next) + 16 + 96 * 4 + 64;
+    aa.pkeys = a.sp_keys; aa.P = (uint32_t)PS; aa.T = (uint32_t)T2; aa.seed = a.seed; aa.n_src = n_src; aa.n_states = pl.n_states;
+    aa.n_fin = 0; aa.partials = 1; aa.n_rounds = 1; aa.round_states = round_states; aa.second_pass = 0;
+    aa.round_src_begin[0] = 0; aa.round_src_begin[1] = (int8_t)n_src;
+    std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
+    aa.out_keys = rk; aa.out_null = rn; aa.out_states = rst; aa.cap = dcap;
+    aa.side_keys = rk; aa.side_null = rn; aa.side_states = rst; aa.side_cap = dcap;        // every table is `multi`: side = the record buffer
+    aa.counters = counters; aa.tasks = tasks; aa.tables = tables; aa.n_tasks = n_tasks; aa.launch_grid = max_tables;
+    volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;
+    hp[4] = 0;
+    aa.host_out = const_cast<uint32_t *>(hp); aa.scatter_flags = nullptr;
+    const size_t lds2 = (size_t)(T2 + 3) * (13 + 8 * (size_t)round_states) + 192 + AGG2_LDS_EXTRA;
+    {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
+        if (!launch_absorb(c, a, n_src, profile, lds, n_wg)) { (void)hipGetLastError(); return ABSORB_NOT_TAKEN; }
+        launch_build_spill_tables(c, sp_count, n_wg, (uint32_t)PS, cap_wp, wpt, tasks, tables, n_tasks);
+        if (!launch_aggregate2(c, aa, n_src, profile, lds2, (uint32_t)std::min<int64_t>(c->n_cu, max_tables)))
+            return fail(PANDRS_HIP_ERR_COMPUTATION, "absorb: the lean aggregate has no instantiation for this profile");
+        HIP_TRY(hipGetLastError());
+    }
+    for (int spin = 0; spin < 4000000 && hp[4] != 1; spin++) __builtin_ia32_pause();
+    if (hp[4] != 1) HIP_TRY(hipStreamSynchronize(c->stream));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    uint32_t h4[4] = {0, 0, 0, 0};
+    if (hp[4] == 1) { for (int i = 0; i < 3; i++) h4[i] = hp[i]; }
+    else {
+        uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+        HIP_TRY(hipMemcpyAsync(h, counters, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 3; i++) h4[i] = h[i];
+    }
+    if (h4[1]) return ABSORB_NOT_TAKEN;            // a spill region or a spill table overflowed: the ordinary path answers
+    uint32_t *hs = reinterpret_cast<uint32_t *>(c->pinned) + 1100;                           // own corner: the merge below reads its counters at +0
+    HIP_TRY(hipMemcpyAsync(hs, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));         // rows spilled: reported, not needed to continue
+    // one merge of everything (the direct path's last step)
+    RowSource ms;
+    ms.n_rows = h4[2];
+    ms.key = KeyDesc{rk, nullptr, rn, DT_CELL};
+    ms.merge_states = rst;
+    ms.merge_stride = dcap;
+    Options saved = c->opt;
+    c->opt.no_direct = 1; c->opt.no_absorb = 1;
+    c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>(est, ms.n_rows), 1);
+    pandrs_hip_timings tsave = c->timings;
+    c->quiet++;
+    const int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, n_keys_out, res_slot);
+    c->quiet--;
+    c->opt = saved;
+    c->timings = tsave;
+    c->timings.estimated_groups = est;
+    c->timings.n_partitions = PS; c->timings.table_slots = T;
+    c->timings.retries = 0;
+    c->timings.absorbed_rows = N - (int64_t)hs[0];         // (the merge synchronised the stream)
+    return st;
+}
+
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
                           bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
     if (res_slot < 0 || res_slot > 2) return fail(PANDRS_HIP_ERR_COMPUTATION, "engine nesting too deep");
@@ -960,9 +1101,46 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                        : engine_workspace_bytes(N + N / 4 + 131072, 1 + n_src + (merge ? 1 : 0), n_src);
     ST_TRY(c->work.ensure(ws, c->stream));
     int64_t est = rs.pre ? std::max<int64_t>(rs.pre->est_groups, 1) : c->opt.groups_hint;
-    if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est));
+    // hot-key absorb-and-spill (absorb.hip) is decided from the estimate's own sample: its key table is kept for one
+    // more look (how many rows do the most frequent keys hold?) when the call could take that path at all
+    int absorb_profile = -1;
+    {
+        auto prof_of = [](const EngSrc &e) {
+            int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
+            return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
+        };
+        bool ok = !merge && !rs.pre && pl.mergeable && c->opt.no_absorb <= 0 && res_slot == 0 && !c->quiet && N >= (int64_t(1) << 24) &&
+                  n_src >= 1 && n_src <= MAX_ABS_SRC && c->opt.partitions <= 0 && !c->opt.generic_aggregate && !c->opt.deterministic;
+        for (auto &e : srcs) ok = ok && !e.valid_bytes && !e.rowidx && e.st_fadd < 0 && e.st_ssq < 0;
+        if (ok) {
+            absorb_profile = prof_of(srcs[0]);
+            for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != absorb_profile) absorb_profile = -1;
+            if (absorb_profile >= 0 && (!absorb_has(n_src, absorb_profile) || !aggregate2_has(n_src, absorb_profile))) absorb_profile = -1;
+        }
+    }
+    if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est, /*keep_table=*/absorb_profile >= 0));
     else c->clustered_rows = false;          // no sample taken: nothing known about the row order
     c->timings.estimated_groups = est;
+    int64_t T_abs = 0;
+    bool do_absorb = false;
+    if (c->est_kept) {
+        int lds_states = 0;
+        for (auto &e : srcs) lds_states += (e.st_add >= 0) + (e.st_min >= 0) + (e.st_max >= 0) + (e.st_nn >= 0);
+        T_abs = absorb_table_slots(c, lds_states);
+        int total_states = 0;
+        for (auto &e : srcs) total_states += e.n_states();
+        const int64_t Td = std::min<int64_t>((int64_t)(((size_t)c->lds_bytes - 512 - 192) / (20 + 8 * (size_t)total_states)) - 3, 32768) & ~int64_t(3);
+        // not where the direct path answers (every group fits one table), not where the table is a drop in the ocean
+        if (T_abs >= 256 && !c->clustered_rows && !(Td >= 64 && est * 2 <= Td && !c->opt.no_direct) && est <= 64 * T_abs) {
+            double share = 0.0;
+            ST_TRY(estimate_coverage(c, rs.key, N, (int64_t)((double)T_abs * 0.80), &share));
+            do_absorb = share >= (c->opt.no_absorb < 0 ? 0.0 : 0.60);        // (no_absorb = -1, tests: whenever it is possible)
+        } else estimate_release(c);
+    }
+    if (do_absorb) {
+        const int32_t st = run_absorb(c, rs, pl, srcs, absorb_profile, T_abs, est, partials, n_aggs, key_dtype, n_keys_out, res_slot);
+        if (st != ABSORB_NOT_TAKEN) return st;
+    }
 
     // ---- low-cardinality direct path: when every group fits one LDS table with room to spare,
     // skip the radix partition altogether.  Each workgroup pre-aggregates a contiguous row range

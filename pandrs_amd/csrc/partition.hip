@@ -33,10 +33,117 @@ __device__ __forceinline__ void estimate_publish(uint32_t *distinct, uint32_t *h
         }
     }
 }
-__global__ void estimate_clear_kernel(uint64_t *table, uint32_t slots, uint32_t *distinct) {
+__global__ void estimate_clear_kernel(uint64_t *table, uint32_t slots, uint32_t *distinct, uint32_t *counts) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < slots) table[i] = EMPTY_KEY;
     if (i < 8) distinct[i] = 0;
+    if (counts && i < slots) counts[i] = 0;
+}
+
+// ---- hot-key coverage of the sample (absorb-and-spill decision, groupby.hip) ---------------------------------------
+// After an estimate whose table was KEPT: the same strided sample is walked again and every row adds 1 to its key's
+// counter (a wave's repeats of one key are added by one lane) ...
+__global__ __launch_bounds__(1024) void estimate_count_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
+                                                              const uint64_t *table, uint32_t table_mask, uint32_t *counts) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = s < n_sample && s * stride < n_rows;
+    uint64_t k = 0;
+    if (live) {
+        const int64_t i = s * stride;
+        k = key_cell(key, i);
+        live = !key_is_null(key, i) && k != EMPTY_KEY;
+    }
+    uint32_t weight = live ? 1u : 0u;
+    for (int round = 0; round < 2; round++) {                  // peel the wave's two most common leading keys
+        const unsigned long long m = __ballot(live && weight == 1u);
+        if (!m) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const uint64_t lk = __shfl(k, leader, 64);
+        const unsigned long long same = __ballot(live && weight == 1u && k == lk);
+        if (live && weight == 1u && k == lk) {
+            if ((int)(threadIdx.x & 63) == leader) weight = (uint32_t)__popcll(same) + 0x80000000u;   // marked: done peeling
+            else live = false;
+        }
+    }
+    if (live) {
+        uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+        for (uint32_t probe = 0; probe <= table_mask; probe++) {
+            const uint64_t cur = table[slot];
+            if (cur == k) { atomicAdd(&counts[slot], weight & 0x7FFFFFFFu); break; }
+            if (cur == EMPTY_KEY) break;                        // cannot happen: the estimate inserted every sampled key
+            slot = (slot + 1) & table_mask;
+        }
+    }
+}
+// ... and ONE workgroup-cooperative pass over the table turns the counters into: rows of the sample that belong to the
+// `budget` most frequent keys.  A histogram of the counts (exact up to 4094, one overflow bin) is built in LDS by every
+// workgroup for its part of the table and added to a global histogram; the last workgroup walks it from the top.
+// out[0] = sampled rows covered, out[1] = keys taken, out[2] = rows counted in all, out[3] = 1 when done (host polls).
+constexpr uint32_t COV_BINS = 4096;
+__global__ __launch_bounds__(1024) void estimate_coverage_kernel(const uint64_t *table, const uint32_t *counts, uint32_t slots,
+                                                                 uint32_t budget, uint32_t *g_hist /* [2][COV_BINS] + [1] done */,
+                                                                 uint32_t *host_out) {
+    __shared__ uint32_t hn[COV_BINS], hr[COV_BINS];
+    __shared__ uint32_t is_last;
+    for (uint32_t b = threadIdx.x; b < COV_BINS; b += 1024) { hn[b] = 0; hr[b] = 0; }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < slots; i += gridDim.x * 1024) {
+        const uint32_t c = counts[i];
+        if (c && table[i] != EMPTY_KEY) {
+            const uint32_t b = min(c, COV_BINS - 1);
+            atomicAdd(&hn[b], 1u);
+            atomicAdd(&hr[b], c);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < COV_BINS; b += 1024) {
+        if (hn[b]) { atomicAdd(&g_hist[b], hn[b]); atomicAdd(&g_hist[COV_BINS + b], hr[b]); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(&g_hist[2 * COV_BINS], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    for (uint32_t b = threadIdx.x; b < COV_BINS; b += 1024) {
+        hn[b] = __hip_atomic_load(&g_hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hr[b] = __hip_atomic_load(&g_hist[COV_BINS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // from the most frequent keys down: thread t owns the four bins COV_BINS - 1 - 4 t ... (descending), one block scan gives the
+    // number of keys in front of them
+    __shared__ uint32_t wt[17], tot[3];
+    if (threadIdx.x < 3) tot[threadIdx.x] = 0;
+    uint32_t ln[4], lr[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = (int)COV_BINS - 1 - (4 * (int)threadIdx.x + q);
+        ln[q] = b >= 1 ? hn[b] : 0u; lr[q] = b >= 1 ? hr[b] : 0u;
+        mine += ln[q];
+    }
+    uint32_t before = block_exclusive_scan<1024>(mine, wt, nullptr);
+    uint32_t rows = 0, keys = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        all += lr[q];
+        if (ln[q] && before < budget) {
+            const uint32_t take = min(ln[q], budget - before);
+            rows += (uint32_t)((unsigned long long)lr[q] * take / ln[q]);
+            keys += take;
+        }
+        before += ln[q];
+    }
+    if (rows) atomicAdd(&tot[0], rows);
+    if (keys) atomicAdd(&tot[1], keys);
+    if (all) atomicAdd(&tot[2], all);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host_out[0] = tot[0]; host_out[1] = tot[1]; host_out[2] = tot[2];
+        __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (uint32_t b = threadIdx.x; b < 2 * COV_BINS + 1; b += 1024) g_hist[b] = 0;       // re-armed for the next call
 }
 __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
                                 uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
@@ -558,17 +665,25 @@ int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint
     return 0;
 }
 
-int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est) {
+constexpr uint32_t EST_SLOTS = 1u << 19;                  // >= 2 x the largest sample
+// the estimate's block: [EST_SLOTS] u64 keys | 256 B counters | [EST_SLOTS] u32 per-key counts | coverage histogram
+static uint32_t *est_counts(pandrs_hip_ctx *c) { return reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS) + 64; }
+static uint32_t *est_cov_hist(pandrs_hip_ctx *c) { return est_counts(c) + EST_SLOTS; }
+
+int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est, bool keep_table) {
     PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
     const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
     const int64_t stride = n_rows / n_sample;
-    constexpr uint32_t slots = 1u << 19;                  // >= 2 x the largest sample
+    constexpr uint32_t slots = EST_SLOTS;
     // a dedicated block that stays armed (table = EMPTY, counters = 0) between calls: cleared behind the previous
     // estimate instead of in front of this one
     if (!c->est_table) {
-        HIP_TRY(hipMalloc((void **)&c->est_table, size_t(slots) * 8 + 256));
+        const size_t bytes = size_t(slots) * 8 + 256 + size_t(slots) * 4 + (2 * COV_BINS + 64) * 4;
+        HIP_TRY(hipMalloc((void **)&c->est_table, bytes));
+        alloc_events()++;
+        HIP_TRY(hipMemsetAsync(c->est_table, 0, bytes, c->stream));
         uint32_t *cnt0 = reinterpret_cast<uint32_t *>(c->est_table + slots);
-        hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->est_table, slots, cnt0);
+        hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->est_table, slots, cnt0, est_counts(c));
     }
     uint64_t *table = c->est_table;
     uint32_t *distinct = reinterpret_cast<uint32_t *>(c->est_table + slots);
@@ -586,7 +701,8 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint32_t hv[3] = {h[0], h[1], h[2]};
-    hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct);
+    c->est_kept = keep_table;
+    if (!keep_table) hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct, (uint32_t *)nullptr);
     double d = std::max<uint32_t>(hv[0], 1), s = (double)n_sample;
     double est;
     if (n_sample == n_rows) est = d;
@@ -614,6 +730,43 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
     }
     *out_est = (int64_t)est;
+    return 0;
+}
+
+// Releases a table kept by estimate_groups(.., keep_table = true) without using it.
+void estimate_release(pandrs_hip_ctx *c) {
+    if (!c->est_kept) return;
+    c->est_kept = false;
+    hipLaunchKernelGGL(estimate_clear_kernel, dim3(EST_SLOTS / 256), dim3(256), 0, c->stream, c->est_table, EST_SLOTS,
+                       reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), (uint32_t *)nullptr);
+}
+
+// Share of the rows (by the kept sample) that belongs to the `budget` most frequent keys; releases the table.
+int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t budget, double *out_share) {
+    *out_share = 0.0;
+    if (!c->est_kept) return 0;
+    PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
+    const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
+    const int64_t stride = n_rows / n_sample;
+    volatile uint32_t *h = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1056;     // own corner of the pinned block
+    h[3] = 0;
+    hipLaunchKernelGGL(estimate_count_kernel, dim3((unsigned)((n_sample + 1023) / 1024)), dim3(1024), 0, c->stream,
+                       key, n_rows, stride, n_sample, c->est_table, EST_SLOTS - 1, est_counts(c));
+    hipLaunchKernelGGL(estimate_coverage_kernel, dim3(64), dim3(1024), 0, c->stream, c->est_table, est_counts(c), EST_SLOTS,
+                       (uint32_t)std::min<int64_t>(std::max<int64_t>(budget, 1), 0x7FFFFFFF), est_cov_hist(c), const_cast<uint32_t *>(h));
+    HIP_TRY(hipGetLastError());
+    for (int spin = 0; spin < 200000 && h[3] != 1; spin++) __builtin_ia32_pause();
+    if (h[3] != 1) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[3] != 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "coverage kernel did not publish its counters");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const uint32_t h0 = h[0], h2 = h[2];
+    const double covered = h0, all = std::max<uint32_t>(h2, 1);
+    c->est_kept = false;
+    hipLaunchKernelGGL(estimate_clear_kernel, dim3(EST_SLOTS / 256), dim3(256), 0, c->stream, c->est_table, EST_SLOTS,
+                       reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), est_counts(c));
+    *out_share = covered / all;
     return 0;
 }
 

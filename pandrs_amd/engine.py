@@ -208,7 +208,7 @@ class Context:
                          if L.PHASE_NAMES[i] and t.phase_ms[i] > 0},
             "algorithmic_bytes": t.algorithmic_bytes, "n_partitions": t.n_partitions,
             "table_slots": t.table_slots, "retries": t.retries,
-            "estimated_groups": t.estimated_groups,
+            "estimated_groups": t.estimated_groups, "absorbed_rows": t.absorbed_rows,
         }
 
     # -- groupby -----------------------------------------------------------------------------------

@@ -1246,3 +1246,81 @@ def test_small_call_path_falls_back_when_groups_outgrow_its_tables(ctx):
     ctx.set_option("no_small", 0)
     check(ctx, [(sparse_keys(rng, 50_000, 10), None, O.I64)], 50_000, [(vals[0][0][:50_000], None, O.F64)], FIVE, [O.I64], exact=EXACT5)
     assert ctx.timings()["n_partitions"] == 0
+
+
+# ---- hot-key absorb-and-spill in front of the radix path (absorb.hip) --------------------------------------------------
+def _skewed_ids(rng, n, g, hot_share=0.8, hot_keys=None):
+    """80 % of the rows on the first fifth of the keys (benches/enhanced_comprehensive_benchmark.rs:53-59)"""
+    hot = rng.random(n) < hot_share
+    return np.where(hot, rng.integers(0, hot_keys or max(g // 5, 1), n), rng.integers(0, g, n))
+
+
+@pytest.mark.parametrize("shape", ["c3_codes", "i64_nulls", "i64_sum_only", "uniform_forced"])
+def test_absorb_and_spill_matches_oracle(ctx, shape):
+    """One pass over the original columns folds the rows whose key found a slot in a workgroup's LDS table, the rest is
+    spilled and goes through the radix path; both halves are merged.  Same answers as the oracle, bit for bit where
+    the reference is (counts, min / max), 1e-9 on f64 sums."""
+    rng = np.random.default_rng({"c3_codes": 1, "i64_nulls": 2, "i64_sum_only": 3, "uniform_forced": 4}[shape])
+    n = 17_000_000
+    if shape == "c3_codes":
+        g = 10_000
+        key = (_skewed_ids(rng, n, g).astype(np.uint32), None, O.U32CODE)
+        vals = [(rng.standard_normal(n), None, O.F64), (rng.standard_normal(n) * 10 + 100, None, O.F64)]
+        aggs = [(c, op) for c in range(2) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+        exact, kd = (2, 3, 6, 7, 8), O.U32CODE
+    elif shape == "i64_nulls":
+        g = 30_000
+        ids = _skewed_ids(rng, n, g, 0.9, 1_000)
+        k = sparse_keys_from(ids)
+        k[::100_003] = -1                                        # the key equal to the table sentinel
+        key = (k, O.pack_mask(rng.random(n) < 0.001), O.I64)      # and a NULL-key group
+        v = rng.standard_normal(n)
+        v[::50_021] = np.nan
+        vals = [(v, O.pack_mask(rng.random(n) < 0.02), O.F64), (rng.standard_normal(n), O.pack_mask(rng.random(n) < 0.5), O.F64)]
+        aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.MEAN), (1, O.SUM), (1, O.MIN), (1, O.MAX), (1, O.COUNT)]
+        exact, kd = (1, 2, 5, 6, 7), O.I64
+    elif shape == "i64_sum_only":
+        g = 200_000
+        key = (sparse_keys_from(_skewed_ids(rng, n, g, 0.95, 4_000)), None, O.I64)
+        vals = [(rng.integers(-1000, 1000, n).astype(np.int64), None, O.I64)]
+        aggs = [(0, O.SUM), (0, O.COUNT)]
+        exact, kd = (0, 1), O.I64
+    else:
+        g = 12_000                                                # uniform keys: almost everything spills (forced)
+        key = (sparse_keys(rng, n, g), None, O.I64)
+        vals = [(rng.standard_normal(n), None, O.F64)]
+        aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX)]
+        exact, kd = (1, 2), O.I64
+    want = O.groupby_agg([key], n, vals, aggs)
+    if shape == "uniform_forced":
+        ctx.set_option("no_absorb", -1)
+    try:
+        got = ctx.groupby_agg([key], n, vals, aggs)
+        t = ctx.timings()
+    finally:
+        ctx.set_option("no_absorb", 0)
+    assert t["absorbed_rows"] > 0, t
+    if shape != "uniform_forced":
+        assert t["absorbed_rows"] > 0.6 * n, t
+    else:
+        assert t["absorbed_rows"] < 0.5 * n, t
+    assert_groupby_equal(got, want, [kd], int_exact_rows=exact)
+    # the ordinary path gives the same groups (and does not absorb)
+    ctx.set_option("no_absorb", 1)
+    try:
+        got2 = ctx.groupby_agg([key], n, vals, aggs)
+        assert ctx.timings()["absorbed_rows"] == 0
+    finally:
+        ctx.set_option("no_absorb", 0)
+    assert_groupby_equal(got2, want, [kd], int_exact_rows=exact)
+
+
+def test_absorb_is_not_tried_on_uniform_keys(ctx):
+    """The decision comes from the estimate's own sample (share of the rows on the most frequent keys): uniform keys
+    must keep the ordinary path, at the cost of two small kernels."""
+    rng = np.random.default_rng(9)
+    n, g = 17_000_000, 12_000
+    key = (sparse_keys(rng, n, g), None, O.I64)
+    vals = [(rng.standard_normal(n), None, O.F64)]
+    ctx.groupby_compute([key], n, vals, [(0, O.SUM), (0, O.MIN), (0, O.MAX)])
+    assert ctx.timings()["absorbed_rows"] == 0
