@@ -24,4 +24,5 @@ for r in rows:
 PY
     fi
     echo "$cfg done: $(tail -1 $out/$cfg.json | cut -c1-200)"
+    mkdir -p $root/gpurun_out/profiles_$tag; cp $root/profiles/${tag}_* $root/gpurun_out/profiles_$tag/ 2>/dev/null
 done
