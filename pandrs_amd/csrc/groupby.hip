@@ -1109,7 +1109,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
             return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
         };
-        bool ok = !merge && !rs.pre && pl.mergeable && c->opt.no_absorb <= 0 && res_slot == 0 && !c->quiet && N >= (int64_t(1) << 24) &&
+        bool ok = !merge && !rs.pre && pl.mergeable && c->opt.no_absorb <= 0 && res_slot == 0 && !c->quiet &&
+                  N >= (int64_t(1) << (c->opt.no_absorb < 0 ? 16 : 24)) &&      // (no_absorb = -1, tests / fuzz: small inputs too)
                   n_src >= 1 && n_src <= MAX_ABS_SRC && c->opt.partitions <= 0 && !c->opt.generic_aggregate && !c->opt.deterministic;
         for (auto &e : srcs) ok = ok && !e.valid_bytes && !e.rowidx && e.st_fadd < 0 && e.st_ssq < 0;
         if (ok) {
