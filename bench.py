@@ -155,7 +155,12 @@ def extra_configs(torch, pa, ctx, device, steps=5):
     v = torch.randn(n, device=device, generator=gen, dtype=torch.float64) * 10 + 100
     timed("north_star_sum", n, "100M rows, i64 key (1M groups), sum of one f64 column",
           lambda: ctx.groupby_compute([(k, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.SUM)]))
-    del k
+    # C1's shape (1 K groups, one f64 sum: the reference's own example, examples/optimized_groupby_example.rs) at 100 M rows: every group
+    # fits a workgroup's LDS table, so the input is read once and nothing else moves (absorb.hip with nothing to spill)
+    k1 = torch.randint(0, 1000, (n,), device=device, generator=gen, dtype=torch.int64) * MIX
+    timed("c1_shape_100m", n, "C1's shape at 100M rows: i64 key (1K groups), sum of one f64 column",
+          lambda: ctx.groupby_compute([(k1, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.SUM)]))
+    del k, k1
     # C3: 100 M rows, u32 string-pool codes, 10 K groups with 80/20 skew, 2 f64 columns x sum/mean/min/max + count
     g = 10_000
     hot = torch.rand(n, device=device, generator=gen) < 0.8

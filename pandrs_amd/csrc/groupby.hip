@@ -1033,9 +1033,10 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     c->opt = saved;
     c->timings = tsave;
     c->timings.estimated_groups = est;
-    c->timings.n_partitions = PS; c->timings.table_slots = T;
-    c->timings.retries = 0;
     c->timings.absorbed_rows = N - (int64_t)hs[0];         // (the merge synchronised the stream)
+    c->timings.n_partitions = hs[0] ? PS : 0;              // nothing spilled: no radix partition took part (the few-groups case)
+    c->timings.table_slots = T;
+    c->timings.retries = 0;
     return st;
 }
 
@@ -1110,7 +1111,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
         };
         bool ok = !merge && !rs.pre && pl.mergeable && c->opt.no_absorb <= 0 && res_slot == 0 && !c->quiet &&
-                  N >= (int64_t(1) << (c->opt.no_absorb < 0 ? 16 : 24)) &&      // (no_absorb = -1, tests / fuzz: small inputs too)
+                  N >= (int64_t(1) << (c->opt.no_absorb < 0 ? 16 : 22)) &&      // (no_absorb = -1, tests / fuzz: small inputs too)
                   n_src >= 1 && n_src <= MAX_ABS_SRC && c->opt.partitions <= 0 && !c->opt.generic_aggregate && !c->opt.deterministic;
         for (auto &e : srcs) ok = ok && !e.valid_bytes && !e.rowidx && e.st_fadd < 0 && e.st_ssq < 0;
         if (ok) {
@@ -1131,8 +1132,15 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         int total_states = 0;
         for (auto &e : srcs) total_states += e.n_states();
         const int64_t Td = std::min<int64_t>((int64_t)(((size_t)c->lds_bytes - 512 - 192) / (20 + 8 * (size_t)total_states)) - 3, 32768) & ~int64_t(3);
-        // not where the direct path answers (every group fits one table), not where the table is a drop in the ocean
-        if (T_abs >= 256 && !c->clustered_rows && !(Td >= 64 && est * 2 <= Td && !c->opt.no_direct) && est <= 64 * T_abs) {
+        const bool direct_would = Td >= 64 && est * 2 <= Td && !c->opt.no_direct && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0);
+        if (T_abs >= 256 && !c->clustered_rows && !c->opt.no_direct && est * 2 <= T_abs) {
+            // every group fits a workgroup's table with room to spare: the absorb pass IS the few-groups direct path (nothing spills),
+            // with the leaner kernel (100 M rows, 1 K groups: 0.59 -> 0.45 ms for one sum, 0.89 -> 0.70 for six aggregates)
+            estimate_release(c);
+            do_absorb = true;
+        } else if (T_abs >= 256 && !c->clustered_rows && !direct_would && est <= 64 * T_abs && N >= (int64_t(1) << (c->opt.no_absorb < 0 ? 16 : 24))) {
+            // not where the direct path answers, not where the table is a drop in the ocean: absorb when the most frequent
+            // keys — as many as the table takes — hold most of the rows
             double share = 0.0;
             ST_TRY(estimate_coverage(c, rs.key, N, (int64_t)((double)T_abs * 0.80), &share));
             do_absorb = share >= (c->opt.no_absorb < 0 ? 0.0 : 0.60);        // (no_absorb = -1, tests: whenever it is possible)

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void estimate_count_kernel(KeyDesc key, int64
         live = !key_is_null(key, i) && k != EMPTY_KEY;
     }
     uint32_t weight = live ? 1u : 0u;
-    for (int round = 0; round < 2; round++) {                  // peel the wave's two most common leading keys
+    for (int round = 0; round < 8; round++) {                  // peel the wave's leading keys: a handful of dominant keys must not cost one global atomic per lane
         const unsigned long long m = __ballot(live && weight == 1u);
         if (!m) break;
         const int leader = __ffsll((long long)m) - 1;
