@@ -451,7 +451,11 @@ int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *comm);
 /* Row-range-sharded group_by(..).aggregate(..) (aggregation.rs:763) over all ranks' rows: local partial states ->
  * owner split -> count exchange -> ONE grouped ncclSend / ncclRecv all-to-all of packed records on the context's
  * stream -> merge.  The result (fetch with groupby_fetch) holds the groups this rank owns; the ranks' key sets are
- * disjoint.  Sum / Mean / Min / Max / Count, one key column; null-mask presence may differ between ranks.  A rank whose
+ * disjoint.  That is the path for Sum / Mean / Min / Max / Count over one key column.  Anything else except First / Last
+ * (Std / Var / Median / Nunique, composite keys of up to 8 columns) takes the row shuffle inside the same call: every row
+ * goes to the owner of its key (the radix partitioner with P = world; a composite key on a hash cell of the tuple), one count
+ * exchange, one grouped all-to-all of all columns, and the owner runs the ordinary groupby on what it received.
+ * Null-mask presence may differ between ranks.  A rank whose
  * local phase fails still joins the count exchange with its status: EVERY rank then returns an error (nobody is left
  * blocked in a collective).  The exchange buffers live in the communicator and are only ever grown. */
 int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, int32_t mem_space,

@@ -269,6 +269,186 @@ static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t
     return st;
 }
 
+// ---- the GENERAL exchange: rows to the owner of their key --------------------------------------------------------------
+// For what partial states cannot express (Std / Var / Median / Nunique, several key columns): every row goes to the rank that
+// owns its key (pandrs_hip_shuffle_split: the radix partitioner with P = world), ONE count exchange, one grouped all-to-all of
+// all columns, and the owner runs the ordinary groupby on what it received.  A composite key is shuffled on a hash cell of
+// the whole tuple (pandrs_hip_key_hash_cells) with the key columns travelling as payload.
+struct ExCol { const void *send; size_t elem; void *recv; };
+
+// `cols`: row-aligned device columns, rank-contiguous by the same split `send_counts` (rows per rank).  recv pointers are
+// filled in (cm->recv arena).  Status agreement as in exchange_records.
+static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const int64_t *send_counts, std::vector<ExCol> &cols,
+                                int32_t local_status, int64_t *out_n_recv) {
+    const int world = cm->world, me = cm->rank, row = world + 1;
+    std::vector<int64_t> mine((size_t)row, 0);
+    for (int p = 0; p < world; p++) mine[p] = local_status ? 0 : send_counts[p];
+    mine[world] = local_status;
+    cm->counts.assign((size_t)world * row, 0);
+    if (cm->nccl) {
+        ST_TRY(cm->small.ensure(4096 + (size_t)world * row * 8 + (size_t)row * 8, c->stream));
+        int64_t *d_mine = cm->small.take<int64_t>(row);
+        int64_t *d_all = cm->small.take<int64_t>((size_t)world * row);
+        HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), (size_t)row * 8, hipMemcpyHostToDevice, c->stream));
+        RCCL_TRY(rccl().AllGather(d_mine, d_all, (size_t)row, RCCL_INT64, cm->nccl, c->stream));
+        HIP_TRY(hipMemcpyAsync(cm->counts.data(), d_all, (size_t)world * row * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        const int32_t st = cm->host.all_gather(cm->host.user, mine.data(), cm->counts.data(), (int64_t)row * 8);
+        if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_gather failed (%d)", st);
+    }
+    for (int r = 0; r < world; r++)
+        if (cm->counts[(size_t)r * row + world] != 0) {
+            if (r == me && local_status) return local_status;
+            return fail(PANDRS_HIP_ERR_COMPUTATION, "rank %d failed in its local phase (status %lld): the exchange is abandoned on every rank",
+                        r, (long long)cm->counts[(size_t)r * row + world]);
+        }
+    int64_t n_recv = 0;
+    for (int r = 0; r < world; r++) n_recv += cm->counts[(size_t)r * row + me];
+    size_t need = 4096;
+    for (auto &col : cols) need += Arena::padded((size_t)std::max<int64_t>(n_recv, 1) * col.elem + 256);
+    ST_TRY(cm->recv.ensure(need, c->stream));
+    for (auto &col : cols) {
+        col.recv = cm->recv.take<uint8_t>((size_t)std::max<int64_t>(n_recv, 1) * col.elem + 256);
+        if (!col.recv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small");
+    }
+    if (cm->nccl) {
+        RCCL_TRY(rccl().GroupStart());
+        int rc = 0;
+        for (auto &col : cols) {
+            int64_t soff = 0, roff = 0;
+            for (int p = 0; p < world && rc == 0; p++) {
+                const int64_t ns = send_counts[p], nr = cm->counts[(size_t)p * row + me];
+                if (ns > 0) rc = rccl().Send((const char *)col.send + (size_t)soff * col.elem, (size_t)ns * col.elem, RCCL_INT8, p, cm->nccl, c->stream);
+                if (nr > 0 && rc == 0) rc = rccl().Recv((char *)col.recv + (size_t)roff * col.elem, (size_t)nr * col.elem, RCCL_INT8, p, cm->nccl, c->stream);
+                soff += ns; roff += nr;
+            }
+        }
+        const int rc_end = rccl().GroupEnd();
+        if (rc != 0) return fail(PANDRS_HIP_ERR_COMPUTATION, "ncclSend / ncclRecv failed: %s", rccl().GetErrorString(rc));
+        RCCL_TRY(rc_end);
+    } else {
+        std::vector<int64_t> sb((size_t)world), so((size_t)world), rb((size_t)world), ro((size_t)world);
+        for (auto &col : cols) {
+            int64_t soff = 0, roff = 0;
+            for (int p = 0; p < world; p++) {
+                sb[p] = send_counts[p] * (int64_t)col.elem; so[p] = soff; soff += sb[p];
+                rb[p] = cm->counts[(size_t)p * row + me] * (int64_t)col.elem; ro[p] = roff; roff += rb[p];
+            }
+            cm->hsend.resize((size_t)soff + 8); cm->hrecv.resize((size_t)roff + 8);
+            if (soff) HIP_TRY(hipMemcpyAsync(cm->hsend.data(), col.send, (size_t)soff, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const int32_t st = cm->host.all_to_all_v(cm->host.user, cm->hsend.data(), sb.data(), so.data(), cm->hrecv.data(), rb.data(), ro.data());
+            if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_to_all_v failed (%d)", st);
+            if (roff) HIP_TRY(hipMemcpyAsync(col.recv, cm->hrecv.data(), (size_t)roff, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    *out_n_recv = n_recv;
+    return 0;
+}
+
+static int32_t dist_groupby_shuffle_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
+                                         int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals, const pandrs_hip_agg_spec *aggs,
+                                         int32_t n_aggs, int64_t *out_n_groups) {
+    if (n_keys < 1 || n_keys > 8 || n_vals > 16 - n_keys) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: 1..8 key columns, keys + values <= 16");
+    for (int a = 0; a < n_aggs; a++)
+        if (aggs[a].op == PANDRS_HIP_AGG_FIRST || aggs[a].op == PANDRS_HIP_AGG_LAST)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "First / Last need the global row order and are not sharded");
+    for (int k = 0; k < n_keys; k++)
+        if (n_keys > 1 && keys[k].dtype != PANDRS_HIP_I64 && keys[k].dtype != PANDRS_HIP_F64 && keys[k].dtype != PANDRS_HIP_U32CODE)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_groupby_agg: key column %d of a composite key cannot travel as shuffle payload (dtype %d)", k, keys[k].dtype);
+    for (int v = 0; v < n_vals; v++)
+        if (vals[v].dtype != PANDRS_HIP_I64 && vals[v].dtype != PANDRS_HIP_F64)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_groupby_agg (row shuffle): value column %d has dtype %d (i64 / f64 only)", v, vals[v].dtype);
+    // 0. one column layout on every rank: a column carries null flags iff SOME rank passes a mask for it
+    const int n_cols = n_keys + n_vals;
+    int64_t flags[17] = {0};
+    for (int k = 0; k < n_keys; k++) flags[k] = keys[k].null_mask ? 1 : 0;
+    for (int v = 0; v < n_vals; v++) flags[n_keys + v] = vals[v].null_mask ? 1 : 0;
+    ST_TRY(agree_max(c, cm, flags, n_cols));
+    std::vector<pandrs_hip_column> cols(keys, keys + n_keys);
+    cols.insert(cols.end(), vals, vals + n_vals);
+    std::vector<uint8_t> zero_host;
+    std::vector<uint64_t> hcells_host;
+    std::vector<int64_t> send_counts((size_t)cm->world, 0);
+    int64_t n_send = 0;
+    auto local_phase = [&]() -> int32_t {
+        for (int i = 0; i < n_cols; i++) {
+            if (flags[i] && !cols[i].null_mask) {
+                const size_t nb = (size_t)(n_rows + 7) / 8 + 8;
+                if (mem_space == PANDRS_HIP_MEM_HOST) {
+                    if (zero_host.size() < nb) zero_host.assign(nb, 0);
+                    cols[i].null_mask = zero_host.data();
+                } else {
+                    if (cm->zeros.cap < nb + 256 || cm->zeros_valid < nb) {
+                        ST_TRY(cm->zeros.ensure(nb + 256, c->stream));
+                        HIP_TRY(hipMemsetAsync(cm->zeros.base, 0, cm->zeros.cap, c->stream));
+                        cm->zeros_valid = cm->zeros.cap;
+                    }
+                    cols[i].null_mask = reinterpret_cast<const uint8_t *>(cm->zeros.base);
+                }
+            }
+        }
+        if (n_keys == 1) {
+            ST_TRY(shuffle_split_entry(c, mem_space, &cols[0], n_vals ? &cols[1] : nullptr, n_vals, n_rows, cm->world, 0, send_counts.data(), &n_send));
+        } else {
+            // the shuffle key: one hash cell per row of the whole tuple; the key columns travel as payload
+            pandrs_hip_column hk{nullptr, nullptr, PANDRS_HIP_CELL64, 0};
+            if (mem_space == PANDRS_HIP_MEM_HOST) {
+                hcells_host.resize((size_t)std::max<int64_t>(n_rows, 1));
+                ST_TRY(key_hash_cells_entry(c, mem_space, cols.data(), n_keys, n_rows, hcells_host.data()));
+                hk.data = hcells_host.data();
+            } else {
+                ST_TRY(cm->stage.ensure((size_t)std::max<int64_t>(n_rows, 1) * 8 + 4096, c->stream));
+                uint64_t *hc = cm->stage.take<uint64_t>((size_t)std::max<int64_t>(n_rows, 1));
+                ST_TRY(key_hash_cells_entry(c, mem_space, cols.data(), n_keys, n_rows, hc));
+                hk.data = hc;
+            }
+            ST_TRY(shuffle_split_entry(c, mem_space, &hk, cols.data(), n_cols, n_rows, cm->world, 0, send_counts.data(), &n_send));
+        }
+        return 0;
+    };
+    const int32_t status = local_phase();
+    // 1. the columns that travel: [cells + key null bytes (single key)] + payload columns + their null bytes
+    std::vector<ExCol> ex;
+    const ShuffleResult &sh = c->sh;
+    const int n_pay = n_keys == 1 ? n_vals : n_cols;
+    if (!status) {
+        if (n_keys == 1) { ex.push_back(ExCol{sh.cells, 8, nullptr}); ex.push_back(ExCol{sh.key_null, 1, nullptr}); }
+        for (int p = 0; p < n_pay; p++) ex.push_back(ExCol{sh.pay[p], 8, nullptr});
+        for (int p = 0; p < n_pay; p++) if (flags[n_keys == 1 ? 1 + p : p]) ex.push_back(ExCol{sh.pay_null[p], 1, nullptr});
+    }
+    int64_t n_recv = 0;
+    ST_TRY(exchange_columns(c, cm, send_counts.data(), ex, status, &n_recv));
+    // 2. the received columns as ordinary groupby inputs (null bytes -> bitmaps)
+    const size_t nb = (size_t)(n_recv + 7) / 8 + 64;
+    ST_TRY(cm->small.ensure((size_t)(n_cols + 1) * Arena::padded(nb) + 4096, c->stream));
+    size_t at = 0;
+    auto next_recv = [&]() { return ex[at++].recv; };
+    std::vector<pandrs_hip_column> k2((size_t)n_keys), v2((size_t)std::max(n_vals, 1));
+    std::vector<const uint8_t *> null_bytes((size_t)n_cols, nullptr);
+    std::vector<void *> data((size_t)n_cols, nullptr);
+    const uint8_t *key_null_bytes = nullptr;
+    if (n_keys == 1) { data[0] = next_recv(); key_null_bytes = (const uint8_t *)next_recv(); }
+    for (int p = 0; p < n_pay; p++) data[n_keys == 1 ? 1 + p : p] = next_recv();
+    for (int p = 0; p < n_pay; p++) { const int i = n_keys == 1 ? 1 + p : p; if (flags[i]) null_bytes[i] = (const uint8_t *)next_recv(); }
+    if (n_keys == 1 && flags[0]) null_bytes[0] = key_null_bytes;
+    for (int i = 0; i < n_cols; i++) {
+        uint8_t *bits = nullptr;
+        if (null_bytes[i]) {
+            bits = cm->small.take<uint8_t>(nb);
+            if (!bits) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small (bitmaps)");
+            if (n_recv) ST_TRY(bytes_to_bitmap_entry(c, PANDRS_HIP_MEM_DEVICE, null_bytes[i], n_recv, bits));
+        }
+        int32_t dt = i < n_keys ? keys[i].dtype : vals[i - n_keys].dtype;
+        if (i < n_keys && (n_keys == 1 || dt == PANDRS_HIP_U32CODE)) dt = PANDRS_HIP_CELL64;      // normalised / zero-extended cells
+        pandrs_hip_column col{data[i], bits, dt, 0};
+        if (i < n_keys) k2[i] = col; else v2[i - n_keys] = col;
+    }
+    return groupby_entry(c, PANDRS_HIP_MEM_DEVICE, k2.data(), n_keys, n_recv, v2.data(), n_vals, aggs, n_aggs, /*partials=*/false, out_n_groups, nullptr);
+}
+
 }  // namespace pandrs
 
 using pandrs::fail;
@@ -329,9 +509,11 @@ int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, 
                                     const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups) {
     if (!ctx || !comm || !keys || !out_n_groups || n_rows < 0 || n_vals < 0 || n_aggs < 0 || (n_vals && !vals) || (n_aggs && !aggs))
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: bad arguments");
-    if (n_keys != 1)
-        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_groupby_agg takes one key column (composite keys: shuffle on pandrs_hip_key_hash_cells)");
     HIP_TRY(hipSetDevice(ctx->device));
+    bool mergeable = n_keys == 1;
+    for (int a = 0; a < n_aggs; a++) mergeable = mergeable && aggs[a].op <= PANDRS_HIP_AGG_COUNT;
+    if (!mergeable)       // Std / Var / Median / Nunique, or a composite key: the rows go to the owner of their key
+        return pandrs::dist_groupby_shuffle_impl(ctx, comm, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs, out_n_groups);
     return pandrs::dist_groupby_impl(ctx, comm, mem_space, keys, n_rows, vals, n_vals, aggs, n_aggs, out_n_groups);
 }
 

@@ -148,11 +148,12 @@ class DistributedGroupBy:
     def groupby_agg(self, keys, n_rows, vals, aggs, fetch=True):
         """Same arguments as Context.groupby_agg; every rank passes its own row range.
         Returns this rank's share of the groups (keys owned by this rank)."""
-        if len(keys) > 1 or any(op not in self.MERGEABLE_OPS for _, op in aggs):
+        eng = self.engine
+        general = len(keys) > 1 or any(op not in self.MERGEABLE_OPS for _, op in aggs)
+        if general and not getattr(eng, "comm", None):
             return self.groupby_by_shuffle(keys, n_rows, vals, aggs)
         torch = self._torch()
-        eng = self.engine
-        if getattr(eng, "comm", None):
+        if getattr(eng, "comm", None):        # (also the general case: pandrs_hip_dist_groupby_agg shuffles the rows itself)
             # the exchange lives in the library (pandrs_hip_dist_groupby_agg: count all-gather + ONE grouped
             # ncclSend / ncclRecv all-to-all on the context's stream); this class is only its caller
             t0 = time.perf_counter()

@@ -607,7 +607,8 @@ class Context:
                                                   self._aggs(aggs), len(aggs), C.byref(ng))
         if st:
             _raise(st)
-        self._last = (len(keys), len(aggs), sp1, ng.value)
+        general = len(keys) > 1 or any(int(op) > L.COUNT for _, op in aggs)
+        self._last = (len(keys), len(aggs), L.MEM_DEVICE if general else sp1, ng.value)     # the row shuffle leaves its result on the device
         return ng.value
 
     def dist_join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):

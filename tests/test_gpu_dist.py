@@ -292,8 +292,18 @@ def test_in_library_exchange_groupby_world1(cctx):
     d = DistributedGroupBy(cctx, _NoDist(), "cuda:0")
     kc, kn, oa = d.groupby_agg([(_dev(k), _dev(km), O.I64)], n, [(_dev(v), None, O.F64), (_dev(w), _dev(wm), O.F64)], aggs)
     assert_groupby_equal((kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy()), want, [O.I64], int_exact_rows=[2, 3, 4, 6])
+    # what partial states cannot express takes the row shuffle inside the same entry point (world 1: RCCL sends to itself)
+    gen = [(0, O.MEDIAN), (1, O.STD), (0, O.NUNIQUE), (1, O.SUM)]
+    cctx.dist_groupby_compute([(_dev(k), _dev(km), O.I64)], n, [(_dev(v), None, O.F64), (_dev(w), _dev(wm), O.F64)], gen)
+    assert_groupby_equal(cctx.groupby_fetch(to_device=False), O.groupby_agg([(k, km, O.I64)], n, [(v, None, O.F64), (w, wm, O.F64)], gen),
+                         [O.I64], int_exact_rows=[0, 2])
+    codes = (np.abs(k) % 5).astype(np.uint32)
+    two = [(0, O.SUM), (0, O.COUNT)]
+    cctx.dist_groupby_compute([(codes, None, O.U32CODE), (k % 100, km, O.I64)], n, [(v, None, O.F64)], two)       # host shards, two keys
+    assert_groupby_equal(cctx.groupby_fetch(to_device=False), O.groupby_agg([(codes, None, O.U32CODE), (k % 100, km, O.I64)], n, [(v, None, O.F64)], two),
+                         [O.U32CODE, O.I64], int_exact_rows=[1])
     with pytest.raises(Exception):
-        cctx.dist_groupby_compute([(k, None, O.I64)], n, [(v, None, O.F64)], [(0, O.MEDIAN)])
+        cctx.dist_groupby_compute([(k, None, O.I64)], n, [(v, None, O.F64)], [(0, O.FIRST)])      # needs the global row order
 
 
 def test_in_library_exchange_join_groupby_world1(cctx):
@@ -411,6 +421,16 @@ def _transport_worker(rank, world, port, outdir, uneven):
                                                (dev(c["rk"][rlo:rhi]), None, O.I64), (dev(c["rg"][rlo:rhi]), rgm, O.I64), rhi - rlo)
     out["join_allocs_in_steady_state"] = np.array([pa.Context.alloc_events() - a0])
     out.update(jn_kc=kc.cpu().numpy().view(np.uint64), jn_kn=kn.cpu().numpy(), jn_oa=oa.cpu().numpy())
+    # the GENERAL exchange inside the library (row shuffle by key owner): Median / Std / Nunique, and a composite key
+    gen_aggs = [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.STD), (1, O.SUM), (0, O.NUNIQUE)]
+    ctx.dist_groupby_compute(keys, hi - lo, vals, gen_aggs)
+    kc, kn, oa = ctx.groupby_fetch(to_device=False)
+    out.update(gen_kc=kc, gen_kn=kn, gen_oa=oa)
+    k2 = (c["v1"][lo:hi] % 7).astype(np.uint32)
+    mk = [(dev(c["k"][lo:hi] % 1000), None, O.I64), (dev(k2), m1, O.U32CODE)]        # the code column's mask: absent on rank 0 only
+    ctx.dist_groupby_compute(mk, hi - lo, vals[:1], [(0, O.SUM), (0, O.MEDIAN), (0, O.COUNT)])
+    kc, kn, oa = ctx.groupby_fetch(to_device=False)
+    out.update(mk_kc=kc, mk_kn=kn, mk_oa=oa)
     # a rank-local failure between collectives: rank `world - 1` passes a value column nothing can sum; EVERY rank must
     # come back with an error instead of waiting in the count exchange
     bad = [(dev(c["v1"][lo:hi].astype(np.uint32)), None, O.U32CODE)] if rank == world - 1 else [(dev(c["v0"][lo:hi]), None, O.F64)]
@@ -449,6 +469,16 @@ def test_in_library_exchange_with_real_ranks_over_a_host_transport(tmp_path, wor
     gotj = cat("jn")
     assert gotj[0].shape[1] == wantj[0].shape[1]
     assert_groupby_equal(gotj, wantj, [O.I64])
+    gen_aggs = [(0, O.MEDIAN), (1, O.MEDIAN), (0, O.STD), (1, O.SUM), (0, O.NUNIQUE)]
+    wantg = O.groupby_agg(keys, c["n"], vals, gen_aggs)
+    gotg = cat("gen")
+    assert gotg[0].shape[1] == wantg[0].shape[1]
+    assert_groupby_equal(gotg, wantg, [O.I64], int_exact_rows=[0, 1, 3, 4])
+    mk = [(c["k"] % 1000, None, O.I64), ((c["v1"] % 7).astype(np.uint32), O.pack_mask(c["m1"]), O.U32CODE)]
+    wantm = O.groupby_agg(mk, c["n"], vals[:1], [(0, O.SUM), (0, O.MEDIAN), (0, O.COUNT)])
+    gotm = cat("mk")
+    assert gotm[0].shape[1] == wantm[0].shape[1]
+    assert_groupby_equal(gotm, wantm, [O.I64, O.U32CODE], int_exact_rows=[1, 2])
     for p in parts:
         assert int(p["gb_allocs_in_steady_state"][0]) == 0 and int(p["join_allocs_in_steady_state"][0]) == 0
         assert int(p["failure_status"][0]) != 0                     # every rank, not only the failing one
