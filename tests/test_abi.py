@@ -31,7 +31,7 @@ def test_struct_layouts_match_header(lib):
     import ctypes as C
     assert C.sizeof(lib.Column) == 24 and C.sizeof(lib.AggSpec) == 8
     assert C.sizeof(lib.Config) == 32
-    assert C.sizeof(lib.Timings) == 8 + 8 * lib.MAX_PHASES + 5 * 8
+    assert C.sizeof(lib.Timings) == 8 + 8 * lib.MAX_PHASES + 6 * 8
     assert C.sizeof(lib.ColumnStats) == 11 * 8
 
 
