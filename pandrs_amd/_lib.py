@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpandrs_hip.so")
+# PANDRS_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box)
+LIB_PATH = os.environ.get("PANDRS_HIP_LIB") or os.path.join(_HERE, "libpandrs_hip.so")
 
 MAX_PHASES = 12
 PHASE_NAMES = ["stage_in", "estimate", "histogram", "scan", "scatter", "aggregate",
