@@ -449,8 +449,8 @@ int32_t pandrs_hip_comm_adopt_transport(const pandrs_hip_transport *transport, i
 int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *comm);
 
 /* Row-range-sharded group_by(..).aggregate(..) (aggregation.rs:763) over all ranks' rows: local partial states ->
- * owner split -> count exchange -> ONE grouped ncclSend / ncclRecv all-to-all of packed records on the context's
- * stream -> merge.  The result (fetch with groupby_fetch) holds the groups this rank owns; the ranks' key sets are
+ * owner split (one block of records per owner, a small column store; no host round trip) -> count exchange straight from the
+ * device counts -> ONE grouped ncclSend / ncclRecv all-to-all, a block per peer, on the context's stream -> merge.  The result (fetch with groupby_fetch) holds the groups this rank owns; the ranks' key sets are
  * disjoint.  That is the path for Sum / Mean / Min / Max / Count over one key column.  Anything else except First / Last
  * (Std / Var / Median / Nunique, composite keys of up to 8 columns) takes the row shuffle inside the same call: every row
  * goes to the owner of its key (the radix partitioner with P = world; a composite key on a hash cell of the tuple), one count

@@ -284,6 +284,11 @@ int32_t groupby_merge_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t key_dt
                             int32_t n_aggs, int64_t *out_n_groups);
 int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
                              uint64_t *out_records, int64_t *out_counts);
+// (in-library exchange, dist.hip: the partial records as one block per owner, no host round trip; the merge of received blocks)
+int32_t partials_split_blocks_entry(pandrs_hip_ctx *c, int32_t n_ranks, uint64_t *out, int64_t *count_row);
+int32_t groupby_merge_blocks_entry(pandrs_hip_ctx *c, int32_t key_dtype, const uint64_t *blocks, const int64_t *roff, int32_t n_src,
+                                   const int32_t *val_dtypes, int32_t n_vals, const uint8_t *val_has_nulls,
+                                   const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups);
 int32_t join_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk, int64_t nl,
                    const pandrs_hip_column *rk, int64_t nr, int32_t how, int64_t *out_n);
 int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *lk,

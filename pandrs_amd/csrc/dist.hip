@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <vector>
+#include <chrono>
+#include <cstdlib>
 
 namespace pandrs {
 
@@ -80,9 +82,9 @@ struct pandrs_hip_comm {
     int rank = 0, world = 1;
     bool owned = false;
     // exchange buffers: grown, never shrunk, never released between calls (no hipMalloc in a steady-state step).
-    // send / recv: packed records; small: counts and flags; zeros: an all-valid null bitmap (written once per growth);
+    // send / recv: the travelling columns; small: counts and flags of ONE collective; crow: this rank's count row (device); zeros: an all-valid null bitmap (written once per growth);
     // stage: the join's exported (g, sum) columns, which must outlive the nested groupby exchange
-    pandrs::Arena send, recv, small, zeros, stage;
+    pandrs::Arena send, recv, small, zeros, stage, crow;
     size_t zeros_valid = 0;                  // bytes of `zeros` known to be zero
     std::vector<int64_t> counts;             // world x (world + 1) matrix of the last count exchange (last column: status)
     std::vector<uint8_t> hsend, hrecv;       // host staging of the callback transport
@@ -124,179 +126,43 @@ static int32_t all_gather_dev(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const void
     return 0;
 }
 
-// The exchange proper.  `send`: device records, rank-contiguous by owner, `send_counts[p]` records of W words for rank p.
-// `local_status`: this rank's status so far; it rides on the count exchange, and when ANY rank reports a failure every
-// rank returns an error together instead of leaving its peers blocked in the all-to-all.
-// -> *out_recv (device, cm->recv arena), *out_n_recv.
-static int32_t exchange_records(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const uint64_t *send, const int64_t *send_counts,
-                                size_t W, int32_t local_status, uint64_t **out_recv, int64_t *out_n_recv) {
-    const int world = cm->world, me = cm->rank, row = world + 1;
-    // 1. counts (+ status): every rank learns the whole world x (world + 1) matrix with one all-gather
-    std::vector<int64_t> mine((size_t)row, 0);
-    for (int p = 0; p < world; p++) mine[p] = local_status ? 0 : send_counts[p];
-    mine[world] = local_status;
-    cm->counts.assign((size_t)world * row, 0);
-    if (cm->nccl) {
-        ST_TRY(cm->small.ensure(4096 + (size_t)world * row * 8 + (size_t)row * 8, c->stream));
-        int64_t *d_mine = cm->small.take<int64_t>(row);
-        int64_t *d_all = cm->small.take<int64_t>((size_t)world * row);
-        HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), (size_t)row * 8, hipMemcpyHostToDevice, c->stream));
-        RCCL_TRY(rccl().AllGather(d_mine, d_all, (size_t)row, RCCL_INT64, cm->nccl, c->stream));
-        HIP_TRY(hipMemcpyAsync(cm->counts.data(), d_all, (size_t)world * row * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    } else {
-        const int32_t st = cm->host.all_gather(cm->host.user, mine.data(), cm->counts.data(), (int64_t)row * 8);
-        if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_gather failed (%d)", st);
-    }
-    for (int r = 0; r < world; r++)
-        if (cm->counts[(size_t)r * row + world] != 0) {
-            if (r == me && local_status) return local_status;           // this rank's own error text is already set
-            return fail(PANDRS_HIP_ERR_COMPUTATION, "rank %d failed in its local phase (status %lld): the exchange is abandoned on every rank",
-                        r, (long long)cm->counts[(size_t)r * row + world]);
-        }
-    int64_t n_recv = 0;
-    for (int r = 0; r < world; r++) {
-        const int64_t v = cm->counts[(size_t)r * row + me];          // what rank r sends to this rank
-        if (v < 0) return fail(PANDRS_HIP_ERR_COMPUTATION, "negative record count from rank %d", r);
-        n_recv += v;
-    }
-    for (int p = 0; p < world; p++)
-        if (cm->counts[(size_t)me * row + p] != send_counts[p])
-            return fail(PANDRS_HIP_ERR_COMPUTATION, "count exchange returned a different row for this rank");
-    // 2. ONE grouped all-to-all of the packed records (every xGMI link busy at once; no ring)
-    ST_TRY(cm->recv.ensure((size_t)std::max<int64_t>(n_recv, 1) * W * 8 + 4096, c->stream));
-    uint64_t *recv = cm->recv.take<uint64_t>((size_t)std::max<int64_t>(n_recv, 1) * W);
-    if (!recv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small");
-    if (cm->nccl) {
-        RCCL_TRY(rccl().GroupStart());
-        int64_t soff = 0, roff = 0;
-        int rc = 0;
-        for (int p = 0; p < world && rc == 0; p++) {
-            const int64_t ns = send_counts[p], nr = cm->counts[(size_t)p * row + me];
-            if (ns > 0) rc = rccl().Send(send + (size_t)soff * W, (size_t)ns * W, RCCL_INT64, p, cm->nccl, c->stream);
-            if (nr > 0 && rc == 0) rc = rccl().Recv(recv + (size_t)roff * W, (size_t)nr * W, RCCL_INT64, p, cm->nccl, c->stream);
-            soff += ns; roff += nr;
-        }
-        const int rc_end = rccl().GroupEnd();
-        if (rc != 0) return fail(PANDRS_HIP_ERR_COMPUTATION, "ncclSend / ncclRecv failed: %s", rccl().GetErrorString(rc));
-        RCCL_TRY(rc_end);
-    } else {
-        std::vector<int64_t> sb((size_t)world), so((size_t)world), rb((size_t)world), ro((size_t)world);
-        int64_t soff = 0, roff = 0;
-        for (int p = 0; p < world; p++) {
-            sb[p] = send_counts[p] * (int64_t)W * 8; so[p] = soff; soff += sb[p];
-            rb[p] = cm->counts[(size_t)p * row + me] * (int64_t)W * 8; ro[p] = roff; roff += rb[p];
-        }
-        cm->hsend.resize((size_t)soff + 8); cm->hrecv.resize((size_t)roff + 8);
-        if (soff) HIP_TRY(hipMemcpyAsync(cm->hsend.data(), send, (size_t)soff, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        const int32_t st = cm->host.all_to_all_v(cm->host.user, cm->hsend.data(), sb.data(), so.data(), cm->hrecv.data(), rb.data(), ro.data());
-        if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_to_all_v failed (%d)", st);
-        if (roff) HIP_TRY(hipMemcpyAsync(recv, cm->hrecv.data(), (size_t)roff, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    *out_recv = recv; *out_n_recv = n_recv;
-    return 0;
-}
-
-// `prior_status`: a failure of the caller's local phase (the join's fused pass): this rank still takes part in every
-// collective below, contributes nothing, and all ranks return an error together.
-static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t mem_space, const pandrs_hip_column *key,
-                                 int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals, const pandrs_hip_agg_spec *aggs,
-                                 int32_t n_aggs, int64_t *out_n_groups, int32_t prior_status = 0) {
-    if (n_vals > 64) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: more than 64 value columns");
-    for (int a = 0; a < n_aggs; a++)
-        if (aggs[a].op > PANDRS_HIP_AGG_COUNT)
-            return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_groupby_agg exchanges partial states: Sum / Mean / Min / Max / Count only "
-                                                         "(the row shuffle for the rest is pandrs_hip_shuffle_split + the host's all-to-all)");
-    // 0. one layout on every rank: a value column has an nn state iff SOME rank passes a null mask for it
-    int64_t flags[65] = {0};
-    for (int i = 0; i < n_vals; i++) flags[i] = (!prior_status && vals[i].null_mask) ? 1 : 0;
-    flags[n_vals] = n_rows > 0 ? 1 : 0;
-    ST_TRY(agree_max(c, cm, flags, n_vals + 1));
-    int32_t status = prior_status;
-    int64_t ng = 0;
-    int32_t n_state = 0;
-    uint64_t *send = nullptr;
-    std::vector<int64_t> send_counts((size_t)cm->world, 0);
-    std::vector<uint8_t> has_nulls((size_t)std::max(n_vals, 1), 0);
-    std::vector<int32_t> dtypes((size_t)std::max(n_vals, 1), 0);
-    for (int i = 0; i < n_vals; i++) { has_nulls[i] = (uint8_t)flags[i]; dtypes[i] = vals[i].dtype; }
-    // the local phase: a failure here must not return before the count exchange (the peers are waiting in it)
-    auto local_phase = [&]() -> int32_t {
-        std::vector<pandrs_hip_column> v2(vals, vals + n_vals);
-        std::vector<uint8_t> zero_host;
-        for (int i = 0; i < n_vals; i++) {
-            if (flags[i] && !vals[i].null_mask) {           // another rank has nulls here: an all-valid bitmap keeps the plan identical
-                const size_t nb = (size_t)(n_rows + 7) / 8 + 8;
-                if (mem_space == PANDRS_HIP_MEM_HOST) {
-                    if (zero_host.size() < nb) zero_host.assign(nb, 0);
-                    v2[i].null_mask = zero_host.data();
-                } else {
-                    if (cm->zeros.cap < nb + 256 || cm->zeros_valid < nb) {       // kept in the communicator: zeroed once per growth
-                        ST_TRY(cm->zeros.ensure(nb + 256, c->stream));
-                        HIP_TRY(hipMemsetAsync(cm->zeros.base, 0, cm->zeros.cap, c->stream));
-                        cm->zeros_valid = cm->zeros.cap;
-                    }
-                    v2[i].null_mask = reinterpret_cast<const uint8_t *>(cm->zeros.base);
-                }
-            }
-        }
-        // 1. local partial aggregation (states retained in the context)
-        ST_TRY(groupby_entry(c, mem_space, key, 1, n_rows, v2.data(), n_vals, aggs, n_aggs, /*partials=*/true, &ng, &n_state));
-        // 2. owner split: packed records, rank-contiguous
-        const size_t W = 2 + (size_t)n_state;
-        ST_TRY(cm->send.ensure((size_t)std::max<int64_t>(ng, 1) * W * 8 + 4096, c->stream));
-        send = cm->send.take<uint64_t>((size_t)std::max<int64_t>(ng, 1) * W);
-        ST_TRY(partials_split_entry(c, PANDRS_HIP_MEM_DEVICE, cm->world, send, send_counts.data()));
-        return 0;
-    };
-    if (!status) status = local_phase();
-    if (status) std::fill(send_counts.begin(), send_counts.end(), 0);
-    // the record width is a function of (dtypes, agreed null flags, aggs) alone: identical on every rank, also on one whose local
-    // phase failed (it sends nothing, but it must still size what it would receive — it receives nothing either: all abort)
-    const size_t W = 2 + (size_t)n_state;
-    // 3. count exchange (+ status agreement) + ONE all-to-all
-    uint64_t *recv = nullptr;
-    int64_t n_recv = 0;
-    ST_TRY(exchange_records(c, cm, send, send_counts.data(), W, status, &recv, &n_recv));
-    // 4. merge what this rank owns (cardinality bounded by the records received: no sampling pass)
-    const int64_t hint_saved = c->opt.groups_hint;
-    c->opt.groups_hint = std::max<int64_t>(n_recv, 1);
-    const int32_t st = groupby_merge_entry(c, PANDRS_HIP_MEM_DEVICE, key->dtype, recv, n_recv, dtypes.data(), n_vals, has_nulls.data(),
-                                           aggs, n_aggs, out_n_groups);
-    c->opt.groups_hint = hint_saved;
-    return st;
-}
-
-// ---- the GENERAL exchange: rows to the owner of their key --------------------------------------------------------------
-// For what partial states cannot express (Std / Var / Median / Nunique, several key columns): every row goes to the rank that
-// owns its key (pandrs_hip_shuffle_split: the radix partitioner with P = world), ONE count exchange, one grouped all-to-all of
-// all columns, and the owner runs the ordinary groupby on what it received.  A composite key is shuffled on a hash cell of
-// the whole tuple (pandrs_hip_key_hash_cells) with the key columns travelling as payload.
+// ---- exchange of row-aligned COLUMNS (partial records as columns; the general row shuffle below)
 struct ExCol { const void *send; size_t elem; void *recv; };
 
 // `cols`: row-aligned device columns, rank-contiguous by the same split `send_counts` (rows per rank).  recv pointers are
-// filled in (cm->recv arena).  Status agreement as in exchange_records.
-static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const int64_t *send_counts, std::vector<ExCol> &cols,
-                                int32_t local_status, int64_t *out_n_recv) {
+// filled in (cm->recv arena).  `local_status`: this rank's status so far; it rides on the count exchange, and when ANY rank
+// reports a failure every rank returns an error together instead of leaving its peers blocked in the all-to-all.
+// `d_count_row` (optional): this rank's counts as a DEVICE row of world + 1 int64 (the split left them there, slot `world` is
+// the status word, written here): the all-gather starts from it and `send_counts` is an OUTPUT — the host first learns its own
+// counts from the gathered matrix, one synchronisation for the whole count exchange.
+static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t *send_counts, std::vector<ExCol> &cols,
+                                int32_t local_status, int64_t *out_n_recv, int64_t *d_count_row = nullptr) {
     const int world = cm->world, me = cm->rank, row = world + 1;
     std::vector<int64_t> mine((size_t)row, 0);
-    for (int p = 0; p < world; p++) mine[p] = local_status ? 0 : send_counts[p];
+    if (!d_count_row) for (int p = 0; p < world; p++) mine[p] = local_status ? 0 : send_counts[p];
     mine[world] = local_status;
     cm->counts.assign((size_t)world * row, 0);
+    if (d_count_row) {
+        if (local_status) HIP_TRY(hipMemsetAsync(d_count_row, 0, (size_t)world * 8, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_count_row + world, &mine[world], 8, hipMemcpyHostToDevice, c->stream));   // (pageable source: copied before the call returns)
+    }
     if (cm->nccl) {
         ST_TRY(cm->small.ensure(4096 + (size_t)world * row * 8 + (size_t)row * 8, c->stream));
-        int64_t *d_mine = cm->small.take<int64_t>(row);
+        int64_t *d_mine = d_count_row ? d_count_row : cm->small.take<int64_t>(row);
         int64_t *d_all = cm->small.take<int64_t>((size_t)world * row);
-        HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), (size_t)row * 8, hipMemcpyHostToDevice, c->stream));
+        if (!d_count_row) HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), (size_t)row * 8, hipMemcpyHostToDevice, c->stream));
         RCCL_TRY(rccl().AllGather(d_mine, d_all, (size_t)row, RCCL_INT64, cm->nccl, c->stream));
         HIP_TRY(hipMemcpyAsync(cm->counts.data(), d_all, (size_t)world * row * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
+        if (d_count_row) {
+            HIP_TRY(hipMemcpyAsync(mine.data(), d_count_row, (size_t)row * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         const int32_t st = cm->host.all_gather(cm->host.user, mine.data(), cm->counts.data(), (int64_t)row * 8);
         if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_gather failed (%d)", st);
     }
+    if (d_count_row) for (int p = 0; p < world; p++) send_counts[p] = cm->counts[(size_t)me * row + p];
     for (int r = 0; r < world; r++)
         if (cm->counts[(size_t)r * row + world] != 0) {
             if (r == me && local_status) return local_status;
@@ -348,6 +214,102 @@ static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const in
     return 0;
 }
 
+// `prior_status`: a failure of the caller's local phase (the join's fused pass): this rank still takes part in every
+// collective below, contributes nothing, and all ranks return an error together.
+static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t mem_space, const pandrs_hip_column *key,
+                                 int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals, const pandrs_hip_agg_spec *aggs,
+                                 int32_t n_aggs, int64_t *out_n_groups, int32_t prior_status = 0) {
+    if (n_vals > 64) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: more than 64 value columns");
+    for (int a = 0; a < n_aggs; a++)
+        if (aggs[a].op > PANDRS_HIP_AGG_COUNT)
+            return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_groupby_agg exchanges partial states: Sum / Mean / Min / Max / Count only "
+                                                         "(the row shuffle for the rest is pandrs_hip_shuffle_split + the host's all-to-all)");
+    // PANDRS_HIP_DIST_TRACE=1: wall time of every stage on stderr (each mark synchronises the stream: a diagnostic, not a mode)
+    static const bool trace = std::getenv("PANDRS_HIP_DIST_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[dist rank %d] %-28s %8.3f ms\n", cm->rank, what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    // 0. one layout on every rank: a value column has an nn state iff SOME rank passes a null mask for it
+    int64_t flags[65] = {0};
+    for (int i = 0; i < n_vals; i++) flags[i] = (!prior_status && vals[i].null_mask) ? 1 : 0;
+    flags[n_vals] = n_rows > 0 ? 1 : 0;
+    ST_TRY(agree_max(c, cm, flags, n_vals + 1));
+    mark("agree_max");
+    int32_t status = prior_status;
+    int64_t ng = 0;
+    int32_t n_state = 0;
+    uint64_t *send = nullptr;
+    std::vector<int64_t> send_counts((size_t)cm->world, 0);
+    ST_TRY(cm->crow.ensure(4096 + (size_t)(cm->world + 1) * 8, c->stream));      // (its own arena: `small` is re-used by every collective)
+    int64_t *d_count_row = cm->crow.take<int64_t>((size_t)cm->world + 1);
+    if (!d_count_row) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small (counts)");
+    std::vector<uint8_t> has_nulls((size_t)std::max(n_vals, 1), 0);
+    std::vector<int32_t> dtypes((size_t)std::max(n_vals, 1), 0);
+    for (int i = 0; i < n_vals; i++) { has_nulls[i] = (uint8_t)flags[i]; dtypes[i] = vals[i].dtype; }
+    // the local phase: a failure here must not return before the count exchange (the peers are waiting in it)
+    auto local_phase = [&]() -> int32_t {
+        std::vector<pandrs_hip_column> v2(vals, vals + n_vals);
+        std::vector<uint8_t> zero_host;
+        for (int i = 0; i < n_vals; i++) {
+            if (flags[i] && !vals[i].null_mask) {           // another rank has nulls here: an all-valid bitmap keeps the plan identical
+                const size_t nb = (size_t)(n_rows + 7) / 8 + 8;
+                if (mem_space == PANDRS_HIP_MEM_HOST) {
+                    if (zero_host.size() < nb) zero_host.assign(nb, 0);
+                    v2[i].null_mask = zero_host.data();
+                } else {
+                    if (cm->zeros.cap < nb + 256 || cm->zeros_valid < nb) {       // kept in the communicator: zeroed once per growth
+                        ST_TRY(cm->zeros.ensure(nb + 256, c->stream));
+                        HIP_TRY(hipMemsetAsync(cm->zeros.base, 0, cm->zeros.cap, c->stream));
+                        cm->zeros_valid = cm->zeros.cap;
+                    }
+                    v2[i].null_mask = reinterpret_cast<const uint8_t *>(cm->zeros.base);
+                }
+            }
+        }
+        // 1. local partial aggregation (states retained in the context)
+        ST_TRY(groupby_entry(c, mem_space, key, 1, n_rows, v2.data(), n_vals, aggs, n_aggs, /*partials=*/true, &ng, &n_state));
+        mark("local partials");
+        // 2. owner split: one block of records per owner; the counts stay on the device (no host round trip here)
+        const size_t W = 2 + (size_t)n_state;
+        ST_TRY(cm->send.ensure((size_t)std::max<int64_t>(ng, 1) * W * 8 + 4096, c->stream));
+        send = cm->send.take<uint64_t>((size_t)std::max<int64_t>(ng, 1) * W);
+        ST_TRY(partials_split_blocks_entry(c, cm->world, send, d_count_row));
+        mark("owner split");
+        return 0;
+    };
+    if (!status) status = local_phase();
+    // 3. count exchange (+ status agreement) straight from the device counts + ONE grouped all-to-all, a block per peer.  The block
+    // width is a function of (dtypes, agreed null flags, aggs) alone: identical on every rank.  A rank whose local phase failed
+    // sends nothing and receives nothing: every rank returns the error together.
+    if (!status && n_state <= 0) status = fail(PANDRS_HIP_ERR_COMPUTATION, "dist_groupby_agg: the local phase left no partial states");
+    const size_t W = 2 + (size_t)std::max(n_state, 0);
+    std::vector<ExCol> ex;
+    ex.push_back(ExCol{send, W * 8, nullptr});
+    int64_t n_recv = 0;
+    ST_TRY(exchange_columns(c, cm, send_counts.data(), ex, status, &n_recv, d_count_row));
+    mark("counts + all-to-all");
+    // 4. merge what this rank owns (cardinality bounded by the records received: no sampling pass)
+    std::vector<int64_t> roff((size_t)cm->world + 1, 0);
+    for (int r = 0; r < cm->world; r++) roff[(size_t)r + 1] = roff[(size_t)r] + cm->counts[(size_t)r * (cm->world + 1) + cm->rank];
+    const int64_t hint_saved = c->opt.groups_hint;
+    c->opt.groups_hint = std::max<int64_t>(n_recv, 1);
+    const int32_t st = groupby_merge_blocks_entry(c, key->dtype, (const uint64_t *)ex[0].recv, roff.data(), cm->world, dtypes.data(), n_vals,
+                                                  has_nulls.data(), aggs, n_aggs, out_n_groups);
+    c->opt.groups_hint = hint_saved;
+    mark("merge");
+    return st;
+}
+
+// ---- the GENERAL exchange: rows to the owner of their key --------------------------------------------------------------
+// For what partial states cannot express (Std / Var / Median / Nunique, several key columns): every row goes to the rank that
+// owns its key (pandrs_hip_shuffle_split: the radix partitioner with P = world), ONE count exchange, one grouped all-to-all of
+// all columns, and the owner runs the ordinary groupby on what it received.  A composite key is shuffled on a hash cell of
+// the whole tuple (pandrs_hip_key_hash_cells) with the key columns travelling as payload.
 static int32_t dist_groupby_shuffle_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t mem_space, const pandrs_hip_column *keys, int32_t n_keys,
                                          int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals, const pandrs_hip_agg_spec *aggs,
                                          int32_t n_aggs, int64_t *out_n_groups) {
@@ -498,7 +460,7 @@ int32_t pandrs_hip_comm_adopt_transport(const pandrs_hip_transport *t, int32_t r
 
 int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *cm) {
     if (!cm) return PANDRS_HIP_OK;
-    cm->send.release(); cm->recv.release(); cm->small.release(); cm->zeros.release(); cm->stage.release();
+    cm->send.release(); cm->recv.release(); cm->small.release(); cm->zeros.release(); cm->stage.release(); cm->crow.release();
     if (cm->owned && cm->nccl) (void)pandrs::rccl().CommDestroy(cm->nccl);
     delete cm;
     return PANDRS_HIP_OK;

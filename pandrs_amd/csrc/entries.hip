@@ -18,7 +18,7 @@ struct Stager {
     std::vector<const void *> pinned;      // host ranges page-locked for this call (GpuConfig.use_pinned_memory)
     // copies `bytes` from a caller pointer into the staging arena when it lives on the host
     const void *in(const void *p, size_t bytes) {
-        if (!p || space == PANDRS_HIP_MEM_DEVICE || status) return p;
+        if (!p || space == PANDRS_HIP_MEM_DEVICE || status || bytes == 0) return p;      // (an empty column is never dereferenced: nothing to stage)
         void *d = c->staging.take<uint8_t>(bytes + 16);
         if (!d) { status = fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small"); return nullptr; }
         if (config_use_pinned_memory() && bytes >= (size_t(1) << 20) &&
@@ -875,6 +875,148 @@ __global__ __launch_bounds__(OS_THREADS) void owner_scatter_kernel(const uint64_
         o[1] = knull[i];
         for (int s = 0; s < n_state; s++) o[2 + s] = states[(size_t)s * in_stride + i];
     }
+}
+
+// The in-library exchange's split (dist.hip).  The retained partial records leave as ONE BLOCK PER OWNER, each block a small
+// column store: block o = [W][n_o] words, W = 2 + n_state (key cell, key-null word, states), at word W * (records of the owners
+// before o) — one message per peer, written and read with unit stride.  Stream-ordered, no host round trip: the scatter derives
+// the block bases from the device counts itself, and its first workgroup leaves the counts as the int64 row the count
+// all-gather sends.
+constexpr int OB_RPT = 4;
+__global__ __launch_bounds__(OS_THREADS) void owner_scatter_blocks_kernel(const uint64_t *keys, const uint8_t *knull,
+                                                                          const uint64_t *states, size_t in_stride,
+                                                                          int n_state, int64_t n, uint32_t n_ranks,
+                                                                          const uint32_t *counts, uint32_t *cursors,
+                                                                          uint64_t *out, int64_t *count_row) {
+    __shared__ uint32_t cnt[1024], base[1024], wt[17];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t r = tid; r < n_ranks; r += OS_THREADS) cnt[r] = 0;
+    {   // exclusive prefix of the owners' counts (n_ranks <= 1024: four per thread)
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t r = tid * 4 + q; v[q] = r < n_ranks ? counts[r] : 0u; sum += v[q]; }
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<OS_THREADS>(sum, wt, &tot);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = tid * 4 + q;
+            if (r < n_ranks) { base[r] = ex; if (blockIdx.x == 0) count_row[r] = (int64_t)v[q]; }
+            ex += v[q];
+        }
+    }
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x * OS_THREADS * OB_RPT;
+    uint32_t own[OB_RPT], rank[OB_RPT];
+#pragma unroll
+    for (int q = 0; q < OB_RPT; q++) {
+        const int64_t i = first + q * OS_THREADS + tid;
+        own[q] = 0xFFFFFFFFu;
+        if (i < n) {
+            own[q] = knull[i] ? 0u : owner_of(keys[i], n_ranks);
+            rank[q] = atomicAdd(&cnt[own[q]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < n_ranks; r += OS_THREADS) {
+        const uint32_t k = cnt[r];
+        cnt[r] = k ? atomicAdd(&cursors[r], k) : 0u;          // this workgroup's first row inside owner r's block
+    }
+    __syncthreads();
+    const size_t W = 2 + (size_t)n_state;
+#pragma unroll
+    for (int q = 0; q < OB_RPT; q++) {
+        if (own[q] == 0xFFFFFFFFu) continue;
+        const int64_t i = first + q * OS_THREADS + tid;
+        const size_t n_o = counts[own[q]];
+        uint64_t *blk = out + W * (size_t)base[own[q]] + (cnt[own[q]] + rank[q]);
+        blk[0] = keys[i];
+        blk[n_o] = knull[i];
+        for (int st = 0; st < n_state; st++) blk[(size_t)(2 + st) * n_o] = states[(size_t)st * in_stride + i];
+    }
+}
+
+// blocks as received (block r = [W][n_r] at word W * roff_r) -> the merge's columns: keys[n] | key_null[n] bytes | states[W - 2][n]
+__global__ __launch_bounds__(256) void unblock_records_kernel(const uint64_t *blocks, const int64_t *roff, uint32_t n_src, int64_t n, int W,
+                                                              uint64_t *keys, uint8_t *knull, uint64_t *states) {
+    __shared__ int64_t off[1025];
+    for (uint32_t r = threadIdx.x; r <= n_src; r += 256) off[r] = roff[r];
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    uint32_t lo = 0, hi = n_src;                               // the source block of row e: off[lo] <= e < off[lo + 1]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= e) lo = mid; else hi = mid; }
+    const size_t n_r = (size_t)(off[lo + 1] - off[lo]);
+    const uint64_t *blk = blocks + (size_t)W * (size_t)off[lo] + (size_t)(e - off[lo]);
+    keys[e] = blk[0];
+    knull[e] = blk[n_r] != 0;
+    for (int st = 0; st < W - 2; st++) states[(size_t)st * (size_t)n + e] = blk[(size_t)(2 + st) * n_r];
+}
+
+// -> `out` (device, >= max(n, 1) * (2 + n_state) words), *count_row (device int64[n_ranks]: records per owner)
+int32_t partials_split_blocks_entry(pandrs_hip_ctx *c, int32_t n_ranks, uint64_t *out, int64_t *count_row) {
+    if (!c || n_ranks < 1 || n_ranks > 1024 || !count_row || !out) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "partials_split: bad arguments");
+    std::lock_guard<std::mutex> lock(c->mu);
+    GroupbyResult &res = c->gb;
+    if (!res.valid || !res.partials) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no partials retained in this context");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = res.n_groups;
+    HIP_TRY(hipMemsetAsync(count_row, 0, (size_t)n_ranks * 8, c->stream));
+    if (n == 0) return 0;
+    if (c->work.cap < (1 << 16)) ST_TRY(c->work.ensure(1 << 16, c->stream));
+    c->work.off = 0;
+    uint32_t *counts = c->work.take<uint32_t>(2048);
+    uint32_t *cursors = counts + 1024;
+    HIP_TRY(hipMemsetAsync(counts, 0, 2048 * 4, c->stream));
+    hipLaunchKernelGGL(owner_count_kernel, dim3((unsigned)((n + OS_THREADS * OS_RPT - 1) / (OS_THREADS * OS_RPT))), dim3(OS_THREADS), 0, c->stream,
+                       res.keys, res.key_null, n, (uint32_t)n_ranks, counts);
+    hipLaunchKernelGGL(owner_scatter_blocks_kernel, dim3((unsigned)((n + OS_THREADS * OB_RPT - 1) / (OS_THREADS * OB_RPT))), dim3(OS_THREADS), 0,
+                       c->stream, res.keys, res.key_null, res.states, (size_t)res.cap, res.n_state, n, (uint32_t)n_ranks, counts, cursors,
+                       out, count_row);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The merge over received blocks (see above): one unblock pass into the staging arena, then the ordinary merge.
+// `roff`: HOST array of n_src + 1 row offsets of the source blocks.
+int32_t groupby_merge_blocks_entry(pandrs_hip_ctx *c, int32_t key_dtype, const uint64_t *blocks, const int64_t *roff, int32_t n_src,
+                                   const int32_t *val_dtypes, int32_t n_vals, const uint8_t *val_has_nulls,
+                                   const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups) {
+    if (!c || !out_n_groups || !roff || n_src < 1 || n_src > 1024 || n_vals < 0 || n_aggs < 0)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_merge: bad arguments");
+    const int64_t n_rows = roff[n_src];
+    if (n_rows < 0 || (n_rows && !blocks)) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "groupby_merge: bad arguments");
+    Plan pl;
+    ST_TRY(build_plan(val_dtypes, val_has_nulls, n_vals, aggs, n_aggs, pl));
+    if (pl.has_median)
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
+                    "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    timings_begin(c);
+    const size_t n_state = 1 + (size_t)pl.n_states, W = 2 + n_state;
+    ST_TRY(c->staging.ensure(size_t(n_rows) * 8 * W + size_t(n_rows) * 16 + (size_t)(n_src + 1) * 8 + (1 << 16), c->stream));
+    RowSource rs;
+    rs.n_rows = n_rows;
+    if (n_rows > 0) {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_STAGE_IN);
+        int64_t *d_off = c->staging.take<int64_t>((size_t)n_src + 1);
+        uint64_t *dk = c->staging.take<uint64_t>(n_rows);
+        uint8_t *dn = c->staging.take<uint8_t>(n_rows);
+        uint64_t *ds = c->staging.take<uint64_t>(size_t(n_rows) * n_state);
+        if (!d_off || !dk || !dn || !ds) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+        HIP_TRY(hipMemcpyAsync(d_off, roff, (size_t)(n_src + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(unblock_records_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                           blocks, d_off, (uint32_t)n_src, n_rows, (int)W, dk, dn, ds);
+        HIP_TRY(hipGetLastError());
+        rs.key = KeyDesc{dk, nullptr, dn, DT_CELL};
+        rs.merge_states = ds;
+        rs.merge_stride = (size_t)n_rows;
+    }
+    ST_TRY(run_engine(c, rs, pl, /*merge=*/true, /*partials=*/false, n_aggs, key_dtype));
+    c->timings.algorithmic_bytes = n_rows * (int64_t)(8 * W) + c->gb.n_groups * (8 + 8 * (int64_t)n_aggs);
+    ST_TRY(timings_end(c));
+    *out_n_groups = c->gb.n_groups;
+    return 0;
 }
 
 int32_t partials_split_entry(pandrs_hip_ctx *c, int32_t mem_space, int32_t n_ranks,
