@@ -18,7 +18,7 @@ def best(fn, reps=4):
         if b is None or t["total_ms"] < b["total_ms"]: b = t
     return b
 def show(tag, t):
-    print("%-44s total %.3f  P %5d T %5d  " % (tag, t["total_ms"], t["n_partitions"], t["table_slots"]) +
+    print("%-44s total %.3f  P %5d T %5d absorbed %5.1f%%  " % (tag, t["total_ms"], t["n_partitions"], t["table_slots"], 100.0 * t.get("absorbed_rows", 0) / n) +
           "  ".join("%s %.3f" % (p, v) for p, v in t["phase_ms"].items()), flush=True)
 c3 = lambda: ctx.groupby_compute([(k, None, pa.U32CODE)], n, [(x, None, pa.F64) for x in v], aggs)
 for optset in sys.argv[1:] or [""]:

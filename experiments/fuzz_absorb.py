@@ -46,12 +46,12 @@ for case in range(n_cases):
         opset = [(O.SUM,), (O.SUM, O.MEAN), (O.SUM, O.MIN, O.MAX), (O.SUM, O.MEAN, O.MIN, O.MAX), (O.MIN, O.MAX)][int(rng.integers(0, 5))]
         if vkind == O.I64 and opset == (O.MIN, O.MAX): opset = (O.SUM, O.MIN, O.MAX)
         aggs = [(c, op) for c in range(nv) for op in opset] + ([(0, O.COUNT)] if rng.random() < 0.5 else [])
-        ctx.set_option("no_absorb", -1); ctx.set_option("no_direct", int(rng.random() < 0.5)); ctx.set_option("no_small", 1)
+        ctx.set_option("no_absorb", -1); ctx.set_option("no_direct", int(rng.random() < 0.5)); ctx.set_option("no_small", 1); ctx.set_option("no_hot_image", int(rng.random() < 0.3))
         try:
             got = ctx.groupby_agg([key], n, vals, aggs)
             t = ctx.timings()
         finally:
-            ctx.set_option("no_absorb", 0); ctx.set_option("no_direct", 0); ctx.set_option("no_small", 0)
+            ctx.set_option("no_absorb", 0); ctx.set_option("no_direct", 0); ctx.set_option("no_small", 0); ctx.set_option("no_hot_image", 0)
         want = O.groupby_agg([key], n, vals, aggs)
         exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT) or (vkind == O.I64 and op == O.SUM)]
         assert_groupby_equal(got, want, [kd], int_exact_rows=exact, rtol=1e-9)

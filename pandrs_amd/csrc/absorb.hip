@@ -71,7 +71,7 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
     const uint32_t beg = min(w * a.chunk, a.n_rows), end = min(beg + a.chunk, a.n_rows);
     const uint32_t PS = a.spill_P, cap_wp = a.spill_cap;
 
-    for (uint32_t s = tid; s < T1; s += AB_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
+    for (uint32_t s = tid; s < T1; s += AB_THREADS) { keys[s] = (a.hot_image && s < T) ? a.hot_image[s] : EMPTY_KEY; gsz[s] = 0; }
     for (int k = 0; k < a.n_lds_states; k++) {
         const uint64_t idv = state_identity(a.lds_kind[k]);
         uint64_t *dst = st + (size_t)k * T1;

@@ -92,7 +92,9 @@ struct AbsorbArgs {
     uint32_t spill_P, spill_cap;
     uint64_t *sp_keys; uint64_t *sp_vals[MAX_ABS_SRC]; uint8_t *sp_valid[MAX_ABS_SRC];
     uint32_t *sp_count;                           // [grid * spill_P] rows in each region
+    const uint64_t *hot_image;                    // optional [T]: the table every workgroup starts from (hot_image_kernel), nullptr = empty
 };
+constexpr uint32_t ABSORB_SEED = 0x9E3779B9u;     // bucket hash of the absorb table (the hot-key image is built with it)
 bool absorb_has(int n_src, int profile);
 bool launch_absorb(pandrs_hip_ctx *c, const AbsorbArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
 void launch_build_spill_tables(pandrs_hip_ctx *c, const uint32_t *sp_count, uint32_t n_wg, uint32_t PS, uint32_t cap_wp, uint32_t wpt,

@@ -165,6 +165,7 @@ struct Options {
     int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
     int64_t no_absorb = 0;           // 1 = never run the hot-key absorb-and-spill pass in front of the radix path
+    int64_t no_hot_image = 0;        // 1 = the absorb tables start empty (first come, first served) instead of from the sample's hot keys
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
     int64_t median_generic = 0;      // 1 = Median / Nunique: skip the LDS group-sort fast path (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)

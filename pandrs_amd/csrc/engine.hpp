@@ -150,7 +150,8 @@ size_t scan_seg_count(size_t n);     // entries the `seg` scratch of exclusive_s
 // keep_table: the sample's key table stays armed with this call's keys until estimate_coverage / estimate_release
 int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est, bool keep_table = false);
 // share of the rows (by the kept sample) held by the `budget` most frequent keys: the absorb-and-spill decision
-int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t budget, double *out_share);
+int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t budget, double *out_share,
+                          int64_t image_T = 0, uint32_t image_seed = 0, double min_share = 0.0, const uint64_t **out_image = nullptr);
 void estimate_release(pandrs_hip_ctx *c);
 // partition starts (offsets[p * NB]) of the first n partitions, gathered into a dense device array
 void gather_part_offsets(pandrs_hip_ctx *c, const uint32_t *offsets, uint32_t NB, uint32_t n, uint32_t *out);

@@ -908,7 +908,7 @@ static int64_t absorb_table_slots(const pandrs_hip_ctx *c, int lds_states) {
     return ((int64_t)(((size_t)c->lds_bytes - 512 - 640) / (12 + 8 * (size_t)lds_states)) - 2) & ~int64_t(3);
 }
 static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, const std::vector<EngSrc> &srcs, int profile, int64_t T,
-                          int64_t est, bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
+                          int64_t est, bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot, const uint64_t *hot_image) {
     const int64_t N = rs.n_rows;
     const int n_src = (int)srcs.size();
     const bool has_v = (profile & 1) != 0;
@@ -945,7 +945,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     if (!rk || !rn || !rst || !counters || !sp_count || !tasks || !tables || !n_tasks) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small (absorb)");
     ST_TRY(c->absorb.ensure((1 + (size_t)n_src) * Arena::padded(region_rows * 8 + 256) + (has_v ? (size_t)n_src * Arena::padded(region_rows + 256) : 0) + (1 << 20), c->stream));
     AbsorbArgs a{};
-    a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = 0x9E3779B9u; a.n_src = n_src;
+    a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = ABSORB_SEED; a.n_src = n_src; a.hot_image = hot_image;
     a.spill_P = (uint32_t)PS; a.spill_cap = cap_wp;
     a.sp_keys = c->absorb.take<uint64_t>(region_rows + 16);
     AggArgs aa{};
@@ -1125,6 +1125,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     c->timings.estimated_groups = est;
     int64_t T_abs = 0;
     bool do_absorb = false;
+    const uint64_t *hot_image = nullptr;
     if (c->est_kept) {
         int lds_states = 0;
         for (auto &e : srcs) lds_states += (e.st_add >= 0) + (e.st_min >= 0) + (e.st_max >= 0) + (e.st_nn >= 0);
@@ -1142,12 +1143,13 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             // not where the direct path answers, not where the table is a drop in the ocean: absorb when the most frequent
             // keys — as many as the table takes — hold most of the rows
             double share = 0.0;
-            ST_TRY(estimate_coverage(c, rs.key, N, (int64_t)((double)T_abs * 0.80), &share));
-            do_absorb = share >= (c->opt.no_absorb < 0 ? 0.0 : 0.60);        // (no_absorb = -1, tests: whenever it is possible)
+            const double min_share = c->opt.no_absorb < 0 ? 0.0 : 0.60;
+            ST_TRY(estimate_coverage(c, rs.key, N, (int64_t)((double)T_abs * 0.80), &share, c->opt.no_hot_image ? 0 : T_abs, ABSORB_SEED, min_share, &hot_image));
+            do_absorb = share >= min_share;        // (no_absorb = -1, tests: whenever it is possible)
         } else estimate_release(c);
     }
     if (do_absorb) {
-        const int32_t st = run_absorb(c, rs, pl, srcs, absorb_profile, T_abs, est, partials, n_aggs, key_dtype, n_keys_out, res_slot);
+        const int32_t st = run_absorb(c, rs, pl, srcs, absorb_profile, T_abs, est, partials, n_aggs, key_dtype, n_keys_out, res_slot, hot_image);
         if (st != ABSORB_NOT_TAKEN) return st;
     }
 

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void estimate_count_kernel(KeyDesc key, int64
 constexpr uint32_t COV_BINS = 4096;
 __global__ __launch_bounds__(1024) void estimate_coverage_kernel(const uint64_t *table, const uint32_t *counts, uint32_t slots,
                                                                  uint32_t budget, uint32_t *g_hist /* [2][COV_BINS] + [1] done */,
-                                                                 uint32_t *host_out) {
+                                                                 uint32_t *thr_out /* device [4] */, uint32_t *host_out) {
     __shared__ uint32_t hn[COV_BINS], hr[COV_BINS];
     __shared__ uint32_t is_last;
     for (uint32_t b = threadIdx.x; b < COV_BINS; b += 1024) { hn[b] = 0; hr[b] = 0; }
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(1024) void estimate_coverage_kernel(const uint64_t 
         ln[q] = b >= 1 ? hn[b] : 0u; lr[q] = b >= 1 ? hr[b] : 0u;
         mine += ln[q];
     }
-    uint32_t before = block_exclusive_scan<1024>(mine, wt, nullptr);
+    const uint32_t before0 = block_exclusive_scan<1024>(mine, wt, nullptr);
+    uint32_t before = before0;
     uint32_t rows = 0, keys = 0, all = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -138,13 +139,62 @@ __global__ __launch_bounds__(1024) void estimate_coverage_kernel(const uint64_t 
     if (rows) atomicAdd(&tot[0], rows);
     if (keys) atomicAdd(&tot[1], keys);
     if (all) atomicAdd(&tot[2], all);
+    // the admission rule of the hot-key image (hot_image_kernel): every key counted more often than bin `thr`, and `take` keys of that bin
+    __shared__ uint32_t s_thr, s_take;
+    if (threadIdx.x == 0) { s_thr = COV_BINS; s_take = 0; }
+    __syncthreads();
+    {
+        uint32_t bf = before0;                       // keys in front of this thread's first bin
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int b = (int)COV_BINS - 1 - (4 * (int)threadIdx.x + q);
+            if (ln[q] && bf < budget) atomicMin(&s_thr, (uint32_t)b);
+            bf += ln[q];
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t bf = before0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int b = (int)COV_BINS - 1 - (4 * (int)threadIdx.x + q);
+            if ((uint32_t)b == s_thr && ln[q]) s_take = min(ln[q], budget - bf);
+            bf += ln[q];
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
+        thr_out[0] = s_thr; thr_out[1] = s_take; thr_out[2] = 0;          // [2]: keys of bin `thr` admitted so far
         host_out[0] = tot[0]; host_out[1] = tot[1]; host_out[2] = tot[2];
         __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (uint32_t b = threadIdx.x; b < 2 * COV_BINS + 1; b += 1024) g_hist[b] = 0;       // re-armed for the next call
 }
+// The hot-key image of the absorb pass (absorb.hip): the sample's most frequent keys — the ones the coverage pass counted —
+// placed exactly where absorb_kernel looks for them (4-key buckets, home bucket then the next one), so that every workgroup
+// starts from a table that already holds the keys worth a slot instead of the first keys it happens to see (first come, first
+// served gave the cold keys 40 % of the slots: C3 absorbed 74 % of its rows where the hot set covers 88 %).
+// `image` [T] is EMPTY on entry; a key whose two buckets are full is left out (its rows spill like a cold key's).
+__global__ __launch_bounds__(1024) void hot_image_kernel(const uint64_t *table, const uint32_t *counts, uint32_t slots, uint32_t *thr,
+                                                         uint64_t *image, uint32_t T, uint32_t seed) {
+    const uint32_t t = thr[0], take = thr[1], NBK = T >> 2;
+    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < slots; i += gridDim.x * 1024) {
+        const uint32_t cnt = counts[i];
+        const uint64_t k = table[i];
+        if (!cnt || k == EMPTY_KEY) continue;
+        const uint32_t b = min(cnt, COV_BINS - 1);
+        if (b < t) continue;
+        if (b == t && atomicAdd(&thr[2], 1u) >= take) continue;
+        uint32_t bk = slot_of(hash32(k, seed), NBK);
+        bool placed = false;
+        for (int hop = 0; hop < 2 && !placed; hop++) {
+            for (int q = 0; q < 4 && !placed; q++)
+                placed = atomicCAS((unsigned long long *)&image[4 * bk + q], EMPTY_KEY, k) == EMPTY_KEY;
+            bk = bk + 1 == NBK ? 0 : bk + 1;
+        }
+    }
+}
+
 __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
                                 uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,9 +716,11 @@ int32_t exclusive_scan_u32(pandrs_hip_ctx *c, const uint32_t *in, size_t n, uint
 }
 
 constexpr uint32_t EST_SLOTS = 1u << 19;                  // >= 2 x the largest sample
-// the estimate's block: [EST_SLOTS] u64 keys | 256 B counters | [EST_SLOTS] u32 per-key counts | coverage histogram
+// the estimate's block: [EST_SLOTS] u64 keys | 256 B counters | [EST_SLOTS] u32 per-key counts | coverage histogram | hot-key image
 static uint32_t *est_counts(pandrs_hip_ctx *c) { return reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS) + 64; }
-static uint32_t *est_cov_hist(pandrs_hip_ctx *c) { return est_counts(c) + EST_SLOTS; }
+static uint32_t *est_cov_hist(pandrs_hip_ctx *c) { return est_counts(c) + EST_SLOTS; }      // [2 * COV_BINS + 1] + threshold words at + 2 * COV_BINS + 16
+constexpr uint32_t EST_IMAGE_SLOTS = 1u << 15;            // the hot-key image (absorb pass): as many slots as an LDS table can have
+static uint64_t *est_image(pandrs_hip_ctx *c) { return reinterpret_cast<uint64_t *>(est_cov_hist(c) + 2 * COV_BINS + 64); }
 
 int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est, bool keep_table) {
     PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
@@ -678,7 +730,7 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     // a dedicated block that stays armed (table = EMPTY, counters = 0) between calls: cleared behind the previous
     // estimate instead of in front of this one
     if (!c->est_table) {
-        const size_t bytes = size_t(slots) * 8 + 256 + size_t(slots) * 4 + (2 * COV_BINS + 64) * 4;
+        const size_t bytes = size_t(slots) * 8 + 256 + size_t(slots) * 4 + (2 * COV_BINS + 64) * 4 + EST_IMAGE_SLOTS * 8;
         HIP_TRY(hipMalloc((void **)&c->est_table, bytes));
         alloc_events()++;
         HIP_TRY(hipMemsetAsync(c->est_table, 0, bytes, c->stream));
@@ -742,8 +794,12 @@ void estimate_release(pandrs_hip_ctx *c) {
 }
 
 // Share of the rows (by the kept sample) that belongs to the `budget` most frequent keys; releases the table.
-int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t budget, double *out_share) {
+// image_T > 0 and a share of at least min_share: *out_image = the hot-key image for an absorb table of image_T slots (hot_image_kernel;
+// valid until the next estimate on this context), else nullptr.
+int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t budget, double *out_share,
+                          int64_t image_T, uint32_t image_seed, double min_share, const uint64_t **out_image) {
     *out_share = 0.0;
+    if (out_image) *out_image = nullptr;
     if (!c->est_kept) return 0;
     PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
     const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
@@ -753,7 +809,8 @@ int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows,
     hipLaunchKernelGGL(estimate_count_kernel, dim3((unsigned)((n_sample + 1023) / 1024)), dim3(1024), 0, c->stream,
                        key, n_rows, stride, n_sample, c->est_table, EST_SLOTS - 1, est_counts(c));
     hipLaunchKernelGGL(estimate_coverage_kernel, dim3(64), dim3(1024), 0, c->stream, c->est_table, est_counts(c), EST_SLOTS,
-                       (uint32_t)std::min<int64_t>(std::max<int64_t>(budget, 1), 0x7FFFFFFF), est_cov_hist(c), const_cast<uint32_t *>(h));
+                       (uint32_t)std::min<int64_t>(std::max<int64_t>(budget, 1), 0x7FFFFFFF), est_cov_hist(c), est_cov_hist(c) + 2 * COV_BINS + 16,
+                       const_cast<uint32_t *>(h));
     HIP_TRY(hipGetLastError());
     for (int spin = 0; spin < 200000 && h[3] != 1; spin++) __builtin_ia32_pause();
     if (h[3] != 1) {
@@ -763,6 +820,12 @@ int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows,
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint32_t h0 = h[0], h2 = h[2];
     const double covered = h0, all = std::max<uint32_t>(h2, 1);
+    if (out_image && image_T >= 16 && image_T <= (int64_t)EST_IMAGE_SLOTS && covered / all >= min_share) {
+        HIP_TRY(hipMemsetAsync(est_image(c), 0xFF, (size_t)image_T * 8, c->stream));
+        hipLaunchKernelGGL(hot_image_kernel, dim3(256), dim3(1024), 0, c->stream, c->est_table, est_counts(c), EST_SLOTS,
+                           est_cov_hist(c) + 2 * COV_BINS + 16, est_image(c), (uint32_t)image_T, image_seed);
+        *out_image = est_image(c);
+    }
     c->est_kept = false;
     hipLaunchKernelGGL(estimate_clear_kernel, dim3(EST_SLOTS / 256), dim3(256), 0, c->stream, c->est_table, EST_SLOTS,
                        reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), est_counts(c));

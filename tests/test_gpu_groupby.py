@@ -1313,6 +1313,21 @@ def test_absorb_and_spill_matches_oracle(ctx, shape):
     finally:
         ctx.set_option("no_absorb", 0)
     assert_groupby_equal(got2, want, [kd], int_exact_rows=exact)
+    # ... and so do absorb tables that start EMPTY (first come, first served) instead of from the sample's hot keys; the
+    # image is what keeps the cold keys out of the slots: it never absorbs less
+    ctx.set_option("no_hot_image", 1)
+    if shape == "uniform_forced":
+        ctx.set_option("no_absorb", -1)
+    try:
+        got3 = ctx.groupby_agg([key], n, vals, aggs)
+        t3 = ctx.timings()
+    finally:
+        ctx.set_option("no_hot_image", 0)
+        ctx.set_option("no_absorb", 0)
+    assert t3["absorbed_rows"] > 0
+    assert_groupby_equal(got3, want, [kd], int_exact_rows=exact)
+    if shape == "c3_codes":
+        assert t["absorbed_rows"] > t3["absorbed_rows"] + 0.03 * n, (t["absorbed_rows"], t3["absorbed_rows"])
 
 
 def test_absorb_is_not_tried_on_uniform_keys(ctx):
