@@ -158,7 +158,8 @@ enum {
     PANDRS_HIP_PHASE_BUILD = 6,       /* join: build side */
     PANDRS_HIP_PHASE_PROBE = 7,       /* join: probe count + write */
     PANDRS_HIP_PHASE_GATHER = 8,
-    PANDRS_HIP_PHASE_OTHER = 9
+    PANDRS_HIP_PHASE_OTHER = 9,
+    PANDRS_HIP_PHASE_PREPARTITION = 10  /* first pass (64 buckets) of a two-pass radix partition: fan-outs >= 6144 */
 };
 
 typedef struct pandrs_hip_ctx pandrs_hip_ctx;
@@ -211,6 +212,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "join_generic"      1 = always build the join with the general segmented sort
  *   "join_one_pass"     1 = single-pass probe (decoupled look-back) instead of count + emit
  *   "join_no_l2"        1 = fused join->groupby never takes the L2-region path for large build sides
+ *   "two_pass"          -1 = the exact radix partition never takes two passes (64 buckets, then the rest) at fan-outs >= 6144;
+ *                       experiments: a value > 1 = another bucket count, "two_pass_min_p" = another threshold
  *   "join_no_pairpart"  1 = the L2-region probe emits its pairs through one cursor instead of pre-partitioned
  *  Median / Nunique
  *   "median_generic"    1 = always the general segmented-sort pass, never the LDS group-sort path

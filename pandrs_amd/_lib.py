@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PANDRS_HIP_LIB") or os.path.join(_HERE, "libpandrs_hi
 
 MAX_PHASES = 12
 PHASE_NAMES = ["stage_in", "estimate", "histogram", "scan", "scatter", "aggregate",
-               "build", "probe", "gather", "other", "", ""]
+               "build", "probe", "gather", "other", "prepartition", ""]
 
 # enums (include/pandrs_hip.h)
 I64, F64, U32CODE, BOOLBITS, CELL64 = 0, 1, 2, 3, 4

@@ -62,6 +62,7 @@ struct ScatterArgs {
     int64_t n_rows, chunk;
     uint32_t P, seed;
     int n_move, n_move8;       // mv[0 .. n_move8) are 8-byte columns, the rest byte-wide
+    int allow_two_pass;        // radix_partition may take two passes at fan-outs >= 6144: the caller has budgeted two_pass_workspace_bytes in c->work
     MoveDesc mv[MAX_MOVE];
 };
 
@@ -160,6 +161,8 @@ int32_t build_plan(const int32_t *val_dtypes, const uint8_t *val_has_nulls, int 
                    const pandrs_hip_agg_spec *aggs, int n_aggs, Plan &pl);
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge, bool partials,
                    int n_aggs, int key_dtype, int n_keys_out = 1, int res_slot = 0);
+// work-arena bytes a two-pass radix_partition of n_rows rows with n_cols8 8-byte and n_cols1 byte-wide moved columns takes on top of the single pass
+size_t two_pass_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
 size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1);
 
 // segsort.hip: sorts every partition [0, n_parts) of (keys, payload) ascending by (key, payload),

@@ -89,7 +89,7 @@ struct SortedGroups {
     int64_t G = 0;
 };
 static int32_t build_sorted_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, SortedGroups *o) {
-    const size_t ws = engine_workspace_bytes(n_rows, 1, 0) + 3 * Arena::padded(size_t(n_rows + 2) * 4)
+    const size_t ws = engine_workspace_bytes(n_rows, 1, 0) + two_pass_workspace_bytes(n_rows, 1, 1) + 3 * Arena::padded(size_t(n_rows + 2) * 4)
                     + Arena::padded(scan_seg_count((size_t)n_rows + 1) * 4) + segsort_workspace_bytes(n_rows, P_MAX + 2, 4) + (size_t(9) << 20);
     ST_TRY(c->work.ensure(ws, c->stream));
     o->pk = c->work.take<uint64_t>(n_rows + 1);
@@ -111,7 +111,7 @@ static int32_t build_sorted_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_
     if (fast && !only) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (group index)");
     PartInfo part{};
     ScatterArgs sa{};
-    sa.key = key; sa.pkeys = o->pk; sa.n_rows = n_rows; sa.P = (uint32_t)P; sa.seed = 0x6A09E667u;
+    sa.key = key; sa.pkeys = o->pk; sa.n_rows = n_rows; sa.P = (uint32_t)P; sa.seed = 0x6A09E667u; sa.allow_two_pass = 1;
     sa.mv[sa.n_move++] = MoveDesc{nullptr, o->prow, 3, 0};
     ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCAN, PANDRS_HIP_PHASE_SCATTER));
     o->null_beg = part.offsets + (size_t)P * part.NB;

@@ -1378,7 +1378,7 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
     if (!prk || !prg || !table) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join, table)");
     PartInfo rpart{};
     ScatterArgs rs{};
-    rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P_f; rs.seed = JN_SEED;
+    rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P_f; rs.seed = JN_SEED; rs.allow_two_pass = 1;
     rs.mv[rs.n_move++] = MoveDesc{gsrc, prg, 0, 0};
     ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
     {
@@ -1551,10 +1551,12 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     bool l2_path = c->opt.partitions <= 0 && !c->opt.join_generic && c->opt.join_no_l2 <= 0 && nl > 0 && nr > 0 &&
                    ((P > 1024 && nl >= 2 * nr) || c->opt.join_no_l2 < 0);
     size_t ws = 2 * engine_workspace_bytes(0, 0, 0) + 3 * Arena::padded(size_t(nl + 1) * 8) + 3 * Arena::padded(size_t(nr + 1) * 8) + (1 << 20);
+    ws += two_pass_workspace_bytes(nl, 1, 0) + two_pass_workspace_bytes(nr, 1, 0);      // both sides may take the two-pass partition (fan-outs >= 6144)
     if (l2_path) ws += Arena::padded(((size_t)P_MAX * 2 * L2_REG + 1) * 16) + Arena::padded(size_t(nl) * 4 + (size_t(1) << 25)) + (1 << 20);
     ST_TRY(c->work.ensure(ws, c->stream));
     P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, (nl + nr) / 32768)), P_MAX);
     P = std::max<int64_t>(P, 1);
+    if (P >= 1024 && c->opt.partitions <= 0) P = std::min<int64_t>((P + 63) / 64 * 64, P_MAX);      // a multiple of 64: the two-pass partition's bucket count
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     int64_t M = 0;
     uint64_t *out_g = nullptr, *out_v = nullptr;
@@ -1619,9 +1621,9 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
             return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (fused join)");
         PartInfo rpart{}, lpart{};
         ScatterArgs rs{}, ls{};
-        rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P; rs.seed = JN_SEED;
+        rs.key = rkey; rs.pkeys = prk; rs.n_rows = nr; rs.P = (uint32_t)P; rs.seed = JN_SEED; rs.allow_two_pass = 1;
         rs.mv[rs.n_move++] = MoveDesc{gsrc, prg, 0, 0};
-        ls.key = lkey; ls.pkeys = plk; ls.n_rows = nl; ls.P = (uint32_t)P; ls.seed = JN_SEED;
+        ls.key = lkey; ls.pkeys = plk; ls.n_rows = nl; ls.P = (uint32_t)P; ls.seed = JN_SEED; ls.allow_two_pass = 1;
         ls.mv[ls.n_move++] = MoveDesc{vsrc, plv, 0, 0};
         ST_TRY(radix_partition(c, rs, &rpart, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD, PANDRS_HIP_PHASE_BUILD));
         ST_TRY(radix_partition(c, ls, &lpart, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER, PANDRS_HIP_PHASE_SCATTER));

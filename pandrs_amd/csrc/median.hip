@@ -778,7 +778,7 @@ static int32_t median_pairs(pandrs_hip_ctx *c, const KeyDesc &kd, const uint64_t
     if (!use_fast) P = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::ceil((double)nv / 4900.0)), P_MAX);
     PartInfo part{};
     ScatterArgs sa{};
-    sa.key = kd; sa.pkeys = pk; sa.n_rows = nv; sa.P = (uint32_t)P; sa.seed = seed;
+    sa.key = kd; sa.pkeys = pk; sa.n_rows = nv; sa.P = (uint32_t)P; sa.seed = seed; sa.allow_two_pass = 1;
     sa.mv[sa.n_move++] = MoveDesc{vals, pv, 0, 0};
     ST_TRY(radix_partition(c, sa, &part, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER, PANDRS_HIP_PHASE_OTHER));
     const uint32_t *null_beg = part.offsets + (size_t)P * part.NB, *null_end = part.offsets + (size_t)(P + 1) * part.NB;
@@ -896,7 +896,7 @@ int32_t median_pass(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, const
     struct Unquiet { pandrs_hip_ctx *c; ~Unquiet() { c->quiet--; } } unq{c};
     uint32_t cap_tab = 64;
     while ((double)cap_tab < 1.5 * (double)G) cap_tab <<= 1;
-    const size_t ws = engine_workspace_bytes(n_rows, 4, 1) + segsort_workspace_bytes(n_rows, P_MAX + 2, 8)
+    const size_t ws = engine_workspace_bytes(n_rows, 4, 1) + two_pass_workspace_bytes(n_rows, 1, 1) + segsort_workspace_bytes(n_rows, P_MAX + 2, 8)
                     + Arena::padded(size_t(cap_tab + 4) * 16) + (1 << 20)
                     + (size_t(n_rows) / SEL_TILE + size_t(n_rows) / SK_MAX_ROWS + 8) * (sizeof(SelTask) + sizeof(SelState) + SK_BINS * 4 + 16) + 8192;
     const size_t ws_all = 2 * ws + 2 * Arena::padded(size_t(n_rows + 1) * 8)       // + one nested level (hot partitions)

@@ -327,13 +327,13 @@ __device__ __forceinline__ uint64_t move_load(const MoveDesc &m, int64_t i) {
     case 2: return reinterpret_cast<const uint8_t *>(m.src)[i];
     case 6: return bit_at(reinterpret_cast<const uint8_t *>(m.src), i) ? 1ull : 0ull;   // null bitmap -> null byte
     case 3: case 5: return (uint64_t)i;                                // row index
-    default: return reinterpret_cast<const uint32_t *>(m.src)[i];      // 4: u32 source
+    default: return reinterpret_cast<const uint32_t *>(m.src)[i];      // 4: u32 source (widened), 7: u32 copy
     }
 }
 __device__ __forceinline__ void move_store(const MoveDesc &m, uint32_t dst, uint64_t v) {
     switch (m.kind) {
     case 0: case 4: case 5: reinterpret_cast<uint64_t *>(m.dst)[dst] = v; break;
-    case 3: reinterpret_cast<uint32_t *>(m.dst)[dst] = (uint32_t)v; break;
+    case 3: case 7: reinterpret_cast<uint32_t *>(m.dst)[dst] = (uint32_t)v; break;
     default: reinterpret_cast<uint8_t *>(m.dst)[dst] = (uint8_t)v;
     }
 }
@@ -864,8 +864,8 @@ size_t engine_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1) {
          + (size_t)n_cols8 * Arena::padded(size_t(n_rows) * 8) + (size_t)n_cols1 * Arena::padded(size_t(n_rows)) + (4 << 20);
 }
 
-int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
-                        int phase_scatter) {
+static int32_t radix_partition_once(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
+                                    int phase_scatter) {
     const int64_t N = sa.n_rows;
     const int SCT = c->opt.scatter_threads == 512 ? 512 : 1024;
     const int SC_TILE = SCT * SC_RPT;
@@ -907,6 +907,64 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
         else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
     }
     out->P = sa.P; out->NB = NB; out->offsets = offsets;
+    return 0;
+}
+
+// The exact partition.  A fan-out of thousands leaves a scatter tile (8 K rows) as 1-row runs — 8-byte stores to 8 K places,
+// 1.4 TB/s — so from P = 6144 up the rows move TWICE in long runs instead: 64 buckets first, then the full fan-out over the
+// bucket-sorted rows, whose tiles see only ~P / 64 partitions each.  part_of is a multiplicative range reduction, so
+// bucket = partition / (P / 64) whenever 64 divides P: the second pass is the ordinary partition of the first pass's output
+// (key cells + a null byte per row; every moved column in its destination type).  62.5 M + 50 M rows of 16 bytes at P = 8192:
+// 2.5 -> 2.1 ms; at P = 4096 and below the single pass is still the faster one.  Needs the temporaries in the work arena; without room (or with "two_pass" = -1) it is the single pass.
+constexpr uint32_t TWO_PASS_BUCKETS = 64;
+constexpr int64_t TWO_PASS_MIN_P = 6144;          // measured crossover (16-byte rows): 17.5 / 20.5 / 26.6 ns per K rows in one pass at P = 2.5 K / 4 K / 8 K, 21-25 in two
+size_t two_pass_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1) {
+    const size_t NBmax = 1024 + 8;
+    return (size_t)(1 + n_cols8) * Arena::padded((size_t)(n_rows + 1) * 8) + (size_t)(1 + n_cols1) * Arena::padded((size_t)n_rows + 16) +
+           2 * Arena::padded(((size_t)(256 + 1) * NBmax + 8) * 4) + Arena::padded(SCAN_SEG * 4 + 64) +
+           Arena::padded((size_t)(256 + 1) * 32) + 65536;
+}
+int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scan,
+                        int phase_scatter) {
+    const int64_t N = sa.n_rows;
+    const bool key_nulls = sa.key.null_bits || sa.key.null_bytes;
+    const uint32_t B1 = c->opt.two_pass > 1 ? (uint32_t)c->opt.two_pass : TWO_PASS_BUCKETS;      // (experiments: another bucket count)
+    bool two = sa.allow_two_pass && c->opt.two_pass >= 0 && sa.P >= (c->opt.two_pass_min_p > 0 ? c->opt.two_pass_min_p : TWO_PASS_MIN_P) && sa.P % B1 == 0 && B1 <= 256 && N >= (int64_t(1) << (c->opt.two_pass_min_p > 0 ? 16 : 22)) &&      // (an explicit threshold, tests: small inputs too)
+              
+               sa.n_move + (key_nulls ? 1 : 0) <= MAX_MOVE;
+    if (!two) return radix_partition_once(c, sa, out, phase_hist, phase_scan, phase_scatter);
+    auto elem_of = [](int kind) -> size_t { return kind == 0 || kind == 4 || kind == 5 ? 8 : (kind == 3 || kind == 7 ? 4 : 1); };
+    size_t need = Arena::padded((size_t)(N + 1) * 8) + (key_nulls ? Arena::padded((size_t)N + 16) : 0);
+    for (int i = 0; i < sa.n_move; i++) need += Arena::padded((size_t)(N + 1) * elem_of(sa.mv[i].kind));
+    const size_t NBmax = 1024 + 8;
+    const size_t sets = 2 * Arena::padded(((size_t)(B1 + 1) * NBmax + 8) * 4) + 2 * Arena::padded(((size_t)(sa.P + 1) * NBmax + 8) * 4) +
+                        2 * Arena::padded(SCAN_SEG * 4 + 64) + 2 * Arena::padded((size_t)(sa.P + 1) * 32) + 65536;
+    if (c->work.cap - c->work.off < need + sets)          // (a caller that budgeted less than it promised: the single pass, not a failure)
+        return radix_partition_once(c, sa, out, phase_hist, phase_scan, phase_scatter);
+    ScatterArgs s1 = sa, s2 = sa;
+    s1.P = B1;
+    uint64_t *tk = c->work.take<uint64_t>((size_t)N + 1);
+    s1.pkeys = tk;
+    for (int i = 0; i < sa.n_move; i++) {
+        const int kind = sa.mv[i].kind;
+        void *t = c->work.take<uint8_t>((size_t)(N + 1) * elem_of(kind));
+        if (!t) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (two-pass partition)");
+        s1.mv[i].dst = t;
+        s2.mv[i].src = t;
+        s2.mv[i].kind = elem_of(kind) == 8 ? 0 : (elem_of(kind) == 4 ? 7 : 2);       // the second pass copies what the first one produced
+    }
+    uint8_t *tnull = nullptr;
+    if (key_nulls) {
+        tnull = c->work.take<uint8_t>((size_t)N + 16);
+        if (!tnull) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (two-pass partition)");
+        s1.mv[s1.n_move++] = sa.key.null_bits ? MoveDesc{sa.key.null_bits, tnull, 6, 0} : MoveDesc{sa.key.null_bytes, tnull, 2, 0};
+    }
+    if (!tk) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (two-pass partition)");
+    PartInfo p1{};
+    ST_TRY(radix_partition_once(c, s1, &p1, PANDRS_HIP_PHASE_PREPARTITION, PANDRS_HIP_PHASE_PREPARTITION, PANDRS_HIP_PHASE_PREPARTITION));
+    s2.key = KeyDesc{tk, nullptr, tnull, DT_CELL};
+    ST_TRY(radix_partition_once(c, s2, out, phase_hist, phase_scan, phase_scatter));
+    sa.offsets = s2.offsets; sa.chunk = s2.chunk; sa.gcur = s2.gcur;
     return 0;
 }
 

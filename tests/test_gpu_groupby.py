@@ -1339,3 +1339,33 @@ def test_absorb_is_not_tried_on_uniform_keys(ctx):
     vals = [(rng.standard_normal(n), None, O.F64)]
     ctx.groupby_compute([key], n, vals, [(0, O.SUM), (0, O.MIN), (0, O.MAX)])
     assert ctx.timings()["absorbed_rows"] == 0
+
+
+def test_two_pass_partition_under_median_and_group_by_row_lists(ctx):
+    """The pair partition of Median / Nunique and group_by's row lists take the two-pass radix partition at fan-outs >= 6144
+    (100 M rows); forced here at 128 partitions.  Same medians, same row lists (ascending rows per group) as the oracle."""
+    rng = np.random.default_rng(2024)
+    n = 9000 * 128                                             # ceil(n / 9000) = 128 partitions: a multiple of the 64 buckets
+    keys = [(sparse_keys(rng, n, 20_000), O.pack_mask(rng.random(n) < 0.002), O.I64)]
+    # no value nulls: the pair partition sees all n rows -> 128 partitions too.  (+ 0.0: no -0.0 among the values — a group holding both
+    # zeros has a Median whose SIGN depends on the rows' order in the reference's stable sort, DESIGN.md section 6)
+    vals = [(np.round(rng.normal(500, 100, n), 1) + 0.0, None, O.F64)]
+    aggs = [(0, O.MEDIAN), (0, O.NUNIQUE), (0, O.SUM)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    ctx.set_option("two_pass_min_p", 64)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)                  # (its inner passes are not timed by phase)
+        cells, nulls, off, rows = ctx.groupby_indices(keys, n)
+        assert ctx.timings()["phase_ms"].get("prepartition", 0) > 0
+    finally:
+        ctx.set_option("two_pass_min_p", 0)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0, 1])
+    off, rows = np.asarray(off), np.asarray(rows)
+    assert off[0] == 0 and off[-1] == n and np.array_equal(np.sort(rows), np.arange(n))
+    k = keys[0][0].copy()
+    null = np.unpackbits(keys[0][1], bitorder="little")[:n].astype(bool)
+    first = rows[off[:-1]]
+    for g in rng.integers(0, len(off) - 1, 200):
+        r = rows[off[g]:off[g + 1]]
+        assert np.all(np.diff(r) > 0)
+        assert np.all(null[r]) if null[first[g]] else (not null[r].any() and np.all(k[r] == k[first[g]]))

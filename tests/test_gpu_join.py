@@ -463,3 +463,32 @@ def test_fused_join_prepartitioned_pairs_fall_back_when_the_group_estimate_is_fa
         assert int(kn.sum()) == 0
     finally:
         c.close()
+
+
+def test_two_pass_partition_gives_the_same_join_and_groups(ctx):
+    """From a fan-out of 6144 the exact radix partition moves the rows twice (64 buckets, then the rest over the bucket-sorted
+    rows; partition.hip).  Forced here at small sizes (explicit threshold + forced fan-out) on both sides of the fused join, with
+    NULL keys, the sentinel-valued key and masked payloads, against the oracle and against the single pass."""
+    rng = np.random.default_rng(77)
+    nb, npb = 500_000, 900_000
+    rkeys = (rng.permutation(nb * 3)[:nb].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    rkeys[7] = -1
+    rg = rng.integers(0, 3000, nb).astype(np.int64)
+    lkeys = rkeys[rng.integers(0, nb, npb)].copy()
+    lkeys[rng.random(npb) < 0.1] = -7
+    lv = rng.integers(-1000, 1000, npb).astype(np.int64)       # i64 payload: sums must be bit-exact
+    args = ((lkeys, O.pack_mask(rng.random(npb) < 0.01), O.I64), (lv, O.pack_mask(rng.random(npb) < 0.05), O.I64), npb,
+            (rkeys, O.pack_mask(rng.random(nb) < 0.01), O.I64), (rg, O.pack_mask(rng.random(nb) < 0.01), O.I64), nb)
+    want = O.join_groupby_sum(*args)
+    ctx.set_option("partitions", 1024)
+    try:
+        ctx.set_option("two_pass_min_p", 512)
+        got = ctx.join_groupby_sum(*args)
+        assert ctx.timings()["phase_ms"].get("prepartition", 0) > 0
+        ctx.set_option("two_pass", -1)
+        got1 = ctx.join_groupby_sum(*args)
+        assert ctx.timings()["phase_ms"].get("prepartition", 0) == 0
+    finally:
+        ctx.set_option("partitions", 0); ctx.set_option("two_pass_min_p", 0); ctx.set_option("two_pass", 0)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0])
+    assert_groupby_equal(got1, want, [O.I64], int_exact_rows=[0])
