@@ -49,6 +49,9 @@ elif cfg == "join_indices":
     fn = lambda: ctx.join_indices_compute((lkey, None, pa.I64), n, (rkey, None, pa.I64), nr, pa.INNER)
 else:
     raise SystemExit("unknown config " + cfg)
+for kv in os.environ.get("PANDRS_OPTS", "").split(","):          # PANDRS_OPTS=name=value,... (A/B of one option on one box)
+    if kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 torch.cuda.synchronize()
 fn()
 best = None

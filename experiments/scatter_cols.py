@@ -14,7 +14,7 @@ def best(fn, reps=5):
         fn(); t = ctx.timings()
         if b is None or t["total_ms"] < b["total_ms"]: b = t
     return b
-for P in (0, 512, 1024):
+for P in ([int(x) for x in sys.argv[1:]] or (0, 512, 1024)):
     ctx.set_option("partitions", P)
     for nv in range(0, 5):
         aggs = [(c, pa.SUM) for c in range(nv)] or [(0, pa.COUNT)]

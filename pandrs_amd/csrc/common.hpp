@@ -173,6 +173,7 @@ struct Options {
     int64_t no_runs = 0;             // 1 = never use the run-folding aggregate kernels
     int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit
     int64_t join_no_pairpart = 0;    // 1 = the L2-region path emits its pairs at one cursor and lets the engine partition them; 2 = tests: undersized regions
+    int64_t scatter_wide = 0;        // 1 = the scatter's wide tile (16 K rows, two staging halves) whenever it fits, -1 = never; 0 = at fan-outs >= 1024 (see scatter_wide_ok)
     int64_t two_pass_min_p = 0;      // experiments: the fan-out from which the two passes are taken (default 6144)
     int64_t two_pass = 0;            // -1 = the exact radix partition never takes two passes (64 buckets, then the rest) at fan-outs >= 6144
     int64_t join_no_l2 = 0;          // 1 = the fused join never takes the L2-resident-table path; -1 = always tries it (testing)

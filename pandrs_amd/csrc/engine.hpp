@@ -14,8 +14,9 @@ constexpr int P_MAX = 8192;      // bounded by the scatter's LDS counters (2 x 4
 constexpr int HI_THREADS = 1024;   // histogram workgroup
 constexpr int SC_RPT = 8;          // scatter: rows per thread per tile
 // (12 rows per thread = 12 K-row tiles, 1.5x longer runs, measured: 84 spilled VGPRs, C2's scatter 1.94 -> 2.54 ms)
-constexpr int SC_POS_BITS = 13;    // the scatter packs (partition << SC_POS_BITS | position in the tile)
-constexpr int SC_TILE_MAX = 1024 * SC_RPT;
+constexpr int SC_RPT_WIDE = 16;    // the wide tile (16 K rows per 1024-thread workgroup): twice the run length, staged in two halves
+constexpr int SC_POS_BITS = 14;    // the scatter packs (partition << SC_POS_BITS | position in the tile)
+constexpr int SC_TILE_MAX = 1024 * SC_RPT_WIDE;
 static_assert(SC_TILE_MAX <= (1 << SC_POS_BITS), "scatter packs the tile position in SC_POS_BITS bits");
 constexpr int AG_THREADS = 1024;   // aggregate workgroup
 constexpr int MAX_ROUNDS = 16;

@@ -580,6 +580,138 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
     }
 }
 
+// The WIDE tile: 16 rows per thread — 16 K rows per 1024-thread workgroup ranked at once, so a (tile, partition) run is twice as
+// long as scatter_tile's (at P = 1024: 16 rows = one 128-byte line per column instead of half of one; with five columns the
+// scatter of C2 behaves like P = 512's) — moved through the SAME 64 KB staging buffer in two halves of the tile's sorted order:
+// a row is staged in the half its sorted position falls in (predicated LDS writes), each half leaves with unit-stride reads.
+// Staged layouts only; LDS: counters | wave_tot | pid[16 K] u16 | pos16[16 K] u16 | stage[8 K] u64.
+template <int THREADS, bool FULL, bool CAPPED>
+__device__ __forceinline__ void scatter_tile_wide(const ScatterArgs &a, int64_t tbase, uint32_t tile_n,
+                                                  uint32_t *cursor, uint32_t *cnt, uint32_t *delta,
+                                                  uint32_t *wave_tot, uint16_t *pid, uint64_t *stage, uint16_t *pos16) {
+    constexpr int RPT = SC_RPT_WIDE, HR = SC_RPT;
+    constexpr uint32_t HALF = THREADS * HR;              // sorted positions per half = rows of the staging buffer
+    constexpr uint32_t SPM = (1u << SC_POS_BITS) - 1;
+    static_assert(THREADS * RPT == 2 * HALF, "two halves");
+    const uint32_t P1 = a.P + 1, tid = threadIdx.x;
+    const uint32_t ipt = (P1 + THREADS - 1) / THREADS;
+    const uint32_t tile_last = tile_n - 1;
+    auto live = [&](int r) { return FULL || (uint32_t)(r * THREADS) + tid < tile_n; };
+
+    for (uint32_t p = tid; p < P1; p += THREADS) cnt[p] = 0;
+    block_sync_lds();
+    uint64_t kc[RPT];
+    uint32_t ps[RPT], nulls;
+    load_key_cells<THREADS, RPT>(a.key, tbase, tid, tile_last, kc, &nulls);
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        bool nul = (nulls >> r) & 1;
+        if (nul) kc[r] = 0ull;
+        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
+        ps[r] = p << SC_POS_BITS;
+        if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);
+    }
+    block_sync_lds();
+    {
+        uint32_t first = tid * ipt, s = 0;
+        for (uint32_t q = 0; q < ipt; q++) if (first + q < P1) s += cnt[first + q];
+        uint32_t ex = block_exclusive_scan<THREADS>(s, wave_tot, nullptr);
+        for (uint32_t q = 0; q < ipt; q++)
+            if (first + q < P1) { delta[first + q] = ex; ex += cnt[first + q]; }
+    }
+    block_sync_lds();
+#pragma unroll
+    for (int r = 0; r < RPT; r++) ps[r] += delta[ps[r] >> SC_POS_BITS];
+    block_sync_lds();
+    if (a.gcur) {
+        const uint32_t g = blockIdx.x & 7;
+        for (uint32_t p = tid; p < P1; p += THREADS) {
+            uint32_t n = cnt[p];
+            uint32_t c = n ? atomicAdd(&a.gcur[p * 8 + g], n) : 0u;
+            if (CAPPED && n && c + n > a.gend[p * 8 + g]) {
+                a.flags[0] = 1;
+                delta[p] = a.total_cap;                                // the trash tile (SC_TILE_MAX rows behind the regions)
+            } else
+            delta[p] = c - delta[p];
+        }
+    } else {
+        for (uint32_t p = tid; p < P1; p += THREADS) {
+            uint32_t c = cursor[p];
+            delta[p] = c - delta[p];
+            cursor[p] = c + cnt[p];
+        }
+    }
+    // a row's sorted position goes to LDS too (pos16[row]): the column loop reads it back per column instead of holding 16 more
+    // registers per thread (rows of dead lanes get a position outside both halves)
+    uint32_t *pos32 = reinterpret_cast<uint32_t *>(pos16);       // rows 2k, 2k + 1 of a thread share one word: 8 reads per staging half
+#pragma unroll
+    for (int r = 0; r < RPT; r++)
+        if (live(r)) pid[ps[r] & SPM] = (uint16_t)(ps[r] >> SC_POS_BITS);
+#pragma unroll
+    for (int k = 0; k < RPT / 2; k++) {
+        const uint32_t lo = live(2 * k) ? (ps[2 * k] & SPM) : 0xFFFFu, hi = live(2 * k + 1) ? (ps[2 * k + 1] & SPM) : 0xFFFFu;
+        pos32[k * THREADS + tid] = lo | (hi << 16);
+    }
+    // ---- keys: two halves.  The destination of sorted position J is delta[pid[J]] + J: two small LDS reads per row and column
+    // instead of 16 registers held across the column loop (the LDS pipe has room, the register file has none: with dst[16] kept
+    // the kernel spilled 350 VGPRs)
+    auto dst_of = [&](uint32_t J) { return delta[pid[J]] + J; };
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++)
+            if (live(r) && ((ps[r] & SPM) >= HALF) == (h == 1)) stage[(ps[r] & SPM) - h * HALF] = kc[r];
+        block_sync_lds();                                 // (the first one also orders delta[] and pid[] before their readers)
+#pragma unroll
+        for (int q = 0; q < HR; q++) {
+            const uint32_t j = q * THREADS + tid, J = h * HALF + j;
+            if (FULL || J < tile_n) a.pkeys[dst_of(J)] = stage[j];
+        }
+        block_sync_lds();
+    }
+    uint64_t v[RPT];
+    if (a.n_move8 > 0) load_column8<THREADS, RPT>(a.mv[0].src, tbase, tid, tile_last, v);
+    for (int m = 0; m < a.n_move8; m++) {
+        uint64_t *out = reinterpret_cast<uint64_t *>(a.mv[m].dst);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int k = 0; k < RPT / 2; k++) {
+                const uint32_t w = pos32[k * THREADS + tid];
+                const uint32_t p0 = (w & 0xFFFFu) - h * HALF, p1 = (w >> 16) - h * HALF;      // (unsigned: the other half and dead rows fall outside)
+                if (p0 < HALF) stage[p0] = v[2 * k];
+                if (p1 < HALF) stage[p1] = v[2 * k + 1];
+            }
+            if (h == 1 && m + 1 < a.n_move8) load_column8<THREADS, RPT>(a.mv[m + 1].src, tbase, tid, tile_last, v);
+            block_sync_lds();
+#pragma unroll
+            for (int q = 0; q < HR; q++) {
+                const uint32_t j = q * THREADS + tid, J = h * HALF + j;
+                if (FULL || J < tile_n) out[dst_of(J)] = stage[j];
+            }
+            block_sync_lds();
+        }
+    }
+    for (int m = a.n_move8; m < a.n_move; m++) {          // validity bytes / byte columns
+        const MoveDesc mv = a.mv[m];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const uint32_t pos = ((pos32[(r >> 1) * THREADS + tid] >> ((r & 1) * 16)) & 0xFFFFu) - h * HALF;
+                if (pos < HALF) stage[pos] = move_load(mv, tbase + tile_idx<THREADS>(tid, r, tile_last));
+            }
+            block_sync_lds();
+#pragma unroll
+            for (int q = 0; q < HR; q++) {
+                const uint32_t j = q * THREADS + tid, J = h * HALF + j;
+                if (FULL || J < tile_n) move_store(mv, dst_of(J), stage[j]);
+            }
+            block_sync_lds();
+        }
+    }
+}
+
 template <int THREADS, bool STAGED, bool CAPPED = false, int RPT = SC_RPT>
 __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     constexpr int TILE = THREADS * RPT;
@@ -591,8 +723,9 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     uint32_t *delta = cnt + P1;
     uint32_t *wave_tot = delta + P1;
     uint16_t *pid = reinterpret_cast<uint16_t *>(wave_tot + 32);
+    uint16_t *pos16 = pid + TILE;                        // (wide tile only)
     uint64_t *stage = reinterpret_cast<uint64_t *>(
-        (reinterpret_cast<uintptr_t>(pid + TILE) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(pid + (RPT == SC_RPT_WIDE ? 2 * TILE : TILE)) + 15) & ~uintptr_t(15));
 
     const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
     if (!a.gcur) for (uint32_t p = tid; p < P1; p += THREADS) cursor[p] = a.offsets[(size_t)p * NB + group_slot(b, NB)];
@@ -601,7 +734,14 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
         // its share of a partition is 1/8 whenever the key distribution is stationary over 8 tiles (64 K rows)
         for (int64_t tbase = (int64_t)b * TILE; tbase < a.n_rows; tbase += (int64_t)NB * TILE) {
             const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, a.n_rows - tbase);
-            if (tile_n == TILE)
+            if constexpr (RPT == SC_RPT_WIDE) {
+                if (tile_n == TILE) scatter_tile_wide<THREADS, true, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage, pos16);
+                else {                                       // the input's last tile: as (up to) two ordinary tiles
+                    constexpr uint32_t T8 = THREADS * SC_RPT;
+                    scatter_tile<THREADS, true, false, true, SC_RPT>(a, tbase, min(tile_n, T8), cursor, cnt, delta, wave_tot, pid, stage);
+                    if (tile_n > T8) scatter_tile<THREADS, true, false, true, SC_RPT>(a, tbase + T8, tile_n - T8, cursor, cnt, delta, wave_tot, pid, stage);
+                }
+            } else if (tile_n == TILE)
                 scatter_tile<THREADS, STAGED, true, true, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
             else
                 scatter_tile<THREADS, STAGED, false, true, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
@@ -611,7 +751,14 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
     for (int64_t tbase = beg; tbase < end; tbase += TILE) {
         const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
-        if (tile_n == TILE)
+        if constexpr (RPT == SC_RPT_WIDE) {
+            if (tile_n == TILE) scatter_tile_wide<THREADS, true, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage, pos16);
+            else {
+                constexpr uint32_t T8 = THREADS * SC_RPT;
+                scatter_tile<THREADS, true, false, false, SC_RPT>(a, tbase, min(tile_n, T8), cursor, cnt, delta, wave_tot, pid, stage);
+                if (tile_n > T8) scatter_tile<THREADS, true, false, false, SC_RPT>(a, tbase + T8, tile_n - T8, cursor, cnt, delta, wave_tot, pid, stage);
+            }
+        } else if (tile_n == TILE)
             scatter_tile<THREADS, STAGED, true, false, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
         else
             scatter_tile<THREADS, STAGED, false, false, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
@@ -833,9 +980,34 @@ int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows,
     return 0;
 }
 
+// the wide tile (scatter_tile_wide) pays when the (tile, partition) runs of the ordinary tile are shorter than a 128-byte line, i.e.
+// from a fan-out of ~1 K up, and its LDS fits; "scatter_wide": 1 = whenever it fits, -1 = never
+static bool scatter_wide_ok(const pandrs_hip_ctx *c, const ScatterArgs &sa, bool shared_cursors, bool staged) {
+    if (c->opt.scatter_wide < 0 || !staged || c->opt.scatter_threads == 512) return false;
+    int n8 = 0;
+    for (int i = 0; i < sa.n_move; i++) n8 += sa.mv[i].kind == 0;
+    // measured (A/B on one box): C2 (5 columns, P = 1024) scatter 2.11 -> 2.04 ms, C4 whole (2 columns, P = 1792) 10.15 -> 9.79; at small
+    // fan-outs the runs are long already and the two staging halves only cost (C5 shard's 64-bucket pass 1.66 -> 1.85)
+    if (c->opt.scatter_wide == 0 && (sa.P < 1024 || (n8 < 2 && sa.P < 1536))) return false;
+    const size_t lds = (size_t)(sa.P + 1) * (shared_cursors ? 8 : 12) + 32 * 4 + (size_t)1024 * SC_RPT_WIDE * 4 + 16 + (size_t)1024 * SC_RPT * 8;
+    return lds <= 160 * 1024 && sa.n_rows >= 4 * 1024 * SC_RPT_WIDE;
+}
+
 template <int THREADS>
-static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t NB, bool staged) {
+static int32_t launch_scatter(pandrs_hip_ctx *c, const ScatterArgs &sa, uint32_t NB, bool staged, bool wide = false) {
     constexpr int TILE = THREADS * SC_RPT;
+    if (wide && THREADS == 1024) {
+        const size_t ldsw = (size_t)(sa.P + 1) * (sa.gcur ? 8 : 12) + 32 * 4 + (size_t)THREADS * SC_RPT_WIDE * 4 + 16 + (size_t)TILE * 8;
+        if (sa.gend) {
+            ST_TRY(set_max_lds(scatter_kernel<1024, true, true, SC_RPT_WIDE>, (int)ldsw));
+            hipLaunchKernelGGL((scatter_kernel<1024, true, true, SC_RPT_WIDE>), dim3(NB), dim3(1024), ldsw, c->stream, sa);
+        } else {
+            ST_TRY(set_max_lds(scatter_kernel<1024, true, false, SC_RPT_WIDE>, (int)ldsw));
+            hipLaunchKernelGGL((scatter_kernel<1024, true, false, SC_RPT_WIDE>), dim3(NB), dim3(1024), ldsw, c->stream, sa);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     size_t lds = (size_t)(sa.P + 1) * (sa.gcur ? 8 : 12) + 32 * 4 + TILE * 2 + 16 + (staged ? TILE * 8 : 0);
     if (lds > 160 * 1024 && staged && !sa.gend) {          // private cursors at the widest fan-outs: no room for the staging tile,
         staged = false;                                     // the rows go out unstaged (slower, same result)
@@ -868,7 +1040,8 @@ static int32_t radix_partition_once(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo
                                     int phase_scatter) {
     const int64_t N = sa.n_rows;
     const int SCT = c->opt.scatter_threads == 512 ? 512 : 1024;
-    const int SC_TILE = SCT * SC_RPT;
+    const bool wide = SCT == 1024 && scatter_wide_ok(c, sa, c->opt.shared_cursors != 0, c->opt.scatter_staged != 0);
+    const int SC_TILE = SCT * (wide ? SC_RPT_WIDE : SC_RPT);
     const uint32_t P1 = sa.P + 1;
     int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
     uint32_t NB = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), 1024);
@@ -904,7 +1077,7 @@ static int32_t radix_partition_once(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo
     {
         PhaseTimer pt(c, phase_scatter);
         if (SCT == 512) ST_TRY(launch_scatter<512>(c, sa, NB, c->opt.scatter_staged != 0));
-        else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0));
+        else ST_TRY(launch_scatter<1024>(c, sa, NB, c->opt.scatter_staged != 0, wide));
     }
     out->P = sa.P; out->NB = NB; out->offsets = offsets;
     return 0;
@@ -987,7 +1160,8 @@ bool sampled_partition_ok(int64_t n_rows, int64_t P) {
 int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int phase_hist, int phase_scatter) {
     const int64_t N = sa.n_rows;
     const uint32_t P1 = sa.P + 1;
-    constexpr int SC_TILE = 1024 * SC_RPT;
+    const bool wide = scatter_wide_ok(c, sa, true, true);
+    const int SC_TILE = 1024 * (wide ? SC_RPT_WIDE : SC_RPT);
     const int64_t n_tiles = (N + SC_TILE - 1) / SC_TILE;
     uint32_t NB = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_tiles, 8), 1024);
     NB = (NB + 7) & ~7u;
@@ -1014,7 +1188,7 @@ int32_t radix_partition_sampled(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *ou
     while (sa.n_move8 < sa.n_move && sa.mv[sa.n_move8].kind == 0) sa.n_move8++;
     {
         PhaseTimer pt(c, phase_scatter);
-        ST_TRY(launch_scatter<1024>(c, sa, NB, true));
+        ST_TRY(launch_scatter<1024>(c, sa, NB, true, wide));
     }
     out->P = sa.P; out->NB = NB; out->offsets = nullptr;
     out->gbeg = gbeg; out->gcur = gcur; out->gend = gend; out->flags = flags; out->total_cap = total_cap;

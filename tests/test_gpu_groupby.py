@@ -1369,3 +1369,31 @@ def test_two_pass_partition_under_median_and_group_by_row_lists(ctx):
         r = rows[off[g]:off[g + 1]]
         assert np.all(np.diff(r) > 0)
         assert np.all(null[r]) if null[first[g]] else (not null[r].any() and np.all(k[r] == k[first[g]]))
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_wide_scatter_tile_gives_the_same_groups(ctx, exact):
+    """From a fan-out of ~1 K the scatter ranks 16 K rows per workgroup at once and stages them in two halves (scatter_tile_wide,
+    partition.hip).  Forced here (scatter_wide = 1) on both layouts — sampled capacity regions and the exact histogram — with NULL
+    keys, the sentinel-valued key, masked value columns (validity bytes ride as byte columns) and a ragged last tile."""
+    rng = np.random.default_rng(4100 + exact)
+    n = 16384 * 37 + 5003                                       # full wide tiles + a last one of less than half a tile
+    k = sparse_keys(rng, n, 60_000)
+    k[::70_001] = -1
+    keys = [(k, O.pack_mask(rng.random(n) < 0.003), O.I64)]
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.1), O.F64), (rng.normal(5, 1, n), None, O.F64),
+            (rng.integers(-1000, 1000, n).astype(np.int64), O.pack_mask(rng.random(n) < 0.5), O.I64)]
+    aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (1, O.MEAN), (1, O.MAX), (2, O.SUM), (2, O.MIN), (2, O.COUNT)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    for name, val in (("scatter_wide", 1), ("exact_partition", exact), ("no_direct", 1), ("no_absorb", 1), ("no_small", 1)):
+        ctx.set_option(name, val)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+        assert ctx.timings()["n_partitions"] >= 16
+        ctx.set_option("scatter_wide", -1)
+        got1 = ctx.groupby_agg(keys, n, vals, aggs)
+    finally:
+        for name in ("scatter_wide", "exact_partition", "no_direct", "no_absorb", "no_small"):
+            ctx.set_option(name, 0)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1, 2, 4, 5, 6, 7])
+    assert_groupby_equal(got1, want, [O.I64], int_exact_rows=[1, 2, 4, 5, 6, 7])
