@@ -585,11 +585,11 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
 // scatter of C2 behaves like P = 512's) — moved through the SAME 64 KB staging buffer in two halves of the tile's sorted order:
 // a row is staged in the half its sorted position falls in (predicated LDS writes), each half leaves with unit-stride reads.
 // Staged layouts only; LDS: counters | wave_tot | pid[16 K] u16 | pos16[16 K] u16 | stage[8 K] u64.
-template <int THREADS, bool FULL, bool CAPPED>
+template <int THREADS, bool FULL, bool CAPPED, int RPT = SC_RPT_WIDE>
 __device__ __forceinline__ void scatter_tile_wide(const ScatterArgs &a, int64_t tbase, uint32_t tile_n,
                                                   uint32_t *cursor, uint32_t *cnt, uint32_t *delta,
                                                   uint32_t *wave_tot, uint16_t *pid, uint64_t *stage, uint16_t *pos16) {
-    constexpr int RPT = SC_RPT_WIDE, HR = SC_RPT;
+    constexpr int HR = RPT / 2;                          // rows per thread and half
     constexpr uint32_t HALF = THREADS * HR;              // sorted positions per half = rows of the staging buffer
     constexpr uint32_t SPM = (1u << SC_POS_BITS) - 1;
     static_assert(THREADS * RPT == 2 * HALF, "two halves");
@@ -715,6 +715,7 @@ __device__ __forceinline__ void scatter_tile_wide(const ScatterArgs &a, int64_t 
 template <int THREADS, bool STAGED, bool CAPPED = false, int RPT = SC_RPT>
 __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     constexpr int TILE = THREADS * RPT;
+    constexpr bool WIDE = TILE == 1024 * SC_RPT_WIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t P1 = a.P + 1;
     // LDS: [cursor[P1] only with private cursors] | cnt[P1] | delta[P1] | wave_tot[32] | pid[TILE] | stage[TILE]
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     uint16_t *pid = reinterpret_cast<uint16_t *>(wave_tot + 32);
     uint16_t *pos16 = pid + TILE;                        // (wide tile only)
     uint64_t *stage = reinterpret_cast<uint64_t *>(
-        (reinterpret_cast<uintptr_t>(pid + (RPT == SC_RPT_WIDE ? 2 * TILE : TILE)) + 15) & ~uintptr_t(15));
+        (reinterpret_cast<uintptr_t>(pid + (WIDE ? 2 * TILE : TILE)) + 15) & ~uintptr_t(15));
 
     const uint32_t NB = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
     if (!a.gcur) for (uint32_t p = tid; p < P1; p += THREADS) cursor[p] = a.offsets[(size_t)p * NB + group_slot(b, NB)];
@@ -734,12 +735,12 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
         // its share of a partition is 1/8 whenever the key distribution is stationary over 8 tiles (64 K rows)
         for (int64_t tbase = (int64_t)b * TILE; tbase < a.n_rows; tbase += (int64_t)NB * TILE) {
             const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, a.n_rows - tbase);
-            if constexpr (RPT == SC_RPT_WIDE) {
-                if (tile_n == TILE) scatter_tile_wide<THREADS, true, true>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage, pos16);
-                else {                                       // the input's last tile: as (up to) two ordinary tiles
+            if constexpr (WIDE) {
+                if (tile_n == TILE) scatter_tile_wide<THREADS, true, true, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage, pos16);
+                else {                                       // the input's last tile: as ordinary tiles
                     constexpr uint32_t T8 = THREADS * SC_RPT;
-                    scatter_tile<THREADS, true, false, true, SC_RPT>(a, tbase, min(tile_n, T8), cursor, cnt, delta, wave_tot, pid, stage);
-                    if (tile_n > T8) scatter_tile<THREADS, true, false, true, SC_RPT>(a, tbase + T8, tile_n - T8, cursor, cnt, delta, wave_tot, pid, stage);
+                    for (uint32_t o = 0; o < tile_n; o += T8)
+                        scatter_tile<THREADS, true, false, true, SC_RPT>(a, tbase + o, min(tile_n - o, T8), cursor, cnt, delta, wave_tot, pid, stage);
                 }
             } else if (tile_n == TILE)
                 scatter_tile<THREADS, STAGED, true, true, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
@@ -751,12 +752,12 @@ __global__ __launch_bounds__(THREADS, 4) void scatter_kernel(ScatterArgs a) {
     const int64_t beg = (int64_t)b * a.chunk, end = min(beg + a.chunk, a.n_rows);
     for (int64_t tbase = beg; tbase < end; tbase += TILE) {
         const uint32_t tile_n = (uint32_t)min<int64_t>(TILE, end - tbase);
-        if constexpr (RPT == SC_RPT_WIDE) {
-            if (tile_n == TILE) scatter_tile_wide<THREADS, true, false>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage, pos16);
+        if constexpr (WIDE) {
+            if (tile_n == TILE) scatter_tile_wide<THREADS, true, false, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage, pos16);
             else {
                 constexpr uint32_t T8 = THREADS * SC_RPT;
-                scatter_tile<THREADS, true, false, false, SC_RPT>(a, tbase, min(tile_n, T8), cursor, cnt, delta, wave_tot, pid, stage);
-                if (tile_n > T8) scatter_tile<THREADS, true, false, false, SC_RPT>(a, tbase + T8, tile_n - T8, cursor, cnt, delta, wave_tot, pid, stage);
+                for (uint32_t o = 0; o < tile_n; o += T8)
+                    scatter_tile<THREADS, true, false, false, SC_RPT>(a, tbase + o, min(tile_n - o, T8), cursor, cnt, delta, wave_tot, pid, stage);
             }
         } else if (tile_n == TILE)
             scatter_tile<THREADS, STAGED, true, false, RPT>(a, tbase, tile_n, cursor, cnt, delta, wave_tot, pid, stage);
