@@ -75,14 +75,14 @@ for case in range(first_case, n_cases):
                     "p_max": int(rng.choice([0, 0, 0, 24])), "generic_aggregate": int(rng.random() < 0.2),
                     "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9),
                     "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15),
-                    "no_small": int(rng.random() < 0.4), "no_absorb": int(rng.choice([0, 0, -1, -1, 1])), "no_hot_image": int(rng.random() < 0.3), "scatter_wide": int(rng.choice([0, 1, 1, -1]))}
+                    "no_small": int(rng.random() < 0.4), "no_absorb": int(rng.choice([0, 0, -1, -1, 1])), "no_hot_image": int(rng.random() < 0.3), "scatter_wide": int(rng.choice([0, 1, 1, -1])), "two_pass_min_p": int(rng.choice([0, 0, 96]))}
             for k, v in opts.items(): ctx.set_option(k, v)
             try:
                 got = ctx.groupby_agg(keys, n, vals, aggs)
                 absorbed = ctx.timings()["absorbed_rows"]
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1,
-                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0}.items(): ctx.set_option(k, v)
+                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
             if opts["deterministic"] and not any(np.isnan(np.asarray(v[0], np.float64)).any() or np.isinf(np.asarray(v[0], np.float64)).any() for v in vals if v[2] == O.F64):
@@ -117,14 +117,15 @@ for case in range(first_case, n_cases):
             args = ((lcells, mask(rng, nl, rng.choice([0, 0.02])), O.I64), (lv, mask(rng, nl, rng.choice([0, 0.05])), vdt), nl,
                     (rcells, mask(rng, nr, rng.choice([0, 0.02])), O.I64), (rg, mask(rng, nr, rng.choice([0, 0.02])), gdt), nr)
             l2 = int(rng.choice([-1, -1, 0, 1]))
-            ctx.set_option("join_no_l2", l2)
+            tp = int(rng.choice([0, 0, 96]))                          # two-pass partition of both sides from 96 partitions up (default: 6144)
+            ctx.set_option("join_no_l2", l2); ctx.set_option("two_pass_min_p", tp)
             try:
                 got = ctx.join_groupby_sum(*args)
             finally:
-                ctx.set_option("join_no_l2", 0)
+                ctx.set_option("join_no_l2", 0); ctx.set_option("two_pass_min_p", 0)
             want = O.join_groupby_sum(*args)
             assert_groupby_equal(got, want, [gdt], int_exact_rows=[0] if vdt == O.I64 else [], rtol=1e-9)
-            desc = "fused join nl=%d nr=%d unique=%d g=%d v=%d l2=%d -> %d groups" % (nl, nr, unique, gdt, vdt, l2, want[0].shape[1])
+            desc = "fused join nl=%d nr=%d unique=%d g=%d v=%d l2=%d two_pass_from=%d -> %d groups" % (nl, nr, unique, gdt, vdt, l2, tp, want[0].shape[1])
         else:                       # ---------------- join
             nl = int(rng.choice([0, 5, 3000, 200_000, 1_500_000])) * (SCALE if rng.random() < 0.5 else 1); nr = int(rng.choice([0, 4, 2500, 150_000, 900_000])) * (SCALE if rng.random() < 0.5 else 1)
             kd = int(rng.choice([O.I64, O.I64, O.U32CODE, O.F64]))

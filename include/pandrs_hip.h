@@ -214,8 +214,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "join_no_l2"        1 = fused join->groupby never takes the L2-region path for large build sides
  *   "scatter_wide"      the scatter's wide tile (16 K rows per workgroup, staged in two halves): 1 = whenever its LDS fits, -1 = never;
  *                       default: at fan-outs >= 1024 with two or more 8-byte value columns (>= 1536 with one)
- *   "two_pass"          -1 = the exact radix partition never takes two passes (64 buckets, then the rest) at fan-outs >= 6144;
- *                       experiments: a value > 1 = another bucket count, "two_pass_min_p" = another threshold
+ *   "two_pass"          -1 = the exact radix partition never takes two passes (64-127 buckets, then the rest) at fan-outs >= 6144;
+ *                       "two_pass_min_p" = another threshold (tests: also lifts the 4 M-row minimum)
  *   "join_no_pairpart"  1 = the L2-region probe emits its pairs through one cursor instead of pre-partitioned
  *  Median / Nunique
  *   "median_generic"    1 = always the general segmented-sort pass, never the LDS group-sort path

@@ -63,6 +63,8 @@ struct ScatterArgs {
     int64_t n_rows, chunk;
     uint32_t P, seed;
     int n_move, n_move8;       // mv[0 .. n_move8) are 8-byte columns, the rest byte-wide
+    uint32_t hash_P, part_shift;   // 0, 0 normally.  First pass of a two-pass partition: partition id = part_of(hash, hash_P) >> part_shift
+                                   // (a monotone coarsening of the final partition ids; P = the number of such buckets)
     int allow_two_pass;        // radix_partition may take two passes at fan-outs >= 6144: the caller has budgeted two_pass_workspace_bytes in c->work
     MoveDesc mv[MAX_MOVE];
 };

@@ -1556,7 +1556,6 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     ST_TRY(c->work.ensure(ws, c->stream));
     P = std::min<int64_t>(std::max<int64_t>(P, std::min<int64_t>(256, (nl + nr) / 32768)), P_MAX);
     P = std::max<int64_t>(P, 1);
-    if (P >= 1024 && c->opt.partitions <= 0) P = std::min<int64_t>((P + 63) / 64 * 64, P_MAX);      // a multiple of 64: the two-pass partition's bucket count
     uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
     int64_t M = 0;
     uint64_t *out_g = nullptr, *out_v = nullptr;

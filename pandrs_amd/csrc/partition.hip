@@ -416,7 +416,7 @@ __device__ __forceinline__ uint32_t group_slot(uint32_t b, uint32_t NB) { return
 
 __global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int64_t n_rows,
                                                                int64_t chunk, uint32_t P,
-                                                               uint32_t seed, uint32_t *hist) {
+                                                               uint32_t seed, uint32_t *hist, uint32_t hash_P, uint32_t part_shift) {
     extern __shared__ uint32_t cnt[];  // P + 1
     const uint32_t NB = gridDim.x, b = blockIdx.x, qb = group_slot(b, NB), tid = threadIdx.x;
     for (uint32_t p = tid; p <= P; p += HI_THREADS) cnt[p] = 0;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(HI_THREADS) void histogram_kernel(KeyDesc key, int6
 #pragma unroll
         for (int r = 0; r < SC_RPT; r++) {
             const bool act = (uint32_t)(r * HI_THREADS) + tid < tile_n;
-            const uint32_t p = ((nulls >> r) & 1) ? P : part_of(hash32(kc[r], seed), P);
+            const uint32_t p = ((nulls >> r) & 1) ? P : part_of(hash32(kc[r], seed), hash_P ? hash_P : P) >> part_shift;
             // consecutive lanes hold consecutive rows: a run of equal partition ids (rows clustered by
             // key) is counted by its first lane in ONE atomic instead of serialising on one LDS address
             const uint32_t lane = tid & 63;
@@ -479,7 +479,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs &a, int64_t tbase
     for (int r = 0; r < RPT; r++) {
         bool nul = (nulls >> r) & 1;
         if (nul) kc[r] = 0ull;
-        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
+        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.hash_P ? a.hash_P : a.P) >> a.part_shift;
         ps[r] = p << SC_POS_BITS;
         if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);   // rank inside (tile, partition)
     }
@@ -607,7 +607,7 @@ __device__ __forceinline__ void scatter_tile_wide(const ScatterArgs &a, int64_t 
     for (int r = 0; r < RPT; r++) {
         bool nul = (nulls >> r) & 1;
         if (nul) kc[r] = 0ull;
-        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.P);
+        uint32_t p = nul ? a.P : part_of(hash32(kc[r], a.seed), a.hash_P ? a.hash_P : a.P) >> a.part_shift;
         ps[r] = p << SC_POS_BITS;
         if (live(r)) ps[r] |= atomicAdd(&cnt[p], 1u);
     }
@@ -1059,7 +1059,7 @@ static int32_t radix_partition_once(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo
     {
         PhaseTimer pt(c, phase_hist);
         hipLaunchKernelGGL(histogram_kernel, dim3(NB), dim3(HI_THREADS), P1 * 4, c->stream,
-                           sa.key, N, chunk, sa.P, sa.seed, hist);
+                           sa.key, N, chunk, sa.P, sa.seed, hist, sa.hash_P, sa.part_shift);
         HIP_TRY(hipGetLastError());
     }
     {
@@ -1085,11 +1085,12 @@ static int32_t radix_partition_once(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo
 }
 
 // The exact partition.  A fan-out of thousands leaves a scatter tile (8 K rows) as 1-row runs — 8-byte stores to 8 K places,
-// 1.4 TB/s — so from P = 6144 up the rows move TWICE in long runs instead: 64 buckets first, then the full fan-out over the
-// bucket-sorted rows, whose tiles see only ~P / 64 partitions each.  part_of is a multiplicative range reduction, so
-// bucket = partition / (P / 64) whenever 64 divides P: the second pass is the ordinary partition of the first pass's output
-// (key cells + a null byte per row; every moved column in its destination type).  62.5 M + 50 M rows of 16 bytes at P = 8192:
-// 2.5 -> 2.1 ms; at P = 4096 and below the single pass is still the faster one.  Needs the temporaries in the work arena; without room (or with "two_pass" = -1) it is the single pass.
+// 1.4 TB/s — so from P = 6144 up the rows move TWICE in long runs instead: 64-127 buckets first, then the full fan-out over the
+// bucket-sorted rows, whose tiles see only ~P / 64 partitions each.  A bucket is the final partition id shifted down
+// (ScatterArgs::hash_P / part_shift): a monotone coarsening, so every bucket is a contiguous range of partitions and the second
+// pass is the ordinary partition of the first pass's output (key cells + a null byte per row; every moved column in its
+// destination type).  62.5 M + 50 M rows of 16 bytes at P = 8192: 2.5 -> 2.1 ms; at P = 4096 and below the single pass is still
+// the faster one.  Needs the temporaries in the work arena; without room (or with "two_pass" = -1) it is the single pass.
 constexpr uint32_t TWO_PASS_BUCKETS = 64;
 constexpr int64_t TWO_PASS_MIN_P = 6144;          // measured crossover (16-byte rows): 17.5 / 20.5 / 26.6 ns per K rows in one pass at P = 2.5 K / 4 K / 8 K, 21-25 in two
 size_t two_pass_workspace_bytes(int64_t n_rows, int n_cols8, int n_cols1) {
@@ -1102,8 +1103,11 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
                         int phase_scatter) {
     const int64_t N = sa.n_rows;
     const bool key_nulls = sa.key.null_bits || sa.key.null_bytes;
-    const uint32_t B1 = c->opt.two_pass > 1 ? (uint32_t)c->opt.two_pass : TWO_PASS_BUCKETS;      // (experiments: another bucket count)
-    bool two = sa.allow_two_pass && c->opt.two_pass >= 0 && sa.P >= (c->opt.two_pass_min_p > 0 ? c->opt.two_pass_min_p : TWO_PASS_MIN_P) && sa.P % B1 == 0 && B1 <= 256 && N >= (int64_t(1) << (c->opt.two_pass_min_p > 0 ? 16 : 22)) &&      // (an explicit threshold, tests: small inputs too)
+    // first-pass buckets: the final partition ids shifted down until <= 64 .. 127 of them are left (any P; a monotone coarsening)
+    uint32_t shift = 0;
+    while (((sa.P - 1) >> shift) + 1 > 2 * TWO_PASS_BUCKETS - 1) shift++;
+    const uint32_t B1 = ((sa.P - 1) >> shift) + 1;
+    bool two = sa.allow_two_pass && c->opt.two_pass >= 0 && sa.P >= (c->opt.two_pass_min_p > 0 ? c->opt.two_pass_min_p : TWO_PASS_MIN_P) && shift > 0 && !sa.hash_P && N >= (int64_t(1) << (c->opt.two_pass_min_p > 0 ? 16 : 22)) &&      // (an explicit threshold, tests: small inputs too)
               
                sa.n_move + (key_nulls ? 1 : 0) <= MAX_MOVE;
     if (!two) return radix_partition_once(c, sa, out, phase_hist, phase_scan, phase_scatter);
@@ -1116,7 +1120,7 @@ int32_t radix_partition(pandrs_hip_ctx *c, ScatterArgs &sa, PartInfo *out, int p
     if (c->work.cap - c->work.off < need + sets)          // (a caller that budgeted less than it promised: the single pass, not a failure)
         return radix_partition_once(c, sa, out, phase_hist, phase_scan, phase_scatter);
     ScatterArgs s1 = sa, s2 = sa;
-    s1.P = B1;
+    s1.P = B1; s1.hash_P = sa.P; s1.part_shift = shift;
     uint64_t *tk = c->work.take<uint64_t>((size_t)N + 1);
     s1.pkeys = tk;
     for (int i = 0; i < sa.n_move; i++) {

@@ -1343,11 +1343,11 @@ def test_absorb_is_not_tried_on_uniform_keys(ctx):
 
 def test_two_pass_partition_under_median_and_group_by_row_lists(ctx):
     """The pair partition of Median / Nunique and group_by's row lists take the two-pass radix partition at fan-outs >= 6144
-    (100 M rows); forced here at 128 partitions.  Same medians, same row lists (ascending rows per group) as the oracle."""
+    (100 M rows); forced here at 132 partitions.  Same medians, same row lists (ascending rows per group) as the oracle."""
     rng = np.random.default_rng(2024)
-    n = 9000 * 128                                             # ceil(n / 9000) = 128 partitions: a multiple of the 64 buckets
+    n = 9000 * 131 + 17                                        # 132 partitions of ~9 K rows: first-pass buckets = partition id >> 1
     keys = [(sparse_keys(rng, n, 20_000), O.pack_mask(rng.random(n) < 0.002), O.I64)]
-    # no value nulls: the pair partition sees all n rows -> 128 partitions too.  (+ 0.0: no -0.0 among the values — a group holding both
+    # no value nulls: the pair partition sees all n rows -> as many partitions.  (+ 0.0: no -0.0 among the values — a group holding both
     # zeros has a Median whose SIGN depends on the rows' order in the reference's stable sort, DESIGN.md section 6)
     vals = [(np.round(rng.normal(500, 100, n), 1) + 0.0, None, O.F64)]
     aggs = [(0, O.MEDIAN), (0, O.NUNIQUE), (0, O.SUM)]

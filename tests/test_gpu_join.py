@@ -480,7 +480,7 @@ def test_two_pass_partition_gives_the_same_join_and_groups(ctx):
     args = ((lkeys, O.pack_mask(rng.random(npb) < 0.01), O.I64), (lv, O.pack_mask(rng.random(npb) < 0.05), O.I64), npb,
             (rkeys, O.pack_mask(rng.random(nb) < 0.01), O.I64), (rg, O.pack_mask(rng.random(nb) < 0.01), O.I64), nb)
     want = O.join_groupby_sum(*args)
-    ctx.set_option("partitions", 1024)
+    ctx.set_option("partitions", 1000)                          # (any fan-out: the first pass's buckets are partition ids shifted down)
     try:
         ctx.set_option("two_pass_min_p", 512)
         got = ctx.join_groupby_sum(*args)
