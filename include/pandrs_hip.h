@@ -216,6 +216,7 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *                       default: at fan-outs >= 1024 with two or more 8-byte value columns (>= 1536 with one)
  *   "two_pass"          -1 = the exact radix partition never takes two passes (64-127 buckets, then the rest) at fan-outs >= 6144;
  *                       "two_pass_min_p" = another threshold (tests: also lifts the 4 M-row minimum)
+ *   "join_pair_p"       the L2-region probe's minimum pair fan-out (0 = the default)
  *   "join_no_pairpart"  1 = the L2-region probe emits its pairs through one cursor instead of pre-partitioned
  *  Median / Nunique
  *   "median_generic"    1 = always the general segmented-sort pass, never the LDS group-sort path

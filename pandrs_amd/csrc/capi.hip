@@ -191,6 +191,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "p_target")) c->opt.p_target = value;
     else if (!std::strcmp(name, "join_generic")) c->opt.join_generic = value;
     else if (!std::strcmp(name, "join_no_l2")) c->opt.join_no_l2 = value;
+    else if (!std::strcmp(name, "join_pair_p")) c->opt.join_pair_p = value;
     else if (!std::strcmp(name, "two_pass")) c->opt.two_pass = value;
     else if (!std::strcmp(name, "scatter_wide")) c->opt.scatter_wide = value;
     else if (!std::strcmp(name, "two_pass_min_p")) c->opt.two_pass_min_p = value;

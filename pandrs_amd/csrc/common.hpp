@@ -176,6 +176,7 @@ struct Options {
     int64_t scatter_wide = 0;        // 1 = the scatter's wide tile (16 K rows, two staging halves) whenever it fits, -1 = never; 0 = at fan-outs >= 1024 (see scatter_wide_ok)
     int64_t two_pass_min_p = 0;      // experiments: the fan-out from which the two passes are taken (default 6144)
     int64_t two_pass = 0;            // -1 = the exact radix partition never takes two passes (64 buckets, then the rest) at fan-outs >= 6144
+    int64_t join_pair_p = 0;         // the L2-region probe's minimum pair fan-out (default 256; fewer = longer runs, the engine slices the partitions)
     int64_t join_no_l2 = 0;          // 1 = the fused join never takes the L2-resident-table path; -1 = always tries it (testing)
     int64_t join_generic = 0;        // 1 = always sort the join build side with the general segmented sort (testing)
     int64_t exact_partition = 0;     // 1 = always run the exact histogram (never the sampled-capacity partition)

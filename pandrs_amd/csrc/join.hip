@@ -1429,7 +1429,8 @@ static int32_t fused_l2_path(pandrs_hip_ctx *c, const KeyDesc &lkey, const void 
         int64_t est_g = 0;
         ST_TRY(estimate_groups(c, KeyDesc{gsrc, nullptr, nullptr, DT_CELL}, nr, &est_g));
         const int64_t T = lean_table_slots(c, 1);
-        int64_t pair_P = std::max<int64_t>(256, (int64_t)std::ceil((double)std::max<int64_t>(est_g, 1) / ((double)T * 0.70)));
+        const int64_t pair_min = c->opt.join_pair_p > 0 ? c->opt.join_pair_p : 256;
+        int64_t pair_P = std::max<int64_t>(pair_min, (int64_t)std::ceil((double)std::max<int64_t>(est_g, 1) / ((double)T * 0.70)));
         const bool lean_ok = !c->opt.agg_v1 && !c->opt.generic_aggregate && (c->opt.p_max <= 0 || pair_P <= c->opt.p_max);
         if (lean_ok && pair_P <= (int64_t)L2_PAIR_PMAX && sampled_partition_ok(nl, pair_P) && (double)nl * 1.5 < 4.0e9) {
             const uint32_t PP1 = (uint32_t)pair_P + 1;
