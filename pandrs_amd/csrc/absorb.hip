@@ -60,7 +60,7 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
     constexpr bool OP_MIN = ((PROFILE >> 2) & 1) != 0, OP_MAX = ((PROFILE >> 3) & 1) != 0;
     constexpr int KIND = (PROFILE >> 4) & 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t T = a.T, T1 = T + 2, tid = threadIdx.x;
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     uint64_t *st = keys + T1;
     uint32_t *gsz = reinterpret_cast<uint32_t *>(st + (size_t)a.n_lds_states * T1);
