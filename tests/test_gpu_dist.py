@@ -448,7 +448,7 @@ def _transport_worker(rank, world, port, outdir, uneven):
     ctx.close()
 
 
-@pytest.mark.parametrize("world,uneven", [(2, "uneven"), (3, "empty")])
+@pytest.mark.parametrize("world,uneven", [(2, "uneven"), (3, "empty"), (5, "uneven")])
 def test_in_library_exchange_with_real_ranks_over_a_host_transport(tmp_path, world, uneven):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
