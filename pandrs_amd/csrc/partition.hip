@@ -991,7 +991,8 @@ static bool scatter_wide_ok(const pandrs_hip_ctx *c, const ScatterArgs &sa, bool
     // fan-outs the runs are long already and the two staging halves only cost (C5 shard's 64-bucket pass 1.66 -> 1.85)
     if (c->opt.scatter_wide == 0 && (sa.P < 1024 || (n8 < 2 && sa.P < 1536))) return false;
     const size_t lds = (size_t)(sa.P + 1) * (shared_cursors ? 8 : 12) + 32 * 4 + (size_t)1024 * SC_RPT_WIDE * 4 + 16 + (size_t)1024 * SC_RPT * 8;
-    return lds <= 160 * 1024 && sa.n_rows >= 4 * 1024 * SC_RPT_WIDE;
+    // (and only with several tiles per CU: a 1 M-record merge has 61 wide tiles for 256 CUs — its scatter took 0.17 ms instead of 0.08)
+    return lds <= 160 * 1024 && sa.n_rows >= (c->opt.scatter_wide > 0 ? 4 : 1024) * 1024 * (int64_t)SC_RPT_WIDE;
 }
 
 template <int THREADS>
