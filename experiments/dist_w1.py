@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pandrs_amd as pa
 d = "cuda:0"; ctx = pa.Context(0)
 ctx.comm_init(pa.Context.comm_unique_id(), 0, 1)
+for kv in os.environ.get("PANDRS_OPTS", "").split(","):
+    if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 gen = torch.Generator(device=d); gen.manual_seed(1)
 n, g = 100_000_000, 1_000_000
 k = torch.randint(0, g, (n,), device=d, generator=gen, dtype=torch.int64) * -7046029254386353131
