@@ -1371,13 +1371,13 @@ def test_two_pass_partition_under_median_and_group_by_row_lists(ctx):
         assert np.all(null[r]) if null[first[g]] else (not null[r].any() and np.all(k[r] == k[first[g]]))
 
 
-@pytest.mark.parametrize("exact", [0, 1])
-def test_wide_scatter_tile_gives_the_same_groups(ctx, exact):
+@pytest.mark.parametrize("exact,tail", [(0, 5003), (1, 5003), (0, 12001), (1, 8192)])
+def test_wide_scatter_tile_gives_the_same_groups(ctx, exact, tail):
     """From a fan-out of ~1 K the scatter ranks 16 K rows per workgroup at once and stages them in two halves (scatter_tile_wide,
     partition.hip).  Forced here (scatter_wide = 1) on both layouts — sampled capacity regions and the exact histogram — with NULL
     keys, the sentinel-valued key, masked value columns (validity bytes ride as byte columns) and a ragged last tile."""
-    rng = np.random.default_rng(4100 + exact)
-    n = 16384 * 37 + 5003                                       # full wide tiles + a last one of less than half a tile
+    rng = np.random.default_rng(4100 + exact + tail)
+    n = 16384 * 37 + tail                                       # full wide tiles + a ragged last one (one or two ordinary tiles)
     k = sparse_keys(rng, n, 60_000)
     k[::70_001] = -1
     keys = [(k, O.pack_mask(rng.random(n) < 0.003), O.I64)]
