@@ -202,6 +202,7 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "agg_ablate"        experiments only: switch parts of the lean aggregate off (see experiments/agg2_ablate.py)
  *   "no_runs"           1 = never the clustered-rows (RUNS) instantiation
  *   "no_direct"         1 = never the few-groups direct path (-1 = allow it below 4 M rows too)
+ *   "no_chao"           1 = the sampled group estimate is the uniform-occupancy model alone (no Chao1 term: tests, A/B)
  *   "no_absorb"         1 = never the hot-key absorb-and-spill pass in front of the radix path (-1 = whenever it is possible: tests)
  *   "no_hot_image"      1 = the absorb tables start empty (first come, first served) instead of from the sample's most frequent keys
  *   "no_slice"          1 = never cut oversized partitions into row slices; "slice_rows" forces the slice length

@@ -164,6 +164,7 @@ struct Options {
     int64_t no_slice = 0;            // 1 = never split oversized partitions across workgroups
     int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
+    int64_t no_chao = 0;             // 1 = the group estimate is the uniform-occupancy model alone (no Chao1 term from the sample's singletons / doubletons)
     int64_t no_absorb = 0;           // 1 = never run the hot-key absorb-and-spill pass in front of the radix path
     int64_t no_hot_image = 0;        // 1 = the absorb tables start empty (first come, first served) instead of from the sample's hot keys
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)

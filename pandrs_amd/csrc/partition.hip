@@ -16,7 +16,8 @@ static int32_t set_max_lds(K kernel, int bytes) {
 }
 
 // ------------------------------------------------------------------------------------ estimate
-// distinct[0] = distinct keys in the sample, [2] = adjacent pairs that differ, [3] = adjacent pairs (one u64, one atomic), [4] = blocks done.
+// distinct[0] = distinct keys in the sample, [2] = adjacent pairs that differ, [3] = adjacent pairs (one u64, one atomic), [4] = blocks done,
+// [5] = keys sighted at least twice, [6] = at least three times (=> singletons f1 = [0] - [5], doubletons f2 = [5] - [6]: the Chao1 estimate).
 // The last block to finish copies [0..2] to `host_out` (pinned, device-visible), so the host needs one stream
 // synchronise and no copy; estimate_clear_kernel then re-arms table and counters for the next call (off the
 // critical path: it runs while the host plans).
@@ -29,13 +30,15 @@ __device__ __forceinline__ void estimate_publish(uint32_t *distinct, uint32_t *h
             host_out[0] = __hip_atomic_load(&distinct[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[1] = __hip_atomic_load(&distinct[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[2] = __hip_atomic_load(&distinct[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[4] = __hip_atomic_load(&distinct[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[5] = __hip_atomic_load(&distinct[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-__global__ void estimate_clear_kernel(uint64_t *table, uint32_t slots, uint32_t *distinct, uint32_t *counts) {
+__global__ void estimate_clear_kernel(uint64_t *table, uint32_t slots, uint32_t *distinct, uint32_t *counts, uint32_t *sight) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < slots) table[i] = EMPTY_KEY;
+    if (i < slots) { table[i] = EMPTY_KEY; sight[i] = 0; }
     if (i < 8) distinct[i] = 0;
     if (counts && i < slots) counts[i] = 0;
 }
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(1024) void hot_image_kernel(const uint64_t *table, 
 }
 
 __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
-                                uint64_t *table, uint32_t table_mask, uint32_t *distinct) {
+                                uint64_t *table, uint32_t table_mask, uint32_t *distinct, uint32_t *sight) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = s < n_sample && s * stride < n_rows;
     uint64_t k = 0;
@@ -225,10 +228,10 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
         if (threadIdx.x == 0 && sb[0])
             atomicAdd(reinterpret_cast<unsigned long long *>(&distinct[2]), ((unsigned long long)sb[0] << 32) | sb[1]);
     }
-    // a dominant key would make every lane CAS the same address: peel the wave's two most common
-    // leading keys first (one lane inserts for all lanes that hold the same key)
+    // a dominant key would make every lane CAS the same address: peel the wave's leading keys first (one lane inserts for all lanes that hold the same key)
     bool peeled = false;       // this lane is (or was represented by) a leader already
-    for (int round = 0; round < 2; round++) {
+    for (int round = 0; round < 8; round++) {          // (8: with a handful of keys in all, every lane is represented — the sighting counters
+                                                        // below would otherwise take one device atomic per sampled row on ten addresses)
         unsigned long long m = __ballot(live && !peeled);
         if (!m) break;
         int leader = __ffsll((long long)m) - 1;
@@ -240,29 +243,41 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
     }
     // new keys are counted per workgroup in LDS and added to the global counter ONCE: a device-scope atomic per
     // inserted key on one address (even wave-aggregated: ~20 K of them) was most of this kernel's 80 us
-    __shared__ uint32_t inserted;
-    if (threadIdx.x == 0) inserted = 0;
+    // ... and so are the keys that reach their SECOND and THIRD sighting (a saturating counter per slot; a hot key costs three
+    // atomics in all, the pre-check keeps the rest away): singletons and doubletons of the sample are what tells "few keys, all
+    // seen" from "a few hot keys in front of a long tail" — the uniform-occupancy model alone under-estimated a 2 K-hot-key /
+    // 1 M-key column 16 x, and the engine paid with three full retries (C2's skewed variants: 12-29 ms instead of ~3.5)
+    __shared__ uint32_t inserted, twice, thrice;
+    if (threadIdx.x == 0) { inserted = 0; twice = 0; thrice = 0; }
     __syncthreads();
     if (live) {
         uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+        bool again = false;
         for (uint32_t probe = 0; probe <= table_mask; probe++) {
             uint64_t cur = table[slot];
-            if (cur == k) break;
+            if (cur == k) { again = true; break; }
             if (cur == EMPTY_KEY) {
                 uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
                 if (old == EMPTY_KEY) { atomicAdd(&inserted, 1u); break; }
-                if (old == k) break;
+                if (old == k) { again = true; break; }
             }
             slot = (slot + 1) & table_mask;
+        }
+        if (again && __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+            const uint32_t o = atomicAdd(&sight[slot], 1u);
+            if (o == 0) atomicAdd(&twice, 1u);
+            else if (o == 1) atomicAdd(&thrice, 1u);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && inserted) atomicAdd(distinct, inserted);
+    if (threadIdx.x == 1 && twice) atomicAdd(&distinct[5], twice);
+    if (threadIdx.x == 2 && thrice) atomicAdd(&distinct[6], thrice);
 }
 
 __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
-                                uint64_t *table, uint32_t table_mask, uint32_t *distinct, uint32_t *host_out) {
-    estimate_body(key, n_rows, stride, n_sample, table, table_mask, distinct);
+                                uint64_t *table, uint32_t table_mask, uint32_t *distinct, uint32_t *host_out, uint32_t *sight) {
+    estimate_body(key, n_rows, stride, n_sample, table, table_mask, distinct, sight);
     estimate_publish(distinct, host_out);
 }
 
@@ -869,6 +884,7 @@ static uint32_t *est_counts(pandrs_hip_ctx *c) { return reinterpret_cast<uint32_
 static uint32_t *est_cov_hist(pandrs_hip_ctx *c) { return est_counts(c) + EST_SLOTS; }      // [2 * COV_BINS + 1] + threshold words at + 2 * COV_BINS + 16
 constexpr uint32_t EST_IMAGE_SLOTS = 1u << 15;            // the hot-key image (absorb pass): as many slots as an LDS table can have
 static uint64_t *est_image(pandrs_hip_ctx *c) { return reinterpret_cast<uint64_t *>(est_cov_hist(c) + 2 * COV_BINS + 64); }
+static uint32_t *est_sight(pandrs_hip_ctx *c) { return reinterpret_cast<uint32_t *>(est_image(c) + EST_IMAGE_SLOTS); }      // [EST_SLOTS] saturating sighting counters
 
 int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est, bool keep_table) {
     PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
@@ -878,19 +894,19 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     // a dedicated block that stays armed (table = EMPTY, counters = 0) between calls: cleared behind the previous
     // estimate instead of in front of this one
     if (!c->est_table) {
-        const size_t bytes = size_t(slots) * 8 + 256 + size_t(slots) * 4 + (2 * COV_BINS + 64) * 4 + EST_IMAGE_SLOTS * 8;
+        const size_t bytes = size_t(slots) * 8 + 256 + size_t(slots) * 4 + (2 * COV_BINS + 64) * 4 + EST_IMAGE_SLOTS * 8 + size_t(slots) * 4;
         HIP_TRY(hipMalloc((void **)&c->est_table, bytes));
         alloc_events()++;
         HIP_TRY(hipMemsetAsync(c->est_table, 0, bytes, c->stream));
         uint32_t *cnt0 = reinterpret_cast<uint32_t *>(c->est_table + slots);
-        hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->est_table, slots, cnt0, est_counts(c));
+        hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->est_table, slots, cnt0, est_counts(c), est_sight(c));
     }
     uint64_t *table = c->est_table;
     uint32_t *distinct = reinterpret_cast<uint32_t *>(c->est_table + slots);
     volatile uint32_t *h = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1024;     // own corner of the pinned block
     h[3] = 0;
     hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)((n_sample + 1023) / 1024)), dim3(1024), 0, c->stream,
-                       key, n_rows, stride, n_sample, table, slots - 1, distinct, const_cast<uint32_t *>(h));
+                       key, n_rows, stride, n_sample, table, slots - 1, distinct, const_cast<uint32_t *>(h), est_sight(c));
     HIP_TRY(hipGetLastError());
     // poll the pinned word the kernel's last block sets (a PCIe write away) before falling back to the runtime's
     // wait, which costs tens of microseconds to wake up
@@ -901,8 +917,9 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint32_t hv[3] = {h[0], h[1], h[2]};
+    const double twice = h[4], thrice = h[5];
     c->est_kept = keep_table;
-    if (!keep_table) hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct, (uint32_t *)nullptr);
+    if (!keep_table) hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct, (uint32_t *)nullptr, est_sight(c));
     double d = std::max<uint32_t>(hv[0], 1), s = (double)n_sample;
     double est;
     if (n_sample == n_rows) est = d;
@@ -918,6 +935,12 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
             if (std::fabs(Gn - G) < 1e-6 * G) { G = Gn; break; }
             G = Gn;
         }
+        // Chao1 from the sample's singletons and doubletons: d + f1 (f1 - 1) / (2 (f2 + 1)).  Equal to the model on uniform keys
+        // (1 M groups: 0.998 M); on a few hot keys in front of a long tail it sees the tail the model cannot (2 K hot keys holding
+        // 80 % of the rows + 1 M others: model 60 K, Chao1 0.96 M).  The larger of the two plans the fan-out.
+        const double f1 = std::max(0.0, d - twice), f2 = std::max(0.0, twice - thrice);
+        const double chao = d + f1 * std::max(0.0, f1 - 1.0) / (2.0 * (f2 + 1.0));
+        if (!c->opt.no_chao) G = std::max(G, chao);
         est = std::min<double>(std::max(G, d), (double)n_rows);
     }
     c->clustered_rows = false;
@@ -938,7 +961,7 @@ void estimate_release(pandrs_hip_ctx *c) {
     if (!c->est_kept) return;
     c->est_kept = false;
     hipLaunchKernelGGL(estimate_clear_kernel, dim3(EST_SLOTS / 256), dim3(256), 0, c->stream, c->est_table, EST_SLOTS,
-                       reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), (uint32_t *)nullptr);
+                       reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), (uint32_t *)nullptr, est_sight(c));
 }
 
 // Share of the rows (by the kept sample) that belongs to the `budget` most frequent keys; releases the table.
@@ -976,7 +999,7 @@ int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows,
     }
     c->est_kept = false;
     hipLaunchKernelGGL(estimate_clear_kernel, dim3(EST_SLOTS / 256), dim3(256), 0, c->stream, c->est_table, EST_SLOTS,
-                       reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), est_counts(c));
+                       reinterpret_cast<uint32_t *>(c->est_table + EST_SLOTS), est_counts(c), est_sight(c));
     *out_share = covered / all;
     return 0;
 }
