@@ -140,7 +140,8 @@ typedef struct pandrs_hip_timings {
     int64_t n_partitions;                     /* radix fan-out chosen (0: the small-call path; fused join: the probe side's fan-out,
                                                  0 = general fallback) */
     int64_t table_slots;                      /* LDS hash-table slots per partition */
-    int64_t retries;                          /* overflow retries taken (fused join: 1 = the partitioned pair output overflowed a
+    int64_t retries;                          /* overflow retries taken; 100 + retries: full LDS tables handed their unplaced rows to a
+                                                 run of their own instead (groupby; the estimate was too low).  (fused join: 1 = the partitioned pair output overflowed a
                                                  region and the one-cursor emission answered; 2 = the groupby engine refused the
                                                  pre-partitioned pairs — a full LDS table — and the whole call was repeated with
                                                  the one-cursor emission) */
@@ -202,6 +203,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "agg_ablate"        experiments only: switch parts of the lean aggregate off (see experiments/agg2_ablate.py)
  *   "no_runs"           1 = never the clustered-rows (RUNS) instantiation
  *   "no_direct"         1 = never the few-groups direct path (-1 = allow it below 4 M rows too)
+ *   "no_overflow_run"   1 = a full LDS table fails the attempt (the call is retried with 4 x the fan-out) instead of handing the rows it
+ *                       could not place to a run of their own, whose groups are appended
  *   "no_chao"           1 = the sampled group estimate is the uniform-occupancy model alone (no Chao1 term: tests, A/B)
  *   "no_absorb"         1 = never the hot-key absorb-and-spill pass in front of the radix path (-1 = whenever it is possible: tests)
  *   "no_hot_image"      1 = the absorb tables start empty (first come, first served) instead of from the sample's most frequent keys

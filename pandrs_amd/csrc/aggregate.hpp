@@ -39,11 +39,16 @@ struct AggArgs {
     double *out_aggs;            // [n_fin][cap]
     uint64_t *out_states;        // [1 + n_states][cap] when partials
     size_t cap;
-    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag, [2] = side records; aggregate2: [8] = workgroups done
+    uint32_t *counters;          // [0] = n_groups, [1] = overflow flag, [2] = side records; aggregate2: [6] = overflow rows, [8] = workgroups done
     // aggregate2: the last workgroup to finish copies counters[0..2] and *scatter_flags to host_out[0..3] (pinned,
     // device-visible) and sets host_out[4] = 1, so the host polls one word instead of copying and synchronising
     const uint32_t *scatter_flags;
     uint32_t *host_out;
+    // aggregate2, optional (ov_keys != nullptr): a row whose key finds no slot in a FULL table (the group estimate was too low)
+    // is appended — key cell, values, validity bytes — at counters[6] instead of failing the call.  The keys of such rows are
+    // in no table (a full table stays full), so they are a disjoint sub-problem: the host groups them on their own and appends
+    // the groups.  Not for `multi` tables (another slice may hold the key); more than ov_cap rows => the overflow flag as before.
+    uint64_t *ov_keys; uint64_t *ov_vals[4]; uint8_t *ov_valid[4]; uint32_t ov_cap;      // (aggregate2 instantiates 1..4 sources)
     // aggregate2's SMALL mode (few rows: no estimate, no partition): workgroup b folds rows [b * s_chunk, ...) of the
     // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) into its LDS table and flushes the table into
     // the context's global table with device-scope atomics; small_output_kernel turns that into the result

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             if (atomicAdd(&a.counters[8], 1u) == gridDim.x - 1) {
                 __threadfence();
                 for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.host_out[6] = __hip_atomic_load(&a.counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (ABLATE == 8) a.host_out[5] = __hip_atomic_load(&a.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.host_out[3] = a.scatter_flags ? __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -231,9 +232,13 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     // collision, the sentinel-valued key): the wave keeps their row indices and handles 64 at a time, one
     // per lane, with the general probe — so the rare path costs per ROW, not per wave that contains one.
     uint32_t qn = 0;                                   // wave-uniform
+    bool cur_multi = false;                            // the table being filled is a slice of an oversized partition
     auto drain = [&](uint32_t n_take) {                // n_take <= 64 entries from the top of the wave's queue
         qn -= n_take;
         if (ABLATE == 8 && lane == 0) atomicAdd(&a.counters[5], n_take);       // experiments: rows that took the retry queue
+        bool ovf = false;
+        uint64_t ov_k = 0, ov_v[NSRC];
+        uint32_t ov_okm = 0;
         if (lane < n_take) {
             const uint32_t i = queue[qn + lane];
             const uint64_t k = SMALL ? key_cell(a.dkey, i) : pkeys[i];
@@ -251,9 +256,36 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             uint32_t slot = T;
             if (knull) { slot = T + 1; misc[23] = 1; }           // NULL key: its own group (grouping.rs:74)
             else if (k == EMPTY_KEY) misc[21] = 1;
-            else slot = swiss_find(k, keys, ctrl, T, seed, SMALL ? 8u : 0xFFFFFFFFu);
-            if (slot > T + 1) misc[20] = 1;            // table full: host retries with more partitions
-            else update(slot, v, okm);
+            // (at most 16 groups = a 256-slot window — 8 overflowed a handful of rows of uniform C2 at load 0.69 —: inserts and lookups obey the same bound, so a key is either inside its window or —
+            // consistently, slots never free up — handed to the overflow path; a FULL table is no longer walked end to end per unplaced row)
+            else slot = swiss_find(k, keys, ctrl, T, seed, SMALL ? 8u : 16u);
+            if (slot <= T + 1) update(slot, v, okm);
+            else ovf = true;                            // table full
+            ov_k = k; ov_okm = okm;
+#pragma unroll
+            for (int c = 0; c < NSRC; c++) ov_v[c] = v[c];
+        }
+        // rows of a full table: appended for a run of their own (see AggArgs::ov_keys), or — no buffer, a `multi` table, the
+        // buffer full — the overflow flag and the host retries with more partitions
+        const unsigned long long om = __ballot(ovf);
+        if (om) {                                       // wave-uniform, rare
+            if (SMALL || !a.ov_keys || cur_multi) { if (ovf) misc[20] = 1; }
+            else {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&a.counters[6], (uint32_t)__popcll(om));
+                base = __shfl(base, 0, 64);
+                const uint32_t pos = base + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
+                if (ovf) {
+                    if (pos < a.ov_cap) {
+                        a.ov_keys[pos] = ov_k;
+#pragma unroll
+                        for (int c = 0; c < NSRC; c++) {
+                            a.ov_vals[c][pos] = ov_v[c];
+                            if (HAS_V) a.ov_valid[c][pos] = (uint8_t)((ov_okm >> c) & 1u);
+                        }
+                    } else misc[20] = 1;
+                }
+            }
         }
     };
 
@@ -266,6 +298,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         const AggTable ntab = get_table(have_next_tab ? tbn : tb);
         const bool multi = tab.multi != 0;
         const uint32_t t_end = tab.task_beg + tab.n_tasks;
+        cur_multi = multi;
 
         for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
         for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;

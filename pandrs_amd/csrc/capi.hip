@@ -98,7 +98,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     if (!c) return PANDRS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release(); c->shuf.release(); c->absorb.release();
+    c->work.release(); c->result.release(); c->staging.release(); c->temp.release(); c->result2.release(); c->result3.release(); c->side.release(); c->super.release(); c->packed.release(); c->pairs.release(); c->groups.release(); c->shuf.release(); c->absorb.release(); c->overflow.release();
     for (int i = 0; i < PANDRS_HIP_MAX_PHASES; i++) { (void)hipEventDestroy(c->ev_begin[i]); (void)hipEventDestroy(c->ev_end[i]); }
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -205,6 +205,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_direct")) c->opt.no_direct = value;
     else if (!std::strcmp(name, "no_absorb")) c->opt.no_absorb = value;
     else if (!std::strcmp(name, "no_chao")) c->opt.no_chao = value;
+    else if (!std::strcmp(name, "no_overflow_run")) c->opt.no_overflow_run = value;
     else if (!std::strcmp(name, "no_hot_image")) c->opt.no_hot_image = value;
     else if (!std::strcmp(name, "no_slice")) c->opt.no_slice = value;
     else if (!std::strcmp(name, "p_max")) c->opt.p_max = value;

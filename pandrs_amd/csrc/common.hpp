@@ -164,6 +164,7 @@ struct Options {
     int64_t no_slice = 0;            // 1 = never split oversized partitions across workgroups
     int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
+    int64_t no_overflow_run = 0;     // 1 = a full LDS table fails the attempt (retry with 4 x the fan-out) instead of handing its unplaced rows to a run of their own
     int64_t no_chao = 0;             // 1 = the group estimate is the uniform-occupancy model alone (no Chao1 term from the sample's singletons / doubletons)
     int64_t no_absorb = 0;           // 1 = never run the hot-key absorb-and-spill pass in front of the radix path
     int64_t no_hot_image = 0;        // 1 = the absorb tables start empty (first come, first served) instead of from the sample's hot keys
@@ -199,7 +200,7 @@ struct pandrs_hip_ctx {
     // arena with what that run allocates (work: per-run scratch; temp: direct-path records;
     // side: slice records; super: two-level columns; packed: multi-key cells and dictionaries;
     // pairs: fused-join pairs; groups: retained group index (CSR); shuf: retained shuffle buckets)
-    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups, shuf, absorb;
+    pandrs::Arena work, result, staging, temp, result2, result3, side, super, packed, pairs, groups, shuf, absorb, overflow;
     pandrs::Options opt;
     pandrs_hip_timings timings{};
     pandrs::GroupbyResult gb, gb2, gb3;   // gb2 / gb3: nested results (slice merges, two-level sub-runs)

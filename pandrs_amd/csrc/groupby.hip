@@ -1326,6 +1326,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     const uint32_t seed = 0x9E3779B9u;
     bool sampled_failed = false;       // a capacity-mode run overflowed a region: repeat with the exact histogram
     bool polled = false;
+    uint32_t ov_cap = 0;
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
         c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
@@ -1408,7 +1409,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                                                        : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
         const int64_t max_slices = slicing ? 2 * (N / slice_rows) + 2 : 0;       // slices of multi-slice partitions
         const size_t side_cap = (size_t)max_slices * (size_t)(T + 2);
-        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2)) + (slicing ? side_cap : 0);
+        // (rows that full tables hand to an overflow run may bring up to one group each: room for them, bounded by what is likely)
+        const bool want_ov = use_v2 && !merge && res_slot == 0 && !c->opt.no_overflow_run && n_src >= 1 && n_src <= 4 && N >= (int64_t(1) << 16);
+        const int64_t ov_rows = want_ov ? std::min<int64_t>(std::max<int64_t>(N / 4, 65536), int64_t(1) << 30) : 0;
+        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2) + std::min<int64_t>(ov_rows, std::max<int64_t>(4 * est, int64_t(1) << 20))) + (slicing ? side_cap : 0);
         size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
         ST_TRY(rarena.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
         res.cap = (int64_t)cap;
@@ -1480,6 +1484,21 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             const int profile = n_rounds == 1 ? uni_profile : -1;
             volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;      // aggregate2's own corner
             if (use_v2) { hp[4] = 0; aa.host_out = const_cast<uint32_t *>(hp); aa.scatter_flags = sampled ? part.flags : nullptr; }
+            // a full table's unplaced rows go to a buffer and are grouped in a run of their own (AggArgs::ov_keys): an estimate that
+            // was too low costs one small extra run instead of the whole call again
+            ov_cap = 0;
+            if (want_ov) {
+                ov_cap = (uint32_t)ov_rows;
+                ST_TRY(c->overflow.ensure((size_t)(1 + n_src) * Arena::padded((size_t)ov_cap * 8 + 256) + (size_t)n_src * Arena::padded((size_t)ov_cap + 256) + 4096, c->stream));
+                aa.ov_keys = c->overflow.take<uint64_t>(ov_cap);
+                for (int s2 = 0; s2 < n_src; s2++) {
+                    aa.ov_vals[s2] = c->overflow.take<uint64_t>(ov_cap);
+                    aa.ov_valid[s2] = c->overflow.take<uint8_t>(ov_cap);
+                    if (!aa.ov_vals[s2] || !aa.ov_valid[s2]) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "overflow arena too small");
+                }
+                if (!aa.ov_keys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "overflow arena too small");
+                aa.ov_cap = ov_cap;
+            } else { aa.ov_keys = nullptr; aa.ov_cap = 0; }
             polled = use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
             if (!polled) launch_aggregate(c, aa, max_spr, profile, lds);
             HIP_TRY(hipGetLastError());
@@ -1492,6 +1511,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (hp[4] == 1) {
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 for (int i = 0; i < 4; i++) h[i] = hp[i];
+                h[6] = hp[6];
                 if (c->opt.agg_ablate == 8) fprintf(stderr, "aggregate2: %u rows took the retry queue\n", hp[5]);
                 have = true;
             }
@@ -1499,7 +1519,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         if (!have) {
             if (sampled)         // the scatter's overflow flag rides on the same read-back
                 HIP_TRY(hipMemcpyAsync(counters + 3, part.flags, 4, hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(h, counters, 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(h, counters, 32, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
         if (sampled && h[3]) {           // a region's sampled capacity was too small (skew the sample did not show)
@@ -1510,6 +1530,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         if (h[1] == 0) {
             res.n_groups = h[0]; res.valid = true;
             const int64_t n_side = h[2];
+            const int64_t n_ov = ov_cap ? (int64_t)h[6] : 0;       // (read NOW: the nested runs below reuse the pinned words)
             if (n_side > 0) {
                 // merge the partial records of the sliced partitions and append their groups
                 RowSource ms;
@@ -1531,8 +1552,37 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 ST_TRY(append_groups(c, res, cap, r2, partials, pl, n_aggs));
                 HIP_TRY(hipStreamSynchronize(c->stream));
             }
-            return 0;
+            if (n_ov > 0) {
+                // the rows the full tables could not place: their keys are in no table, so their groups are simply appended
+                RowSource os;
+                os.n_rows = n_ov;
+                os.key = KeyDesc{aa.ov_keys, nullptr, nullptr, DT_CELL};
+                for (int s2 = 0; s2 < n_src; s2++) {
+                    os.val_data[s2] = aa.ov_vals[s2];
+                    os.val_null_bits[s2] = nullptr;
+                    os.val_valid_bytes[s2] = (uni_profile & 1) ? aa.ov_valid[s2] : nullptr;
+                }
+                Options saved = c->opt;
+                c->opt.partitions = 0; c->opt.groups_hint = 0; c->opt.no_absorb = 1;
+                pandrs_hip_timings tsave = c->timings;
+                c->quiet++;
+                int32_t st = run_engine(c, os, pl, /*merge=*/false, partials, n_aggs, key_dtype, 1, res_slot + 1);
+                c->quiet--;
+                c->opt = saved;
+                c->timings = tsave;
+                if (st) return st;
+                GroupbyResult &r2 = res_slot == 0 ? c->gb2 : c->gb3;
+                if ((size_t)res.n_groups + (size_t)r2.n_groups <= cap) {
+                    ST_TRY(append_groups(c, res, cap, r2, partials, pl, n_aggs));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    c->timings.retries = attempt + 100;  // (100 + attempt: an overflow run answered)
+                    return 0;
+                }
+                res.valid = false;                       // more new groups than the result has room for: the attempt failed after all
+                h[1] = 1;
+            } else return 0;
         }
+        if (h[1] == 0) return 0;
         if (P >= P_LIMIT) {
             if (c->opt.partitions <= 0 && res_slot == 0 && !c->quiet)      // the estimate was far too low: two-level with a safe bound
                 return run_two_level(c, rs, pl, merge, partials, n_aggs, key_dtype, n_keys_out, res_slot, N,
