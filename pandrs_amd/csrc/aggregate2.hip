@@ -91,6 +91,33 @@ __device__ __forceinline__ uint64_t enc_val(uint64_t bits) {
     return ((uint64_t)(hi ^ (sm | 0x80000000u)) << 32) | (uint32_t)(lo ^ sm);
 }
 
+// ---- wave-wide reductions on the VALU alone (DPP row shifts + row broadcasts; no LDS crossbar): the total ends in lane 63
+// and is read back as a wave-uniform value.  OP: 0 = f64 add, 1 = u64 add, 2 = u64 min, 3 = u64 max; `ident` is OP's identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_move64(uint64_t x, uint64_t ident) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ident, (int)(uint32_t)x, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ident >> 32), (int)(uint32_t)(x >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int OP>
+__device__ __forceinline__ uint64_t wave_op64(uint64_t a, uint64_t b) {
+    if (OP == 0) return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    if (OP == 1) return a + b;
+    if (OP == 2) return b < a ? b : a;
+    return b > a ? b : a;
+}
+template <int OP>
+__device__ __forceinline__ uint64_t wave_reduce64(uint64_t x, uint64_t ident) {
+    x = wave_op64<OP>(x, dpp_move64<0x111, 0xF>(x, ident));          // row_shr:1
+    x = wave_op64<OP>(x, dpp_move64<0x112, 0xF>(x, ident));          // row_shr:2
+    x = wave_op64<OP>(x, dpp_move64<0x114, 0xF>(x, ident));          // row_shr:4
+    x = wave_op64<OP>(x, dpp_move64<0x118, 0xF>(x, ident));          // row_shr:8   -> lane 15 of every row: the row's total
+    x = wave_op64<OP>(x, dpp_move64<0x142, 0xA>(x, ident));          // row_bcast:15 into rows 1, 3
+    x = wave_op64<OP>(x, dpp_move64<0x143, 0xC>(x, ident));          // row_bcast:31 into rows 2, 3 -> lane 63: the wave's total
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int NSRC, int PROFILE, int ABLATE, int DEPTH, bool SMALL = false>
 __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr bool HAS_V = (PROFILE & 1) != 0, OP_ADD = ((PROFILE >> 1) & 1) != 0;
@@ -228,6 +255,40 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             }
         }
     };
+    // ---- all placed rows of the wave in ONE slot (see the call site): VALU-only wave reductions, then lane 0 applies the totals —
+    // same rules as update(): nulls skipped, NaN ignored by min / max, sums re-associate (as everywhere)
+    auto wave_fold = [&](uint32_t slot, unsigned long long okw, bool ok, const uint64_t (&v)[NSRC], uint32_t okm) {
+        if (lane == 0) atomicAdd(&gsz[slot], (uint32_t)__popcll(okw));
+        if (ABLATE == 2) return;
+#pragma unroll
+        for (int c = 0; c < NSRC; c++) {
+            const bool valid = ok && (!HAS_V || ((okm >> c) & 1));
+            if (HAS_V && nn_idx[c] >= 0) {
+                const unsigned long long vm = __ballot(valid);
+                if (lane == 0 && vm) atomicAdd((unsigned long long *)&st[(size_t)nn_idx[c] * T1 + slot], (unsigned long long)__popcll(vm));
+            }
+            if (OP_ADD) {
+                const uint64_t tot = wave_reduce64<KIND == 0 ? 0 : 1>(valid ? v[c] : 0ull, 0ull);       // (+0.0 has the bits of 0)
+                if (lane == 0) {
+                    if (KIND == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)c * T1 + slot]), __longlong_as_double((long long)tot));
+                    else atomicAdd((unsigned long long *)&st[(size_t)c * T1 + slot], (unsigned long long)tot);
+                }
+            }
+            if (MM > 0 && ABLATE != 1) {
+                bool cmp = valid;
+                if (KIND == 0) { const double dv = __longlong_as_double((long long)v[c]); cmp = cmp && dv == dv; }
+                const uint64_t e = enc_val<KIND>(v[c]);
+                if (OP_MIN) {
+                    const uint64_t mn = wave_reduce64<2>(cmp ? e : ~0ull, ~0ull);
+                    if (lane == 0 && mn != ~0ull) atomicMin((unsigned long long *)&st[(size_t)(m_base + c * MM) * T1 + slot], (unsigned long long)mn);
+                }
+                if (OP_MAX) {
+                    const uint64_t mx = wave_reduce64<3>(cmp ? e : 0ull, 0ull);      // max of the codes; stored negated like every max state
+                    if (lane == 0 && mx != 0ull) atomicMin((unsigned long long *)&st[(size_t)(m_base + c * MM + MM - 1) * T1 + slot], (unsigned long long)~mx);
+                }
+            }
+        }
+    };
     // ---- rows the fast path could not place (first sight of a key, a key outside its home group, a tag
     // collision, the sentinel-valued key): the wave keeps their row indices and handles 64 at a time, one
     // per lane, with the general probe — so the rare path costs per ROW, not per wave that contains one.
@@ -361,6 +422,19 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                     if (act && !ok) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(miss >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)miss, 0u))] = row;
                     qn += (uint32_t)__popcll(miss);
                     if (qn >= 64) drain(64);
+                }
+                // a slice of an oversized partition is mostly ONE key (a hot key, the NULL group): 64 lanes adding to the same
+                // LDS words serialise (13 atomics x 64 lanes per batch for C2's profile: ~830 LDS cycles per 64 rows).  When every
+                // placed row of the wave sits in the same slot, the wave folds its rows on the VALU first and one lane updates the table.
+                if (cur_multi) {                               // wave-uniform (a property of the table)
+                    const unsigned long long okw = __ballot(ok);
+                    if (okw) {
+                        const uint32_t s0 = __shfl(idx, __ffsll((long long)okw) - 1, 64);
+                        if (__ballot(ok && idx == s0) == okw && __popcll(okw) >= 8) {
+                            wave_fold(s0, okw, ok, v, okm);
+                            continue;
+                        }
+                    }
                 }
                 if (ok) update(idx, v, okm);
             }

@@ -1456,3 +1456,33 @@ def test_full_tables_hand_their_unplaced_rows_to_a_run_of_their_own(ctx):
     assert 1 <= t1["retries"] < 100, t1                         # the retry with more partitions
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1, 2, 4, 5, 6])
     assert_groupby_equal(got1, want, [O.I64], int_exact_rows=[1, 2, 4, 5, 6])
+
+
+@pytest.mark.parametrize("vkind", [O.F64, O.I64])
+def test_slices_of_a_hot_partition_fold_their_rows_per_wave(ctx, vkind):
+    """A slice of an oversized partition is mostly ONE key (a hot key, the NULL group): when all placed rows of a wave sit in one
+    slot the lean aggregate reduces them on the VALU (DPP row shifts / broadcasts) and one lane updates the table (aggregate2.hip,
+    wave_fold).  Half the rows on one key, a tenth on the NULL key, the rest on 50 K keys; masked values, NaN / inf among them; small
+    forced slices so that many tables are slices.  Same answers as the oracle (integer sums and min / max bit for bit)."""
+    rng = np.random.default_rng(91 + vkind)
+    n = 3_000_000
+    k = sparse_keys(rng, n, 50_000)
+    k[rng.random(n) < 0.5] = 424_242_424_242
+    keys = [(k, O.pack_mask(rng.random(n) < 0.1), O.I64)]
+    if vkind == O.F64:
+        v0 = rng.normal(100, 10, n); v0[::70_001] = np.nan; v0[::90_001] = np.inf
+        v1 = rng.normal(-5, 3, n)
+    else:
+        v0 = rng.integers(-10**9, 10**9, n).astype(np.int64); v1 = rng.integers(-50, 50, n).astype(np.int64)
+    vals = [(v0, O.pack_mask(rng.random(n) < 0.2), vkind), (v1, O.pack_mask(rng.random(n) < 0.01), vkind)]
+    aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.MEAN), (1, O.SUM), (1, O.MIN), (1, O.MAX), (1, O.COUNT)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    for name, val in (("slice_rows", 40_000), ("no_absorb", 1), ("no_direct", 1)):
+        ctx.set_option(name, val)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+    finally:
+        for name in ("slice_rows", "no_absorb", "no_direct"):
+            ctx.set_option(name, 0)
+    exact = [1, 2, 5, 6, 7] + ([0, 4] if vkind == O.I64 else [])
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
