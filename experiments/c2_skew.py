@@ -9,7 +9,7 @@ gen = torch.Generator(device=d); gen.manual_seed(1)
 n, g = 100_000_000, 1_000_000
 vals = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100 for _ in range(4)]
 aggs4 = [(c, op) for c in range(4) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)]
-CASES = ((0.0, 1), (0.8, g // 5), (0.8, 2000), (0.95, 2000), (0.5, 1), (0.9, 1))
+CASES = ((0.0, 1), (0.8, g // 5), (0.8, 2000), (0.95, 2000), (0.5, 1), (0.9, 1), (0.8, 1000), (0.9, 500), (0.7, 100))
 for share, hot in [CASES[int(i)] for i in sys.argv[1:]] or CASES:
     sel = torch.rand(n, device=d, generator=gen) < share
     k = torch.where(sel, torch.randint(0, hot, (n,), device=d, generator=gen), torch.randint(0, g, (n,), device=d, generator=gen)) * -7046029254386353131

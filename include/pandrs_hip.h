@@ -137,7 +137,8 @@ typedef struct pandrs_hip_timings {
     double phase_ms[PANDRS_HIP_MAX_PHASES];   /* per phase, see PANDRS_HIP_PHASE_*: from the phase's first launch to its last (phases
                                                  of one call may overlap); small calls (the two-launch path) record none */
     int64_t algorithmic_bytes;                /* SURVEY.md §8d formula for this call */
-    int64_t n_partitions;                     /* radix fan-out chosen (0: the small-call path; fused join: the probe side's fan-out,
+    int64_t n_partitions;                     /* radix fan-out chosen (0: the small-call path; -1: hot-key absorb pass with a COMPACT spill —
+                                                 the rest of the rows went through a run of their own; fused join: the probe side's fan-out,
                                                  0 = general fallback) */
     int64_t table_slots;                      /* LDS hash-table slots per partition */
     int64_t retries;                          /* overflow retries taken; 100 + retries: full LDS tables handed their unplaced rows to a

@@ -152,7 +152,29 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
                     }
                 }
                 // ---- spill: straight into the row's radix partition, at this workgroup's cursor for it ----
-                if (active && slot == AB_NONE) {
+                const bool spill = active && slot == AB_NONE;
+                if (PS == 1) {
+                    // one region per workgroup (the compact spill of a long tail: compact_spill_kernel closes the gaps afterwards):
+                    // one LDS atomic per wave and batch instead of one per spilled lane on the same word
+                    const unsigned long long sm = __ballot(spill);
+                    if (sm) {                                  // wave-uniform
+                        uint32_t base = 0;
+                        if ((tid & 63) == 0) base = atomicAdd(&misc[32], (uint32_t)__popcll(sm));
+                        base = __shfl(base, 0, 64);
+                        const uint32_t at = base + (uint32_t)__popcll(sm & ((1ull << (tid & 63)) - 1ull));
+                        if (spill) {
+                            if (at < cap_wp) {
+                                const size_t pos = (size_t)w * cap_wp + at;
+                                a.sp_keys[pos] = k;
+#pragma unroll
+                                for (int c = 0; c < NSRC; c++) {
+                                    a.sp_vals[c][pos] = v[h][c];
+                                    if (HAS_V) a.sp_valid[c][pos] = ok[h][c] ? 1 : 0;
+                                }
+                            } else misc[20] = 1;
+                        }
+                    }
+                } else if (spill) {
                     const uint32_t p = part_of(hash32(k, a.seed), PS);
                     const uint32_t at = atomicAdd(&misc[32 + p], 1u);
                     if (at < cap_wp) {
@@ -203,6 +225,45 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
         }
         run += tot;
     }
+}
+
+// Compact spill: the workgroups' regions (region w = rows [w * cap_wp, w * cap_wp + sp_count[w])) copied back to back — the input of
+// an ordinary engine run over the rows the absorb tables did not take.  blockIdx.y = workgroup region, blockIdx.x strides over its rows.
+struct CompactArgs {
+    const uint32_t *sp_count; uint32_t n_wg, cap_wp; int n_src, has_v;
+    const uint64_t *src_keys; const uint64_t *src_vals[MAX_ABS_SRC]; const uint8_t *src_valid[MAX_ABS_SRC];
+    uint64_t *dst_keys; uint64_t *dst_vals[MAX_ABS_SRC]; uint8_t *dst_valid[MAX_ABS_SRC];
+    uint32_t *total;                                 // [0] = rows in all
+};
+__global__ __launch_bounds__(256) void compact_spill_kernel(CompactArgs a) {
+    __shared__ uint32_t s_off;
+    const uint32_t w = blockIdx.y;
+    if (threadIdx.x < 64) {                          // rows of the regions before w (n_wg <= 1024: 16 per lane)
+        uint32_t part = 0;
+        for (uint32_t r = threadIdx.x; r < w; r += 64) part += a.sp_count[r];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+        if (threadIdx.x == 0) s_off = part;
+    }
+    __syncthreads();
+    const uint32_t n = a.sp_count[w], off = s_off;
+    if (w == a.n_wg - 1 && blockIdx.x == 0 && threadIdx.x == 0) a.total[0] = off + n;
+    const size_t base = (size_t)w * a.cap_wp;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        a.dst_keys[off + i] = a.src_keys[base + i];
+        for (int c = 0; c < a.n_src; c++) {
+            a.dst_vals[c][off + i] = a.src_vals[c][base + i];
+            if (a.has_v) a.dst_valid[c][off + i] = a.src_valid[c][base + i];
+        }
+    }
+}
+void launch_compact_spill(pandrs_hip_ctx *c, const AbsorbArgs &a, uint32_t n_wg, uint64_t *dst_keys, uint64_t *const *dst_vals, uint8_t *const *dst_valid,
+                          bool has_v, uint32_t *total) {
+    CompactArgs ca{};
+    ca.sp_count = a.sp_count; ca.n_wg = n_wg; ca.cap_wp = a.spill_cap; ca.n_src = a.n_src; ca.has_v = has_v ? 1 : 0;
+    ca.src_keys = a.sp_keys; ca.dst_keys = dst_keys; ca.total = total;
+    for (int s2 = 0; s2 < a.n_src; s2++) { ca.src_vals[s2] = a.sp_vals[s2]; ca.src_valid[s2] = a.sp_valid[s2]; ca.dst_vals[s2] = dst_vals[s2]; ca.dst_valid[s2] = dst_valid[s2]; }
+    hipLaunchKernelGGL(compact_spill_kernel, dim3(8, n_wg), dim3(256), 0, c->stream, ca);
 }
 
 // The lean aggregate's work list over the spill regions: table (p, j) = partition p, workgroups [j * wpt, (j + 1) * wpt);

@@ -102,6 +102,8 @@ struct AbsorbArgs {
 constexpr uint32_t ABSORB_SEED = 0x9E3779B9u;     // bucket hash of the absorb table (the hot-key image is built with it)
 bool absorb_has(int n_src, int profile);
 bool launch_absorb(pandrs_hip_ctx *c, const AbsorbArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
+void launch_compact_spill(pandrs_hip_ctx *c, const AbsorbArgs &a, uint32_t n_wg, uint64_t *dst_keys, uint64_t *const *dst_vals, uint8_t *const *dst_valid,
+                          bool has_v, uint32_t *total);
 void launch_build_spill_tables(pandrs_hip_ctx *c, const uint32_t *sp_count, uint32_t n_wg, uint32_t PS, uint32_t cap_wp, uint32_t wpt,
                                AggTask *tasks, AggTable *tables, uint32_t *counts);
 

@@ -921,8 +921,12 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     if (T2 < 64) return ABSORB_NOT_TAKEN;
     int64_t PS = 1;
     while ((double)est / (double)PS > (double)T2 * 0.60 && PS < 64) PS *= 2;
-    if ((double)est / (double)PS > (double)T2 * 0.80) return ABSORB_NOT_TAKEN;
-    const uint32_t cap_wp = (uint32_t)((((int64_t)chunk / PS) * 2 + 256 + 15) & ~int64_t(15));
+    // more groups behind the hot keys than 64 spill partitions of LDS tables hold (a long tail): COMPACT spill — the rows the tables
+    // do not take are appended to one buffer, the ordinary engine groups them (partial states), and one merge joins both halves
+    const bool compact = (double)est / (double)PS > (double)T2 * 0.80;
+    if (compact) PS = 1;                          // one region per workgroup, sized for all of its rows; closed up by compact_spill_kernel
+    if (compact && (res_slot != 0 || N >= (int64_t(1) << 32) - (int64_t(1) << 22))) return ABSORB_NOT_TAKEN;
+    const uint32_t cap_wp = compact ? (uint32_t)((chunk + 15) & ~15u) : (uint32_t)((((int64_t)chunk / PS) * 2 + 256 + 15) & ~int64_t(15));
     const size_t region_rows = (size_t)n_wg * (size_t)PS * cap_wp;
     if (region_rows >= (size_t(1) << 32) - (size_t(1) << 20)) return ABSORB_NOT_TAKEN;
     // tables over the regions: one per CU (two measured 3 % slower: a table's fixed cost), each fed by `wpt` consecutive workgroups' regions of one partition
@@ -931,7 +935,9 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     const uint32_t wpt = (n_wg + tpp - 1) / tpp;
     const uint32_t max_tables = (uint32_t)PS * ((n_wg + wpt - 1) / wpt), max_tasks = (uint32_t)PS * n_wg;
     const size_t n_state = 1 + (size_t)pl.n_states;
-    const size_t dcap = (size_t)n_wg * (size_t)(T + 2) + (size_t)max_tables * (size_t)(T2 + 2);
+    // (compact: room for the partial records of the spilled rows' groups behind the absorbed ones)
+    const size_t tail_groups = compact ? (size_t)std::min<int64_t>(N, std::max<int64_t>(2 * est, int64_t(1) << 20)) : 0;
+    const size_t dcap = (size_t)n_wg * (size_t)(T + 2) + (size_t)max_tables * (size_t)(T2 + 2) + tail_groups;
     ST_TRY(c->temp.ensure(Arena::padded(dcap * 8) + Arena::padded(dcap) + n_state * Arena::padded(dcap * 8 + 256) + Arena::padded((size_t)max_tasks * 16 + 256) +
                           Arena::padded((size_t)max_tables * 16 + 256) + Arena::padded((size_t)n_wg * PS * 4 + 256) + 65536, c->stream));
     uint64_t *rk = c->temp.take<uint64_t>(dcap);
@@ -943,7 +949,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     AggTable *tables = c->temp.take<AggTable>(max_tables + 8);
     uint32_t *n_tasks = c->temp.take<uint32_t>(64);
     if (!rk || !rn || !rst || !counters || !sp_count || !tasks || !tables || !n_tasks) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small (absorb)");
-    ST_TRY(c->absorb.ensure((1 + (size_t)n_src) * Arena::padded(region_rows * 8 + 256) + (has_v ? (size_t)n_src * Arena::padded(region_rows + 256) : 0) + (1 << 20), c->stream));
+    ST_TRY(c->absorb.ensure((compact ? 2 : 1) * ((1 + (size_t)n_src) * Arena::padded(region_rows * 8 + 256) + (has_v ? (size_t)n_src * Arena::padded(region_rows + 256) : 0)) + (1 << 20), c->stream));
     AbsorbArgs a{};
     a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = ABSORB_SEED; a.n_src = n_src; a.hot_image = hot_image;
     a.spill_P = (uint32_t)PS; a.spill_cap = cap_wp;
@@ -998,15 +1004,64 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
         if (!launch_absorb(c, a, n_src, profile, lds, n_wg)) { (void)hipGetLastError(); return ABSORB_NOT_TAKEN; }
-        launch_build_spill_tables(c, sp_count, n_wg, (uint32_t)PS, cap_wp, wpt, tasks, tables, n_tasks);
-        if (!launch_aggregate2(c, aa, n_src, profile, lds2, (uint32_t)std::min<int64_t>(c->n_cu, max_tables)))
-            return fail(PANDRS_HIP_ERR_COMPUTATION, "absorb: the lean aggregate has no instantiation for this profile");
+        if (!compact) {
+            launch_build_spill_tables(c, sp_count, n_wg, (uint32_t)PS, cap_wp, wpt, tasks, tables, n_tasks);
+            if (!launch_aggregate2(c, aa, n_src, profile, lds2, (uint32_t)std::min<int64_t>(c->n_cu, max_tables)))
+                return fail(PANDRS_HIP_ERR_COMPUTATION, "absorb: the lean aggregate has no instantiation for this profile");
+        }
         HIP_TRY(hipGetLastError());
     }
+    uint32_t h4[4] = {0, 0, 0, 0};
+    int64_t n_compact = 0;
+    if (compact) {
+        // the spilled rows, closed up, through the ordinary engine (partial states), appended behind the absorbed records
+        uint64_t *ck = c->absorb.take<uint64_t>(region_rows + 16), *cv[MAX_ABS_SRC]{};
+        uint8_t *cvalid[MAX_ABS_SRC]{};
+        for (int s2 = 0; s2 < n_src; s2++) {
+            cv[s2] = c->absorb.take<uint64_t>(region_rows + 16);
+            cvalid[s2] = has_v ? c->absorb.take<uint8_t>(region_rows + 16) : nullptr;
+            if (!cv[s2] || (has_v && !cvalid[s2])) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "absorb arena too small (compact spill)");
+        }
+        if (!ck) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "absorb arena too small (compact spill)");
+        launch_compact_spill(c, a, n_wg, ck, cv, cvalid, has_v, counters + 4);
+        HIP_TRY(hipGetLastError());
+        uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
+        HIP_TRY(hipMemcpyAsync(h, counters, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[1]) return ABSORB_NOT_TAKEN;
+        const int64_t n_abs = h[2];
+        n_compact = h[4];
+        h4[2] = (uint32_t)n_abs;
+        if (n_compact > 0) {
+            RowSource sp;
+            sp.n_rows = n_compact;
+            sp.key = KeyDesc{ck, nullptr, nullptr, DT_CELL};              // (NULL keys and the sentinel-valued key are always absorbed)
+            for (int s2 = 0; s2 < n_src; s2++) {
+                sp.val_data[s2] = cv[s2];
+                sp.val_null_bits[s2] = nullptr;
+                sp.val_valid_bytes[s2] = has_v ? cvalid[s2] : nullptr;
+            }
+            Options saved = c->opt;
+            c->opt.no_direct = 1; c->opt.no_absorb = 1; c->opt.partitions = 0;        // (the direct path would take the temp arena the records live in)
+            c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>(est, n_compact), 1);
+            pandrs_hip_timings tsave = c->timings;
+            c->quiet++;
+            const int32_t st2 = run_engine(c, sp, pl, /*merge=*/false, /*partials=*/true, n_aggs, key_dtype, 1, res_slot + 1);
+            c->quiet--;
+            c->opt = saved;
+            c->timings = tsave;
+            if (st2) return st2;
+            const GroupbyResult &r2 = c->gb2;
+            if ((size_t)n_abs + (size_t)r2.n_groups > dcap) return ABSORB_NOT_TAKEN;
+            GroupbyResult rec{};
+            rec.keys = rk; rec.key_null = rn; rec.states = rst; rec.n_groups = n_abs;
+            ST_TRY(append_groups(c, rec, dcap, r2, /*partials=*/true, pl, n_aggs));
+            h4[2] = (uint32_t)rec.n_groups;
+        }
+    } else {
     for (int spin = 0; spin < 4000000 && hp[4] != 1; spin++) __builtin_ia32_pause();
     if (hp[4] != 1) HIP_TRY(hipStreamSynchronize(c->stream));
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    uint32_t h4[4] = {0, 0, 0, 0};
     if (hp[4] == 1) { for (int i = 0; i < 3; i++) h4[i] = hp[i]; }
     else {
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);
@@ -1014,9 +1069,10 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int i = 0; i < 3; i++) h4[i] = h[i];
     }
+    }
     if (h4[1]) return ABSORB_NOT_TAKEN;            // a spill region or a spill table overflowed: the ordinary path answers
     uint32_t *hs = reinterpret_cast<uint32_t *>(c->pinned) + 1100;                           // own corner: the merge below reads its counters at +0
-    HIP_TRY(hipMemcpyAsync(hs, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));         // rows spilled: reported, not needed to continue
+    HIP_TRY(hipMemcpyAsync(hs, counters + (compact ? 4 : 3), 4, hipMemcpyDeviceToHost, c->stream));   // rows spilled: reported, not needed to continue
     // one merge of everything (the direct path's last step)
     RowSource ms;
     ms.n_rows = h4[2];
@@ -1034,7 +1090,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     c->timings = tsave;
     c->timings.estimated_groups = est;
     c->timings.absorbed_rows = N - (int64_t)hs[0];         // (the merge synchronised the stream)
-    c->timings.n_partitions = hs[0] ? PS : 0;              // nothing spilled: no radix partition took part (the few-groups case)
+    c->timings.n_partitions = hs[0] ? (compact ? -1 : PS) : 0;   // nothing spilled: no radix partition took part (the few-groups case); -1: compact spill
     c->timings.table_slots = T;
     c->timings.retries = 0;
     return st;
@@ -1139,9 +1195,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             // with the leaner kernel (100 M rows, 1 K groups: 0.59 -> 0.45 ms for one sum, 0.89 -> 0.70 for six aggregates)
             estimate_release(c);
             do_absorb = true;
-        } else if (T_abs >= 256 && !c->clustered_rows && !direct_would && est <= 64 * T_abs && N >= (int64_t(1) << (c->opt.no_absorb < 0 ? 16 : 24))) {
-            // not where the direct path answers, not where the table is a drop in the ocean: absorb when the most frequent
-            // keys — as many as the table takes — hold most of the rows
+        } else if (T_abs >= 256 && !c->clustered_rows && !direct_would && (est <= 64 * T_abs || (c->est_repeat_share >= 0.5 && res_slot == 0)) &&
+                   N >= (int64_t(1) << (c->opt.no_absorb < 0 ? 16 : 24))) {
+            // not where the direct path answers, not where the table is a drop in the ocean — unless the sample itself shows a hot set
+            // (half its rows on keys sighted three times or more: a long tail behind hot keys, compact spill): absorb when the most
+            // frequent keys — as many as the table takes — hold most of the rows
             double share = 0.0;
             const double min_share = c->opt.no_absorb < 0 ? 0.0 : 0.60;
             ST_TRY(estimate_coverage(c, rs.key, N, (int64_t)((double)T_abs * 0.80), &share, c->opt.no_hot_image ? 0 : T_abs, ABSORB_SEED, min_share, &hot_image));

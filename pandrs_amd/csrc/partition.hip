@@ -178,15 +178,19 @@ __global__ __launch_bounds__(1024) void estimate_coverage_kernel(const uint64_t 
 // starts from a table that already holds the keys worth a slot instead of the first keys it happens to see (first come, first
 // served gave the cold keys 40 % of the slots: C3 absorbed 74 % of its rows where the hot set covers 88 %).
 // `image` [T] is EMPTY on entry; a key whose two buckets are full is left out (its rows spill like a cold key's).
+// `band`: 0 = keys counted >= 16 x the threshold, 1 = [4 x, 16 x), 2 = [1 x, 4 x) — three launches, the hottest keys first: a key
+// that finds its two buckets full is left out, and that must be a cold one (all keys at once left 5-10 % of the HOT keys of a
+// 500-key hot set out: 6 M of their rows spilled and met again, serialised, in one LDS slot of the spill run)
 __global__ __launch_bounds__(1024) void hot_image_kernel(const uint64_t *table, const uint32_t *counts, uint32_t slots, uint32_t *thr,
-                                                         uint64_t *image, uint32_t T, uint32_t seed) {
+                                                         uint64_t *image, uint32_t T, uint32_t seed, int band) {
     const uint32_t t = thr[0], take = thr[1], NBK = T >> 2;
+    const uint32_t lo = band == 0 ? 16 * t : band == 1 ? 4 * t : t, hi = band == 0 ? 0xFFFFFFFFu : band == 1 ? 16 * t : 4 * t;
     for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < slots; i += gridDim.x * 1024) {
         const uint32_t cnt = counts[i];
         const uint64_t k = table[i];
         if (!cnt || k == EMPTY_KEY) continue;
         const uint32_t b = min(cnt, COV_BINS - 1);
-        if (b < t) continue;
+        if (b < t || cnt < lo || cnt >= hi) continue;
         if (b == t && atomicAdd(&thr[2], 1u) >= take) continue;
         uint32_t bk = slot_of(hash32(k, seed), NBK);
         bool placed = false;
@@ -922,6 +926,7 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     if (!keep_table) hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct, (uint32_t *)nullptr, est_sight(c));
     double d = std::max<uint32_t>(hv[0], 1), s = (double)n_sample;
     double est;
+    c->est_repeat_share = 0.0;
     if (n_sample == n_rows) est = d;
     else if (s - d < 64.0) est = (double)n_rows;                  // too few repeats in the sample to measure: (nearly) all distinct
     else {
@@ -939,6 +944,8 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         // (1 M groups: 0.998 M); on a few hot keys in front of a long tail it sees the tail the model cannot (2 K hot keys holding
         // 80 % of the rows + 1 M others: model 60 K, Chao1 0.96 M).  The larger of the two plans the fan-out.
         const double f1 = std::max(0.0, d - twice), f2 = std::max(0.0, twice - thrice);
+        // share of the sampled rows on keys sighted three times or more (s - f1 - 2 f2): uniform 1 M groups 5 %, 2 K hot keys with 80 % of the rows 80 %
+        c->est_repeat_share = std::max(0.0, s - f1 - 2.0 * f2) / s;
         const double chao = d + f1 * std::max(0.0, f1 - 1.0) / (2.0 * (f2 + 1.0));
         if (!c->opt.no_chao) G = std::max(G, chao);
         est = std::min<double>(std::max(G, d), (double)n_rows);
@@ -993,8 +1000,9 @@ int32_t estimate_coverage(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows,
     const double covered = h0, all = std::max<uint32_t>(h2, 1);
     if (out_image && image_T >= 16 && image_T <= (int64_t)EST_IMAGE_SLOTS && covered / all >= min_share) {
         HIP_TRY(hipMemsetAsync(est_image(c), 0xFF, (size_t)image_T * 8, c->stream));
-        hipLaunchKernelGGL(hot_image_kernel, dim3(256), dim3(1024), 0, c->stream, c->est_table, est_counts(c), EST_SLOTS,
-                           est_cov_hist(c) + 2 * COV_BINS + 16, est_image(c), (uint32_t)image_T, image_seed);
+        for (int band = 0; band < 3; band++)
+            hipLaunchKernelGGL(hot_image_kernel, dim3(256), dim3(1024), 0, c->stream, c->est_table, est_counts(c), EST_SLOTS,
+                               est_cov_hist(c) + 2 * COV_BINS + 16, est_image(c), (uint32_t)image_T, image_seed, band);
         *out_image = est_image(c);
     }
     c->est_kept = false;

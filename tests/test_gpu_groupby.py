@@ -1255,12 +1255,12 @@ def _skewed_ids(rng, n, g, hot_share=0.8, hot_keys=None):
     return np.where(hot, rng.integers(0, hot_keys or max(g // 5, 1), n), rng.integers(0, g, n))
 
 
-@pytest.mark.parametrize("shape", ["c3_codes", "i64_nulls", "i64_sum_only", "uniform_forced"])
+@pytest.mark.parametrize("shape", ["c3_codes", "i64_nulls", "i64_sum_only", "uniform_forced", "hot_set_long_tail"])
 def test_absorb_and_spill_matches_oracle(ctx, shape):
     """One pass over the original columns folds the rows whose key found a slot in a workgroup's LDS table, the rest is
     spilled and goes through the radix path; both halves are merged.  Same answers as the oracle, bit for bit where
     the reference is (counts, min / max), 1e-9 on f64 sums."""
-    rng = np.random.default_rng({"c3_codes": 1, "i64_nulls": 2, "i64_sum_only": 3, "uniform_forced": 4}[shape])
+    rng = np.random.default_rng({"c3_codes": 1, "i64_nulls": 2, "i64_sum_only": 3, "uniform_forced": 4, "hot_set_long_tail": 5}[shape])
     n = 17_000_000
     if shape == "c3_codes":
         g = 10_000
@@ -1285,6 +1285,18 @@ def test_absorb_and_spill_matches_oracle(ctx, shape):
         vals = [(rng.integers(-1000, 1000, n).astype(np.int64), None, O.I64)]
         aggs = [(0, O.SUM), (0, O.COUNT)]
         exact, kd = (0, 1), O.I64
+    elif shape == "hot_set_long_tail":
+        # 85 % of the rows on 800 keys in front of 2 M others: far more groups than the spill tables hold -> COMPACT spill (the rows the
+        # tables do not take are closed up and go through the ordinary engine as partial states; one merge joins both halves)
+        g = 2_000_000
+        k = sparse_keys_from(_skewed_ids(rng, n, g, 0.85, 800))
+        k[::100_003] = -1
+        key = (k, O.pack_mask(rng.random(n) < 0.001), O.I64)
+        v = rng.standard_normal(n)
+        v[::50_021] = np.nan
+        vals = [(v, O.pack_mask(rng.random(n) < 0.02), O.F64), (rng.standard_normal(n), O.pack_mask(rng.random(n) < 0.3), O.F64)]
+        aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.MEAN), (1, O.SUM), (1, O.MIN), (1, O.MAX), (1, O.COUNT)]
+        exact, kd = (1, 2, 5, 6, 7), O.I64
     else:
         g = 12_000                                                # uniform keys: almost everything spills (forced)
         key = (sparse_keys(rng, n, g), None, O.I64)
@@ -1300,6 +1312,8 @@ def test_absorb_and_spill_matches_oracle(ctx, shape):
     finally:
         ctx.set_option("no_absorb", 0)
     assert t["absorbed_rows"] > 0, t
+    if shape == "hot_set_long_tail":
+        assert t["n_partitions"] == -1, t                        # the compact spill
     if shape != "uniform_forced":
         assert t["absorbed_rows"] > 0.6 * n, t
     else:
