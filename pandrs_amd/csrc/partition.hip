@@ -257,8 +257,10 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
     if (live) {
         uint32_t slot = hash32(k, 0x1234567u) & table_mask;
         bool again = false;
+        uint32_t seen = 0;                               // the slot's sighting counter, loaded WITH the key (one round trip, not two)
         for (uint32_t probe = 0; probe <= table_mask; probe++) {
             uint64_t cur = table[slot];
+            seen = __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == k) { again = true; break; }
             if (cur == EMPTY_KEY) {
                 uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
@@ -267,7 +269,7 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
             }
             slot = (slot + 1) & table_mask;
         }
-        if (again && __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+        if (again && seen < 2u) {
             const uint32_t o = atomicAdd(&sight[slot], 1u);
             if (o == 0) atomicAdd(&twice, 1u);
             else if (o == 1) atomicAdd(&thrice, 1u);
