@@ -17,7 +17,8 @@ static int32_t set_max_lds(K kernel, int bytes) {
 
 // ------------------------------------------------------------------------------------ estimate
 // distinct[0] = distinct keys in the sample, [2] = adjacent pairs that differ, [3] = adjacent pairs (one u64, one atomic), [4] = blocks done,
-// [5] = keys sighted at least twice, [6] = at least three times (=> singletons f1 = [0] - [5], doubletons f2 = [5] - [6]: the Chao1 estimate).
+// of the SUB-sample (every fourth block): [7] = distinct keys, [5] = keys sighted at least twice, [6] = at least three times
+// (=> singletons f1 = [7] - [5], doubletons f2 = [5] - [6]: the Chao1 estimate).
 // The last block to finish copies [0..2] to `host_out` (pinned, device-visible), so the host needs one stream
 // synchronise and no copy; estimate_clear_kernel then re-arms table and counters for the next call (off the
 // critical path: it runs while the host plans).
@@ -32,6 +33,7 @@ __device__ __forceinline__ void estimate_publish(uint32_t *distinct, uint32_t *h
             host_out[2] = __hip_atomic_load(&distinct[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[4] = __hip_atomic_load(&distinct[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[5] = __hip_atomic_load(&distinct[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[6] = __hip_atomic_load(&distinct[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -251,34 +253,40 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
     // atomics in all, the pre-check keeps the rest away): singletons and doubletons of the sample are what tells "few keys, all
     // seen" from "a few hot keys in front of a long tail" — the uniform-occupancy model alone under-estimated a 2 K-hot-key /
     // 1 M-key column 16 x, and the engine paid with three full retries (C2's skewed variants: 12-29 ms instead of ~3.5)
-    __shared__ uint32_t inserted, twice, thrice;
-    if (threadIdx.x == 0) { inserted = 0; twice = 0; thrice = 0; }
+    // The sighting counters are kept by every FOURTH block of the sample only (a 64 K-row sub-sample with its own distinct count:
+    // Chao1 needs d, f1, f2 of ONE sample, and the coherent counter loads — a quarter of a million of them on a few hot lines when
+    // the keys are few — were 20-30 us of a 40 us kernel).
+    __shared__ uint32_t inserted, once, twice, thrice;
+    if (threadIdx.x == 0) { inserted = 0; once = 0; twice = 0; thrice = 0; }
     __syncthreads();
+    const bool sub = (blockIdx.x & 3u) == 0u;
     if (live) {
         uint32_t slot = hash32(k, 0x1234567u) & table_mask;
-        bool again = false;
-        uint32_t seen = 0;                               // the slot's sighting counter, loaded WITH the key (one round trip, not two)
+        uint32_t seen = 3;                               // the slot's sighting counter, loaded WITH the key (one round trip, not two)
+        bool placed = false;
         for (uint32_t probe = 0; probe <= table_mask; probe++) {
             uint64_t cur = table[slot];
-            seen = __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == k) { again = true; break; }
+            if (sub) seen = __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == k) { placed = true; break; }
             if (cur == EMPTY_KEY) {
                 uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
-                if (old == EMPTY_KEY) { atomicAdd(&inserted, 1u); break; }
-                if (old == k) { again = true; break; }
+                if (old == EMPTY_KEY) { atomicAdd(&inserted, 1u); placed = true; break; }
+                if (old == k) { placed = true; break; }
             }
             slot = (slot + 1) & table_mask;
         }
-        if (again && seen < 2u) {
+        if (sub && placed && seen < 3u) {
             const uint32_t o = atomicAdd(&sight[slot], 1u);
-            if (o == 0) atomicAdd(&twice, 1u);
-            else if (o == 1) atomicAdd(&thrice, 1u);
+            if (o == 0) atomicAdd(&once, 1u);
+            else if (o == 1) atomicAdd(&twice, 1u);
+            else if (o == 2) atomicAdd(&thrice, 1u);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && inserted) atomicAdd(distinct, inserted);
     if (threadIdx.x == 1 && twice) atomicAdd(&distinct[5], twice);
     if (threadIdx.x == 2 && thrice) atomicAdd(&distinct[6], thrice);
+    if (threadIdx.x == 3 && once) atomicAdd(&distinct[7], once);
 }
 
 __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int64_t n_sample,
@@ -923,7 +931,9 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint32_t hv[3] = {h[0], h[1], h[2]};
-    const double twice = h[4], thrice = h[5];
+    const double twice = h[4], thrice = h[5], d_sub = h[6];
+    double s_sub = 0.0;                                  // rows of the sub-sample (every fourth 1024-row block of the sample)
+    for (int64_t b = 0; b * 1024 < n_sample; b += 4) s_sub += (double)std::min<int64_t>(1024, n_sample - b * 1024);
     c->est_kept = keep_table;
     if (!keep_table) hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct, (uint32_t *)nullptr, est_sight(c));
     double d = std::max<uint32_t>(hv[0], 1), s = (double)n_sample;
@@ -944,12 +954,14 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         }
         // Chao1 from the sample's singletons and doubletons: d + f1 (f1 - 1) / (2 (f2 + 1)).  Equal to the model on uniform keys
         // (1 M groups: 0.998 M); on a few hot keys in front of a long tail it sees the tail the model cannot (2 K hot keys holding
-        // 80 % of the rows + 1 M others: model 60 K, Chao1 0.96 M).  The larger of the two plans the fan-out.
-        const double f1 = std::max(0.0, d - twice), f2 = std::max(0.0, twice - thrice);
-        // share of the sampled rows on keys sighted three times or more (s - f1 - 2 f2): uniform 1 M groups 5 %, 2 K hot keys with 80 % of the rows 80 %
-        c->est_repeat_share = std::max(0.0, s - f1 - 2.0 * f2) / s;
-        const double chao = d + f1 * std::max(0.0, f1 - 1.0) / (2.0 * (f2 + 1.0));
-        if (!c->opt.no_chao) G = std::max(G, chao);
+        // 80 % of the rows + 1 M others: model 60 K, Chao1 0.96 M).
+        const double f1 = std::max(0.0, d_sub - twice), f2 = std::max(0.0, twice - thrice);
+        // share of the sub-sample's rows on keys sighted three times or more (s - f1 - 2 f2): uniform 1 M groups ~1 %, 2 K hot keys with 80 % of the rows ~75 %
+        c->est_repeat_share = s_sub > 0 ? std::max(0.0, s_sub - f1 - 2.0 * f2) / s_sub : 0.0;
+        const double chao = d_sub + f1 * std::max(0.0, f1 - 1.0) / (2.0 * (f2 + 1.0));
+        // (only where it disagrees by more than its own noise — f2 is a few hundred keys of a 64 K-row sub-sample at 20 M groups —
+        // so that uniform keys keep the model's steadier figure)
+        if (!c->opt.no_chao && chao > 1.3 * G) G = chao;
         est = std::min<double>(std::max(G, d), (double)n_rows);
     }
     c->clustered_rows = false;
