@@ -161,6 +161,19 @@ def extra_configs(torch, pa, ctx, device, steps=5):
     timed("c1_shape_100m", n, "C1's shape at 100M rows: i64 key (1K groups), sum of one f64 column",
           lambda: ctx.groupby_compute([(k1, None, pa.I64)], n, [(v, None, pa.F64)], [(0, pa.SUM)]))
     del k, k1
+    # C2's 80/20-skew variant (benches/enhanced_comprehensive_benchmark.rs:53-59): 80 % of the rows on a fifth of the 1 M keys,
+    # the same four f64 columns x sum/mean/min/max.  (The sampled estimate cannot see the tail here; full tables hand their unplaced
+    # rows to a run of their own.)
+    g = 1_000_000
+    hot = torch.rand(n, device=device, generator=gen) < 0.8
+    ks = torch.where(hot, torch.randint(0, g // 5, (n,), device=device, generator=gen), torch.randint(0, g, (n,), device=device, generator=gen)) * MIX
+    del hot
+    vs = [v] + [torch.randn(n, device=device, generator=gen, dtype=torch.float64) * 10 + 100 for _ in range(3)]
+    aggs16 = [(c, op) for c in range(4) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)]
+    timed("c2_skew_80_20", n, "C2 with 80/20 skew: 100M rows, i64 key (1M groups, 80% of the rows on 200K of them), sum/mean/min/max over 4 f64 cols",
+          lambda: ctx.groupby_compute([(ks, None, pa.I64)], n, [(x, None, pa.F64) for x in vs], aggs16),
+          bytes_alg=n * 40 + g * (8 + 8 * 16))
+    del ks, vs
     # C3: 100 M rows, u32 string-pool codes, 10 K groups with 80/20 skew, 2 f64 columns x sum/mean/min/max + count
     g = 10_000
     hot = torch.rand(n, device=device, generator=gen) < 0.8
