@@ -1545,9 +1545,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             // a full table's unplaced rows go to a buffer and are grouped in a run of their own (AggArgs::ov_keys): an estimate that
             // was too low costs one small extra run instead of the whole call again
             ov_cap = 0;
-            if (want_ov) {
+            if (want_ov && c->overflow.ensure((size_t)(1 + n_src) * Arena::padded((size_t)ov_rows * 8 + 256) + (size_t)n_src * Arena::padded((size_t)ov_rows + 256) + 4096, c->stream) == 0) {
+                // (a configured memory limit that leaves no room for the buffer: the call goes on without it — a full table then fails the attempt as before)
                 ov_cap = (uint32_t)ov_rows;
-                ST_TRY(c->overflow.ensure((size_t)(1 + n_src) * Arena::padded((size_t)ov_cap * 8 + 256) + (size_t)n_src * Arena::padded((size_t)ov_cap + 256) + 4096, c->stream));
                 aa.ov_keys = c->overflow.take<uint64_t>(ov_cap);
                 for (int s2 = 0; s2 < n_src; s2++) {
                     aa.ov_vals[s2] = c->overflow.take<uint64_t>(ov_cap);
