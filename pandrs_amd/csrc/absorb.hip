@@ -29,7 +29,7 @@ constexpr uint32_t AB_NONE = 0xFFFFFFFFu;
 
 // One bucket of four keys: the slot of k, a slot claimed for k, or AB_NONE.  No loop: at most two claims are tried
 // (a lost race for the first free slot moves on to the next free one the snapshot showed).
-__device__ __forceinline__ uint32_t absorb_try_bucket(uint64_t k, uint64_t *keys, uint32_t bk) {
+__device__ __forceinline__ uint32_t absorb_try_bucket(uint64_t k, uint64_t *keys, uint32_t bk, bool claim = true) {
     const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(keys + 4 * bk);
     const ulonglong2 lo = bp[0], hi = bp[1];
     const uint64_t c4[4] = {lo.x, lo.y, hi.x, hi.y};
@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t absorb_try_bucket(uint64_t k, uint64_t *keys
         if (c4[q] == EMPTY_KEY) { e1 = e0; e0 = q; }
     }
     if (hit >= 0) return 4 * bk + hit;
-    if (e0 >= 0) {
+    if (claim && e0 >= 0) {
         const uint64_t old = atomicCAS((unsigned long long *)&keys[4 * bk + e0], EMPTY_KEY, k);
         if (old == EMPTY_KEY || old == k) return 4 * bk + e0;
         if (e1 >= 0) {
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
     __syncthreads();
 
     const uint32_t NBK = T >> 2;
+    const bool claim = a.image_only == 0;
     auto fetch = [&](uint32_t i0, uint64_t (&k2)[2], uint64_t (&v)[2][NSRC], bool (&ok)[2][NSRC], bool (&kn)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
                     else if (k == EMPTY_KEY) { slot = T; misc[21] = 1; }
                     else {
                         const uint32_t b0 = slot_of(hash32(k, a.seed), NBK);
-                        slot = absorb_try_bucket(k, keys, b0);
-                        if (slot == AB_NONE) slot = absorb_try_bucket(k, keys, b0 + 1 == NBK ? 0 : b0 + 1);
+                        slot = absorb_try_bucket(k, keys, b0, claim);
+                        if (slot == AB_NONE) slot = absorb_try_bucket(k, keys, b0 + 1 == NBK ? 0 : b0 + 1, claim);
                     }
                 }
                 if (slot != AB_NONE) {

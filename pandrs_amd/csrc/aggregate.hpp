@@ -97,6 +97,8 @@ struct AbsorbArgs {
     uint32_t spill_P, spill_cap;
     uint64_t *sp_keys; uint64_t *sp_vals[MAX_ABS_SRC]; uint8_t *sp_valid[MAX_ABS_SRC];
     uint32_t *sp_count;                           // [grid * spill_P] rows in each region
+    int image_only;                               // 1: the table takes no key beyond the image (every workgroup then absorbs the SAME keys:
+                                                  // the spilled rows' keys are disjoint from the absorbed ones — the compact spill relies on it)
     const uint64_t *hot_image;                    // optional [T]: the table every workgroup starts from (hot_image_kernel), nullptr = empty
 };
 constexpr uint32_t ABSORB_SEED = 0x9E3779B9u;     // bucket hash of the absorb table (the hot-key image is built with it)

@@ -925,7 +925,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     // do not take are appended to one buffer, the ordinary engine groups them (partial states), and one merge joins both halves
     const bool compact = (double)est / (double)PS > (double)T2 * 0.80;
     if (compact) PS = 1;                          // one region per workgroup, sized for all of its rows; closed up by compact_spill_kernel
-    if (compact && (res_slot != 0 || N >= (int64_t(1) << 32) - (int64_t(1) << 22))) return ABSORB_NOT_TAKEN;
+    if (compact && (res_slot != 0 || !hot_image || N >= (int64_t(1) << 32) - (int64_t(1) << 22))) return ABSORB_NOT_TAKEN;
     const uint32_t cap_wp = compact ? (uint32_t)((chunk + 15) & ~15u) : (uint32_t)((((int64_t)chunk / PS) * 2 + 256 + 15) & ~int64_t(15));
     const size_t region_rows = (size_t)n_wg * (size_t)PS * cap_wp;
     if (region_rows >= (size_t(1) << 32) - (size_t(1) << 20)) return ABSORB_NOT_TAKEN;
@@ -935,9 +935,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     const uint32_t wpt = (n_wg + tpp - 1) / tpp;
     const uint32_t max_tables = (uint32_t)PS * ((n_wg + wpt - 1) / wpt), max_tasks = (uint32_t)PS * n_wg;
     const size_t n_state = 1 + (size_t)pl.n_states;
-    // (compact: room for the partial records of the spilled rows' groups behind the absorbed ones)
-    const size_t tail_groups = compact ? (size_t)std::min<int64_t>(N, std::max<int64_t>(2 * est, int64_t(1) << 20)) : 0;
-    const size_t dcap = (size_t)n_wg * (size_t)(T + 2) + (size_t)max_tables * (size_t)(T2 + 2) + tail_groups;
+    const size_t dcap = (size_t)n_wg * (size_t)(T + 2) + (size_t)max_tables * (size_t)(T2 + 2);
     ST_TRY(c->temp.ensure(Arena::padded(dcap * 8) + Arena::padded(dcap) + n_state * Arena::padded(dcap * 8 + 256) + Arena::padded((size_t)max_tasks * 16 + 256) +
                           Arena::padded((size_t)max_tables * 16 + 256) + Arena::padded((size_t)n_wg * PS * 4 + 256) + 65536, c->stream));
     uint64_t *rk = c->temp.take<uint64_t>(dcap);
@@ -951,7 +949,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     if (!rk || !rn || !rst || !counters || !sp_count || !tasks || !tables || !n_tasks) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small (absorb)");
     ST_TRY(c->absorb.ensure((compact ? 2 : 1) * ((1 + (size_t)n_src) * Arena::padded(region_rows * 8 + 256) + (has_v ? (size_t)n_src * Arena::padded(region_rows + 256) : 0)) + (1 << 20), c->stream));
     AbsorbArgs a{};
-    a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = ABSORB_SEED; a.n_src = n_src; a.hot_image = hot_image;
+    a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = ABSORB_SEED; a.n_src = n_src; a.hot_image = hot_image; a.image_only = compact ? 1 : 0;
     a.spill_P = (uint32_t)PS; a.spill_cap = cap_wp;
     a.sp_keys = c->absorb.take<uint64_t>(region_rows + 16);
     AggArgs aa{};
@@ -1033,30 +1031,54 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
         n_compact = h[4];
         h4[2] = (uint32_t)n_abs;
         if (n_compact > 0) {
-            RowSource sp;
-            sp.n_rows = n_compact;
-            sp.key = KeyDesc{ck, nullptr, nullptr, DT_CELL};              // (NULL keys and the sentinel-valued key are always absorbed)
-            for (int s2 = 0; s2 < n_src; s2++) {
-                sp.val_data[s2] = cv[s2];
-                sp.val_null_bits[s2] = nullptr;
-                sp.val_valid_bytes[s2] = has_v ? cvalid[s2] : nullptr;
-            }
+            // The tables of this mode take no keys beyond the image (AbsorbArgs::image_only): every workgroup absorbs the SAME keys, so
+            // the spilled rows' keys are disjoint from the absorbed ones.  (1) merge the absorbed records (a few hundred thousand) in a
+            // nested run; (2) group the spilled rows with the ordinary engine AS THE RESULT of this call; (3) append (1)'s groups.
+            // (Merging the spilled rows' groups as partial records with the absorbed ones cost 11 ms for a 16 M-group tail.)
+            RowSource ms;
+            ms.n_rows = n_abs;
+            ms.key = KeyDesc{rk, nullptr, rn, DT_CELL};
+            ms.merge_states = rst;
+            ms.merge_stride = dcap;
             Options saved = c->opt;
-            c->opt.no_direct = 1; c->opt.no_absorb = 1; c->opt.partitions = 0;        // (the direct path would take the temp arena the records live in)
-            c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>(est, n_compact), 1);
             pandrs_hip_timings tsave = c->timings;
+            c->opt.no_direct = 1; c->opt.no_absorb = 1; c->opt.partitions = 0;
+            c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>((int64_t)T + 2, n_abs), 1);
             c->quiet++;
-            const int32_t st2 = run_engine(c, sp, pl, /*merge=*/false, /*partials=*/true, n_aggs, key_dtype, 1, res_slot + 1);
+            int32_t st2 = n_abs > 0 ? run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot + 1) : 0;
+            GroupbyResult &r2 = c->gb2;
+            const int64_t n_hot = n_abs > 0 && !st2 ? r2.n_groups : 0;
+            if (!st2) {
+                RowSource sp;
+                sp.n_rows = n_compact;
+                sp.key = KeyDesc{ck, nullptr, nullptr, DT_CELL};          // (NULL keys and the sentinel-valued key are always absorbed)
+                for (int s2 = 0; s2 < n_src; s2++) {
+                    sp.val_data[s2] = cv[s2];
+                    sp.val_null_bits[s2] = nullptr;
+                    sp.val_valid_bytes[s2] = has_v ? cvalid[s2] : nullptr;
+                }
+                c->opt.groups_hint = 0;                                   // its own estimate: the tail's cardinality is what the first one could not see
+                c->reserve_groups = n_hot;
+                st2 = run_engine(c, sp, pl, /*merge=*/false, partials, n_aggs, key_dtype, 1, res_slot);
+                c->reserve_groups = 0;
+            }
             c->quiet--;
             c->opt = saved;
+            pandrs_hip_timings tnested = c->timings;
             c->timings = tsave;
             if (st2) return st2;
-            const GroupbyResult &r2 = c->gb2;
-            if ((size_t)n_abs + (size_t)r2.n_groups > dcap) return ABSORB_NOT_TAKEN;
-            GroupbyResult rec{};
-            rec.keys = rk; rec.key_null = rn; rec.states = rst; rec.n_groups = n_abs;
-            ST_TRY(append_groups(c, rec, dcap, r2, /*partials=*/true, pl, n_aggs));
-            h4[2] = (uint32_t)rec.n_groups;
+            GroupbyResult &res = c->gb;
+            if (n_hot > 0) {
+                ST_TRY(append_groups(c, res, (size_t)res.cap, r2, partials, pl, n_aggs));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            (void)tnested;
+            c->timings.estimated_groups = est;
+            c->timings.absorbed_rows = N - n_compact;
+            c->timings.n_partitions = -1;
+            c->timings.table_slots = T;
+            c->timings.retries = 0;
+            return 0;
         }
     } else {
     for (int spin = 0; spin < 4000000 && hp[4] != 1; spin++) __builtin_ia32_pause();
@@ -1201,6 +1223,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             // (half its rows on keys sighted three times or more: a long tail behind hot keys, compact spill): absorb when the most
             // frequent keys — as many as the table takes — hold most of the rows
             double share = 0.0;
+            // (the same bar behind a long tail — the compact spill.  0.65 kept 95 % of C2's rows on 2 K keys, of which the table holds 1.2 K, on the
+            // radix path (4.6 instead of 5.4 ms) but sent a join's pair groupby with 60 % of the pairs in 16 groups + 4 M singleton groups there too: 20 ms instead of 4.9)
             const double min_share = c->opt.no_absorb < 0 ? 0.0 : 0.60;
             ST_TRY(estimate_coverage(c, rs.key, N, (int64_t)((double)T_abs * 0.80), &share, c->opt.no_hot_image ? 0 : T_abs, ABSORB_SEED, min_share, &hot_image));
             do_absorb = share >= min_share;        // (no_absorb = -1, tests: whenever it is possible)
@@ -1470,7 +1494,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // (rows that full tables hand to an overflow run may bring up to one group each: room for them, bounded by what is likely)
         const bool want_ov = use_v2 && !merge && res_slot == 0 && !c->opt.no_overflow_run && n_src >= 1 && n_src <= 4 && N >= (int64_t(1) << 16);
         const int64_t ov_rows = want_ov ? std::min<int64_t>(std::max<int64_t>(N / 4, 65536), int64_t(1) << 30) : 0;
-        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2) + std::min<int64_t>(ov_rows, std::max<int64_t>(4 * est, int64_t(1) << 20))) + (slicing ? side_cap : 0);
+        size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2) + std::min<int64_t>(ov_rows, std::max<int64_t>(4 * est, int64_t(1) << 20))) + (slicing ? side_cap : 0) +
+                     (res_slot == 0 ? (size_t)c->reserve_groups : 0);       // (+ groups a caller will append: the absorb pass's compact spill)
         size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)n_aggs;
         ST_TRY(rarena.ensure((size_t)n_keys_out * (Arena::padded(cap * 8) + Arena::padded(cap)) + std::max<size_t>(out_cols, 1) * Arena::padded(cap * 8 + 256) + 8192, c->stream));
         res.cap = (int64_t)cap;
@@ -1723,7 +1748,7 @@ static int32_t run_two_level(pandrs_hip_ctx *c, const RowSource &rs, const Plan 
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     // ---- result arrays for the concatenation (every row could be its own group)
-    const size_t cap = (size_t)N + 8;
+    const size_t cap = (size_t)N + 8 + (res_slot == 0 ? (size_t)c->reserve_groups : 0);
     const size_t out_cols = partials ? (size_t)(1 + pl.n_states) : (size_t)std::max(n_aggs, 1);
     res = GroupbyResult{};
     res.n_keys = n_keys_out; res.n_aggs = n_aggs; res.n_state = 1 + pl.n_states; res.partials = partials;

@@ -868,6 +868,8 @@ struct FusedArgs {
     uint64_t cap;                   // capacity of out_g / out_v
     uint64_t *out_g, *out_v;
     uint32_t *flags;
+    uint32_t l_limit;               // > 0: a partition with more probe rows than this raises flags[5] and is skipped — one workgroup would
+                                    // walk a hot probe key's rows alone (31 M rows: 46 ms); the host takes the L2-region path instead
 };
 
 constexpr uint32_t FJ_SLOTS = 8192;                 // LDS multimap slots per partition
@@ -891,6 +893,7 @@ __global__ __launch_bounds__(JN_THREADS) void fused_probe_kernel(FusedArgs a) {
     const uint32_t nR = rend - rbeg;
     if (nR > FJ_MAXROWS) { if (tid == 0) a.flags[0] = 1; return; }
     if (lbeg == lend || nR == 0) return;
+    if (a.l_limit && lend - lbeg > a.l_limit) { if (tid == 0) a.flags[5] = 1; return; }
     uint64_t *sk = reinterpret_cast<uint64_t *>(smem);
     uint64_t *sg = sk + FJ_SLOTS;
     uint32_t *fill = reinterpret_cast<uint32_t *>(sg + FJ_SLOTS);
@@ -1565,6 +1568,7 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
     bool use_pre = false;
     c->pair_fallback = false;
     // the LDS multimaps cannot hold the build side when even the maximum fan-out leaves partitions too large
+    bool l2_tried = false, skew_rerouted = false;
     bool general = c->opt.join_generic != 0 || (double)nr / (double)P > FJ_MAXROWS * 0.95;
     for (int attempt = 0;; attempt++) {
         if (general) {
@@ -1608,6 +1612,7 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         }
         if (l2_path) {
             l2_path = false;                        // one try; whatever it declines goes down the LDS-multimap path below
+            l2_tried = true;
             const size_t mark = c->work.off;
             int32_t st = fused_l2_path(c, lkey, vsrc, nl, rkey, gsrc, nr, flags, &out_g, &out_v, &M, &pre, &use_pre);
             if (st == 0) break;
@@ -1636,6 +1641,10 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
         fa.roff = rpart.offsets; fa.loff = lpart.offsets; fa.rNB = rpart.NB; fa.lNB = lpart.NB; fa.P = (uint32_t)P;
         fa.cursor = reinterpret_cast<unsigned long long *>(flags + 2); fa.cap = cap_pairs;
         fa.out_g = out_g; fa.out_v = out_v; fa.flags = flags;
+        // a hot probe key: one partition with a large share of the probe rows, one workgroup for all of them.  The L2-region path
+        // deals its probe tiles by ticket and does not care — taken instead when such a partition shows up (once)
+        const bool may_reroute = !l2_tried && !skew_rerouted && c->opt.partitions <= 0 && !c->opt.join_generic && c->opt.join_no_l2 <= 0 && nl >= (int64_t(1) << 22);
+        fa.l_limit = may_reroute ? (uint32_t)std::min<int64_t>(std::max<int64_t>(32 * (nl / P), 262144), 0x7FFFFFFF) : 0u;
         const size_t lds = (size_t)FJ_SLOTS * 16 + FJ_BUCKETS * 4 + 16 + FJ_RPT * 16 * 4 + 64;
         uint64_t total = 0;
         for (;;) {
@@ -1646,9 +1655,10 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
                 hipLaunchKernelGGL(fused_probe_kernel, dim3((unsigned)P), dim3(JN_THREADS), lds, c->stream, fa);
                 HIP_TRY(hipGetLastError());
             }
-            HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(h, flags, 32, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+            if (h[5] && fa.l_limit) break;
             if (h[0] || total <= fa.cap) break;
             // duplicate build keys produced more pairs than probe rows: size the buffer exactly, probe again
             if (total >= (1ull << 32) - 16384)
@@ -1660,6 +1670,11 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
             if (!out_g || !out_v) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "pairs arena too small");
             fa.cap = cap_pairs;
             HIP_TRY(hipMemsetAsync(flags, 0, 256, c->stream));
+        }
+        if (h[5] && fa.l_limit) {                    // a hot probe key: the L2-region path, whatever the sizes say
+            skew_rerouted = true; l2_path = true;
+            ST_TRY(c->work.ensure(ws + Arena::padded(((size_t)P_MAX * 2 * L2_REG + 1) * 16) + Arena::padded(size_t(nl) * 4 + (size_t(1) << 25)) + (1 << 20), c->stream));
+            continue;
         }
         if (h[0]) {
             // first overflow: more partitions (unlucky hashing); then the general path (hot build keys, huge builds)

@@ -1338,7 +1338,10 @@ def test_absorb_and_spill_matches_oracle(ctx, shape):
     finally:
         ctx.set_option("no_hot_image", 0)
         ctx.set_option("no_absorb", 0)
-    assert t3["absorbed_rows"] > 0
+    if shape == "hot_set_long_tail":
+        assert t3["absorbed_rows"] == 0                      # (the compact spill needs the image: its tables take no other key)
+    else:
+        assert t3["absorbed_rows"] > 0
     assert_groupby_equal(got3, want, [kd], int_exact_rows=exact)
     if shape == "c3_codes":
         assert t["absorbed_rows"] > t3["absorbed_rows"] + 0.03 * n, (t["absorbed_rows"], t3["absorbed_rows"])
