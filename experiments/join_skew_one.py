@@ -11,7 +11,8 @@ MIX = -7046029254386353131
 nl, nr = 62_500_000, 50_000_000
 rkey = torch.randperm(nr, device=d, generator=gen) * MIX
 rgrp = torch.where(torch.rand(nr, device=d, generator=gen) < 0.6, torch.randint(0, 16, (nr,), device=d, generator=gen), 1000 + torch.arange(nr, device=d))
-lkey = rkey[torch.randint(0, nr, (nl,), device=d, generator=gen)]
+sel = torch.rand(nl, device=d, generator=gen) < float(os.environ.get('HOT_SHARE', '0'))
+lkey = rkey[torch.where(sel, torch.randint(0, int(os.environ.get('HOT_KEYS', '1')), (nl,), device=d, generator=gen), torch.randint(0, nr, (nl,), device=d, generator=gen))]
 lval = torch.randn(nl, device=d, generator=gen, dtype=torch.float64)
 for _ in range(3):
     ctx.join_groupby_sum((lkey, None, pa.I64), (lval, None, pa.F64), nl, (rkey, None, pa.I64), (rgrp, None, pa.I64), nr)
