@@ -225,7 +225,9 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "join_no_pairpart"  1 = the L2-region probe emits its pairs through one cursor instead of pre-partitioned
  *  Median / Nunique
  *   "median_generic"    1 = always the general segmented-sort pass, never the LDS group-sort path
- * Unknown names are rejected with PANDRS_HIP_ERR_INVALID_ARGUMENT. */
+ * Unknown names are rejected with PANDRS_HIP_ERR_INVALID_ARGUMENT.
+ * Diagnostics (environment, read once): PANDRS_HIP_ENGINE_TRACE=1 prints one line per engine attempt (rows, estimate, fan-out, table
+ * slots, kernel family, nesting level) on stderr; PANDRS_HIP_DIST_TRACE=1 the wall time of every stage of a distributed groupby. */
 int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *ctx, const char *name, int64_t value);
 int32_t pandrs_hip_get_timings(pandrs_hip_ctx *ctx, pandrs_hip_timings *out);
 

@@ -1411,6 +1411,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     uint32_t ov_cap = 0;
     for (int attempt = 0;; attempt++) {
         c->work.off = 0;
+        static const bool trace = std::getenv("PANDRS_HIP_ENGINE_TRACE") != nullptr;       // one line per attempt on stderr (a diagnostic)
+        if (trace) fprintf(stderr, "[engine] slot %d merge %d partials %d rows %lld est %lld P %lld T %lld attempt %d lean %d profile %d clustered %d pre %d\n", res_slot, (int)merge, (int)partials,
+                           (long long)N, (long long)est, (long long)P, (long long)T, attempt, (int)use_v2, uni_profile, (int)c->clustered_rows, rs.pre ? 1 : 0);
         c->timings.n_partitions = P; c->timings.table_slots = T; c->timings.retries = attempt;
         const uint32_t P1 = (uint32_t)P + 1;
         // capacity mode (no histogram pass): aggregate2 only (it walks a partition's 8 row ranges), unclustered rows
