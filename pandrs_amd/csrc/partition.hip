@@ -236,15 +236,19 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
     }
     // a dominant key would make every lane CAS the same address: peel the wave's leading keys first (one lane inserts for all lanes that hold the same key)
     bool peeled = false;       // this lane is (or was represented by) a leader already
+    uint32_t mult = 1;         // sampled rows this lane stands for (rows clustered by key put one key many times into a wave:
+                               // counted once, a hot key's few waves looked like a doubleton and Chao1 lost an 18 x long tail)
     for (int round = 0; round < 8; round++) {          // (8: with a handful of keys in all, every lane is represented — the sighting counters
                                                         // below would otherwise take one device atomic per sampled row on ten addresses)
         unsigned long long m = __ballot(live && !peeled);
         if (!m) break;
         int leader = __ffsll((long long)m) - 1;
         uint64_t lk = __shfl(k, leader, 64);
+        const unsigned long long same = __ballot(live && !peeled && k == lk);
         if (live && !peeled && k == lk) {
             peeled = true;
             if ((int)(threadIdx.x & 63) != leader) live = false;           // the leader inserts on their behalf
+            else mult = (uint32_t)__popcll(same);                          // ... and counts their sightings with its own
         }
     }
     // new keys are counted per workgroup in LDS and added to the global counter ONCE: a device-scope atomic per
@@ -276,10 +280,10 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
             slot = (slot + 1) & table_mask;
         }
         if (sub && placed && seen < 3u) {
-            const uint32_t o = atomicAdd(&sight[slot], 1u);
+            const uint32_t o = atomicAdd(&sight[slot], mult), n2 = o + mult;
             if (o == 0) atomicAdd(&once, 1u);
-            else if (o == 1) atomicAdd(&twice, 1u);
-            else if (o == 2) atomicAdd(&thrice, 1u);
+            if (o < 2u && n2 >= 2u) atomicAdd(&twice, 1u);
+            if (o < 3u && n2 >= 3u) atomicAdd(&thrice, 1u);
         }
     }
     __syncthreads();
@@ -973,6 +977,9 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         const double share = std::min(1.0, (b + 3.0 * std::sqrt(b + 1.0)) / pairs);
         est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
     }
+    if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
+        fprintf(stderr, "[estimate] rows %lld sample %lld distinct %u | adjacent pairs %u differing %u | sub-sample %0.f distinct %0.f twice %0.f thrice %0.f | estimate %0.f clustered %d\n",
+                (long long)n_rows, (long long)n_sample, hv[0], hv[2], hv[1], s_sub, d_sub, twice, thrice, est, (int)c->clustered_rows);
     *out_est = (int64_t)est;
     return 0;
 }
