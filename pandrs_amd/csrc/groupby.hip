@@ -1162,7 +1162,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             srcs.push_back(e);
         }
     }
-    if ((partials || merge) && !pl.mergeable)
+    // (First / Last: min / max of the row index merge like any other state, and the value is looked up behind the merge — inside
+    // one call, for the row slices of an oversized partition; across shards a row index means nothing.  Std / Var do not.)
+    const bool nested_slice_merge = merge && !partials && c->quiet > 0 && !pl.needs_second_pass;
+    if ((partials || merge) && !pl.mergeable && !nested_slice_merge)
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                     "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
     const int n_src = (int)srcs.size();
@@ -1488,7 +1491,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
 
         // ---- aggregate
         // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
-        const bool slicing = !c->opt.no_slice && pl.mergeable && n_rounds == 1;
+        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!pl.needs_second_pass && !partials)) && n_rounds == 1;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
                                                        : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
@@ -1624,6 +1627,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 ms.key = KeyDesc{aa.side_keys, nullptr, aa.side_null, DT_CELL};
                 ms.merge_states = aa.side_states;
                 ms.merge_stride = side_cap;
+                for (int s2 = 0; s2 < pl.n_src; s2++) {        // First / Last finish with a look-up in the original column
+                    ms.fin_data[s2] = rs.fin_data[s2] ? rs.fin_data[s2] : rs.val_data[s2];
+                    ms.fin_null_bits[s2] = rs.fin_data[s2] ? rs.fin_null_bits[s2] : rs.val_null_bits[s2];
+                }
                 Options saved = c->opt;
                 c->opt.no_slice = 1; c->opt.no_direct = 1; c->opt.partitions = 0;
                 c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>(n_side, est), 1);   // an upper bound: no second estimate

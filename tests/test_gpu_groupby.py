@@ -198,6 +198,29 @@ def test_hot_key_partitions_are_sliced(ctx):
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5, 6, 7])
 
 
+def test_first_last_of_a_hot_key_are_sliced_too(ctx):
+    """First / Last keep the min / max row index per group: those merge across the row slices of an oversized partition like any
+    other state, and the value is looked up behind the merge (one workgroup used to walk the hot key's whole partition)."""
+    rng = np.random.default_rng(203)
+    n, g = 3_000_000, 400_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.5] = 424242
+    keys = [(k, O.pack_mask(rng.random(n) < 0.02), O.I64)]
+    vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.3), O.F64),
+            (rng.integers(-99, 99, n).astype(np.int64), None, O.I64)]
+    aggs = [(0, O.FIRST), (0, O.LAST), (1, O.FIRST), (1, O.LAST), (0, O.SUM), (1, O.MAX), (0, O.COUNT)]
+    for slice_rows in (0, 40_000):
+        ctx.set_option("slice_rows", slice_rows)
+        try:
+            check(ctx, keys, n, vals, aggs, [O.I64], exact=[0, 1, 2, 3, 5, 6])
+        finally:
+            ctx.set_option("slice_rows", 0)
+    # (partial records for other shards still refuse First / Last: a row index means nothing there)
+    import pandrs_amd as pa
+    with pytest.raises(pa.OperationFailed):
+        ctx.groupby_partials(keys, n, vals, aggs)
+
+
 @pytest.mark.parametrize("skew", [False, True])
 def test_mid_cardinality_takes_few_sliced_partitions(ctx, skew):
     """>= 16 M rows, >= 4 states, a few thousand groups: the engine picks 16-64 large partitions and
