@@ -12,6 +12,12 @@ struct AggTable { uint32_t task_beg, n_tasks, part, multi; };
 // where a partition's rows are: exact layout (histogram) or capacity layout (radix_partition_sampled)
 struct SegSource { const uint32_t *offsets; uint32_t NB; const uint32_t *gbeg, *gcur, *gend; };
 
+// Std / Var over partial records (the row slices of an oversized partition): record i stands for n_i rows with sum s_i and
+// squared deviations M2_i around ITS mean; the merged group has M2 = sum M2_i + sum n_i (s_i / n_i - S / N)^2 — the second
+// term is the merge's own second pass over the records (a sum of non-negative terms: no cancellation)
+struct MergeVar { const uint64_t *sum_col, *nn_col; int8_t ssq, sum, nn, pad[5]; };   // nn_col nullptr / nn -1: the group size
+constexpr int MAX_MERGE_VAR = 8;
+
 struct AggArgs {
     const uint64_t *pkeys;
     const uint32_t *offsets;     // partition p rows = [offsets[p*NB], offsets[(p+1)*NB])
@@ -48,6 +54,7 @@ struct AggArgs {
     // is appended — key cell, values, validity bytes — at counters[6] instead of failing the call.  The keys of such rows are
     // in no table (a full table stays full), so they are a disjoint sub-problem: the host groups them on their own and appends
     // the groups.  Not for `multi` tables (another slice may hold the key); more than ov_cap rows => the overflow flag as before.
+    MergeVar mvar[MAX_MERGE_VAR]; int n_mvar;      // merge mode with a second pass
     uint64_t *ov_keys; uint64_t *ov_vals[4]; uint8_t *ov_valid[4]; uint32_t ov_cap;      // (aggregate2 instantiates 1..4 sources)
     // aggregate2's SMALL mode (few rows: no estimate, no partition): workgroup b folds rows [b * s_chunk, ...) of the
     // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) into its LDS table and flushes the table into

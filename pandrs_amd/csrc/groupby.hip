@@ -545,6 +545,18 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
                     if (slot == T) continue;        // unreachable: every key was inserted above
                 }
                 const uint64_t g = gsz[slot];
+                if (a.n_mvar > 0) {                 // partial records (aggregate.hpp, MergeVar): n_i (m_i - m)^2
+                    for (int v = 0; v < a.n_mvar; v++) {
+                        const MergeVar &mv = a.mvar[v];
+                        const uint64_t nn_i = mv.nn_col ? mv.nn_col[i] : (uint64_t)a.pgsize[i];
+                        if (nn_i == 0) continue;
+                        const double sum = __longlong_as_double((long long)st[(size_t)mv.sum * T1 + slot]);
+                        const uint64_t nn = mv.nn >= 0 ? st[(size_t)mv.nn * T1 + slot] : g;
+                        const double dlt = __longlong_as_double((long long)mv.sum_col[i]) / (double)nn_i - sum / (double)nn;
+                        atomicAdd(reinterpret_cast<double *>(&st[(size_t)mv.ssq * T1 + slot]), (double)nn_i * dlt * dlt);
+                    }
+                    continue;
+                }
                 for (int c = 0; c < nsrc; c++) {
                     const SrcDev &sd = a.src[s0 + c];
                     if (sd.st_ssq < 0) continue;
@@ -1162,9 +1174,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             srcs.push_back(e);
         }
     }
-    // (First / Last: min / max of the row index merge like any other state, and the value is looked up behind the merge — inside
-    // one call, for the row slices of an oversized partition; across shards a row index means nothing.  Std / Var do not.)
-    const bool nested_slice_merge = merge && !partials && c->quiet > 0 && !pl.needs_second_pass;
+    // (Inside one call, for the row slices of an oversized partition, these merge after all.  First / Last: min / max of the row
+    // index merge like any other state and the value is looked up behind the merge — across shards a row index means nothing.
+    // Std / Var: every slice runs the two passes over its own rows, the merge adds the between-slice term — aggregate.hpp, MergeVar.)
+    const bool nested_slice_merge = merge && !partials && c->quiet > 0;
     if ((partials || merge) && !pl.mergeable && !nested_slice_merge)
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                     "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
@@ -1482,6 +1495,17 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 place(e.st_fadd, sd.st_fadd); place(e.st_ssq, sd.st_ssq);
             }
         }
+        if (merge && pl.needs_second_pass) {
+            if (n_rounds != 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "Std / Var records merge in one round only");
+            for (int s2 = 0; s2 < pl.n_src; s2++) {
+                if (pl.st_ssq[s2] < 0) continue;
+                if (aa.n_mvar >= MAX_MERGE_VAR) return fail(PANDRS_HIP_ERR_COMPUTATION, "too many Std / Var columns to merge");
+                const int8_t ssum = pl.src_kind[s2] == 0 ? pl.st_add[s2] : pl.st_fadd[s2], snn = pl.st_nn[s2];
+                MergeVar &mv = aa.mvar[aa.n_mvar++];
+                mv.ssq = st_lds[pl.st_ssq[s2]]; mv.sum = st_lds[ssum]; mv.nn = snn >= 0 ? st_lds[snn] : (int8_t)-1;
+                mv.sum_col = aa.src[ssum].vals; mv.nn_col = snn >= 0 ? aa.src[snn].vals : nullptr;
+            }
+        }
         PartInfo part;
         if (rs.pre) part = rs.pre->part;
         else if (sampled) ST_TRY(radix_partition_sampled(c, sa, &part, PANDRS_HIP_PHASE_HISTOGRAM, PANDRS_HIP_PHASE_SCATTER));
@@ -1491,7 +1515,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
 
         // ---- aggregate
         // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
-        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!pl.needs_second_pass && !partials)) && n_rounds == 1;
+        int n_var_src = 0;
+        for (int s2 = 0; s2 < pl.n_src; s2++) n_var_src += pl.st_ssq[s2] >= 0;
+        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
                                                        : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));

@@ -221,6 +221,28 @@ def test_first_last_of_a_hot_key_are_sliced_too(ctx):
         ctx.groupby_partials(keys, n, vals, aggs)
 
 
+def test_std_var_of_a_hot_key_are_sliced_too(ctx):
+    """Std / Var: every row slice of an oversized partition runs the reference's two passes over its own rows; the merge of the
+    slices' records adds the between-slice term n_i (m_i - m)^2 in a second pass of its own (aggregate.hpp, MergeVar)."""
+    rng = np.random.default_rng(204)
+    n, g = 3_000_000, 400_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.5] = 424242
+    k[rng.random(n) < 0.05] = -1
+    keys = [(k, O.pack_mask(rng.random(n) < 0.02), O.I64)]
+    drift = np.linspace(0.0, 50.0, n)                 # slice means differ: the between-slice term matters
+    vals = [(1e6 + drift + rng.normal(0, 1, n), O.pack_mask(rng.random(n) < 0.3), O.F64),
+            (rng.integers(-99, 99, n).astype(np.int64) + (np.arange(n) // 100_000), None, O.I64),
+            (rng.normal(0, 1, n), None, O.F64)]
+    aggs = [(0, O.STD), (0, O.VAR), (1, O.STD), (1, O.VAR), (2, O.STD), (0, O.MEAN), (1, O.SUM), (2, O.FIRST), (0, O.COUNT)]
+    for slice_rows in (0, 40_000):
+        ctx.set_option("slice_rows", slice_rows)
+        try:
+            check(ctx, keys, n, vals, aggs, [O.I64], exact=[6, 7, 8])
+        finally:
+            ctx.set_option("slice_rows", 0)
+
+
 @pytest.mark.parametrize("skew", [False, True])
 def test_mid_cardinality_takes_few_sliced_partitions(ctx, skew):
     """>= 16 M rows, >= 4 states, a few thousand groups: the engine picks 16-64 large partitions and
