@@ -206,6 +206,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "no_direct"         1 = never the few-groups direct path (-1 = allow it below 4 M rows too)
  *   "no_overflow_run"   1 = a full LDS table fails the attempt (the call is retried with 4 x the fan-out) instead of handing the rows it
  *                       could not place to a run of their own, whose groups are appended
+ *   "sorted_dictionary" 1 = a column of a composite key that is too wide for its share of the 64-bit cell gets its dictionary codes by
+ *                       ordering the rows (any cardinality) instead of listing its distinct cells and a hashed look-up per row
  *   "no_chao"           1 = the sampled group estimate is the uniform-occupancy model alone (no Chao1 term: tests, A/B)
  *   "no_absorb"         1 = never the hot-key absorb-and-spill pass in front of the radix path (-1 = whenever it is possible: tests)
  *   "no_hot_image"      1 = the absorb tables start empty (first come, first served) instead of from the sample's most frequent keys

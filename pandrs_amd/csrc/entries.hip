@@ -223,6 +223,88 @@ __global__ void dense_emit_kernel(const uint64_t *pk, const uint32_t *prow, cons
     }
 }
 
+// dictionary encoding of one key column WITHOUT ordering its rows: the ordinary engine lists the column's distinct cells
+// (a count-only run), their position in that list is the code, and every row looks its cell up in an open-addressing
+// table key -> position (16-byte entries, load <= 0.5: a few probes, L2 / MALL resident for all but huge dictionaries)
+struct DictEntry { uint64_t key; uint32_t id, pad; };
+__global__ void dict_build_kernel(const uint64_t *gkeys, const uint8_t *gnull, uint32_t G, DictEntry *table, uint32_t mask,
+                                  uint32_t *special, uint64_t *dict, uint8_t *dict_null) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G) return;
+    const uint64_t k = gkeys[i];
+    const bool nul = gnull[i] != 0;
+    dict[i] = nul ? 0ull : k;
+    dict_null[i] = nul ? 1 : 0;
+    if (nul) { special[1] = i; return; }
+    if (k == EMPTY_KEY) { special[0] = i; return; }         // (the table's own free marker: kept beside it)
+    uint32_t slot = hash32(k, 0x3C6EF372u) & mask;
+    for (uint32_t probes = 0; probes <= mask; probes++) {
+        if (atomicCAS((unsigned long long *)&table[slot].key, EMPTY_KEY, k) == EMPTY_KEY) { table[slot].id = i; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void dict_lookup_kernel(KeyDesc key, int64_t n, const DictEntry *table, uint32_t mask, const uint32_t *special,
+                                   uint32_t *code) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t id = 0;
+    if (key_is_null(key, i)) id = special[1];
+    else {
+        const uint64_t k = key_cell(key, i);
+        if (k == EMPTY_KEY) id = special[0];
+        else {
+            uint32_t slot = hash32(k, 0x3C6EF372u) & mask;
+            for (uint32_t probes = 0; probes <= mask; probes++) {
+                const DictEntry e = table[slot];
+                if (e.key == k) { id = e.id; break; }
+                if (e.key == EMPTY_KEY) break;               // unreachable: every cell of the column is in the list
+                slot = (slot + 1) & mask;
+            }
+        }
+    }
+    code[i] = id;
+}
+// -> 0 and *G_out, or SMALL_NOT_TAKEN-like -1 when the column has more distinct cells than one engine run lists (the caller
+// then orders the rows instead: build_sorted_groups)
+static int32_t hashed_dictionary(pandrs_hip_ctx *c, const KeyDesc &key, int dtype, int64_t n_rows, uint32_t *code, uint64_t *dict,
+                                 uint8_t *dict_null, int64_t dict_cap, int64_t *G_out) {
+    Plan cpl;
+    int32_t cdt = PANDRS_HIP_I64; uint8_t chn = 0;
+    pandrs_hip_agg_spec cspec{}; cspec.col = 0; cspec.op = PANDRS_HIP_AGG_COUNT;
+    ST_TRY(build_plan(&cdt, &chn, 1, &cspec, 1, cpl));
+    RowSource krs;
+    krs.n_rows = n_rows; krs.key = key;
+    Options saved = c->opt;
+    c->opt.groups_hint = 0; c->opt.partitions = 0;
+    pandrs_hip_timings tsave = c->timings;
+    c->quiet++;
+    int32_t st = run_engine(c, krs, cpl, /*merge=*/false, /*partials=*/false, 1, dtype, 1);
+    c->quiet--;
+    c->opt = saved;
+    c->timings = tsave;
+    if (st) {
+        if (c->capacity_exceeded) { c->capacity_exceeded = false; return -1; }
+        return st;
+    }
+    const int64_t G = c->gb.n_groups;
+    if (G <= 0 || G > dict_cap) return -1;
+    uint32_t slots = 1024;
+    while ((int64_t)slots < 2 * G) slots <<= 1;
+    ST_TRY(c->work.ensure((size_t)slots * sizeof(DictEntry) + 8192, c->stream));
+    DictEntry *table = c->work.take<DictEntry>(slots);
+    uint32_t *special = c->work.take<uint32_t>(64);
+    if (!table || !special) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (dictionary)");
+    HIP_TRY(hipMemsetAsync(table, 0xFF, (size_t)slots * sizeof(DictEntry), c->stream));
+    HIP_TRY(hipMemsetAsync(special, 0, 256, c->stream));
+    hipLaunchKernelGGL(dict_build_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream, c->gb.keys, c->gb.key_null,
+                       (uint32_t)G, table, slots - 1, special, dict, dict_null);
+    hipLaunchKernelGGL(dict_lookup_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, key, n_rows, table,
+                       slots - 1, special, code);
+    HIP_TRY(hipGetLastError());
+    *G_out = G;
+    return 0;
+}
+
 // Stages the remaining key columns, measures the code widths and replaces `key` (on entry: key
 // column 0) by the packed cells.  `pd` is kept for unpack_keys_kernel.
 static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_column *keys, int n_keys, int64_t n_rows,
@@ -283,18 +365,24 @@ static int32_t pack_multi_key(pandrs_hip_ctx *c, Stager &stg, const pandrs_hip_c
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                         "multi-key groupby: the key columns need more than 64 bits even with every column "
                         "dictionary-encoded (%u bits); not supported on the device path", total);
-        SortedGroups sg;
-        ST_TRY(build_sorted_groups(c, pd.key[w], n_rows, &sg));
         uint32_t *code = c->packed.take<uint32_t>(n_rows);
-        uint64_t *dict = c->packed.take<uint64_t>(sg.G);
-        uint8_t *dnull = c->packed.take<uint8_t>(sg.G);
+        uint64_t *dict = c->packed.take<uint64_t>(n_rows);
+        uint8_t *dnull = c->packed.take<uint8_t>(n_rows);
         if (!code || !dict || !dnull) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "packed arena too small (dictionary)");
-        hipLaunchKernelGGL(dense_emit_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
-                           sg.pk, sg.prow, sg.null_beg, (uint32_t)n_rows, sg.flag, sg.gid, code, dict, dnull);
-        HIP_TRY(hipGetLastError());
+        int64_t G = 0;
+        int32_t hst = c->opt.sorted_dictionary ? -1 : hashed_dictionary(c, pd.key[w], keys[w].dtype, n_rows, code, dict, dnull, n_rows, &G);
+        if (hst > 0) return hst;
+        if (hst < 0) {           // more distinct cells than one engine run lists: order the rows by the column instead
+            SortedGroups sg;
+            ST_TRY(build_sorted_groups(c, pd.key[w], n_rows, &sg));
+            hipLaunchKernelGGL(dense_emit_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                               sg.pk, sg.prow, sg.null_beg, (uint32_t)n_rows, sg.flag, sg.gid, code, dict, dnull);
+            HIP_TRY(hipGetLastError());
+            G = sg.G;
+        }
         pd.dense[w] = code; pd.dict[w] = dict; pd.dict_null[w] = dnull;
         uint32_t bits = 1;
-        while (bits < 32 && ((uint64_t)(sg.G - 1) >> bits)) bits++;
+        while (bits < 32 && ((uint64_t)(G - 1) >> bits)) bits++;
         total -= need[w]; need[w] = bits; total += bits;
     }
     uint32_t shift = 0;

@@ -781,10 +781,34 @@ def test_multi_key_wider_than_64_bits_is_dictionary_encoded(ctx):
     k1 = (b, None, O.I64)
     k2 = (rng.integers(0, 3, n).astype(np.uint32), O.pack_mask(rng.random(n) < 0.1), O.U32CODE)
     v = (rng.normal(1, 2, n), None, O.F64)
-    check(ctx, [k0, k1, k2], n, [v], [(0, O.SUM), (0, O.MIN), (0, O.COUNT), (0, O.MEDIAN)], [O.I64, O.I64, O.U32CODE], exact=[1, 2, 3])
-    check_group_indices(ctx, [k0, k1], n)
+    a[rng.random(n) < 0.01] = -1                              # the table-sentinel cell as a key value
     f = (rng.choice(np.array([0.0, -0.0, np.nan, 1e300, -1e300, 5e-324]), n), None, O.F64)   # full-range f64 key
-    check(ctx, [f, k1], n, [v], [(0, O.MAX), (0, O.COUNT)], [O.F64, O.I64], exact=[0, 1])
+    # the codes come from a list of the column's distinct cells + a hashed look-up per row, or (any cardinality) from ordering its rows
+    for sorted_dictionary in (0, 1):
+        ctx.set_option("sorted_dictionary", sorted_dictionary)
+        try:
+            check(ctx, [k0, k1, k2], n, [v], [(0, O.SUM), (0, O.MIN), (0, O.COUNT), (0, O.MEDIAN)], [O.I64, O.I64, O.U32CODE], exact=[1, 2, 3])
+            check_group_indices(ctx, [k0, k1], n)
+            check(ctx, [f, k1], n, [v], [(0, O.MAX), (0, O.COUNT)], [O.F64, O.I64], exact=[0, 1])
+        finally:
+            ctx.set_option("sorted_dictionary", 0)
+
+
+def test_wide_low_cardinality_key_column_of_a_composite_key(ctx):
+    """Three keys whose f64 column (0.0 / 1.0 / 2.0: 63 bits of span) pushes the codes past 64 bits: its dictionary is the engine's
+    own list of the column's distinct cells (ordering 4 M rows into three groups was the slow way), and a column with
+    many distinct cells (900 K hashed ids) takes the same route."""
+    rng = np.random.default_rng(2025)
+    n = 4_000_000
+    ids = rng.integers(0, 60_000, n)
+    k0 = ((ids // 21) * 11, None, O.I64)
+    k1 = ((ids % 7).astype(np.uint32), None, O.U32CODE)
+    k2 = (((ids // 7) % 3).astype(np.float64), O.pack_mask(rng.random(n) < 0.001), O.F64)
+    v = (rng.normal(1, 2, n), None, O.F64)
+    check(ctx, [k0, k1, k2], n, [v], [(0, O.SUM), (0, O.MAX), (0, O.COUNT)], [O.I64, O.U32CODE, O.F64], exact=[1, 2])
+    big = (sparse_keys_from(rng.integers(0, 900_000, n)), None, O.I64)
+    big2 = (sparse_keys_from(rng.integers(0, 5, n) + 7), O.pack_mask(rng.random(n) < 0.01), O.I64)
+    check(ctx, [big, big2], n, [v], [(0, O.MIN), (0, O.COUNT)], [O.I64, O.I64], exact=[0, 1])
 
 
 def test_column_population_std_like_parallel_std(ctx):
