@@ -212,6 +212,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "no_absorb"         1 = never the hot-key absorb-and-spill pass in front of the radix path (-1 = whenever it is possible: tests)
  *   "no_hot_image"      1 = the absorb tables start empty (first come, first served) instead of from the sample's most frequent keys
  *   "no_slice"          1 = never cut oversized partitions into row slices; "slice_rows" forces the slice length
+ *   "wide_slices"       1 = the pieces of an oversized partition are as long as the cutting threshold (4 x the average partition) instead of
+ *                       average-sized (A/B: a piece is one workgroup's job, long pieces are the aggregate pass's tail)
  *   "no_small"          1 = never the two-launch path for calls of <= 2 M rows; "small_chunk" rows per workgroup there
  *   "deterministic"     1 = f64 Sum / Mean / Std / Var re-folded in ascending row order (bit-identical to the
  *                       reference's sequential fold; about 3 x the default time)

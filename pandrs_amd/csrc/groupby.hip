@@ -27,9 +27,11 @@
 namespace pandrs {
 
 // ------------------------------------------------------------------------------------ aggregate
-// one workgroup: partition sizes -> task list (a partition of more than slice_rows rows becomes
-// ceil(size / slice_rows) tasks flagged `multi`; empty partitions get no task)
-__global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1,
+// one workgroup: partition sizes -> task list (a partition of more than over_rows rows becomes
+// ceil(size / slice_rows) tasks flagged `multi`; empty partitions get no task).  over_rows >= slice_rows: a partition
+// is cut only when it is far above the average, and then into pieces the size of an average partition — a piece is one
+// workgroup's job, and a job four times the usual one is the kernel's tail.
+__global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offsets, uint32_t NB, uint32_t P1, uint32_t over_rows,
                                                            uint32_t slice_rows, AggTask *tasks, uint32_t *n_tasks,
                                                            uint32_t max_tasks) {
     __shared__ uint32_t wt[17];
@@ -40,14 +42,14 @@ __global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offse
         uint32_t p = base + threadIdx.x, beg = 0, end = 0, ns = 0;
         if (p < P1) {
             beg = offsets[(size_t)p * NB]; end = offsets[(size_t)(p + 1) * NB];
-            ns = (end - beg + slice_rows - 1) / slice_rows;
+            ns = end - beg > over_rows ? (end - beg + slice_rows - 1) / slice_rows : (end > beg ? 1u : 0u);
         }
         uint32_t tot;
         uint32_t ex = block_exclusive_scan<1024>(ns, wt, &tot) + carry;
         for (uint32_t q = 0; q < ns; q++) {
             if (ex + q < max_tasks) {
                 uint32_t b = beg + q * slice_rows;
-                tasks[ex + q] = AggTask{p, b, min(b + slice_rows, end), ns > 1 ? 1u : 0u};
+                tasks[ex + q] = AggTask{p, b, ns > 1 ? min(b + slice_rows, end) : end, ns > 1 ? 1u : 0u};
             }
         }
         __syncthreads();
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offse
 
 // aggregate2's work list: tables (one per partition; an oversized partition is cut into tables of <= slice_rows
 // rows flagged `multi`) and, per table, the row ranges that feed it.  One workgroup; counts[0] = tasks, [1] = tables.
-__global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32_t P1, uint32_t slice_rows, AggTask *tasks,
+__global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32_t P1, uint32_t over_rows, uint32_t slice_rows_in, AggTask *tasks,
                                                             AggTable *tables, uint32_t *counts, uint32_t max_tasks,
                                                             uint32_t max_tables) {
     __shared__ uint32_t wt[17];
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32
             }
             for (uint32_t g = 0; g < n_seg; g++) R += se[g] - sb[g];
         }
-        const uint32_t n_tab = R ? (uint32_t)((R + slice_rows - 1) / slice_rows) : 0u;
+        const uint32_t n_tab = R > over_rows ? (uint32_t)((R + slice_rows_in - 1) / slice_rows_in) : (R ? 1u : 0u);
+        const uint64_t slice_rows = n_tab > 1 ? (uint64_t)slice_rows_in : max(R, (uint64_t)1);      // (one table: one virtual range)
         // tasks = non-empty intersections of the segments with the tables' virtual row ranges
         uint32_t n_task = 0;
         {
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32
             uint32_t ti = ex_task, tb = ex_tab, g = 0;
             uint64_t v0 = 0;                       // virtual row where segment g starts
             for (uint32_t j = 0; j < n_tab; j++) {
-                const uint64_t lo = (uint64_t)j * slice_rows, hi = min((uint64_t)(j + 1) * slice_rows, R);
+                const uint64_t lo = (uint64_t)j * slice_rows, hi = min((uint64_t)(j + 1) * slice_rows, (uint64_t)R);
                 const uint32_t first = ti;
                 while (g < n_seg) {
                     const uint64_t len = se[g] - sb[g];
@@ -1521,7 +1524,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
                                                        : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
-        const int64_t max_slices = slicing ? 2 * (N / slice_rows) + 2 : 0;       // slices of multi-slice partitions
+        // (cut when far above the average, into pieces of the average size: build_tasks_kernel.  A forced or mid-cardinality
+        // slice length is both at once.)
+        const int64_t piece_rows = (c->opt.slice_rows > 0 || auto_slice_rows > 0 || c->opt.wide_slices) ? slice_rows
+                                 : std::min<int64_t>(slice_rows, std::max<int64_t>(int64_t(1) << 16, N / std::max<int64_t>(P, 1)));
+        const int64_t max_slices = slicing ? N / piece_rows + N / slice_rows + 2 : 0;       // slices of multi-slice partitions
         const size_t side_cap = (size_t)max_slices * (size_t)(T + 2);
         // (rows that full tables hand to an overflow run may bring up to one group each: room for them, bounded by what is likely)
         const bool want_ov = use_v2 && !merge && res_slot == 0 && !c->opt.no_overflow_run && n_src >= 1 && n_src <= 4 && N >= (int64_t(1) << 16);
@@ -1582,13 +1589,14 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !tables || !n_tasks)
                 return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (slices)");
             const uint32_t srows = slicing ? (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu;
+            const uint32_t prows = slicing ? (uint32_t)std::min<int64_t>(piece_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu;
             if (use_v2) {
                 const SegSource ss{offsets, NB, part.gbeg, part.gcur, part.gend};
-                hipLaunchKernelGGL(build_tables_kernel, dim3(1), dim3(1024), 0, c->stream, ss, P1, srows, tasks, tables, n_tasks,
+                hipLaunchKernelGGL(build_tables_kernel, dim3(1), dim3(1024), 0, c->stream, ss, P1, srows, prows, tasks, tables, n_tasks,
                                    max_tasks, max_tables);
                 aa.tables = tables; aa.launch_grid = max_tables;
             } else {
-                hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1, srows, tasks, n_tasks, max_tasks);
+                hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1, srows, prows, tasks, n_tasks, max_tasks);
                 aa.launch_grid = max_tasks;
             }
             aa.tasks = tasks; aa.n_tasks = n_tasks;

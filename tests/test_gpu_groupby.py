@@ -179,12 +179,13 @@ def test_hot_key_partitions_are_sliced(ctx):
     vals = [(rng.normal(100, 10, n), O.pack_mask(rng.random(n) < 0.05), O.F64),
             (rng.integers(-99, 99, n).astype(np.int64), None, O.I64)]
     aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (0, O.MAX), (0, O.COUNT), (1, O.SUM), (1, O.MIN), (1, O.MAX)]
-    for slice_rows in (0, 50_000):
-        ctx.set_option("slice_rows", slice_rows)
+    # (pieces of the average partition's size by default; as long as the cutting threshold with wide_slices; a forced length)
+    for slice_rows, wide in ((0, 0), (0, 1), (50_000, 0)):
+        ctx.set_option("slice_rows", slice_rows); ctx.set_option("wide_slices", wide)
         try:
             check(ctx, keys, n, vals, aggs, [O.I64], exact=[2, 3, 4, 5, 6, 7])
         finally:
-            ctx.set_option("slice_rows", 0)
+            ctx.set_option("slice_rows", 0); ctx.set_option("wide_slices", 0)
     # partials of a sliced input stay mergeable
     ctx.set_option("slice_rows", 50_000)
     try:
