@@ -255,7 +255,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             }
         }
     };
-    // ---- all placed rows of the wave in ONE slot (see the call site): VALU-only wave reductions, then lane 0 applies the totals —
+    // ---- many placed rows of the wave in ONE slot (see the call site; `ok` marks them): VALU-only wave reductions, then lane 0 applies the totals —
     // same rules as update(): nulls skipped, NaN ignored by min / max, sums re-associate (as everywhere)
     auto wave_fold = [&](uint32_t slot, unsigned long long okw, bool ok, const uint64_t (&v)[NSRC], uint32_t okm) {
         if (lane == 0) atomicAdd(&gsz[slot], (uint32_t)__popcll(okw));
@@ -426,12 +426,18 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 // a slice of an oversized partition is mostly ONE key (a hot key, the NULL group): 64 lanes adding to the same
                 // LDS words serialise (13 atomics x 64 lanes per batch for C2's profile: ~830 LDS cycles per 64 rows).  When every
                 // placed row of the wave sits in the same slot, the wave folds its rows on the VALU first and one lane updates the table.
-                if (cur_multi) {                               // wave-uniform (a property of the table)
+                // The same holds, less extremely, for a hot key that shares an ordinary table with other keys (a key holding 2-3 x the
+                // average partition's rows is not cut out: 250 K rows x 13 same-address atomics per table, 6.6 ms for C2's shape with
+                // half the rows on 200 keys): the lanes in the FIRST placed lane's slot fold when they are many, the others update as usual.
+                {
                     const unsigned long long okw = __ballot(ok);
                     if (okw) {
                         const uint32_t s0 = __shfl(idx, __ffsll((long long)okw) - 1, 64);
-                        if (__ballot(ok && idx == s0) == okw && __popcll(okw) >= 8) {
-                            wave_fold(s0, okw, ok, v, okm);
+                        const bool same = ok && idx == s0;
+                        const unsigned long long samew = __ballot(same);
+                        if ((uint32_t)__popcll(samew) >= (cur_multi ? 8u : 16u)) {
+                            wave_fold(s0, samew, same, v, okm);
+                            if (ok && !same) update(idx, v, okm);
                             continue;
                         }
                     }

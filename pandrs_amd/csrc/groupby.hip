@@ -1424,7 +1424,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                              (int64_t)((double)P_LIMIT * 0.6 * (double)T * LOAD));
     P = std::min<int64_t>(std::max<int64_t>(P, 1), P_LIMIT);
 
-    const uint32_t seed = 0x9E3779B9u;
+    // (a nested merge — the records of an oversized partition's pieces, of the direct path's chunks — hashes with a seed of its own:
+    // the pieces' keys all come from a few of the parent's partitions, i.e. from a few RANGES of the parent's hash, and
+    // part_of() maps a range of the same hash onto a handful of the merge's partitions, which then overflow and cost a retry)
+    const uint32_t seed = (merge && res_slot > 0) ? 0x68E31DA5u : 0x9E3779B9u;
     bool sampled_failed = false;       // a capacity-mode run overflowed a region: repeat with the exact histogram
     bool polled = false;
     uint32_t ov_cap = 0;
@@ -1523,7 +1526,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
-                                                       : std::max<int64_t>(int64_t(1) << 18, 4 * (N / std::max<int64_t>(P, 1)));
+                                                       : std::max<int64_t>(int64_t(1) << 18, (c->opt.wide_slices ? 4 : 2) * (N / std::max<int64_t>(P, 1)));
         // (cut when far above the average, into pieces of the average size: build_tasks_kernel.  A forced or mid-cardinality
         // slice length is both at once.)
         const int64_t piece_rows = (c->opt.slice_rows > 0 || auto_slice_rows > 0 || c->opt.wide_slices) ? slice_rows
