@@ -214,6 +214,9 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "no_slice"          1 = never cut oversized partitions into row slices; "slice_rows" forces the slice length
  *   "wide_slices"       1 = the pieces of an oversized partition are as long as the cutting threshold (4 x the average partition) instead of
  *                       average-sized (A/B: a piece is one workgroup's job, long pieces are the aggregate pass's tail)
+ *   "slice_over"        experiments: a partition is cut when it holds more than this many average partitions' rows (default 2)
+ *   "fold_min", "fold_min_multi"  experiments: lanes of a wave in one table slot from which the lean aggregate folds them on the VALU
+ *                       (ordinary tables: default 40; pieces of an oversized partition: default 8; 65 = never)
  *   "no_small"          1 = never the two-launch path for calls of <= 2 M rows; "small_chunk" rows per workgroup there
  *   "deterministic"     1 = f64 Sum / Mean / Std / Var re-folded in ascending row order (bit-identical to the
  *                       reference's sequential fold; about 3 x the default time)

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                         const uint32_t s0 = __shfl(idx, __ffsll((long long)okw) - 1, 64);
                         const bool same = ok && idx == s0;
                         const unsigned long long samew = __ballot(same);
-                        if ((uint32_t)__popcll(samew) >= (cur_multi ? 8u : 16u)) {
+                        if ((uint32_t)__popcll(samew) >= (cur_multi ? a.fold_min_multi : a.fold_min)) {
                             wave_fold(s0, samew, same, v, okm);
                             if (ok && !same) update(idx, v, okm);
                             continue;
@@ -692,7 +692,12 @@ bool aggregate2_small_has(int n_src, int profile) {
     if (n_src < 1 || n_src > 2) return false;
     switch (profile) { case 2: case 3: case 14: case 15: case 12: case 18: case 30: return true; default: return false; }
 }
-bool launch_aggregate2_small(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid) {
+// lanes of a wave in one slot from which they are folded on the VALU instead of serialising on the slot's LDS words
+// (experiments/fold_cut_sweep.py: two keys sharing a wave 25 + 25 fold slower than they serialise — 80 % of the rows on 2000 keys 5.1 ms with 16, 4.7 with 32..48)
+constexpr uint32_t FOLD_MIN = 40, FOLD_MIN_MULTI = 8;
+bool launch_aggregate2_small(pandrs_hip_ctx *c, const AggArgs &a_in, int n_src, int profile, size_t lds, uint32_t grid) {
+    AggArgs a = a_in;
+    a.fold_min = a.fold_min_multi = 65;        // (never: small tables see few rows per key)
     switch (n_src) {
     case 1: return launch_small_profile<1>(c, a, profile, lds, grid);
     case 2: return launch_small_profile<2>(c, a, profile, lds, grid);
@@ -715,7 +720,10 @@ bool aggregate2_has(int n_src, int profile) {
     }
 }
 
-bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid) {
+bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a_in, int n_src, int profile, size_t lds, uint32_t grid) {
+    AggArgs a = a_in;
+    a.fold_min = c->opt.fold_min > 0 ? (uint32_t)c->opt.fold_min : FOLD_MIN;
+    a.fold_min_multi = c->opt.fold_min_multi > 0 ? (uint32_t)c->opt.fold_min_multi : FOLD_MIN_MULTI;
     if ((c->opt.agg_depth > 0 || c->opt.agg_ablate > 0) && profile == 14 && (n_src == 4 || n_src == 2)) {
         // experiments only: what the kernel's time is made of (ablate: 1 no min / max work, 2 key lookup + group
         // size only, 3 the HBM stream alone, 4 ... without epilogue, 6 full work on L2-resident rows) and the ring depth

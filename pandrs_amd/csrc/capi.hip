@@ -208,6 +208,9 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_overflow_run")) c->opt.no_overflow_run = value;
     else if (!std::strcmp(name, "sorted_dictionary")) c->opt.sorted_dictionary = value;
     else if (!std::strcmp(name, "wide_slices")) c->opt.wide_slices = value;
+    else if (!std::strcmp(name, "fold_min")) c->opt.fold_min = value;
+    else if (!std::strcmp(name, "fold_min_multi")) c->opt.fold_min_multi = value;
+    else if (!std::strcmp(name, "slice_over")) c->opt.slice_over = value;
     else if (!std::strcmp(name, "no_hot_image")) c->opt.no_hot_image = value;
     else if (!std::strcmp(name, "no_slice")) c->opt.no_slice = value;
     else if (!std::strcmp(name, "p_max")) c->opt.p_max = value;

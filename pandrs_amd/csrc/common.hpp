@@ -164,6 +164,8 @@ struct Options {
     int64_t no_slice = 0;            // 1 = never split oversized partitions across workgroups
     int64_t slice_rows = 0;          // 0 = auto; rows per slice of an oversized partition
     int64_t no_direct = 0;           // 1 = never take the partition-free low-cardinality path
+    int64_t fold_min = 0, fold_min_multi = 0;   // experiments: lanes in one slot from which a wave folds them (0 = default 40 / 8; 65 = never)
+    int64_t slice_over = 0;          // experiments: a partition is cut when it holds more than this many average partitions' rows (0 = default 2)
     int64_t wide_slices = 0;         // 1 = an oversized partition is cut into pieces as long as the cutting threshold (4 x the average partition) instead of average-sized ones (A/B)
     int64_t sorted_dictionary = 0;   // 1 = a too-wide column of a composite key is dictionary-encoded by ordering its rows (the path that takes any cardinality) instead of a hashed look-up
     int64_t no_overflow_run = 0;     // 1 = a full LDS table fails the attempt (retry with 4 x the fan-out) instead of handing its unplaced rows to a run of their own

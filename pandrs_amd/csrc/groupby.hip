@@ -1526,7 +1526,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
-                                                       : std::max<int64_t>(int64_t(1) << 18, (c->opt.wide_slices ? 4 : 2) * (N / std::max<int64_t>(P, 1)));
+                                                       : std::max<int64_t>(int64_t(1) << 18, (c->opt.wide_slices ? 4 : (c->opt.slice_over > 0 ? c->opt.slice_over : 2)) * (N / std::max<int64_t>(P, 1)));
         // (cut when far above the average, into pieces of the average size: build_tasks_kernel.  A forced or mid-cardinality
         // slice length is both at once.)
         const int64_t piece_rows = (c->opt.slice_rows > 0 || auto_slice_rows > 0 || c->opt.wide_slices) ? slice_rows
