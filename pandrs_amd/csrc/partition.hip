@@ -34,6 +34,8 @@ __device__ __forceinline__ void estimate_publish(uint32_t *distinct, uint32_t *h
             host_out[4] = __hip_atomic_load(&distinct[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[5] = __hip_atomic_load(&distinct[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host_out[6] = __hip_atomic_load(&distinct[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[7] = __hip_atomic_load(&distinct[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[8] = __hip_atomic_load(&distinct[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -41,7 +43,7 @@ __device__ __forceinline__ void estimate_publish(uint32_t *distinct, uint32_t *h
 __global__ void estimate_clear_kernel(uint64_t *table, uint32_t slots, uint32_t *distinct, uint32_t *counts, uint32_t *sight) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < slots) { table[i] = EMPTY_KEY; sight[i] = 0; }
-    if (i < 8) distinct[i] = 0;
+    if (i < 12) distinct[i] = 0;
     if (counts && i < slots) counts[i] = 0;
 }
 
@@ -212,10 +214,14 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
     // second signal, for CLUSTERED inputs (e.g. rows sorted by key), where a strided sample shows no
     // repeats at all: the share of adjacent row pairs whose keys differ.  #groups <= #runs = boundaries + 1
     // whatever the order, so it bounds the estimate from above.  distinct[2] = boundaries, [3] = pairs.
-    bool pair = false, differs = false;
+    // ... and its control, FAR pairs: this sampled row against the one 32 lanes on (32 x stride rows away).  A dominant key makes
+    // neighbours share their key in ANY row order — and then far pairs share it as often; rows clustered by key do not.
+    // distinct[8] = far pairs that differ, [9] = far pairs.
+    bool pair = false, differs = false, nul = false;
+    const bool in_range = live;
     if (live) {
         int64_t i = s * stride;
-        const bool nul = key_is_null(key, i);
+        nul = key_is_null(key, i);
         k = key_cell(key, i);
         if (i + 1 < n_rows) {
             const bool nul2 = key_is_null(key, i + 1);
@@ -225,14 +231,25 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
         live = !nul && k != EMPTY_KEY;
     }
     {   // one atomic pair per workgroup (same-address global atomics serialise)
-        __shared__ uint32_t sb[2];
-        if (threadIdx.x < 2) sb[threadIdx.x] = 0;
+        __shared__ uint32_t sb[4];
+        if (threadIdx.x < 4) sb[threadIdx.x] = 0;
         __syncthreads();
-        const unsigned long long mp = __ballot(pair), md = __ballot(differs);
-        if ((threadIdx.x & 63) == 0) { if (mp) atomicAdd(&sb[0], (uint32_t)__popcll(mp)); if (md) atomicAdd(&sb[1], (uint32_t)__popcll(md)); }
+        const uint64_t kf = __shfl_down(k, 32, 64);
+        const int nf = __shfl_down((int)nul, 32, 64), rf = __shfl_down((int)in_range, 32, 64);
+        const bool fpair = in_range && (threadIdx.x & 63) < 32 && rf != 0;
+        const bool fdiff = fpair && ((int)nul != nf || (!nul && k != kf));
+        const unsigned long long mp = __ballot(pair), md = __ballot(differs), fp = __ballot(fpair), fd = __ballot(fdiff);
+        if ((threadIdx.x & 63) == 0) {
+            if (mp) atomicAdd(&sb[0], (uint32_t)__popcll(mp));
+            if (md) atomicAdd(&sb[1], (uint32_t)__popcll(md));
+            if (fp) atomicAdd(&sb[2], (uint32_t)__popcll(fp));
+            if (fd) atomicAdd(&sb[3], (uint32_t)__popcll(fd));
+        }
         __syncthreads();
         if (threadIdx.x == 0 && sb[0])
             atomicAdd(reinterpret_cast<unsigned long long *>(&distinct[2]), ((unsigned long long)sb[0] << 32) | sb[1]);
+        if (threadIdx.x == 64 && sb[2])
+            atomicAdd(reinterpret_cast<unsigned long long *>(&distinct[8]), ((unsigned long long)sb[2] << 32) | sb[3]);
     }
     // a dominant key would make every lane CAS the same address: peel the wave's leading keys first (one lane inserts for all lanes that hold the same key)
     bool peeled = false;       // this lane is (or was represented by) a leader already
@@ -970,7 +987,11 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     }
     c->clustered_rows = false;
     if (hv[2] >= 1024) {
-        c->clustered_rows = (double)hv[1] < 0.5 * (double)hv[2] && !c->opt.no_runs;    // most neighbours share their key
+        // most neighbours share their key — and far more often than rows far apart do (a dominant key alone puts equal keys next to
+        // each other in any order: 90 % of the rows on one key read as "clustered", which kept the lean aggregate and the absorb pass away)
+        const double near_same = 1.0 - (double)hv[1] / (double)hv[2];
+        const double far_same = h[8] >= 256 ? 1.0 - (double)h[7] / (double)h[8] : 0.0;
+        c->clustered_rows = near_same > 0.5 && far_same < 0.5 * near_same && !c->opt.no_runs;
         // runs of equal keys: an upper bound on the group count in any row order (exact for sorted
         // input); + 3 sigma of the sampled share so that noise cannot push it below the truth
         const double pairs = (double)hv[2], b = (double)hv[1];
@@ -978,8 +999,8 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
     }
     if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
-        fprintf(stderr, "[estimate] rows %lld sample %lld distinct %u | adjacent pairs %u differing %u | sub-sample %0.f distinct %0.f twice %0.f thrice %0.f | estimate %0.f clustered %d\n",
-                (long long)n_rows, (long long)n_sample, hv[0], hv[2], hv[1], s_sub, d_sub, twice, thrice, est, (int)c->clustered_rows);
+        fprintf(stderr, "[estimate] rows %lld sample %lld distinct %u | adjacent pairs %u differing %u (far pairs %u differing %u) | sub-sample %0.f distinct %0.f twice %0.f thrice %0.f | estimate %0.f clustered %d\n",
+                (long long)n_rows, (long long)n_sample, hv[0], hv[2], hv[1], h[8], h[7], s_sub, d_sub, twice, thrice, est, (int)c->clustered_rows);
     *out_est = (int64_t)est;
     return 0;
 }

@@ -199,6 +199,27 @@ def test_hot_key_partitions_are_sliced(ctx):
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 4, 5, 6, 7])
 
 
+def test_a_dominant_key_is_not_read_as_clustered_rows(ctx):
+    """90 % of the rows on ONE key in random order: neighbours share their key most of the time, but so do rows far apart (the
+    estimate's far-pair control) — the call keeps the lean aggregate / the absorb pass instead of the clustered-rows kernels;
+    the same rows SORTED by key must give the same groups."""
+    rng = np.random.default_rng(207)
+    n, g = 20_000_000, 300_000
+    ids = rng.integers(0, g, n)
+    ids[rng.random(n) < 0.9] = 7
+    keys = [(sparse_keys_from(ids), None, O.I64)]
+    vals = [(rng.normal(3, 2, n), None, O.F64), (rng.normal(-1, 5, n), None, O.F64)]
+    aggs = [(c, op) for c in range(2) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    exact = [2, 3, 6, 7, 8]
+    check(ctx, keys, n, vals, aggs, [O.I64], exact=exact)
+    t = ctx.timings()
+    assert t["absorbed_rows"] > 0.8 * n, t             # (the absorb pass took the hot key: only possible when the rows did not read as clustered)
+    order = np.argsort(ids, kind="stable")
+    keys_sorted = [(sparse_keys_from(ids[order]), None, O.I64)]
+    # (sorted: the hot key's run is far longer than the far pairs reach, so it still reads as a dominant key — any path must stay exact)
+    check(ctx, keys_sorted, n, [(vals[0][0][order], None, O.F64), (vals[1][0][order], None, O.F64)], aggs, [O.I64], exact=exact)
+
+
 def test_first_last_of_a_hot_key_are_sliced_too(ctx):
     """First / Last keep the min / max row index per group: those merge across the row slices of an oversized partition like any
     other state, and the value is looked up behind the merge (one workgroup used to walk the hot key's whole partition)."""
