@@ -126,7 +126,52 @@ __global__ __launch_bounds__(AB_THREADS) void absorb_kernel(AbsorbArgs a) {
                         if (slot == AB_NONE) slot = absorb_try_bucket(k, keys, b0 + 1 == NBK ? 0 : b0 + 1, claim);
                     }
                 }
-                if (slot != AB_NONE) {
+                // many lanes of the wave in ONE slot (a dominant key: 64 lanes adding to the same LDS words serialise): the lanes in the
+                // first placed lane's slot fold on the VALU and one lane applies the totals (as aggregate2's wave_fold), the others go on below
+                bool folded = false;
+                if (a.fold) {                                  // (uniform; off for ordinary inputs: the check alone cost C3 3 %)
+                    const unsigned long long placed = __ballot(slot != AB_NONE);
+                    if (placed) {                              // wave-uniform
+                        // (v_readlane with a scalar lane index: __shfl would be a ds_bpermute, i.e. one more op on the LDS pipe this kernel is bound by)
+                        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)slot, __builtin_amdgcn_readfirstlane(__ffsll((long long)placed) - 1));
+                        const bool same = slot == s0;
+                        const unsigned long long samew = __ballot(same);
+                        if (__popcll(samew) >= 40) {
+                            const bool l0 = (tid & 63) == 0;
+                            if (l0) atomicAdd(&gsz[s0], (uint32_t)__popcll(samew));
+#pragma unroll
+                            for (int c = 0; c < NSRC; c++) {
+                                const bool valid = same && ok[h][c];
+                                if (HAS_V && a.st_nn[c] >= 0) {
+                                    const unsigned long long vm = __ballot(valid);
+                                    if (l0 && vm) atomicAdd((unsigned long long *)&st[(size_t)a.st_nn[c] * T1 + s0], (unsigned long long)__popcll(vm));
+                                }
+                                if (OP_ADD) {
+                                    const uint64_t tot = wave_reduce64<KIND == 0 ? 0 : 1>(valid ? v[h][c] : 0ull, 0ull);
+                                    if (l0) {
+                                        if (KIND == 0) atomicAdd(reinterpret_cast<double *>(&st[(size_t)a.st_add[c] * T1 + s0]), __longlong_as_double((long long)tot));
+                                        else atomicAdd((unsigned long long *)&st[(size_t)a.st_add[c] * T1 + s0], (unsigned long long)tot);
+                                    }
+                                }
+                                if (OP_MIN || OP_MAX) {
+                                    bool cmp = valid;
+                                    if (KIND == 0) { const double dv = __longlong_as_double((long long)v[h][c]); cmp = cmp && dv == dv; }
+                                    const uint64_t e = KIND == 0 ? enc_f64(__longlong_as_double((long long)v[h][c])) : enc_i64((int64_t)v[h][c]);
+                                    if (OP_MIN) {
+                                        const uint64_t mn = wave_reduce64<2>(cmp ? e : ~0ull, ~0ull);
+                                        if (l0 && mn != ~0ull) atomicMin((unsigned long long *)&st[(size_t)a.st_min[c] * T1 + s0], (unsigned long long)mn);
+                                    }
+                                    if (OP_MAX) {
+                                        const uint64_t mx = wave_reduce64<3>(cmp ? e : 0ull, 0ull);
+                                        if (l0 && mx != 0ull) atomicMax((unsigned long long *)&st[(size_t)a.st_max[c] * T1 + s0], (unsigned long long)mx);
+                                    }
+                                }
+                            }
+                            folded = same;
+                        }
+                    }
+                }
+                if (slot != AB_NONE && !folded) {
                     atomicAdd(&gsz[slot], 1u);
                     uint64_t enc[NSRC], cur_mn[NSRC], cur_mx[NSRC];
 #pragma unroll

@@ -77,6 +77,33 @@ __device__ __forceinline__ uint64_t state_identity(int8_t kind) {
     default: return 0ull;   // +0.0 / 0
     }
 }
+// ---- wave-wide reductions on the VALU alone (DPP row shifts + row broadcasts; no LDS crossbar): the total ends in lane 63
+// and is read back as a wave-uniform value.  OP: 0 = f64 add, 1 = u64 add, 2 = u64 min, 3 = u64 max; `ident` is OP's identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_move64(uint64_t x, uint64_t ident) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ident, (int)(uint32_t)x, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ident >> 32), (int)(uint32_t)(x >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int OP>
+__device__ __forceinline__ uint64_t wave_op64(uint64_t a, uint64_t b) {
+    if (OP == 0) return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    if (OP == 1) return a + b;
+    if (OP == 2) return b < a ? b : a;
+    return b > a ? b : a;
+}
+template <int OP>
+__device__ __forceinline__ uint64_t wave_reduce64(uint64_t x, uint64_t ident) {
+    x = wave_op64<OP>(x, dpp_move64<0x111, 0xF>(x, ident));          // row_shr:1
+    x = wave_op64<OP>(x, dpp_move64<0x112, 0xF>(x, ident));          // row_shr:2
+    x = wave_op64<OP>(x, dpp_move64<0x114, 0xF>(x, ident));          // row_shr:4
+    x = wave_op64<OP>(x, dpp_move64<0x118, 0xF>(x, ident));          // row_shr:8   -> lane 15 of every row: the row's total
+    x = wave_op64<OP>(x, dpp_move64<0x142, 0xA>(x, ident));          // row_bcast:15 into rows 1, 3
+    x = wave_op64<OP>(x, dpp_move64<0x143, 0xC>(x, ident));          // row_bcast:31 into rows 2, 3 -> lane 63: the wave's total
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // natural (ABI / partial) representation of an LDS state cell
 __device__ __forceinline__ uint64_t state_natural(int8_t kind, uint64_t cell) {
     switch (kind) {
@@ -105,6 +132,7 @@ struct AbsorbArgs {
     uint32_t spill_P, spill_cap;
     uint64_t *sp_keys; uint64_t *sp_vals[MAX_ABS_SRC]; uint8_t *sp_valid[MAX_ABS_SRC];
     uint32_t *sp_count;                           // [grid * spill_P] rows in each region
+    int fold;                                     // 1: waves fold the lanes that sit in one slot (set when the sample's neighbours often share their key)
     int image_only;                               // 1: the table takes no key beyond the image (every workgroup then absorbs the SAME keys:
                                                   // the spilled rows' keys are disjoint from the absorbed ones — the compact spill relies on it)
     const uint64_t *hot_image;                    // optional [T]: the table every workgroup starts from (hot_image_kernel), nullptr = empty

@@ -91,33 +91,6 @@ __device__ __forceinline__ uint64_t enc_val(uint64_t bits) {
     return ((uint64_t)(hi ^ (sm | 0x80000000u)) << 32) | (uint32_t)(lo ^ sm);
 }
 
-// ---- wave-wide reductions on the VALU alone (DPP row shifts + row broadcasts; no LDS crossbar): the total ends in lane 63
-// and is read back as a wave-uniform value.  OP: 0 = f64 add, 1 = u64 add, 2 = u64 min, 3 = u64 max; `ident` is OP's identity.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp_move64(uint64_t x, uint64_t ident) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ident, (int)(uint32_t)x, CTRL, ROW_MASK, 0xF, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ident >> 32), (int)(uint32_t)(x >> 32), CTRL, ROW_MASK, 0xF, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int OP>
-__device__ __forceinline__ uint64_t wave_op64(uint64_t a, uint64_t b) {
-    if (OP == 0) return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
-    if (OP == 1) return a + b;
-    if (OP == 2) return b < a ? b : a;
-    return b > a ? b : a;
-}
-template <int OP>
-__device__ __forceinline__ uint64_t wave_reduce64(uint64_t x, uint64_t ident) {
-    x = wave_op64<OP>(x, dpp_move64<0x111, 0xF>(x, ident));          // row_shr:1
-    x = wave_op64<OP>(x, dpp_move64<0x112, 0xF>(x, ident));          // row_shr:2
-    x = wave_op64<OP>(x, dpp_move64<0x114, 0xF>(x, ident));          // row_shr:4
-    x = wave_op64<OP>(x, dpp_move64<0x118, 0xF>(x, ident));          // row_shr:8   -> lane 15 of every row: the row's total
-    x = wave_op64<OP>(x, dpp_move64<0x142, 0xA>(x, ident));          // row_bcast:15 into rows 1, 3
-    x = wave_op64<OP>(x, dpp_move64<0x143, 0xC>(x, ident));          // row_bcast:31 into rows 2, 3 -> lane 63: the wave's total
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 template <int NSRC, int PROFILE, int ABLATE, int DEPTH, bool SMALL = false>
 __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     constexpr bool HAS_V = (PROFILE & 1) != 0, OP_ADD = ((PROFILE >> 1) & 1) != 0;
@@ -432,7 +405,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                 {
                     const unsigned long long okw = __ballot(ok);
                     if (okw) {
-                        const uint32_t s0 = __shfl(idx, __ffsll((long long)okw) - 1, 64);
+                        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)idx, __builtin_amdgcn_readfirstlane(__ffsll((long long)okw) - 1));   // (not __shfl: that is a ds_bpermute, LDS pipe)
                         const bool same = ok && idx == s0;
                         const unsigned long long samew = __ballot(same);
                         if ((uint32_t)__popcll(samew) >= (cur_multi ? a.fold_min_multi : a.fold_min)) {

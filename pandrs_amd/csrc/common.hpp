@@ -222,6 +222,7 @@ struct pandrs_hip_ctx {
     void *small_table = nullptr;      // the small path's armed global table (groupby.hip run_small)
     uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)
     int64_t reserve_groups = 0;       // result rows the next res_slot-0 engine run keeps free behind its groups (a caller appends there)
+    double est_near_same = 0.0;       // of the last estimate's sample: share of adjacent row pairs with equal keys (a dominant key or clustered rows)
     double est_repeat_share = 0.0;    // of the last estimate's sample: rows on keys sighted >= 3 times (a hot set shows here whatever the tail's length)
     bool est_kept = false;            // the table still holds the last estimate's keys (estimate_coverage / estimate_release pending)
     bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)

@@ -965,6 +965,7 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     ST_TRY(c->absorb.ensure((compact ? 2 : 1) * ((1 + (size_t)n_src) * Arena::padded(region_rows * 8 + 256) + (has_v ? (size_t)n_src * Arena::padded(region_rows + 256) : 0)) + (1 << 20), c->stream));
     AbsorbArgs a{};
     a.key = rs.key; a.n_rows = (uint32_t)N; a.chunk = chunk; a.T = (uint32_t)T; a.seed = ABSORB_SEED; a.n_src = n_src; a.hot_image = hot_image; a.image_only = compact ? 1 : 0;
+    a.fold = c->est_near_same > 0.3 ? 1 : 0;       // (a key with > 55 % of the rows, or long runs: 40 of a wave's 64 lanes in one slot is likely)
     a.spill_P = (uint32_t)PS; a.spill_cap = cap_wp;
     a.sp_keys = c->absorb.take<uint64_t>(region_rows + 16);
     AggArgs aa{};
@@ -1218,7 +1219,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
     }
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est, /*keep_table=*/absorb_profile >= 0));
-    else c->clustered_rows = false;          // no sample taken: nothing known about the row order
+    else { c->clustered_rows = false; c->est_near_same = 0.0; }          // no sample taken: nothing known about the row order
     c->timings.estimated_groups = est;
     int64_t T_abs = 0;
     bool do_absorb = false;

@@ -986,6 +986,7 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         est = std::min<double>(std::max(G, d), (double)n_rows);
     }
     c->clustered_rows = false;
+    c->est_near_same = hv[2] >= 1024 ? 1.0 - (double)hv[1] / (double)hv[2] : 0.0;
     if (hv[2] >= 1024) {
         // most neighbours share their key — and far more often than rows far apart do (a dominant key alone puts equal keys next to
         // each other in any order: 90 % of the rows on one key read as "clustered", which kept the lean aggregate and the absorb pass away)
