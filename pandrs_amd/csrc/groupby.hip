@@ -1694,7 +1694,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                     os.val_valid_bytes[s2] = (uni_profile & 1) ? aa.ov_valid[s2] : nullptr;
                 }
                 Options saved = c->opt;
-                c->opt.partitions = 0; c->opt.groups_hint = 0; c->opt.no_absorb = 1;
+                c->opt.partitions = 0; c->opt.no_absorb = 1;
+                c->opt.groups_hint = n_ov <= 4096 ? n_ov : 0;       // (a handful of rows: every row its own group at worst — no sample, no round trip for it)
                 pandrs_hip_timings tsave = c->timings;
                 c->quiet++;
                 int32_t st = run_engine(c, os, pl, /*merge=*/false, partials, n_aggs, key_dtype, 1, res_slot + 1);
