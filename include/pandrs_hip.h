@@ -10,7 +10,9 @@
  *   - plain pointers and sizes only; no C++/torch types.
  *   - every function returns a pandrs_hip_status (0 = ok); on failure a thread-local
  *     message is available from pandrs_hip_last_error().  Nothing panics/aborts
- *     across the ABI (reference: Result<T, pandrs::Error>, src/core/error.rs:6).
+ *     across the ABI (reference: Result<T, pandrs::Error>, src/core/error.rs:6): every
+ *     entry point catches C++ exceptions of its host code (std::bad_alloc ->
+ *     PANDRS_HIP_ERR_OUT_OF_MEMORY, anything else -> PANDRS_HIP_ERR_COMPUTATION).
  *   - `mem_space` says where the caller's column / output pointers live:
  *     PANDRS_HIP_MEM_HOST (library stages H2D/D2H itself) or PANDRS_HIP_MEM_DEVICE
  *     (pointers are HBM addresses on the context's device; nothing crosses PCIe).
@@ -204,6 +206,10 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "agg_ablate"        experiments only: switch parts of the lean aggregate off (see experiments/agg2_ablate.py)
  *   "no_runs"           1 = never the clustered-rows (RUNS) instantiation
  *   "no_direct"         1 = never the few-groups direct path (-1 = allow it below 4 M rows too)
+ *   "test_throw"        tests of the exception firewall (ctx may be NULL): 1 = the entry point's host code throws std::bad_alloc
+ *                       (-> PANDRS_HIP_ERR_OUT_OF_MEMORY), 2 = std::out_of_range, 3 = a non-std exception, 4 = an oversized
+ *                       std::vector::resize (2 - 4 -> PANDRS_HIP_ERR_COMPUTATION, or OUT_OF_MEMORY for bad_alloc); never a crash
+ *   "tail_groups_hint"  tests: the group estimate handed to the tail run of the absorb pass's compact spill (0 = its own sample)
  *   "no_overflow_run"   1 = a full LDS table fails the attempt (the call is retried with 4 x the fan-out) instead of handing the rows it
  *                       could not place to a run of their own, whose groups are appended
  *   "sorted_dictionary" 1 = a column of a composite key that is too wide for its share of the 64-bit cell gets its dictionary codes by
@@ -410,6 +416,19 @@ int32_t pandrs_hip_gather_u32(pandrs_hip_ctx *ctx, int32_t mem_space, const uint
  * fill value's bit pattern), 4 for U32CODE, and one 0/1 byte per row for BOOLBITS. */
 int32_t pandrs_hip_gather_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *src,
                                  int64_t n_src, const int64_t *idx, int64_t n, uint64_t fill_bits, void *out);
+/* One output column of the join whose pairs this context still holds (the last pandrs_hip_join_indices):
+ * out[i] = the gather above with idx = the pairs' left rows (side 0) or right rows (side 1).  This is
+ * join_impl's column assembly (join.rs:286-552) with the index pairs never leaving HBM: a shim fetches the
+ * joined COLUMNS, not 16 bytes of indices per output row.  `src` lives in src_mem_space (a resident column
+ * descriptor from pandrs_hip_column_upload, or a host column, which is staged); `out` (element sizes as for
+ * pandrs_hip_gather_column, pandrs_hip_join_indices' *out_n_rows elements) lives in out_mem_space. */
+int32_t pandrs_hip_join_gather(pandrs_hip_ctx *ctx, int32_t src_mem_space, const pandrs_hip_column *src,
+                               int64_t n_src, int32_t side, uint64_t fill_bits, int32_t out_mem_space, void *out);
+/* The join-key column of that frame (join.rs:364-470): the LEFT key's value where the pair has a left row (a null
+ * there becomes the fill value), else the RIGHT key's value at the pair's right row (right / outer joins). */
+int32_t pandrs_hip_join_gather_key(pandrs_hip_ctx *ctx, int32_t src_mem_space, const pandrs_hip_column *left_key,
+                                   int64_t n_left, const pandrs_hip_column *right_key, int64_t n_right,
+                                   uint64_t fill_bits, int32_t out_mem_space, void *out);
 /* bit-packed source (BooleanColumn), byte-per-row output */
 int32_t pandrs_hip_gather_bool(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *src_bits,
                                const uint8_t *src_null_mask, const int64_t *idx, int64_t n,

@@ -39,7 +39,7 @@ namespace pandrs {
 
 // ---- errors (src/core/error.rs) ---------------------------------------------------------------------
 struct Error : std::runtime_error {
-    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount, Empty, Type, BelowThreshold };
+    enum Kind { ColumnNotFound, ColumnTypeMismatch, OperationFailed, Computation, InvalidInput, DuplicateColumnName, InconsistentRowCount, Empty, Type, BelowThreshold, Index };
     Kind kind;
     Error(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
 };
@@ -209,6 +209,11 @@ public:
     std::vector<Column> columns;
     std::vector<std::string> column_names;
     std::unordered_map<std::string, size_t> column_indices;
+    // the StringMultiIndex a multi-key group_by(..).aggregate(..) sets instead of key columns (aggregation.rs:812-853,
+    // split_dataframe/index.rs:94-111): one tuple of key strings per row, the level names = the grouping columns
+    std::vector<std::vector<std::string>> multi_index;
+    std::vector<std::string> multi_index_names;
+    bool has_multi_index() const { return !multi_index_names.empty(); }
 
     OptimizedDataFrame &add_column(const std::string &name, Column column) {
         if (column_indices.count(name)) throw Error(Error::DuplicateColumnName, name);
@@ -252,7 +257,8 @@ public:
     size_t row_count() const { return row_count_; }
     size_t column_count() const { return columns.size(); }
 
-    GroupBy group_by(const std::vector<std::string> &cols) const;                      // grouping.rs:22-28
+    GroupBy group_by(const std::vector<std::string> &cols) const;                      // grouping.rs:22-28: as_multi_index = true
+    GroupBy group_by_with_options(const std::vector<std::string> &cols, bool as_multi_index) const;   // grouping.rs:38-115
     std::map<std::string, OptimizedDataFrame> par_groupby(const std::vector<std::string> &cols) const;   // grouping.rs:124-331
 
     OptimizedDataFrame inner_join(const OptimizedDataFrame &o, const std::string &l, const std::string &r) const { return join_impl(o, l, r, JoinType::Inner); }
@@ -323,8 +329,9 @@ private:
         int64_t n = 0;      // a key-type mismatch surfaces as ColumnTypeMismatch from the library (:98-104)
         detail::check(pandrs_hip_join_indices(detail::context(), dev ? PANDRS_HIP_MEM_DEVICE : PANDRS_HIP_MEM_HOST, &lv, (int64_t)detail::col_len(lc), &rv,
                                               (int64_t)detail::col_len(rc), (int32_t)how, &n));
-        std::vector<int64_t> li(n), ri(n);
-        detail::check(pandrs_hip_join_fetch(detail::context(), PANDRS_HIP_MEM_HOST, li.data(), ri.data()));
+        // the pairs stay in HBM (the context retains them); every output column is ONE gather through them and one
+        // transfer of the finished column (pandrs_hip_join_gather) — not 16 bytes of indices per output row
+        const int32_t space = dev ? PANDRS_HIP_MEM_DEVICE : PANDRS_HIP_MEM_HOST;
         OptimizedDataFrame result;
         if (n == 0) {       // empty result: NON-KEY columns only, suffix decided against the LEFT frame (:227-284)
             for (auto &name : column_names) if (name != left_on) result.add_column(name, gather(column(name), {}));
@@ -332,26 +339,31 @@ private:
                 if (name != right_on) result.add_column(contains_column(name) ? name + "_right" : name, gather(other.column(name), {}));
             return result;
         }
-        for (auto &name : column_names) if (name != left_on) result.add_column(name, gather(column(name), li));     // :290-361
-        {   // key column: the left value, else the right one (:364-472)
-            Column a = gather(lc, li), b = gather(rc, ri);
-            std::visit([&](auto &x) {
-                using T = std::decay_t<decltype(x)>;
-                auto &y = std::get<T>(b);
-                if constexpr (std::is_same_v<T, BooleanColumn>) {
-                    std::vector<bool> v(n);
-                    for (int64_t i = 0; i < n; i++) v[i] = li[i] >= 0 ? x.get(i) : y.get(i);
-                    x = BooleanColumn(v);
-                } else if constexpr (std::is_same_v<T, StringColumn>) {
-                    for (int64_t i = 0; i < n; i++) if (li[i] < 0) x.indices[i] = y.indices[i];
-                } else {
-                    for (int64_t i = 0; i < n; i++) if (li[i] < 0) x.data[i] = y.data[i];
-                }
-            }, a);
-            result.add_column(left_on, std::move(a));
-        }
+        auto joined = [&](const OptimizedDataFrame &f, const std::string &name, int side, const pandrs_hip_column *key_right, int64_t n_right) -> Column {
+            const Column &src = f.column(name);
+            pandrs_hip_column v = dev ? f.view_of(name) : detail::view(src);
+            const int64_t n_src = (int64_t)detail::col_len(src);
+            auto call = [&](uint64_t fill, void *out) {
+                if (key_right) detail::check(pandrs_hip_join_gather_key(detail::context(), space, &v, n_src, key_right, n_right, fill, PANDRS_HIP_MEM_HOST, out));
+                else detail::check(pandrs_hip_join_gather(detail::context(), space, &v, n_src, side, fill, PANDRS_HIP_MEM_HOST, out));
+            };
+            switch (src.index()) {
+            case 0: { Int64Column o; o.data.resize(n); call(0, o.data.data()); return o; }
+            case 1: { Float64Column o; o.data.resize(n); call(0, o.data.data()); return o; }
+            case 2: { StringColumn o; o.indices.resize(n); call(StringPool::global().get_or_insert(""), o.indices.data()); return o; }
+            default: {
+                std::vector<uint8_t> bytes(n);
+                call(0, bytes.data());
+                std::vector<bool> b(n);
+                for (int64_t i = 0; i < n; i++) b[i] = bytes[i] != 0;
+                return BooleanColumn(b);
+            }
+            }
+        };
+        for (auto &name : column_names) if (name != left_on) result.add_column(name, joined(*this, name, 0, nullptr, 0));     // :290-361
+        result.add_column(left_on, joined(*this, left_on, 0, &rv, (int64_t)detail::col_len(rc)));       // key column: the left value, else the right one (:364-472)
         for (auto &name : other.column_names)                                                                       // :475-552
-            if (name != right_on) result.add_column(result.contains_column(name) ? name + "_right" : name, gather(other.column(name), ri));
+            if (name != right_on) result.add_column(result.contains_column(name) ? name + "_right" : name, joined(other, name, 1, nullptr, 0));
         return result;
     }
     friend class GroupBy;
@@ -363,8 +375,10 @@ public:
     using Aggregation = std::tuple<std::string, AggregateOp, std::string>;      // (column, op, alias)
     const OptimizedDataFrame &df;
     std::vector<std::string> group_by_columns;
+    bool create_multi_index = false;       // types.rs:54; set by group_by for >= 2 keys (grouping.rs:27, :107)
 
-    GroupBy(const OptimizedDataFrame &d, std::vector<std::string> cols) : df(d), group_by_columns(std::move(cols)) {}
+    GroupBy(const OptimizedDataFrame &d, std::vector<std::string> cols, bool multi_index = false)
+        : df(d), group_by_columns(std::move(cols)), create_multi_index(multi_index) {}
 
     // aggregation.rs:763-871: key column(s) as strings, then one Float64 column per alias in request order
     OptimizedDataFrame aggregate(const std::vector<Aggregation> &aggregations) const {
@@ -393,10 +407,19 @@ public:
         for (auto &v : oa) pa.push_back(v.data());
         detail::check(pandrs_hip_groupby_fetch(detail::context(), PANDRS_HIP_MEM_HOST, pk.data(), pn.data(), pa.data()));
         OptimizedDataFrame result;
-        for (size_t k = 0; k < nk; k++) {
-            std::vector<std::string> strs(g);
-            for (int64_t i = 0; i < g; i++) strs[i] = detail::key_string(keys[k].dtype, kc[k][i], kn[k][i] != 0);
-            result.add_column(group_by_columns[k], StringColumn(strs));                                           // :856-860
+        std::vector<std::vector<std::string>> key_strings(nk, std::vector<std::string>(g));
+        for (size_t k = 0; k < nk; k++)
+            for (int64_t i = 0; i < g; i++) key_strings[k][i] = detail::key_string(keys[k].dtype, kc[k][i], kn[k][i] != 0);
+        if (create_multi_index && nk > 1) {
+            // :812-853: the key tuples become a StringMultiIndex (from_tuples refuses an empty list, multi_index.rs:160),
+            // the result holds the aggregate columns only
+            if (g == 0) throw Error(Error::Index, "Empty tuple list was passed");
+            result.multi_index.assign((size_t)g, std::vector<std::string>(nk));
+            for (int64_t i = 0; i < g; i++)
+                for (size_t k = 0; k < nk; k++) result.multi_index[i][k] = key_strings[k][i];
+            result.multi_index_names = group_by_columns;
+        } else {
+            for (size_t k = 0; k < nk; k++) result.add_column(group_by_columns[k], StringColumn(key_strings[k]));    // :856-860
         }
         for (size_t a = 0; a < na; a++) result.add_column(std::get<2>(aggregations[a]), Float64Column(oa[a]));  // :863-867
         return result;
@@ -518,9 +541,10 @@ public:
     }
 };
 
-inline GroupBy OptimizedDataFrame::group_by(const std::vector<std::string> &cols) const {
+inline GroupBy OptimizedDataFrame::group_by(const std::vector<std::string> &cols) const { return group_by_with_options(cols, true); }
+inline GroupBy OptimizedDataFrame::group_by_with_options(const std::vector<std::string> &cols, bool as_multi_index) const {
     for (auto &c : cols) if (!contains_column(c)) throw Error(Error::ColumnNotFound, c);       // grouping.rs:53-57
-    return GroupBy(*this, cols);
+    return GroupBy(*this, cols, as_multi_index && cols.size() > 1);                              // grouping.rs:107
 }
 inline std::map<std::string, OptimizedDataFrame> OptimizedDataFrame::par_groupby(const std::vector<std::string> &cols) const {
     for (auto &c : cols) if (!contains_column(c)) throw Error(Error::ColumnNotFound, c);
@@ -554,15 +578,28 @@ public:
     }
     OptimizedDataFrame execute() const {
         OptimizedDataFrame df = source_;
-        for (auto &op : ops_) {
+        for (size_t oi = 0; oi < ops_.size(); oi++) {
+            const Op &op = ops_[oi];
             if (op.is_aggregate) {
                 for (auto &a : op.aggregations) {                   // lazy.rs:377-382: only these five ops
                     const AggregateOp o = std::get<1>(a);
                     if (o != AggregateOp::Sum && o != AggregateOp::Mean && o != AggregateOp::Min && o != AggregateOp::Max && o != AggregateOp::Count)
                         throw Error(Error::OperationFailed, "Aggregation operation " + GroupBy::op_name(o) + " is not supported in LazyFrame");
                 }
-                df = df.group_by(op.group_by).aggregate(op.aggregations);
+                // the arm builds its frame inline and never a multi-index: key columns always (lazy.rs:390-394;
+                // tests/optimized_groupby_test.rs:184 asserts 3 columns for two keys)
+                df = df.group_by_with_options(op.group_by, false).aggregate(op.aggregations);
             } else {
+                // Join(Inner) immediately followed by Aggregate([g], [(v, Sum, alias)]) with v a left column and g a right
+                // column (lazy.rs:405-425 then :186) = BASELINE config 5: ONE fused device operator, no joined rows
+                if (op.how == JoinType::Inner && oi + 1 < ops_.size() && ops_[oi + 1].is_aggregate) {
+                    OptimizedDataFrame fused;
+                    if (fused_join_groupby_sum(df, *op.right, op.left_on, op.right_on, ops_[oi + 1], fused)) {
+                        df = std::move(fused);
+                        oi++;
+                        continue;
+                    }
+                }
                 switch (op.how) {                                   // lazy.rs:405-425
                 case JoinType::Inner: df = df.inner_join(*op.right, op.left_on, op.right_on); break;
                 case JoinType::Left: df = df.left_join(*op.right, op.left_on, op.right_on); break;
@@ -582,6 +619,39 @@ private:
         std::string left_on, right_on;
         JoinType how;
     };
+    // the shape test of hip_shim.rs `lazy_join_groupby_sum_hip` (same conditions, same result frame)
+    static bool fused_join_groupby_sum(const OptimizedDataFrame &left, const OptimizedDataFrame &right, const std::string &left_on,
+                                       const std::string &right_on, const Op &agg, OptimizedDataFrame &out) {
+        if (agg.group_by.size() != 1 || agg.aggregations.size() != 1 || std::get<1>(agg.aggregations[0]) != AggregateOp::Sum) return false;
+        const std::string &group_col = agg.group_by[0], &value_col = std::get<0>(agg.aggregations[0]), &alias = std::get<2>(agg.aggregations[0]);
+        if (!left.contains_column(left_on) || !right.contains_column(right_on)) return false;     // the join arm throws ColumnNotFound
+        if (value_col == left_on || !left.contains_column(value_col) || left.contains_column(group_col)) return false;
+        std::string right_name;
+        const std::string suffix = "_right";
+        if (group_col.size() > suffix.size() && group_col.compare(group_col.size() - suffix.size(), suffix.size(), suffix) == 0 &&
+            left.contains_column(group_col.substr(0, group_col.size() - suffix.size())) && right.contains_column(group_col.substr(0, group_col.size() - suffix.size())))
+            right_name = group_col.substr(0, group_col.size() - suffix.size());               // join.rs:478-482
+        else if (right.contains_column(group_col)) right_name = group_col;
+        else return false;
+        if (right_name == right_on) return false;
+        const Column &lk = left.column(left_on), &lv = left.column(value_col), &rk = right.column(right_on), &rg = right.column(right_name);
+        if (lk.index() != rk.index() || lv.index() > 1 || rg.index() == 3) return false;
+        if (std::visit([](auto &x) { return !x.null_mask.empty(); }, rg)) return false;       // a null g would surface as the join's fill value (join.rs:304-307)
+        const bool dev = left.is_resident() && right.is_resident();
+        pandrs_hip_column a = dev ? left.view_of(left_on) : detail::view(lk), b = dev ? left.view_of(value_col) : detail::view(lv),
+                          c = dev ? right.view_of(right_on) : detail::view(rk), d = dev ? right.view_of(right_name) : detail::view(rg);
+        int64_t g = 0;
+        detail::check(pandrs_hip_join_groupby_sum(detail::context(), dev ? PANDRS_HIP_MEM_DEVICE : PANDRS_HIP_MEM_HOST, &a, &b, (int64_t)left.row_count(), &c, &d,
+                                                  (int64_t)right.row_count(), &g));
+        std::vector<uint64_t> cells(g); std::vector<uint8_t> nulls(g); std::vector<double> sums(g);
+        uint64_t *pk[1] = {cells.data()}; uint8_t *pn[1] = {nulls.data()}; double *pa[1] = {sums.data()};
+        detail::check(pandrs_hip_groupby_fetch(detail::context(), PANDRS_HIP_MEM_HOST, pk, pn, pa));
+        std::vector<std::string> strs(g);
+        for (int64_t i = 0; i < g; i++) strs[i] = detail::key_string(d.dtype, cells[i], nulls[i] != 0);
+        out.add_column(group_col, StringColumn(strs));
+        out.add_column(alias, Float64Column(sums));
+        return true;
+    }
     OptimizedDataFrame source_;
     std::vector<Op> ops_;
 };

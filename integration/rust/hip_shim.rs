@@ -1,17 +1,28 @@
 // hip_shim.rs — the crate-side shim over hip_ffi.rs: add as src/gpu/hip_shim.rs (cfg(hip_available)) together with
 // hip_ffi.rs.  NOT compiled in this repository's build image (no Rust toolchain); the same ABI calls, in the same
 // order, are what include/pandrs_hip.hpp (C++) and pandrs_amd/frame.py (Python) make and what their tests replay.
-// tests/test_rust_shim.py checks every field and method this file touches on a reference type against
-// /root/reference/src (all of them are `pub` or `pub(crate)` there: the shim lives inside the crate).
+// tests/test_rust_shim.py checks (a) every field and method this file touches on a reference type against
+// /root/reference/src (all of them are `pub` or `pub(crate)` there: the shim lives inside the crate), and (b) for
+// every patched call site, that the TYPE the call site's file imports for each argument is the type this file's
+// signature names (round 3 shipped a lazy.rs call that handed the public frame to a split-frame parameter).
+//
+// The crate has TWO frame types and TWO AggregateOp enums:
+//   split frame   crate::optimized::split_dataframe::core::OptimizedDataFrame      fields pub(crate)  (core.rs:13-24)
+//   public frame  crate::optimized::dataframe::OptimizedDataFrame                   fields pub(super)  (dataframe/core.rs:22-33)
+//   split op      crate::optimized::split_dataframe::group::types::AggregateOp      (types.rs:11-34)
+//   public op     crate::optimized::operations::AggregateOp                         (operations.rs:3-26, same order)
+// Entry points are typed on exactly one of each and say which in their name: `*_split` is called from
+// split_dataframe/*, `lazy_*` from src/optimized/lazy.rs (public frame, public op: lazy.rs:7-8).
 //
 // Seams served (see patches/*.patch):
 //   OptimizedDataFrame::group_by    src/optimized/split_dataframe/group/grouping.rs:38-115  (GroupBy.groups, filled lazily)
 //   OptimizedDataFrame::par_groupby src/optimized/split_dataframe/group/grouping.rs:124-331
-//   GroupBy::aggregate              src/optimized/split_dataframe/group/aggregation.rs:763
+//   GroupBy::aggregate              src/optimized/split_dataframe/group/aggregation.rs:763   (incl. the StringMultiIndex branch :812-853)
 //   LazyFrame::execute, Aggregate   src/optimized/lazy.rs:186
-//   OptimizedDataFrame::join_impl   src/optimized/split_dataframe/join.rs:106-224
-// The PUBLIC frame (src/optimized/dataframe/transformations.rs:524-577 aggregate, :628-905 the four joins, :524
-// par_groupby) needs no patch of its own: every wrapper Arc-clones its columns into a split frame and calls the seams
+//   LazyFrame::execute, Join followed by Aggregate (sum of a left column by a right column): the fused C5 operator
+//   OptimizedDataFrame::join_impl   src/optimized/split_dataframe/join.rs:106-552  (pairs AND column assembly on the device)
+// The PUBLIC frame's own operators (src/optimized/dataframe/transformations.rs:524-577 aggregate, :628-905 the four
+// joins, :524 par_groupby) need no patch: every wrapper Arc-clones its columns into a split frame and calls the seams
 // above, and the clone keeps the Arc's data pointer — the key of the resident cache below — so a column uploaded
 // for one call is found again by the next, whichever frame object carries it.
 #![cfg(hip_available)]
@@ -19,34 +30,51 @@
 use std::cell::RefCell;
 use std::collections::HashMap;
 use std::ffi::CStr;
-use std::sync::Arc;
+use std::sync::{Arc, Mutex, OnceLock};
 
 use super::hip_ffi::*;
 use crate::column::string_pool::GLOBAL_STRING_POOL;
-use crate::column::{Column, ColumnTrait, Float64Column, StringColumn, StringColumnOptimizationMode};
+use crate::column::{BooleanColumn, Column, ColumnTrait, Float64Column, Int64Column, StringColumn, StringColumnOptimizationMode};
 use crate::core::error::{Error, Result};
-use crate::optimized::split_dataframe::core::OptimizedDataFrame;
-use crate::optimized::split_dataframe::group::types::AggregateOp;
+use crate::index::StringMultiIndex;
+use crate::optimized::dataframe::OptimizedDataFrame as PublicFrame;
+use crate::optimized::operations::AggregateOp as PublicAggregateOp;
+use crate::optimized::split_dataframe::core::OptimizedDataFrame as SplitFrame;
+use crate::optimized::split_dataframe::group::types::AggregateOp as SplitAggregateOp;
 use crate::optimized::split_dataframe::join::JoinType;
 
-/// One context (HIP stream + workspace + resident columns) per thread: contexts are independent, so rayon workers
-/// never contend.
+/// Both AggregateOp enums list the same variants in the same order — the order of pandrs_hip_agg_op
+/// (include/pandrs_hip.h:70-87) — so the discriminant IS the ABI code.
+pub trait HipAggOp: Copy {
+    fn code(self) -> i32;
+}
+impl HipAggOp for SplitAggregateOp {
+    fn code(self) -> i32 {
+        self as i32
+    }
+}
+impl HipAggOp for PublicAggregateOp {
+    fn code(self) -> i32 {
+        self as i32
+    }
+}
+
+/// One compute context (HIP stream + workspace) per thread: contexts are independent, so rayon workers never
+/// contend (tests/concurrency_test.rs:351-398).  Resident columns are NOT per thread: see RESIDENT below.
 pub struct HipContext {
     ctx: *mut PandrsHipCtx,
-    resident: ResidentCache,
 }
 
 impl HipContext {
     fn new() -> Result<Self> {
         let mut ctx: *mut PandrsHipCtx = std::ptr::null_mut();
         check(unsafe { pandrs_hip_ctx_create(-1, &mut ctx) })?;
-        Ok(HipContext { ctx, resident: ResidentCache::default() })
+        Ok(HipContext { ctx })
     }
 }
 
 impl Drop for HipContext {
     fn drop(&mut self) {
-        // pandrs_hip_ctx_destroy frees the columns still resident
         unsafe { pandrs_hip_ctx_destroy(self.ctx) };
     }
 }
@@ -55,13 +83,13 @@ thread_local! {
     static CTX: RefCell<Option<HipContext>> = RefCell::new(None);
 }
 
-fn with_ctx<T>(f: impl FnOnce(&mut HipContext) -> Result<T>) -> Result<T> {
+fn with_ctx<T>(f: impl FnOnce(*mut PandrsHipCtx) -> Result<T>) -> Result<T> {
     CTX.with(|slot| {
         let mut slot = slot.borrow_mut();
         if slot.is_none() {
             *slot = Some(HipContext::new()?);
         }
-        f(slot.as_mut().unwrap())
+        f(slot.as_ref().unwrap().ctx)
     })
 }
 
@@ -88,6 +116,11 @@ pub fn hip_wanted(row_count: usize) -> bool {
     }
 }
 
+/// Whether a device-side failure falls back to the CPU body (GpuConfig.fallback_to_cpu, src/gpu/mod.rs:26).
+pub fn hip_fallback_to_cpu() -> bool {
+    crate::gpu::get_gpu_manager().map(|m| m.context().config().fallback_to_cpu).unwrap_or(true)
+}
+
 fn mask_ptr(mask: &Option<Arc<[u8]>>) -> *const u8 {
     mask.as_ref().map_or(std::ptr::null(), |m| m.as_ptr())
 }
@@ -111,112 +144,151 @@ fn view(col: &Column) -> Option<PandrsHipColumn> {
     })
 }
 
-// ---- resident columns ----------------------------------------------------------------------------------------------
+// ---- resident columns: ONE cache per process ------------------------------------------------------------------------
 // Columns are immutable Arc<[T]> buffers (src/column/int64_column.rs:10): uploaded once, a column serves every later
 // aggregate / join from HBM (through PANDRS_HIP_MEM_HOST every call would stage it over PCIe again: 75 ms instead of
-// 3.3 ms for 100 M rows x 5 columns).  Key: the data Arc's pointer.  Each entry keeps Weak handles of the Arcs it
-// was uploaded from: a Weak keeps the ALLOCATION alive after the last strong reference is gone, so the address
-// cannot be reused while the entry exists, and `alive()` turning false is the signal to evict.
+// 3.3 ms for 100 M rows x 5 columns).  The cache is process-wide (round 3 had one per thread: four rayon workers
+// grouping the same frame uploaded it four times): it owns a context of its own that does nothing but upload and
+// release, and hands out descriptors — plain HBM addresses, readable by every context on the device
+// (include/pandrs_hip.h, "resident columns").  Key: the data Arc's pointer.  Each entry keeps Weak handles of the
+// Arcs it was uploaded from: a Weak keeps the ALLOCATION alive after the last strong reference is gone, so the
+// address cannot be reused while the entry exists, and `alive()` turning false is the signal to evict.  An entry
+// in use by a call in flight on ANY thread is pinned (`pins` > 0) and never evicted; every library call is
+// synchronous, so an unpinned entry has no reader.
 struct ResidentEntry {
     desc: PandrsHipColumn,
     bytes: usize,
-    alive: Box<dyn Fn() -> bool>,
+    alive: Box<dyn Fn() -> bool + Send>,
     last_use: u64,
+    pins: usize,
 }
 
-#[derive(Default)]
 struct ResidentCache {
+    owner: HipContext,
     entries: HashMap<usize, ResidentEntry>,
     bytes: usize,
     clock: u64,
-    pin_epoch: u64,     // entries used at or after this tick belong to the call in progress: never evicted
 }
 
-fn liveness<T: ?Sized + 'static>(data: &Arc<T>, mask: &Option<Arc<[u8]>>) -> Box<dyn Fn() -> bool> {
+// the raw context pointer is only ever used under the cache's mutex
+unsafe impl Send for ResidentCache {}
+
+static RESIDENT: OnceLock<Mutex<Option<ResidentCache>>> = OnceLock::new();
+
+fn liveness<T: ?Sized + Send + Sync + 'static>(data: &Arc<T>, mask: &Option<Arc<[u8]>>) -> Box<dyn Fn() -> bool + Send> {
     let d = Arc::downgrade(data);
     let m = mask.as_ref().map(Arc::downgrade);
     Box::new(move || d.strong_count() > 0 && m.as_ref().map_or(true, |m| m.strong_count() > 0))
 }
 
-impl ResidentCache {
-    fn release(ctx: *mut PandrsHipCtx, e: &ResidentEntry) {
-        unsafe { pandrs_hip_column_release(ctx, &e.desc) };
-    }
+/// The columns one call reads: pinned in the cache until dropped.
+struct Pinned {
+    keys: Vec<usize>,
+}
 
-    /// Every public entry point of this file calls this first: descriptors handed out from here on stay valid
-    /// until the library call that uses them has returned.
-    fn begin_call(&mut self) {
-        self.clock += 1;
-        self.pin_epoch = self.clock;
+impl Drop for Pinned {
+    fn drop(&mut self) {
+        if let Some(lock) = RESIDENT.get() {
+            if let Ok(mut guard) = lock.lock() {
+                if let Some(cache) = guard.as_mut() {
+                    for k in &self.keys {
+                        if let Some(e) = cache.entries.get_mut(k) {
+                            e.pins -= 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+impl ResidentCache {
+    fn release(&mut self, key: usize) {
+        if let Some(e) = self.entries.remove(&key) {
+            self.bytes -= e.bytes;
+            unsafe { pandrs_hip_column_release(self.owner.ctx, &e.desc) };
+        }
     }
 
     /// Device descriptor of `col`, uploading it on first sight.  Dropped columns are evicted on every call; when
-    /// the budget (half of GpuConfig.memory_limit, the other half is the library's workspace) would be exceeded,
-    /// the least recently used live entries go first.
-    fn get(&mut self, ctx: *mut PandrsHipCtx, col: &Column, n_rows: usize) -> Result<Option<PandrsHipColumn>> {
+    /// the budget (half of GpuConfig.memory_limit — DEFAULT 1 GB, src/gpu/mod.rs:37: raise it for frames beyond
+    /// 512 MB, INTEGRATION.md — the other half is the library's workspace) would be exceeded, the least recently
+    /// used unpinned entries go first.
+    fn get(&mut self, col: &Column, n_rows: usize, pinned: &mut Pinned) -> Result<Option<PandrsHipColumn>> {
         let host = match view(col) {
             Some(v) => v,
             None => return Ok(None),
         };
-        let dead: Vec<usize> = self.entries.iter().filter(|(_, e)| !(e.alive)()).map(|(k, _)| *k).collect();
+        self.clock += 1;
+        let dead: Vec<usize> = self.entries.iter().filter(|(_, e)| e.pins == 0 && !(e.alive)()).map(|(k, _)| *k).collect();
         for k in dead {
-            if let Some(e) = self.entries.remove(&k) {
-                self.bytes -= e.bytes;
-                Self::release(ctx, &e);
-            }
+            self.release(k);
         }
         let key = host.data as usize;
         if let Some(e) = self.entries.get_mut(&key) {
             if e.desc.dtype == host.dtype && e.desc.null_mask.is_null() == host.null_mask.is_null() {
                 e.last_use = self.clock;
+                e.pins += 1;
+                pinned.keys.push(key);
                 return Ok(Some(e.desc));
             }
+            if e.pins > 0 {
+                // the same buffer, seen as another column type by a call in flight: serve this call from the host copy
+                return Err(Error::Computation("resident column is in use under another type".to_string()));
+            }
         }
-        if let Some(e) = self.entries.remove(&key) {       // same buffer seen as another column type: start over
-            self.bytes -= e.bytes;
-            Self::release(ctx, &e);
-        }
+        self.release(key);                                  // same buffer seen as another column type: start over
         let elem = match host.dtype { PANDRS_HIP_U32CODE => 4, PANDRS_HIP_BOOLBITS => 0, _ => 8 };
         let bytes = if elem == 0 { (n_rows + 7) / 8 } else { n_rows * elem } + if host.null_mask.is_null() { 0 } else { (n_rows + 7) / 8 };
         let budget = crate::gpu::get_gpu_manager().map(|m| m.context().config().memory_limit / 2).unwrap_or(usize::MAX);
         while self.bytes + bytes > budget {
-            let pin = self.pin_epoch;
-            let oldest = self.entries.iter().filter(|(_, e)| e.last_use < pin).min_by_key(|(_, e)| e.last_use).map(|(k, _)| *k);
+            let oldest = self.entries.iter().filter(|(_, e)| e.pins == 0).min_by_key(|(_, e)| e.last_use).map(|(k, _)| *k);
             match oldest {
-                Some(k) => {
-                    let e = self.entries.remove(&k).unwrap();
-                    self.bytes -= e.bytes;
-                    Self::release(ctx, &e);
-                }
-                // the columns of THIS call alone exceed the budget: the caller keeps its CPU body
+                Some(k) => self.release(k),
+                // the columns of the calls in flight alone exceed the budget: the caller keeps its CPU body
                 None => return Err(Error::Computation("resident columns exceed GpuConfig.memory_limit / 2".to_string())),
             }
         }
         let mut desc = PandrsHipColumn { data: std::ptr::null(), null_mask: std::ptr::null(), dtype: host.dtype, reserved: 0 };
-        check(unsafe { pandrs_hip_column_upload(ctx, &host, n_rows as i64, &mut desc) })?;
+        check(unsafe { pandrs_hip_column_upload(self.owner.ctx, &host, n_rows as i64, &mut desc) })?;
         let alive = match col {
             Column::Int64(c) => liveness(&c.data, &c.null_mask),
             Column::Float64(c) => liveness(&c.data, &c.null_mask),
             Column::String(c) => liveness(&c.indices, &c.null_mask),
             Column::Boolean(c) => liveness(&c.data.data, &c.null_mask),
         };
-        self.entries.insert(key, ResidentEntry { desc, bytes, alive, last_use: self.clock });
+        self.entries.insert(key, ResidentEntry { desc, bytes, alive, last_use: self.clock, pins: 1 });
+        pinned.keys.push(key);
         self.bytes += bytes;
         Ok(Some(desc))
     }
 }
 
-/// Device descriptors of several columns of one frame; None as soon as one of them has no device form.
-fn resident_all(hc: &mut HipContext, df: &OptimizedDataFrame, names: &[&String]) -> Result<Option<Vec<PandrsHipColumn>>> {
-    let mut out = Vec::with_capacity(names.len());
-    for name in names {
-        let col = &df.columns[df.column_indices[*name]];
-        match hc.resident.get(hc.ctx, col, df.row_count())? {
-            Some(d) => out.push(d),
-            None => return Ok(None),
+/// Device descriptors of `cols` (each with its row count), pinned until the returned guard is dropped; None as soon
+/// as one of them has no device form.
+fn resident(cols: &[(&Column, usize)]) -> Result<Option<(Vec<PandrsHipColumn>, Pinned)>> {
+    let lock = RESIDENT.get_or_init(|| Mutex::new(None));
+    let mut guard = lock.lock().map_err(|_| Error::Computation("resident cache poisoned".to_string()))?;
+    if guard.is_none() {
+        *guard = Some(ResidentCache { owner: HipContext::new()?, entries: HashMap::new(), bytes: 0, clock: 0 });
+    }
+    let cache = guard.as_mut().unwrap();
+    let mut pinned = Pinned { keys: Vec::new() };
+    let mut out = Vec::with_capacity(cols.len());
+    for (col, n_rows) in cols {
+        match cache.get(col, *n_rows, &mut pinned) {
+            Ok(Some(d)) => out.push(d),
+            Ok(None) => {
+                drop(guard);                               // (Pinned::drop takes the lock)
+                return Ok(None);
+            }
+            Err(e) => {
+                drop(guard);
+                return Err(e);
+            }
         }
     }
-    Ok(Some(out))
+    Ok(Some((out, pinned)))
 }
 
 fn no_device_form() -> Error {
@@ -237,35 +309,45 @@ fn key_string(col: &Column, cell: u64, is_null: bool, null_string: &str) -> Stri
     }
 }
 
-/// GroupBy::aggregate's body (aggregation.rs:763-871) on the device.  `null_string`: "NULL" for aggregate / the lazy
-/// arm.  Needs neither GroupBy.groups nor any per-row host work: the seam sits BEFORE the lazily filled map is touched.
-pub fn groupby_aggregate_hip(
-    df: &OptimizedDataFrame,
+/// What every groupby seam shares: key strings per key column ([key][group]) and one f64 vector per aggregation.
+struct GroupedOutput {
+    key_strings: Vec<Vec<String>>,
+    aggs: Vec<Vec<f64>>,
+    n_groups: usize,
+}
+
+/// The device call behind GroupBy::aggregate and the lazy Aggregate arm, on borrowed columns — typed on neither frame.
+fn groupby_columns_hip<Op: HipAggOp>(
+    column_of: &dyn Fn(&str) -> Result<Column>,
+    n_rows: usize,
     group_by_columns: &[String],
-    aggregations: &[(String, AggregateOp, String)],
+    aggregations: &[(String, Op, String)],
     null_string: &str,
-) -> Result<OptimizedDataFrame> {
+) -> Result<GroupedOutput> {
     // distinct value columns, in first-use order
     let mut val_names: Vec<&String> = Vec::new();
     let mut specs: Vec<PandrsHipAggSpec> = Vec::new();
     for (col, op, _) in aggregations {
         let idx = match val_names.iter().position(|n| *n == col) {
             Some(i) => i,
-            None => { val_names.push(col); val_names.len() - 1 }
+            None => {
+                val_names.push(col);
+                val_names.len() - 1
+            }
         };
-        specs.push(PandrsHipAggSpec { col: idx as i32, op: *op as i32 });      // types.rs:11-34 order = pandrs_hip_agg_op
+        specs.push(PandrsHipAggSpec { col: idx as i32, op: op.code() });
     }
-    let key_names: Vec<&String> = group_by_columns.iter().collect();
-    let n_rows = df.row_count() as i64;
+    // (Arc clones: the data pointers — the resident cache's keys — are the frame's own)
+    let key_cols: Vec<Column> = group_by_columns.iter().map(|n| column_of(n)).collect::<Result<_>>()?;
+    let val_cols: Vec<Column> = val_names.iter().map(|n| column_of(n)).collect::<Result<_>>()?;
+    let all: Vec<(&Column, usize)> = key_cols.iter().chain(val_cols.iter()).map(|c| (c, n_rows)).collect();
+    let (descs, _pinned) = resident(&all)?.ok_or_else(no_device_form)?;
+    let (keys, vals) = descs.split_at(key_cols.len());
 
-    with_ctx(|hc| {
-        hc.resident.begin_call();
-        let keys = resident_all(hc, df, &key_names)?.ok_or_else(no_device_form)?;
-        let vals = resident_all(hc, df, &val_names)?.ok_or_else(no_device_form)?;
-        let ctx = hc.ctx;
+    with_ctx(|ctx| {
         let mut n_groups: i64 = 0;
         check(unsafe {
-            pandrs_hip_groupby_agg(ctx, PANDRS_HIP_MEM_DEVICE, keys.as_ptr(), keys.len() as i32, n_rows,
+            pandrs_hip_groupby_agg(ctx, PANDRS_HIP_MEM_DEVICE, keys.as_ptr(), keys.len() as i32, n_rows as i64,
                                    vals.as_ptr(), vals.len() as i32, specs.as_ptr(), specs.len() as i32, &mut n_groups)
         })?;
         let g = n_groups as usize;
@@ -276,34 +358,155 @@ pub fn groupby_aggregate_hip(
         let pn: Vec<*mut u8> = key_null.iter_mut().map(|v| v.as_mut_ptr()).collect();
         let pa: Vec<*mut f64> = aggs.iter_mut().map(|v| v.as_mut_ptr()).collect();
         check(unsafe { pandrs_hip_groupby_fetch(ctx, PANDRS_HIP_MEM_HOST, pk.as_ptr(), pn.as_ptr(), pa.as_ptr()) })?;
+        let key_strings = key_cols
+            .iter()
+            .enumerate()
+            .map(|(i, col)| (0..g).map(|r| key_string(col, key_cells[i][r], key_null[i][r] != 0, null_string)).collect())
+            .collect();
+        Ok(GroupedOutput { key_strings, aggs, n_groups: g })
+    })
+}
 
-        // result frame exactly as aggregation.rs:812-867 builds it: one string column per key, one f64 column per alias
-        let mut result = OptimizedDataFrame::new();
-        for (i, name) in group_by_columns.iter().enumerate() {
-            let col = &df.columns[df.column_indices[name]];
-            let strings: Vec<String> = (0..g).map(|r| key_string(col, key_cells[i][r], key_null[i][r] != 0, null_string)).collect();
+/// GroupBy::aggregate's body (aggregation.rs:763-871) on the device, for the SPLIT frame.  Needs neither
+/// GroupBy.groups nor any per-row host work: the seam sits BEFORE the lazily filled map is touched.
+/// `create_multi_index` is GroupBy.create_multi_index (types.rs:54; set by group_by for >= 2 keys, grouping.rs:27):
+/// the result then carries a StringMultiIndex of the key tuples and NO key columns (aggregation.rs:812-853).
+pub fn groupby_aggregate_split_hip(
+    df: &SplitFrame,
+    group_by_columns: &[String],
+    aggregations: &[(String, SplitAggregateOp, String)],
+    create_multi_index: bool,
+) -> Result<SplitFrame> {
+    let column_of = |name: &str| -> Result<Column> {
+        let idx = df.column_indices.get(name).ok_or_else(|| Error::ColumnNotFound(name.to_string()))?;
+        Ok(df.columns[*idx].clone())
+    };
+    let out = groupby_columns_hip(&column_of, df.row_count(), group_by_columns, aggregations, "NULL")?;
+    let mut result = SplitFrame::new();
+    if create_multi_index && group_by_columns.len() > 1 {
+        // aggregation.rs:812-853: tuples per group -> StringMultiIndex::from_tuples (an empty list is its Err,
+        // multi_index.rs:160) -> set_index_from_multi_index -> aggregate columns only
+        let tuples: Vec<Vec<String>> = (0..out.n_groups).map(|r| out.key_strings.iter().map(|k| k[r].clone()).collect()).collect();
+        let names = Some(group_by_columns.iter().map(|name| Some(name.clone())).collect());
+        let multi_index = StringMultiIndex::from_tuples(tuples, names)?;
+        result.set_index_from_multi_index(multi_index)?;
+    } else {
+        // aggregation.rs:856-860: one string column per key
+        for (name, strings) in group_by_columns.iter().zip(out.key_strings.into_iter()) {
             result.add_column(name.clone(), Column::String(StringColumn::new(strings)))?;
         }
-        for ((_, _, alias), values) in aggregations.iter().zip(aggs.into_iter()) {
-            result.add_column(alias.clone(), Column::Float64(Float64Column::new(values)))?;
-        }
-        Ok(result)
+    }
+    for ((_, _, alias), values) in aggregations.iter().zip(out.aggs.into_iter()) {
+        result.add_column(alias.clone(), Column::Float64(Float64Column::new(values)))?;
+    }
+    Ok(result)
+}
+
+/// The Aggregate arm of LazyFrame::execute (lazy.rs:186-404) on the device, for the PUBLIC frame and the PUBLIC
+/// AggregateOp (lazy.rs:7-8).  The arm never builds a multi-index: key columns always (lazy.rs:390-394;
+/// tests/optimized_groupby_test.rs:184 asserts 3 columns for two keys).  The public frame's fields are pub(super)
+/// to src/optimized/dataframe, so columns are reached through `column(name)` / `into_column()` like the arm does.
+pub fn lazy_aggregate_hip(
+    df: &PublicFrame,
+    group_by: &[String],
+    aggregations: &[(String, PublicAggregateOp, String)],
+) -> Result<PublicFrame> {
+    let column_of = |name: &str| -> Result<Column> { Ok(df.column(name)?.into_column()) };
+    let out = groupby_columns_hip(&column_of, df.row_count(), group_by, aggregations, "NULL")?;
+    let mut result = PublicFrame::new();
+    for (name, strings) in group_by.iter().zip(out.key_strings.into_iter()) {
+        result.add_column(name.clone(), Column::String(StringColumn::new(strings)))?;
+    }
+    for ((_, _, alias), values) in aggregations.iter().zip(out.aggs.into_iter()) {
+        result.add_column(alias.clone(), Column::Float64(Float64Column::new(values)))?;
+    }
+    Ok(result)
+}
+
+/// `Operation::Join { Inner }` immediately followed by `Operation::Aggregate { [g], [(v, Sum, alias)] }`
+/// (lazy.rs:405-425 then :186) as ONE device operator (pandrs_hip_join_groupby_sum, BASELINE config 5): the joined
+/// rows are never materialised.  Ok(None) = the pair of operations is not that shape and the caller runs the two
+/// arms as before.  The shape: `v` names a non-key column of the LEFT frame (Int64 / Float64) and `g` a non-key
+/// column of the RIGHT frame under the name the join gives it (`_right` suffix when the left frame has that name,
+/// join.rs:478-482), without nulls (a null `g` would surface as the join's fill value 0 / "" and merge with that
+/// group, join.rs:304-307 — kept on the two-step path).
+pub fn lazy_join_groupby_sum_hip(
+    left: &PublicFrame,
+    right: &PublicFrame,
+    left_on: &str,
+    right_on: &str,
+    group_col: &str,
+    value_col: &str,
+    alias: &str,
+) -> Result<Option<PublicFrame>> {
+    // resolve the two names against the JOINED frame's column list (left non-key, key, right non-key)
+    if value_col == left_on || !left.contains_column(value_col) {
+        return Ok(None);
+    }
+    if left.contains_column(group_col) {
+        return Ok(None);                                   // `g` is a left column (or the key): not the fused shape
+    }
+    let right_name = match group_col.strip_suffix("_right") {
+        Some(base) if left.contains_column(base) && right.contains_column(base) => base,
+        _ if right.contains_column(group_col) => group_col,
+        _ => return Ok(None),
+    };
+    if right_name == right_on {
+        return Ok(None);
+    }
+    let (lk, lv) = (left.column(left_on)?.into_column(), left.column(value_col)?.into_column());
+    let (rk, rg) = (right.column(right_on)?.into_column(), right.column(right_name)?.into_column());
+    if lk.column_type() != rk.column_type() {
+        return Ok(None);                                   // the join arm reports ColumnTypeMismatch (join.rs:98-104)
+    }
+    if !matches!(lv, Column::Int64(_) | Column::Float64(_)) || matches!(rg, Column::Boolean(_)) {
+        return Ok(None);
+    }
+    let g_has_nulls = match &rg {
+        Column::Int64(c) => c.null_mask.is_some(),
+        Column::Float64(c) => c.null_mask.is_some(),
+        Column::String(c) => c.null_mask.is_some(),
+        Column::Boolean(c) => c.null_mask.is_some(),
+    };
+    if g_has_nulls {
+        return Ok(None);
+    }
+    let (n_left, n_right) = (left.row_count(), right.row_count());
+    let cols = [(&lk, n_left), (&lv, n_left), (&rk, n_right), (&rg, n_right)];
+    let (d, _pinned) = match resident(&cols)? {
+        Some(x) => x,
+        None => return Ok(None),
+    };
+    with_ctx(|ctx| {
+        let mut n_groups: i64 = 0;
+        check(unsafe {
+            pandrs_hip_join_groupby_sum(ctx, PANDRS_HIP_MEM_DEVICE, &d[0], &d[1], n_left as i64, &d[2], &d[3], n_right as i64, &mut n_groups)
+        })?;
+        let g = n_groups as usize;
+        let (mut cells, mut nulls, mut sums) = (vec![0u64; g], vec![0u8; g], vec![0f64; g]);
+        let (pk, pn, pa) = ([cells.as_mut_ptr()], [nulls.as_mut_ptr()], [sums.as_mut_ptr()]);
+        check(unsafe { pandrs_hip_groupby_fetch(ctx, PANDRS_HIP_MEM_HOST, pk.as_ptr(), pn.as_ptr(), pa.as_ptr()) })?;
+        // the Aggregate arm's result frame (lazy.rs:386-401): the key as a string column, then the alias
+        let strings: Vec<String> = (0..g).map(|r| key_string(&rg, cells[r], nulls[r] != 0, "NULL")).collect();
+        let mut result = PublicFrame::new();
+        result.add_column(group_col.to_string(), Column::String(StringColumn::new(strings)))?;
+        result.add_column(alias.to_string(), Column::Float64(Float64Column::new(sums)))?;
+        Ok(Some(result))
     })
 }
 
 /// group_by's own result (grouping.rs:59-104): every group's key strings and its ascending row list, from the
 /// device-built CSR (pandrs_hip_groupby_indices).  `null_string`: "NULL" for group_by, "NA" for par_groupby (:152).
 pub fn group_indices_hip(
-    df: &OptimizedDataFrame,
+    df: &SplitFrame,
     group_by_columns: &[String],
     null_string: &str,
 ) -> Result<HashMap<Vec<String>, Vec<usize>>> {
-    let key_names: Vec<&String> = group_by_columns.iter().collect();
     let n_rows = df.row_count();
-    with_ctx(|hc| {
-        hc.resident.begin_call();
-        let keys = resident_all(hc, df, &key_names)?.ok_or_else(no_device_form)?;
-        let ctx = hc.ctx;
+    let key_cols: Vec<&Column> = group_by_columns.iter().map(|name| &df.columns[df.column_indices[name]]).collect();
+    let all: Vec<(&Column, usize)> = key_cols.iter().map(|c| (*c, n_rows)).collect();
+    let (keys, _pinned) = resident(&all)?.ok_or_else(no_device_form)?;
+    with_ctx(|ctx| {
         let mut n_groups: i64 = 0;
         check(unsafe { pandrs_hip_groupby_indices(ctx, PANDRS_HIP_MEM_DEVICE, keys.as_ptr(), keys.len() as i32, n_rows as i64, &mut n_groups) })?;
         let g = n_groups as usize;
@@ -316,10 +519,10 @@ pub fn group_indices_hip(
         check(unsafe { pandrs_hip_groupby_indices_fetch(ctx, PANDRS_HIP_MEM_HOST, pk.as_ptr(), pn.as_ptr(), offsets.as_mut_ptr(), rows.as_mut_ptr()) })?;
         let mut groups: HashMap<Vec<String>, Vec<usize>> = HashMap::with_capacity(g);
         for grp in 0..g {
-            let key: Vec<String> = group_by_columns
+            let key: Vec<String> = key_cols
                 .iter()
                 .enumerate()
-                .map(|(i, name)| key_string(&df.columns[df.column_indices[name]], key_cells[i][grp], key_null[i][grp] != 0, null_string))
+                .map(|(i, col)| key_string(col, key_cells[i][grp], key_null[i][grp] != 0, null_string))
                 .collect();
             let list = rows[offsets[grp] as usize..offsets[grp + 1] as usize].iter().map(|&r| r as usize);
             // two cells with one string (0.0 / -0.0 never collide: "0" vs "-0"; NaN payloads are collapsed by the library)
@@ -331,7 +534,7 @@ pub fn group_indices_hip(
 
 /// par_groupby's body (grouping.rs:124-331): key parts joined with "_" (:189), nulls as "NA" (:152), one sub-frame
 /// per group through the reference's own filter_by_indices (data_ops.rs:124).
-pub fn par_groupby_hip(df: &OptimizedDataFrame, group_by_columns: &[&str]) -> Result<HashMap<String, OptimizedDataFrame>> {
+pub fn par_groupby_hip(df: &SplitFrame, group_by_columns: &[&str]) -> Result<HashMap<String, SplitFrame>> {
     let cols: Vec<String> = group_by_columns.iter().map(|s| s.to_string()).collect();
     let groups = group_indices_hip(df, &cols, "NA")?;
     let mut merged: HashMap<String, Vec<usize>> = HashMap::with_capacity(groups.len());
@@ -348,34 +551,131 @@ pub fn par_groupby_hip(df: &OptimizedDataFrame, group_by_columns: &[&str]) -> Re
     Ok(result)
 }
 
-/// join_impl's index build (join.rs:106-224): (left row, right row) pairs in the reference's order; -1 <=> None.
-pub fn join_indices_hip(left: &Column, right: &Column, join_type: JoinType) -> Result<(Vec<i64>, Vec<i64>)> {
+fn empty_like(col: &Column) -> Column {
+    match col {
+        Column::Int64(_) => Column::Int64(Int64Column::new(Vec::new())),
+        Column::Float64(_) => Column::Float64(Float64Column::new(Vec::new())),
+        Column::String(_) => Column::String(StringColumn::new(Vec::new())),
+        Column::Boolean(_) => Column::Boolean(BooleanColumn::new(Vec::new())),
+    }
+}
+
+const NO_STRING: u32 = u32::MAX;        // fill code of a gathered string column: the miss / null of join.rs:336 (-> "")
+
+/// One column of the joined frame through the pairs the context retains (join.rs:290-361 left side, :475-552
+/// right side; misses and nulls become 0 / 0.0 / "" / false, the result has no null mask).  `key_right`: this is
+/// the join-key column (join.rs:364-470) and rows without a left row take the right key's value.
+fn joined_column(
+    ctx: *mut PandrsHipCtx,
+    like: &Column,
+    desc: &PandrsHipColumn,
+    n_src: usize,
+    side: i32,
+    key_right: Option<(&PandrsHipColumn, usize)>,
+    n_out: usize,
+) -> Result<Column> {
+    let fill: u64 = if desc.dtype == PANDRS_HIP_U32CODE { NO_STRING as u64 } else { 0 };
+    let gather = |out: *mut core::ffi::c_void| -> Result<()> {
+        check(unsafe {
+            match key_right {
+                Some((rk, n_right)) => pandrs_hip_join_gather_key(ctx, PANDRS_HIP_MEM_DEVICE, desc, n_src as i64, rk, n_right as i64, fill, PANDRS_HIP_MEM_HOST, out),
+                None => pandrs_hip_join_gather(ctx, PANDRS_HIP_MEM_DEVICE, desc, n_src as i64, side, fill, PANDRS_HIP_MEM_HOST, out),
+            }
+        })
+    };
+    Ok(match like {
+        Column::Int64(_) => {
+            let mut data = vec![0i64; n_out];
+            gather(data.as_mut_ptr() as _)?;
+            Column::Int64(Int64Column::new(data))
+        }
+        Column::Float64(_) => {
+            let mut data = vec![0f64; n_out];
+            gather(data.as_mut_ptr() as _)?;
+            Column::Float64(Float64Column::new(data))
+        }
+        Column::String(_) => {
+            let mut codes = vec![0u32; n_out];
+            gather(codes.as_mut_ptr() as _)?;
+            let data: Vec<String> = codes
+                .iter()
+                .map(|&c| if c == NO_STRING { String::new() } else { GLOBAL_STRING_POOL.get(c).unwrap_or_default() })
+                .collect();
+            Column::String(StringColumn::new(data))
+        }
+        Column::Boolean(_) => {
+            let mut bytes = vec![0u8; n_out];
+            gather(bytes.as_mut_ptr() as _)?;
+            Column::Boolean(BooleanColumn::new(bytes.iter().map(|&b| b != 0).collect()))
+        }
+    })
+}
+
+/// join_impl from the key-type check on (join.rs:106-552): the index pairs AND the assembly of the joined frame on
+/// the device.  The pairs stay in HBM (pandrs_hip_join_indices retains them); every output column is one gather on
+/// a resident column and ONE transfer of the finished column — no 16 bytes of indices per output row over PCIe, no
+/// per-element `get()`.  Ok(None) = some column has no device form (a Legacy-mode StringColumn): the CPU body runs.
+pub fn join_frame_split_hip(
+    left: &SplitFrame,
+    right: &SplitFrame,
+    left_on: &str,
+    right_on: &str,
+    join_type: JoinType,
+) -> Result<Option<SplitFrame>> {
     let how = match join_type {
         JoinType::Inner => PANDRS_HIP_JOIN_INNER,
         JoinType::Left => PANDRS_HIP_JOIN_LEFT,
         JoinType::Right => PANDRS_HIP_JOIN_RIGHT,
         JoinType::Outer => PANDRS_HIP_JOIN_OUTER,
     };
-    with_ctx(|hc| {
-        hc.resident.begin_call();
-        let l = hc.resident.get(hc.ctx, left, left.len())?.ok_or_else(no_device_form)?;
-        let r = hc.resident.get(hc.ctx, right, right.len())?.ok_or_else(no_device_form)?;
-        let ctx = hc.ctx;
+    let (n_left, n_right) = (left.row_count(), right.row_count());
+    let mut cols: Vec<(&Column, usize)> = left.column_names.iter().map(|n| (&left.columns[left.column_indices[n]], n_left)).collect();
+    cols.extend(right.column_names.iter().map(|n| (&right.columns[right.column_indices[n]], n_right)));
+    let (descs, _pinned) = match resident(&cols)? {
+        Some(x) => x,
+        None => return Ok(None),
+    };
+    let n_lc = left.column_names.len();
+    let lkey = left.column_names.iter().position(|n| n == left_on).ok_or_else(|| Error::ColumnNotFound(left_on.to_string()))?;
+    let rkey = right.column_names.iter().position(|n| n == right_on).ok_or_else(|| Error::ColumnNotFound(right_on.to_string()))?;
+    with_ctx(|ctx| {
         let mut n: i64 = 0;
-        check(unsafe { pandrs_hip_join_indices(ctx, PANDRS_HIP_MEM_DEVICE, &l, left.len() as i64, &r, right.len() as i64, how, &mut n) })?;
-        let (mut li, mut ri) = (vec![0i64; n as usize], vec![0i64; n as usize]);
-        check(unsafe { pandrs_hip_join_fetch(ctx, PANDRS_HIP_MEM_HOST, li.as_mut_ptr(), ri.as_mut_ptr()) })?;
-        Ok((li, ri))
+        check(unsafe {
+            pandrs_hip_join_indices(ctx, PANDRS_HIP_MEM_DEVICE, &descs[lkey], n_left as i64, &descs[n_lc + rkey], n_right as i64, how, &mut n)
+        })?;
+        let n_out = n as usize;
+        let mut result = SplitFrame::new();
+        // left non-key columns in left order (join.rs:290-361); empty result: empty columns of the same types (:227-284)
+        for (i, name) in left.column_names.iter().enumerate() {
+            if i != lkey {
+                let col = if n_out == 0 { empty_like(cols[i].0) } else { joined_column(ctx, cols[i].0, &descs[i], n_left, 0, None, n_out)? };
+                result.add_column(name.clone(), col)?;
+            }
+        }
+        // the key column, named left_on (join.rs:364-470) — the empty result has none (:227-284)
+        if n_out > 0 {
+            let col = joined_column(ctx, cols[lkey].0, &descs[lkey], n_left, 0, Some((&descs[n_lc + rkey], n_right)), n_out)?;
+            result.add_column(left_on.to_string(), col)?;
+        }
+        // right non-key columns, `_right` on a name the left frame has (join.rs:475-552)
+        for (i, name) in right.column_names.iter().enumerate() {
+            if i != rkey {
+                let new_name = if left.column_indices.contains_key(name) { format!("{}{}", name, "_right") } else { name.clone() };
+                let j = n_lc + i;
+                let col = if n_out == 0 { empty_like(cols[j].0) } else { joined_column(ctx, cols[j].0, &descs[j], n_right, 1, None, n_out)? };
+                result.add_column(new_name, col)?;
+            }
+        }
+        Ok(Some(result))
     })
 }
 
 /// K1 (split_dataframe/aggregate.rs:21-215, column/{int64,float64}_column.rs:100-199, jit/simd.rs:9-112): one pass.
 pub fn column_stats_hip(col: &Column) -> Result<PandrsHipColumnStats> {
-    with_ctx(|hc| {
-        hc.resident.begin_call();
-        let v = hc.resident.get(hc.ctx, col, col.len())?.ok_or_else(no_device_form)?;
+    let (d, _pinned) = resident(&[(col, col.len())])?.ok_or_else(no_device_form)?;
+    with_ctx(|ctx| {
         let mut st: PandrsHipColumnStats = unsafe { std::mem::zeroed() };
-        check(unsafe { pandrs_hip_reduce_stats(hc.ctx, PANDRS_HIP_MEM_DEVICE, &v, col.len() as i64, &mut st) })?;
+        check(unsafe { pandrs_hip_reduce_stats(ctx, PANDRS_HIP_MEM_DEVICE, &d[0], col.len() as i64, &mut st) })?;
         Ok(st)
     })
 }

@@ -102,6 +102,8 @@ SYMBOLS = {
     "pandrs_hip_bytes_to_bitmap": (C.c_int32, [_P, C.c_int32, _P, C.c_int64, _P]),
     "pandrs_hip_key_hash_cells": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int32, C.c_int64, _P]),
     "pandrs_hip_gather_column": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64, _P, C.c_int64, C.c_uint64, _P]),
+    "pandrs_hip_join_gather": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64, C.c_int32, C.c_uint64, C.c_int32, _P]),
+    "pandrs_hip_join_gather_key": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64, C.POINTER(Column), C.c_int64, C.c_uint64, C.c_int32, _P]),
     "pandrs_hip_reduce_moments": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64, C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pandrs_hip_join_indices": (C.c_int32, [_P, C.c_int32, C.POINTER(Column), C.c_int64,

@@ -19,11 +19,11 @@ using pandrs::fail;
 
 extern "C" {
 
-int32_t pandrs_hip_abi_version(void) { return PANDRS_HIP_ABI_VERSION; }
+int32_t pandrs_hip_abi_version(void) try { return PANDRS_HIP_ABI_VERSION; } catch (...) { return pandrs::on_exception("pandrs_hip_abi_version"); }
 
-const char *pandrs_hip_last_error(void) { return pandrs::last_error().c_str(); }
+const char *pandrs_hip_last_error(void) { return pandrs::last_error().text; }
 
-int32_t pandrs_hip_init(const pandrs_hip_config *cfg) {
+int32_t pandrs_hip_init(const pandrs_hip_config *cfg) try {
     std::lock_guard<std::mutex> lock(g_mu);
     if (cfg) { g_cfg = *cfg; g_cfg_explicit = true; }
     else g_cfg_explicit = false;
@@ -36,23 +36,23 @@ int32_t pandrs_hip_init(const pandrs_hip_config *cfg) {
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", g_cfg.device_id, n);
     g_inited = true;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_init"); }
 
-int32_t pandrs_hip_shutdown(void) {
+int32_t pandrs_hip_shutdown(void) try {
     std::lock_guard<std::mutex> lock(g_mu);
     g_inited = false;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_shutdown"); }
 
-int32_t pandrs_hip_device_count(int32_t *out_count) {
+int32_t pandrs_hip_device_count(int32_t *out_count) try {
     if (!out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null out_count");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     *out_count = e == hipSuccess ? n : 0;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_device_count"); }
 
-int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx) {
+int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx) try {
     if (!out_ctx) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null out_ctx");
     *out_ctx = nullptr;
     {
@@ -92,9 +92,9 @@ int32_t pandrs_hip_ctx_create(int32_t device_id, pandrs_hip_ctx **out_ctx) {
     pandrs::arena_limit() = g_cfg.memory_limit > 0 ? (size_t)g_cfg.memory_limit : 0;   // GpuConfig.memory_limit
     *out_ctx = c;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_ctx_create"); }
 
-int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
+int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) try {
     if (!c) return PANDRS_HIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -108,26 +108,26 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) {
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_ctx_destroy"); }
 
-int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *c) {
+int32_t pandrs_hip_ctx_synchronize(pandrs_hip_ctx *c) try {
     if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_ctx_synchronize"); }
 
-int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *c, int64_t workspace_bytes) {
+int32_t pandrs_hip_ctx_reserve(pandrs_hip_ctx *c, int64_t workspace_bytes) try {
     if (!c || workspace_bytes < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     return c->work.ensure((size_t)workspace_bytes, c->stream);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_ctx_reserve"); }
 
 // ---- resident columns -------------------------------------------------------------------------------------------
 // The reference's columns are immutable Arc<[T]> (src/column/int64_column.rs:10) that every operator Arc-clones
 // (src/optimized/dataframe/transformations.rs:524-577): uploaded ONCE, a column serves every later aggregate / join
 // from HBM.  One hipMalloc per column: data, then the null bitmap on a 256-byte boundary.
-int32_t pandrs_hip_column_upload(pandrs_hip_ctx *c, const pandrs_hip_column *host, int64_t n_rows, pandrs_hip_column *out) {
+int32_t pandrs_hip_column_upload(pandrs_hip_ctx *c, const pandrs_hip_column *host, int64_t n_rows, pandrs_hip_column *out) try {
     if (!c || !host || !out || n_rows < 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
     if (host->dtype < PANDRS_HIP_I64 || host->dtype > PANDRS_HIP_CELL64) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad dtype %d", host->dtype);
     if (!host->data && n_rows > 0) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null data pointer");
@@ -151,9 +151,9 @@ int32_t pandrs_hip_column_upload(pandrs_hip_ctx *c, const pandrs_hip_column *hos
     out->data = base; out->null_mask = mb ? reinterpret_cast<const uint8_t *>(base + dpad) : nullptr;
     out->dtype = host->dtype; out->reserved = 0;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_column_upload"); }
 
-int32_t pandrs_hip_column_release(pandrs_hip_ctx *c, const pandrs_hip_column *col) {
+int32_t pandrs_hip_column_release(pandrs_hip_ctx *c, const pandrs_hip_column *col) try {
     if (!c || !col) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
     std::lock_guard<std::mutex> lock(c->mu);
     auto it = c->resident.find(col->data);
@@ -164,23 +164,31 @@ int32_t pandrs_hip_column_release(pandrs_hip_ctx *c, const pandrs_hip_column *co
     c->resident_bytes -= it->second.bytes;
     c->resident.erase(it);
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_column_release"); }
 
-int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations) {
+int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations) try {
     if (!out_device_allocations) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null output");
     *out_device_allocations = pandrs::alloc_events().load();
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_alloc_events"); }
 
-int32_t pandrs_hip_resident_bytes(pandrs_hip_ctx *c, int64_t *out_bytes, int64_t *out_columns) {
+int32_t pandrs_hip_resident_bytes(pandrs_hip_ctx *c, int64_t *out_bytes, int64_t *out_columns) try {
     if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
     std::lock_guard<std::mutex> lock(c->mu);
     if (out_bytes) *out_bytes = (int64_t)c->resident_bytes;
     if (out_columns) *out_columns = (int64_t)c->resident.size();
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_resident_bytes"); }
 
-int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t value) {
+int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t value) try {
+    if (name && !std::strcmp(name, "test_throw")) {
+        // tests of the exception firewall (common.hpp on_exception; needs no context): the entry point's host code throws
+        if (value == 1) throw std::bad_alloc();
+        if (value == 2) { std::vector<int> v; (void)v.at(7); }                 // std::out_of_range, as a container would raise it
+        if (value == 3) throw 42;                                              // not a std::exception
+        if (value == 4) { std::vector<uint8_t> v; v.resize(~size_t(0) >> 1); } // a real oversized staging resize: std::length_error / bad_alloc
+        return PANDRS_HIP_OK;
+    }
     if (!c || !name) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
     std::lock_guard<std::mutex> lock(c->mu);
     if (!std::strcmp(name, "groups_hint")) c->opt.groups_hint = value;
@@ -206,6 +214,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_absorb")) c->opt.no_absorb = value;
     else if (!std::strcmp(name, "no_chao")) c->opt.no_chao = value;
     else if (!std::strcmp(name, "no_overflow_run")) c->opt.no_overflow_run = value;
+    else if (!std::strcmp(name, "tail_groups_hint")) c->opt.tail_groups_hint = value;
     else if (!std::strcmp(name, "sorted_dictionary")) c->opt.sorted_dictionary = value;
     else if (!std::strcmp(name, "wide_slices")) c->opt.wide_slices = value;
     else if (!std::strcmp(name, "fold_min")) c->opt.fold_min = value;
@@ -224,49 +233,49 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "agg_depth")) c->opt.agg_depth = value;
     else return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_ctx_set_option"); }
 
-int32_t pandrs_hip_get_timings(pandrs_hip_ctx *c, pandrs_hip_timings *out) {
+int32_t pandrs_hip_get_timings(pandrs_hip_ctx *c, pandrs_hip_timings *out) try {
     if (!c || !out) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
     std::lock_guard<std::mutex> lock(c->mu);
     if (c->timings_pending) { (void)hipSetDevice(c->device); (void)pandrs::timings_resolve(c); }
     *out = c->timings;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_get_timings"); }
 
 int32_t pandrs_hip_groupby_agg(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
                                int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals,
                                int32_t n_vals, const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
-                               int64_t *out_n_groups) {
+                               int64_t *out_n_groups) try {
     ST_TRY(pandrs::below_threshold(n_rows));
     return pandrs::groupby_entry(ctx, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs,
                                  false, out_n_groups, nullptr);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_groupby_agg"); }
 
 int32_t pandrs_hip_groupby_partials(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
                                     int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals,
                                     int32_t n_vals, const pandrs_hip_agg_spec *aggs, int32_t n_aggs,
-                                    int64_t *out_n_groups, int32_t *out_n_state) {
+                                    int64_t *out_n_groups, int32_t *out_n_state) try {
     return pandrs::groupby_entry(ctx, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs,
                                  true, out_n_groups, out_n_state);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_groupby_partials"); }
 
 int32_t pandrs_hip_partials_split(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t n_ranks,
-                                  uint64_t *out_records, int64_t *out_counts) {
+                                  uint64_t *out_records, int64_t *out_counts) try {
     return pandrs::partials_split_entry(ctx, mem_space, n_ranks, out_records, out_counts);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_partials_split"); }
 
 int32_t pandrs_hip_groupby_merge(pandrs_hip_ctx *ctx, int32_t mem_space, int32_t key_dtype,
                                  const uint64_t *records,
                                  int64_t n_rows, const int32_t *val_dtypes, int32_t n_vals,
                                  const uint8_t *val_has_nulls, const pandrs_hip_agg_spec *aggs,
-                                 int32_t n_aggs, int64_t *out_n_groups) {
+                                 int32_t n_aggs, int64_t *out_n_groups) try {
     return pandrs::groupby_merge_entry(ctx, mem_space, key_dtype, records, n_rows,
                                        val_dtypes, n_vals, val_has_nulls, aggs, n_aggs, out_n_groups);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_groupby_merge"); }
 
 int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t *const *out_keys,
-                                 uint8_t *const *out_key_null, double *const *out_aggs) {
+                                 uint8_t *const *out_key_null, double *const *out_aggs) try {
     if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
     std::lock_guard<std::mutex> lock(c->mu);
     pandrs::GroupbyResult &r = c->gb;
@@ -287,16 +296,16 @@ int32_t pandrs_hip_groupby_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t 
             HIP_TRY(hipMemcpyAsync(out_aggs[a], r.aggs + (size_t)a * r.cap, g * 8, kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_groupby_fetch"); }
 
 int32_t pandrs_hip_groupby_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
-                                   int32_t n_keys, int64_t n_rows, int64_t *out_n_groups) {
+                                   int32_t n_keys, int64_t n_rows, int64_t *out_n_groups) try {
     ST_TRY(pandrs::below_threshold(n_rows));
     return pandrs::groupby_indices_entry(ctx, mem_space, keys, n_keys, n_rows, out_n_groups);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_groupby_indices"); }
 
 int32_t pandrs_hip_groupby_indices_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t *const *out_keys,
-                                         uint8_t *const *out_key_null, int64_t *out_offsets, int64_t *out_rows) {
+                                         uint8_t *const *out_key_null, int64_t *out_offsets, int64_t *out_rows) try {
     if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
     std::lock_guard<std::mutex> lock(c->mu);
     pandrs::GroupsResult &r = c->gr;
@@ -314,17 +323,17 @@ int32_t pandrs_hip_groupby_indices_fetch(pandrs_hip_ctx *c, int32_t mem_space, u
     if (out_rows && n > 0) HIP_TRY(hipMemcpyAsync(out_rows, r.rows, n * 8, kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_groupby_indices_fetch"); }
 
 int32_t pandrs_hip_shuffle_split(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *key,
                                  const pandrs_hip_column *payload, int32_t n_payload, int64_t n_rows,
-                                 int32_t n_ranks, int32_t drop_null_keys, int64_t *out_counts, int64_t *out_n_rows) {
+                                 int32_t n_ranks, int32_t drop_null_keys, int64_t *out_counts, int64_t *out_n_rows) try {
     return pandrs::shuffle_split_entry(ctx, mem_space, key, payload, n_payload, n_rows, n_ranks, drop_null_keys,
                                        out_counts, out_n_rows);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_shuffle_split"); }
 
 int32_t pandrs_hip_shuffle_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t *out_cells, uint8_t *out_key_null,
-                                 uint64_t *const *out_payload, uint8_t *const *out_payload_null) {
+                                 uint64_t *const *out_payload, uint8_t *const *out_payload_null) try {
     if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
     std::lock_guard<std::mutex> lock(c->mu);
     pandrs::ShuffleResult &r = c->sh;
@@ -342,27 +351,27 @@ int32_t pandrs_hip_shuffle_fetch(pandrs_hip_ctx *c, int32_t mem_space, uint64_t 
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_shuffle_fetch"); }
 
 int32_t pandrs_hip_key_hash_cells(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *keys,
-                                  int32_t n_keys, int64_t n_rows, uint64_t *out_cells) {
+                                  int32_t n_keys, int64_t n_rows, uint64_t *out_cells) try {
     return pandrs::key_hash_cells_entry(ctx, mem_space, keys, n_keys, n_rows, out_cells);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_key_hash_cells"); }
 
 int32_t pandrs_hip_bytes_to_bitmap(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *bytes, int64_t n,
-                                   uint8_t *out_bitmap) {
+                                   uint8_t *out_bitmap) try {
     return pandrs::bytes_to_bitmap_entry(ctx, mem_space, bytes, n, out_bitmap);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_bytes_to_bitmap"); }
 
 int32_t pandrs_hip_join_indices(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *left_key,
                                 int64_t n_left, const pandrs_hip_column *right_key, int64_t n_right,
-                                int32_t how, int64_t *out_n_rows) {
+                                int32_t how, int64_t *out_n_rows) try {
     ST_TRY(pandrs::below_threshold(n_left > n_right ? n_left : n_right));
     return pandrs::join_entry(ctx, mem_space, left_key, n_left, right_key, n_right, how, out_n_rows);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_join_indices"); }
 
 int32_t pandrs_hip_join_fetch(pandrs_hip_ctx *c, int32_t mem_space, int64_t *out_left_idx,
-                              int64_t *out_right_idx) {
+                              int64_t *out_right_idx) try {
     if (!c) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null ctx");
     std::lock_guard<std::mutex> lock(c->mu);
     if (!c->jn.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no join result retained in this context");
@@ -374,47 +383,58 @@ int32_t pandrs_hip_join_fetch(pandrs_hip_ctx *c, int32_t mem_space, int64_t *out
     if (out_right_idx) HIP_TRY(hipMemcpyAsync(out_right_idx, c->jn.right_idx, n * 8, kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_join_fetch"); }
 
 int32_t pandrs_hip_gather_i64(pandrs_hip_ctx *ctx, int32_t mem_space, const int64_t *src,
-                              const uint8_t *m, const int64_t *idx, int64_t n, int64_t fill, int64_t *out) {
+                              const uint8_t *m, const int64_t *idx, int64_t n, int64_t fill, int64_t *out) try {
     return pandrs::gather_entry(ctx, mem_space, 0, src, m, idx, n, (uint64_t)fill, out);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_gather_i64"); }
 int32_t pandrs_hip_gather_f64(pandrs_hip_ctx *ctx, int32_t mem_space, const double *src,
-                              const uint8_t *m, const int64_t *idx, int64_t n, double fill, double *out) {
+                              const uint8_t *m, const int64_t *idx, int64_t n, double fill, double *out) try {
     uint64_t b;
     std::memcpy(&b, &fill, 8);
     return pandrs::gather_entry(ctx, mem_space, 0, src, m, idx, n, b, out);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_gather_f64"); }
 int32_t pandrs_hip_gather_u32(pandrs_hip_ctx *ctx, int32_t mem_space, const uint32_t *src,
-                              const uint8_t *m, const int64_t *idx, int64_t n, uint32_t fill, uint32_t *out) {
+                              const uint8_t *m, const int64_t *idx, int64_t n, uint32_t fill, uint32_t *out) try {
     return pandrs::gather_entry(ctx, mem_space, 1, src, m, idx, n, fill, out);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_gather_u32"); }
 int32_t pandrs_hip_gather_bool(pandrs_hip_ctx *ctx, int32_t mem_space, const uint8_t *src_bits,
-                               const uint8_t *m, const int64_t *idx, int64_t n, uint8_t fill, uint8_t *out) {
+                               const uint8_t *m, const int64_t *idx, int64_t n, uint8_t fill, uint8_t *out) try {
     return pandrs::gather_entry(ctx, mem_space, 2, src_bits, m, idx, n, fill, out);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_gather_bool"); }
 
 int32_t pandrs_hip_join_groupby_sum(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *lk,
                                     const pandrs_hip_column *lv, int64_t nl, const pandrs_hip_column *rk,
-                                    const pandrs_hip_column *rg, int64_t nr, int64_t *out_n_groups) {
+                                    const pandrs_hip_column *rg, int64_t nr, int64_t *out_n_groups) try {
     ST_TRY(pandrs::below_threshold(nl > nr ? nl : nr));
     return pandrs::join_groupby_sum_entry(ctx, mem_space, lk, lv, nl, rk, rg, nr, out_n_groups);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_join_groupby_sum"); }
 
 int32_t pandrs_hip_reduce_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col,
-                                 int64_t n, double out[4], int64_t *out_count) {
+                                 int64_t n, double out[4], int64_t *out_count) try {
     ST_TRY(pandrs::below_threshold(n));
     return pandrs::reduce_entry(ctx, mem_space, col, n, out, out_count);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_reduce_column"); }
 
 int32_t pandrs_hip_gather_column(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *src, int64_t n_src,
-                                 const int64_t *idx, int64_t n, uint64_t fill_bits, void *out) {
+                                 const int64_t *idx, int64_t n, uint64_t fill_bits, void *out) try {
     return pandrs::gather_column_entry(ctx, mem_space, src, n_src, idx, n, fill_bits, out);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_gather_column"); }
+
+int32_t pandrs_hip_join_gather(pandrs_hip_ctx *ctx, int32_t src_mem_space, const pandrs_hip_column *src, int64_t n_src,
+                               int32_t side, uint64_t fill_bits, int32_t out_mem_space, void *out) try {
+    return pandrs::join_gather_entry(ctx, src_mem_space, src, n_src, side, fill_bits, out_mem_space, out);
+} catch (...) { return pandrs::on_exception("pandrs_hip_join_gather"); }
+
+int32_t pandrs_hip_join_gather_key(pandrs_hip_ctx *ctx, int32_t src_mem_space, const pandrs_hip_column *left_key, int64_t n_left,
+                                   const pandrs_hip_column *right_key, int64_t n_right, uint64_t fill_bits, int32_t out_mem_space, void *out) try {
+    if (!right_key) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join_gather_key: null right key column");
+    return pandrs::join_gather_entry(ctx, src_mem_space, left_key, n_left, 0, fill_bits, out_mem_space, out, right_key, n_right);
+} catch (...) { return pandrs::on_exception("pandrs_hip_join_gather_key"); }
 
 int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
-                                  double *out_sum, double *out_sum_sq, int64_t *out_count) {
+                                  double *out_sum, double *out_sum_sq, int64_t *out_count) try {
     if (!out_sum || !out_sum_sq || !out_count) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "reduce_moments: bad arguments");
     ST_TRY(pandrs::below_threshold(n));
     double o[4];
@@ -422,12 +442,12 @@ int32_t pandrs_hip_reduce_moments(pandrs_hip_ctx *ctx, int32_t mem_space, const 
     if (st) return st;
     *out_sum = o[0];
     return 0;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_reduce_moments"); }
 
 int32_t pandrs_hip_reduce_stats(pandrs_hip_ctx *ctx, int32_t mem_space, const pandrs_hip_column *col, int64_t n,
-                                pandrs_hip_column_stats *out) {
+                                pandrs_hip_column_stats *out) try {
     ST_TRY(pandrs::below_threshold(n));
     return pandrs::reduce_stats_entry(ctx, mem_space, col, n, out);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_reduce_stats"); }
 
 }  // extern "C"

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -17,18 +19,36 @@
 namespace pandrs {
 
 // ---- thread-local error string (pandrs_hip_last_error) ---------------------------------------
-inline std::string &last_error() {
-    thread_local std::string e;
+// A fixed buffer, not a std::string: recording an error must not allocate (the error may BE an allocation failure).
+struct ErrorText { char text[512]; };
+inline ErrorText &last_error() {
+    thread_local ErrorText e{};
     return e;
 }
-inline int32_t fail(int32_t status, const char *fmt, ...) {
-    char buf[512];
+inline int32_t fail(int32_t status, const char *fmt, ...) noexcept {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    vsnprintf(last_error().text, sizeof last_error().text, fmt, ap);
     va_end(ap);
-    last_error() = buf;
     return status;
+}
+
+// ---- the exception firewall of the C ABI -------------------------------------------------------
+// "Nothing panics / aborts across the ABI" (include/pandrs_hip.h; the reference returns Result<T, pandrs::Error>,
+// src/core/error.rs:6).  The host code behind the entry points uses std::vector / std::mutex / new; an exception that
+// left an extern "C" frame would unwind into the caller's language (Rust: undefined behaviour or an abort).  Every
+// entry point is a function-try-block whose handler calls this: std::bad_alloc -> PANDRS_HIP_ERR_OUT_OF_MEMORY,
+// anything else -> PANDRS_HIP_ERR_COMPUTATION, with pandrs_hip_last_error() set.
+inline int32_t on_exception(const char *entry) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "%s: host allocation failed (std::bad_alloc)", entry);
+    } catch (const std::exception &e) {
+        return fail(PANDRS_HIP_ERR_COMPUTATION, "%s: C++ exception: %s", entry, e.what());
+    } catch (...) {
+        return fail(PANDRS_HIP_ERR_COMPUTATION, "%s: unknown C++ exception", entry);
+    }
 }
 
 #define HIP_TRY(expr)                                                                     \
@@ -169,6 +189,7 @@ struct Options {
     int64_t wide_slices = 0;         // 1 = an oversized partition is cut into pieces as long as the cutting threshold (4 x the average partition) instead of average-sized ones (A/B)
     int64_t sorted_dictionary = 0;   // 1 = a too-wide column of a composite key is dictionary-encoded by ordering its rows (the path that takes any cardinality) instead of a hashed look-up
     int64_t no_overflow_run = 0;     // 1 = a full LDS table fails the attempt (retry with 4 x the fan-out) instead of handing its unplaced rows to a run of their own
+    int64_t tail_groups_hint = 0;    // tests: the group estimate handed to the compact spill's tail run (0 = its own estimate); a low value makes its tables overflow
     int64_t no_chao = 0;             // 1 = the group estimate is the uniform-occupancy model alone (no Chao1 term from the sample's singletons / doubletons)
     int64_t no_absorb = 0;           // 1 = never run the hot-key absorb-and-spill pass in front of the radix path
     int64_t no_hot_image = 0;        // 1 = the absorb tables start empty (first come, first served) instead of from the sample's hot keys
@@ -311,7 +332,9 @@ int32_t join_groupby_sum_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandr
                                int64_t nr, int64_t *out_n_groups);
 int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void *src,
                      const uint8_t *mask, const int64_t *idx, int64_t n, uint64_t fill_bits,
-                     void *out, int64_t n_src = -1);
+                     void *out, int64_t n_src = -1, const int64_t *only_where_negative = nullptr);
+int32_t join_gather_entry(pandrs_hip_ctx *c, int32_t src_mem_space, const pandrs_hip_column *src, int64_t n_src, int32_t side,
+                          uint64_t fill_bits, int32_t out_mem_space, void *out, const pandrs_hip_column *key_right = nullptr, int64_t n_right = 0);
 int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *src, int64_t n_src,
                             const int64_t *idx, int64_t n, uint64_t fill_bits, void *out);
 int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_column *col, int64_t n,

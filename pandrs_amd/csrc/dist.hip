@@ -417,16 +417,16 @@ using pandrs::fail;
 
 extern "C" {
 
-int32_t pandrs_hip_comm_unique_id(char out_id[128]) {
+int32_t pandrs_hip_comm_unique_id(char out_id[128]) try {
     if (!out_id) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "null out_id");
     ST_TRY(pandrs::rccl_load());
     pandrs::RcclUniqueId id;
     RCCL_TRY(pandrs::rccl().GetUniqueId(&id));
     std::memcpy(out_id, id.internal, 128);
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_comm_unique_id"); }
 
-int32_t pandrs_hip_comm_init(pandrs_hip_ctx *ctx, const char id[128], int32_t rank, int32_t world, pandrs_hip_comm **out) {
+int32_t pandrs_hip_comm_init(pandrs_hip_ctx *ctx, const char id[128], int32_t rank, int32_t world, pandrs_hip_comm **out) try {
     if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "comm_init: bad arguments");
     ST_TRY(pandrs::rccl_load());
     HIP_TRY(hipSetDevice(ctx->device));
@@ -438,37 +438,37 @@ int32_t pandrs_hip_comm_init(pandrs_hip_ctx *ctx, const char id[128], int32_t ra
     cm->rank = rank; cm->world = world; cm->owned = true;
     *out = cm;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_comm_init"); }
 
-int32_t pandrs_hip_comm_adopt(void *nccl_comm, int32_t rank, int32_t world, pandrs_hip_comm **out) {
+int32_t pandrs_hip_comm_adopt(void *nccl_comm, int32_t rank, int32_t world, pandrs_hip_comm **out) try {
     if (!nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "comm_adopt: bad arguments");
     ST_TRY(pandrs::rccl_load());
     auto *cm = new pandrs_hip_comm();
     cm->nccl = nccl_comm; cm->rank = rank; cm->world = world; cm->owned = false;
     *out = cm;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_comm_adopt"); }
 
-int32_t pandrs_hip_comm_adopt_transport(const pandrs_hip_transport *t, int32_t rank, int32_t world, pandrs_hip_comm **out) {
+int32_t pandrs_hip_comm_adopt_transport(const pandrs_hip_transport *t, int32_t rank, int32_t world, pandrs_hip_comm **out) try {
     if (!t || !out || world < 1 || rank < 0 || rank >= world || !t->all_gather || !t->all_reduce_max_i64 || !t->all_to_all_v)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "comm_adopt_transport: bad arguments (all three callbacks are required)");
     auto *cm = new pandrs_hip_comm();
     cm->host = *t; cm->rank = rank; cm->world = world; cm->owned = false;
     *out = cm;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_comm_adopt_transport"); }
 
-int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *cm) {
+int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *cm) try {
     if (!cm) return PANDRS_HIP_OK;
     cm->send.release(); cm->recv.release(); cm->small.release(); cm->zeros.release(); cm->stage.release(); cm->crow.release();
     if (cm->owned && cm->nccl) (void)pandrs::rccl().CommDestroy(cm->nccl);
     delete cm;
     return PANDRS_HIP_OK;
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_comm_destroy"); }
 
 int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, int32_t mem_space, const pandrs_hip_column *keys,
                                     int32_t n_keys, int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals,
-                                    const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups) {
+                                    const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups) try {
     if (!ctx || !comm || !keys || !out_n_groups || n_rows < 0 || n_vals < 0 || n_aggs < 0 || (n_vals && !vals) || (n_aggs && !aggs))
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: bad arguments");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -477,12 +477,12 @@ int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, 
     if (!mergeable)       // Std / Var / Median / Nunique, or a composite key: the rows go to the owner of their key
         return pandrs::dist_groupby_shuffle_impl(ctx, comm, mem_space, keys, n_keys, n_rows, vals, n_vals, aggs, n_aggs, out_n_groups);
     return pandrs::dist_groupby_impl(ctx, comm, mem_space, keys, n_rows, vals, n_vals, aggs, n_aggs, out_n_groups);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_dist_groupby_agg"); }
 
 int32_t pandrs_hip_dist_join_groupby_sum(pandrs_hip_ctx *ctx, pandrs_hip_comm *cm, int32_t mem_space,
                                          const pandrs_hip_column *left_key, const pandrs_hip_column *left_val, int64_t n_left,
                                          const pandrs_hip_column *right_key, const pandrs_hip_column *right_group, int64_t n_right,
-                                         int64_t *out_n_groups) {
+                                         int64_t *out_n_groups) try {
     using namespace pandrs;
     if (!ctx || !cm || !left_key || !left_val || !right_key || !right_group || !out_n_groups || n_left < 0 || n_right < 0)
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_join_groupby_sum: bad arguments");
@@ -557,6 +557,6 @@ int32_t pandrs_hip_dist_join_groupby_sum(pandrs_hip_ctx *ctx, pandrs_hip_comm *c
     const int32_t local_status = local_phase();
     const pandrs_hip_agg_spec sum_spec{0, PANDRS_HIP_AGG_SUM};
     return dist_groupby_impl(c, cm, PANDRS_HIP_MEM_DEVICE, &gk, local_status ? 0 : got, &gv, 1, &sum_spec, 1, out_n_groups, local_status);
-}
+} catch (...) { return pandrs::on_exception("pandrs_hip_dist_join_groupby_sum"); }
 
 }  // extern "C"

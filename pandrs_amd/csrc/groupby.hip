@@ -1048,23 +1048,19 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
         h4[2] = (uint32_t)n_abs;
         if (n_compact > 0) {
             // The tables of this mode take no keys beyond the image (AbsorbArgs::image_only): every workgroup absorbs the SAME keys, so
-            // the spilled rows' keys are disjoint from the absorbed ones.  (1) merge the absorbed records (a few hundred thousand) in a
-            // nested run; (2) group the spilled rows with the ordinary engine AS THE RESULT of this call; (3) append (1)'s groups.
+            // the spilled rows' keys are disjoint from the absorbed ones.  (1) group the spilled rows with the ordinary engine AS THE
+            // RESULT of this call, with room reserved behind its groups; (2) merge the absorbed records (a few hundred thousand) in a
+            // nested run; (3) append (2)'s groups.  The order matters: run (1) may itself nest into slot res_slot + 1 (a slice merge of
+            // an oversized partition, the overflow run of an underestimated tail), so slot res_slot + 1 must not hold anything yet.
+            // The absorbed records live in c->temp, which no run below touches (no_direct, no_absorb).
             // (Merging the spilled rows' groups as partial records with the absorbed ones cost 11 ms for a 16 M-group tail.)
-            RowSource ms;
-            ms.n_rows = n_abs;
-            ms.key = KeyDesc{rk, nullptr, rn, DT_CELL};
-            ms.merge_states = rst;
-            ms.merge_stride = dcap;
             Options saved = c->opt;
             pandrs_hip_timings tsave = c->timings;
             c->opt.no_direct = 1; c->opt.no_absorb = 1; c->opt.partitions = 0;
-            c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>((int64_t)T + 2, n_abs), 1);
             c->quiet++;
-            int32_t st2 = n_abs > 0 ? run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot + 1) : 0;
-            GroupbyResult &r2 = c->gb2;
-            const int64_t n_hot = n_abs > 0 && !st2 ? r2.n_groups : 0;
-            if (!st2) {
+            const int64_t hot_bound = std::min<int64_t>((int64_t)T + 2, n_abs);     // image keys + the NULL key + the sentinel-valued key
+            int32_t st2;
+            {
                 RowSource sp;
                 sp.n_rows = n_compact;
                 sp.key = KeyDesc{ck, nullptr, nullptr, DT_CELL};          // (NULL keys and the sentinel-valued key are always absorbed)
@@ -1073,10 +1069,22 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
                     sp.val_null_bits[s2] = nullptr;
                     sp.val_valid_bytes[s2] = has_v ? cvalid[s2] : nullptr;
                 }
-                c->opt.groups_hint = 0;                                   // its own estimate: the tail's cardinality is what the first one could not see
-                c->reserve_groups = n_hot;
-                st2 = run_engine(c, sp, pl, /*merge=*/false, partials, n_aggs, key_dtype, 1, res_slot);
+                c->opt.groups_hint = std::max<int64_t>(c->opt.tail_groups_hint, 0);   // (0:) its own estimate: the tail's cardinality is what the first one could not see
+                c->reserve_groups = hot_bound;
+                st2 = run_engine(c, sp, pl, /*merge=*/false, partials, n_aggs, key_dtype, n_keys_out, res_slot);
                 c->reserve_groups = 0;
+            }
+            GroupbyResult &r2 = c->gb2;
+            int64_t n_hot = 0;
+            if (!st2 && n_abs > 0) {
+                RowSource ms;
+                ms.n_rows = n_abs;
+                ms.key = KeyDesc{rk, nullptr, rn, DT_CELL};
+                ms.merge_states = rst;
+                ms.merge_stride = dcap;
+                c->opt.groups_hint = std::max<int64_t>(hot_bound, 1);
+                st2 = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, 1, res_slot + 1);
+                if (!st2) n_hot = r2.n_groups;
             }
             c->quiet--;
             c->opt = saved;

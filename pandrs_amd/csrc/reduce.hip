@@ -215,9 +215,10 @@ int32_t reduce_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_hip_colu
 // kind 0: 8-byte elements, 1: 4-byte, 2: bit-packed source -> byte per row
 template <int KIND>
 __global__ void gather_kernel(const void *src, const uint8_t *null_bits, const int64_t *idx, int64_t n,
-                              uint64_t fill, void *out, int64_t n_src) {
+                              uint64_t fill, void *out, int64_t n_src, const int64_t *only_where_negative) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (only_where_negative && only_where_negative[i] >= 0) return;     // (the join-key column: rows that have a left row keep it)
     int64_t j = idx[i];
     bool take = j >= 0 && (n_src < 0 || j < n_src) && !(null_bits && bit_at(null_bits, j));   // n_src < 0: length not known to the ABI
     if (KIND == 0) reinterpret_cast<uint64_t *>(out)[i] = take ? reinterpret_cast<const uint64_t *>(src)[j] : fill;
@@ -226,7 +227,7 @@ __global__ void gather_kernel(const void *src, const uint8_t *null_bits, const i
 }
 
 int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void *src, const uint8_t *mask,
-                     const int64_t *idx, int64_t n, uint64_t fill_bits, void *out, int64_t n_src) {
+                     const int64_t *idx, int64_t n, uint64_t fill_bits, void *out, int64_t n_src, const int64_t *only_where_negative) {
     if (!c || n < 0 || (n && (!idx || !out))) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "gather: bad arguments");
     if (n == 0) return 0;
     if (mem_space == PANDRS_HIP_MEM_HOST)
@@ -239,9 +240,9 @@ int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void 
     {
         PhaseTimer pt(c, PANDRS_HIP_PHASE_GATHER);
         dim3 grid((unsigned)((n + 255) / 256)), block(256);
-        if (kind == 0) hipLaunchKernelGGL(gather_kernel<0>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src);
-        else if (kind == 1) hipLaunchKernelGGL(gather_kernel<1>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src);
-        else hipLaunchKernelGGL(gather_kernel<2>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src);
+        if (kind == 0) hipLaunchKernelGGL(gather_kernel<0>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src, only_where_negative);
+        else if (kind == 1) hipLaunchKernelGGL(gather_kernel<1>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src, only_where_negative);
+        else hipLaunchKernelGGL(gather_kernel<2>, grid, block, 0, c->stream, src, mask, idx, n, fill_bits, out, n_src, only_where_negative);
         HIP_TRY(hipGetLastError());
     }
     int64_t esz = kind == 0 ? 8 : (kind == 1 ? 4 : 1);
@@ -297,6 +298,77 @@ int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_h
     ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, d_src, d_mask, d_idx, n, fill_bits, d_out, n_src));
     std::lock_guard<std::mutex> lock(c->mu);
     HIP_TRY(hipMemcpyAsync(out, d_out, size_t(n) * esz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// One output column of a join, gathered through the RETAINED pairs of the context's last pandrs_hip_join_indices (side 0: the
+// left row of every pair, side 1: the right row) — join.rs:286-552 without the pairs ever leaving HBM.  The source column may be
+// resident (PANDRS_HIP_MEM_DEVICE) or a host column (staged); the output goes to either memory space.
+// `key_right` (the join-key column, join.rs:364-470): rows whose pair has no left row take the RIGHT key column's value at the
+// pair's right row instead of the fill value (`src` is then the left key column, side 0).
+int32_t join_gather_entry(pandrs_hip_ctx *c, int32_t src_mem_space, const pandrs_hip_column *src, int64_t n_src, int32_t side,
+                          uint64_t fill_bits, int32_t out_mem_space, void *out, const pandrs_hip_column *key_right, int64_t n_right) {
+    if (!c || !src || n_src < 0 || (side != 0 && side != 1) || (key_right && (side != 0 || n_right < 0)))
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join_gather: bad arguments");
+    if (src->dtype < PANDRS_HIP_I64 || src->dtype > PANDRS_HIP_BOOLBITS)
+        return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join_gather: bad dtype %d", src->dtype);
+    if (key_right && key_right->dtype != src->dtype)
+        return fail(PANDRS_HIP_ERR_TYPE_MISMATCH, "join_gather_key: the key columns have dtypes %d and %d", src->dtype, key_right->dtype);
+    const int kind = src->dtype == PANDRS_HIP_U32CODE ? 1 : (src->dtype == PANDRS_HIP_BOOLBITS ? 2 : 0);
+    const size_t esz = kind == 0 ? 8 : (kind == 1 ? 4 : 1);
+    struct Staged { const void *data; const uint8_t *mask; int64_t n; };
+    Staged s0{src->data, src->null_mask, n_src}, s1{key_right ? key_right->data : nullptr, key_right ? key_right->null_mask : nullptr, n_right};
+    const int64_t *d_left = nullptr, *d_right = nullptr;
+    void *d_out = out;
+    int64_t n = 0;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (!c->jn.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no join result retained in this context");
+        n = c->jn.n_rows;
+        if (n == 0) return 0;
+        if (!out) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "join_gather: null output");
+        d_left = c->jn.left_idx; d_right = c->jn.right_idx;
+        HIP_TRY(hipSetDevice(c->device));
+        const bool stage_src = src_mem_space == PANDRS_HIP_MEM_HOST, stage_out = out_mem_space == PANDRS_HIP_MEM_HOST;
+        auto col_bytes = [&](const pandrs_hip_column *col, int64_t rows) { return Arena::padded(dtype_bytes(col->dtype, rows) + 16) + Arena::padded((size_t)(rows + 7) / 8 + 16); };
+        size_t need = 4096;
+        if (stage_src) need += col_bytes(src, n_src) + (key_right ? col_bytes(key_right, n_right) : 0);
+        if (stage_out) need += Arena::padded(size_t(n) * esz + 16);
+        if (stage_src || stage_out) ST_TRY(c->staging.ensure(need, c->stream));
+        auto stage = [&](const pandrs_hip_column *col, Staged &st) -> int32_t {
+            st.data = nullptr; st.mask = nullptr;
+            if (st.n <= 0 || !col->data) return 0;
+            const size_t sbytes = dtype_bytes(col->dtype, st.n), mbytes = (size_t)(st.n + 7) / 8;
+            void *p = c->staging.take<uint8_t>(sbytes + 16);
+            if (!p) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+            HIP_TRY(hipMemcpyAsync(p, col->data, sbytes, hipMemcpyHostToDevice, c->stream));
+            st.data = p;
+            if (col->null_mask) {
+                uint8_t *m = c->staging.take<uint8_t>(mbytes + 16);
+                if (!m) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+                HIP_TRY(hipMemcpyAsync(m, col->null_mask, mbytes, hipMemcpyHostToDevice, c->stream));
+                st.mask = m;
+            }
+            return 0;
+        };
+        if (stage_src) {
+            ST_TRY(stage(src, s0));
+            if (key_right) ST_TRY(stage(key_right, s1));
+        }
+        if (stage_out) {
+            d_out = c->staging.take<uint8_t>(size_t(n) * esz + 16);
+            if (!d_out) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "staging arena too small");
+        }
+    }
+    // a source without rows is never dereferenced: the kernel's bounds test (n_src = 0) sends every row to the fill value
+    ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, s0.data ? s0.data : (const void *)d_left, s0.mask, side ? d_right : d_left, n, fill_bits, d_out,
+                        s0.data ? s0.n : 0));
+    if (key_right)
+        ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, s1.data ? s1.data : (const void *)d_left, s1.mask, d_right, n, fill_bits, d_out, s1.data ? s1.n : 0,
+                            /*only_where_negative=*/d_left));
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (out_mem_space == PANDRS_HIP_MEM_HOST) HIP_TRY(hipMemcpyAsync(out, d_out, size_t(n) * esz, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -82,6 +82,12 @@ class ResidentColumn:
     def __iter__(self):        # unpacks like a triple: (self, None, dtype)
         return iter((self, None, self.dtype))
 
+    def __getitem__(self, i):  # ... and indexes like one (col[0] is the data, col[2] the dtype)
+        return (self, None, self.dtype)[i]
+
+    def __len__(self):
+        return 3
+
 
 class Context:
     def __init__(self, device=0):

@@ -754,7 +754,11 @@ class LazyFrame:
 
     def execute(self):
         df = self.source
-        for op in self.operations:
+        ops = list(self.operations)
+        i = 0
+        while i < len(ops):
+            op = ops[i]
+            i += 1
             if op[0] == "aggregate":
                 _, group_by, aggregations = op
                 for _, agg_op, _ in aggregations:             # lazy.rs:377-382: only these five ops
@@ -762,8 +766,47 @@ class LazyFrame:
                                                         AggregateOp.Max, AggregateOp.Count):
                         raise OperationFailed(L.ERR_OPERATION_FAILED,
                                               "Aggregation operation %s is not supported" % AggregateOp(int(agg_op)).name)
-                df = df.group_by(group_by).aggregate(aggregations)
+                # the arm builds its result inline and never a multi-index: key columns always (lazy.rs:390-394;
+                # tests/optimized_groupby_test.rs:184 asserts 3 columns for two keys)
+                df = df.group_by_with_options(group_by, False).aggregate(aggregations)
             else:
                 _, right, left_on, right_on, jt = op
+                # Join(Inner) immediately followed by Aggregate([g], [(v, Sum, alias)]) — lazy.rs:405-425 then :186 — with v a
+                # left column and g a right column is BASELINE config 5: one fused device operator
+                # (pandrs_hip_join_groupby_sum), the joined rows are never materialised
+                if jt == JoinType.Inner and i < len(ops) and ops[i][0] == "aggregate":
+                    fused = _fused_join_groupby_sum(df, right, left_on, right_on, ops[i][1], ops[i][2])
+                    if fused is not None:
+                        df = fused
+                        i += 1
+                        continue
                 df = df._join_impl(right, left_on, right_on, jt)     # lazy.rs:405-425
         return df
+
+
+def _fused_join_groupby_sum(left, right, left_on, right_on, group_by, aggregations):
+    """The shape test of hip_shim.rs `lazy_join_groupby_sum_hip` (same conditions, same result frame); None = not
+    that shape, the two arms run one after the other."""
+    if len(group_by) != 1 or len(aggregations) != 1 or AggregateOp(int(aggregations[0][1])) != AggregateOp.Sum:
+        return None
+    group_col, (value_col, _, alias) = group_by[0], aggregations[0]
+    if left_on not in left.column_indices or right_on not in right.column_indices:
+        return None                                          # the join arm raises ColumnNotFound
+    if value_col == left_on or not left.contains_column(value_col) or left.contains_column(group_col):
+        return None
+    if group_col.endswith("_right") and left.contains_column(group_col[:-6]) and right.contains_column(group_col[:-6]):
+        right_name = group_col[:-6]                          # join.rs:478-482
+    elif right.contains_column(group_col):
+        right_name = group_col
+    else:
+        return None
+    if right_name == right_on:
+        return None
+    lk, lv, rk, rg = left.column(left_on), left.column(value_col), right.column(right_on), right.column(right_name)
+    if lk.dtype != rk.dtype or lv.dtype not in (L.I64, L.F64) or rg.dtype == L.BOOLBITS or rg.null_mask is not None:
+        return None
+    kc, kn, sums = get_context().join_groupby_sum(lk.view(), lv.view(), left.row_count(), rk.view(), rg.view(), right.row_count())
+    result = OptimizedDataFrame()
+    result.add_column(group_col, StringColumn(_key_strings(rg.dtype, kc[0], kn[0])))
+    result.add_column(alias, Float64Column(sums[0]))
+    return result

@@ -356,6 +356,70 @@ static void test_resident_frame_skips_the_staging() {
     detail::check(pandrs_hip_resident_bytes(detail::context(), &rb, &rc));
     CHECK(rc == 0 && rb == 0);
 }
+// group_by builds a multi-index for >= 2 keys (grouping.rs:22-28 passes as_multi_index = true): aggregate() then returns NO key
+// columns and a StringMultiIndex of the key tuples (aggregation.rs:812-853); group_by_with_options(.., false) and the lazy arm
+// (lazy.rs:390-394, tests/optimized_groupby_test.rs:184) keep the key columns
+static void test_multi_key_group_by_builds_a_multi_index() {
+    OptimizedDataFrame df;
+    df.add_column("category", StringColumn({"A", "A", "B", "B", "A"}));
+    df.add_column("group", StringColumn({"X", "Y", "X", "Y", "X"}));
+    df.add_column("values", Int64Column({10, 20, 30, 40, 50}));
+    auto gb = df.group_by({"category", "group"});
+    CHECK(gb.create_multi_index);
+    auto r = gb.aggregate({{"values", AggregateOp::Sum, "sum"}, {"values", AggregateOp::Count, "n"}});
+    CHECK(r.column_count() == 2 && !r.contains_column("category") && !r.contains_column("group"));
+    CHECK(r.has_multi_index() && (r.multi_index_names == std::vector<std::string>{"category", "group"}) && r.multi_index.size() == 4 && r.row_count() == 4);
+    std::map<std::vector<std::string>, double> sums, counts;
+    for (size_t i = 0; i < r.multi_index.size(); i++) {
+        sums[r.multi_index[i]] = std::get<Float64Column>(r.column("sum")).data[i];
+        counts[r.multi_index[i]] = std::get<Float64Column>(r.column("n")).data[i];
+    }
+    CHECK((sums[{"A", "X"}] == 60.0) && (sums[{"A", "Y"}] == 20.0) && (sums[{"B", "X"}] == 30.0) && (sums[{"B", "Y"}] == 40.0) && (counts[{"A", "X"}] == 2.0));
+    CHECK(!df.group_by({"category"}).create_multi_index);                                  // one key: never (grouping.rs:107)
+    auto flat = df.group_by_with_options({"category", "group"}, false).aggregate({{"values", AggregateOp::Sum, "sum"}});
+    CHECK(flat.column_count() == 3 && !flat.has_multi_index() && (flat.column_names == std::vector<std::string>{"category", "group", "sum"}));
+    auto lazy = LazyFrame(df).aggregate({"category", "group"}, {{"values", AggregateOp::Sum, "sum"}}).execute();
+    CHECK(lazy.column_count() == 3 && !lazy.has_multi_index());
+    OptimizedDataFrame none;                                  // no rows: from_tuples refuses an empty tuple list (multi_index.rs:160)
+    none.add_column("a", Int64Column(std::vector<int64_t>{})); none.add_column("b", Int64Column(std::vector<int64_t>{})); none.add_column("v", Float64Column(std::vector<double>{}));
+    bool threw = false;
+    try { none.group_by({"a", "b"}).aggregate({{"v", AggregateOp::Sum, "s"}}); } catch (const Error &e) { threw = e.kind == Error::Index; }
+    CHECK(threw);
+}
+// LazyFrame: Join(Inner) immediately followed by Aggregate([g], [(v, Sum, alias)]) (lazy.rs:405-425 then :186) runs as the fused
+// device operator (BASELINE config 5, pandrs_hip_join_groupby_sum); same frame as the two arms one after the other
+static void test_lazy_join_then_aggregate_is_fused() {
+    const int64_t n_left = 200000, n_right = 5000;
+    std::vector<int64_t> lid(n_left), rid(n_right), g(n_right), other(n_left);
+    std::vector<double> v(n_left);
+    uint64_t x = 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int64_t i = 0; i < n_right; i++) { rid[i] = i * 7 + 3; g[i] = (int64_t)(rnd() % 37) - 5; }
+    for (int64_t i = 0; i < n_left; i++) { lid[i] = (int64_t)(rnd() % (uint64_t)(n_right + 500)) * 7 + 3; v[i] = (double)(rnd() % 1000) / 8.0; other[i] = i; }
+    OptimizedDataFrame left, right;
+    left.add_column("id", Int64Column(lid)); left.add_column("v", Float64Column(v)); left.add_column("g", Int64Column(other));
+    right.add_column("id", Int64Column(rid)); right.add_column("g", Int64Column(g)); right.add_column("w", Int64Column(g));
+    // `g` exists on both sides: the joined frame calls the right one "g_right" (join.rs:478-482); "w" keeps its name
+    for (const char *gname : {"g_right", "w"}) {
+        auto fused = LazyFrame(left).join(right, "id", "id", JoinType::Inner).aggregate({gname}, {{"v", AggregateOp::Sum, "total"}}).execute();
+        auto two_step = left.inner_join(right, "id", "id").group_by({gname}).aggregate({{"v", AggregateOp::Sum, "total"}});
+        CHECK((fused.column_names == std::vector<std::string>{gname, "total"}) && fused.row_count() == two_step.row_count() && fused.row_count() == 37);
+        auto a = by_key(fused, gname, "total"), b = by_key(two_step, gname, "total");
+        CHECK(a.size() == b.size());
+        for (auto &kv : b) CHECK(a.count(kv.first) && std::fabs(a[kv.first] - kv.second) <= 1e-9 * std::fabs(kv.second));
+    }
+    // not the fused shape (grouping by a LEFT column; a null in g): the two arms run, same answers as calling them by hand
+    auto by_left = LazyFrame(left).join(right, "id", "id", JoinType::Inner).aggregate({"v"}, {{"w", AggregateOp::Sum, "s"}}).execute();
+    CHECK(by_left.row_count() == left.inner_join(right, "id", "id").group_by({"v"}).aggregate({{"w", AggregateOp::Sum, "s"}}).row_count());
+    OptimizedDataFrame rn;
+    std::vector<bool> nulls(n_right, false); nulls[0] = nulls[17] = true;
+    rn.add_column("id", Int64Column(rid)); rn.add_column("w", Int64Column::with_nulls(g, nulls));
+    auto with_null = LazyFrame(left).join(rn, "id", "id", JoinType::Inner).aggregate({"w"}, {{"v", AggregateOp::Sum, "total"}}).execute();
+    auto want_null = left.inner_join(rn, "id", "id").group_by({"w"}).aggregate({{"v", AggregateOp::Sum, "total"}});
+    auto a = by_key(with_null, "w", "total"), b = by_key(want_null, "w", "total");
+    CHECK(a.size() == b.size() && !a.count("NULL"));          // a null g is the join's fill value 0 (join.rs:304-307), not a NULL group
+    for (auto &kv : b) CHECK(a.count(kv.first) && std::fabs(a[kv.first] - kv.second) <= 1e-9 * std::fabs(kv.second));
+}
 
 int main() {
     int32_t n_dev = 0;
@@ -376,6 +440,8 @@ int main() {
     RUN(test_concurrent_callers_share_one_frame);
     RUN(test_random_frame_matches_the_oracle);
     RUN(test_resident_frame_skips_the_staging);
+    RUN(test_multi_key_group_by_builds_a_multi_index);
+    RUN(test_lazy_join_then_aggregate_is_fused);
     std::printf("%d tests, %d failed checks\n", g_run, g_failed);
     return g_failed ? 2 : 0;
 }

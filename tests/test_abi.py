@@ -63,9 +63,37 @@ def test_every_set_option_name_is_documented_in_the_header():
     import re
     capi = open(os.path.join(ROOT, "pandrs_amd", "csrc", "capi.hip")).read()
     body = capi[capi.index("int32_t pandrs_hip_ctx_set_option("):]
-    body = body[:body.index("return PANDRS_HIP_OK;")]
+    body = body[:body.index('on_exception("pandrs_hip_ctx_set_option")')]
     accepted = set(re.findall(r'std::strcmp\(name, "(\w+)"\)', body))
     header = open(os.path.join(ROOT, "include", "pandrs_hip.h")).read()
     doc = header[header.index("Tuning / testing knobs"):header.index("int32_t pandrs_hip_ctx_set_option(")]
     documented = set(re.findall(r'"(\w+)"', doc))
     assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
+
+
+def test_every_entry_point_has_the_exception_firewall():
+    """Every extern "C" function the header declares is defined as a function-try-block whose handler maps the exception to a
+    status (common.hpp on_exception): std::bad_alloc -> OUT_OF_MEMORY, anything else -> COMPUTATION.  (pandrs_hip_last_error
+    returns a pointer into a fixed thread-local buffer and cannot throw.)"""
+    header = open(os.path.join(ROOT, "include", "pandrs_hip.h")).read()
+    declared = set(re.findall(r"^int32_t\s*(pandrs_hip_[a-z0-9_]+)\s*\(", header, re.M))
+    guarded, defined = set(), set()
+    for f in ("capi.hip", "dist.hip"):
+        src = open(os.path.join(ROOT, "pandrs_amd", "csrc", f)).read()
+        src = src[src.index('extern "C" {'):]
+        defined |= set(re.findall(r"^int32_t\s+(pandrs_hip_\w+)\s*\(", src, re.M))
+        guarded |= set(re.findall(r'catch \(\.\.\.\) \{ return pandrs::on_exception\("(pandrs_hip_\w+)"\); \}', src))
+        for m in re.finditer(r"^int32_t\s+(pandrs_hip_\w+)\s*\([^{;]*\)\s*(try)?\s*\{", src, re.M):
+            assert m.group(2) == "try", "%s in %s is not a function-try-block" % (m.group(1), f)
+    assert declared == defined == guarded, (declared ^ defined, defined ^ guarded)
+
+
+def test_exceptions_become_status_codes(lib):
+    handle = lib.load()
+    assert handle.pandrs_hip_ctx_set_option(None, b"test_throw", 1) == lib.ERR_OUT_OF_MEMORY
+    assert b"bad_alloc" in handle.pandrs_hip_last_error()
+    assert handle.pandrs_hip_ctx_set_option(None, b"test_throw", 2) == lib.ERR_COMPUTATION
+    assert b"C++ exception" in handle.pandrs_hip_last_error()
+    assert handle.pandrs_hip_ctx_set_option(None, b"test_throw", 3) == lib.ERR_COMPUTATION
+    assert handle.pandrs_hip_ctx_set_option(None, b"test_throw", 4) in (lib.ERR_OUT_OF_MEMORY, lib.ERR_COMPUTATION)
+    assert handle.pandrs_hip_ctx_set_option(None, b"test_throw", 0) == 0

@@ -36,4 +36,4 @@ def test_cpp_mirror_replays_the_reference_tests():
         _build(exe)
         r = subprocess.run([exe], capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert "13 tests, 0 failed checks" in r.stdout
+        assert "15 tests, 0 failed checks" in r.stdout

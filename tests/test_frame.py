@@ -112,6 +112,123 @@ def test_two_key_groupby_like_reference():
 
 
 @pytest.mark.gpu
+def test_lazy_two_keys_keep_their_key_columns():
+    """tests/optimized_groupby_test.rs:138-186 through LazyFrame: `column_count() == 3` for two keys (:184).  The lazy arm builds
+    its frame inline and never a multi-index (lazy.rs:390-394) — round 3's mirror routed it through group_by(), which does."""
+    df = OptimizedDataFrame()
+    df.add_column("category", StringColumn(["A", "A", "B", "B", "A"]))
+    df.add_column("group", StringColumn(["X", "Y", "X", "Y", "X"]))
+    df.add_column("values", Int64Column([10, 20, 30, 40, 50]))
+    res = LazyFrame.new(df).aggregate(["category", "group"], [("values", AggregateOp.Sum, "sum")]).execute()
+    assert res.row_count() == 4 and res.column_count() == 3 and res.multi_index is None
+    assert res.column_names == ["category", "group", "sum"]
+    got = {(a, b): v for a, b, v in zip(res.column("category").to_list(), res.column("group").to_list(), res.column("sum").data)}
+    assert got == {("A", "X"): 60.0, ("A", "Y"): 20.0, ("B", "X"): 30.0, ("B", "Y"): 40.0}
+
+
+@pytest.mark.gpu
+def test_lazy_join_then_aggregate_runs_the_fused_operator(monkeypatch):
+    """LazyFrame: Join(Inner) immediately followed by Aggregate([g], [(v, Sum, alias)]) (lazy.rs:405-425, then :186) with v from the
+    left frame and g from the right one is BASELINE config 5: the mirror answers it with pandrs_hip_join_groupby_sum (no joined
+    rows).  Same frame as the oracle's join -> gather -> groupby and as the two arms run one after the other."""
+    from oracle import oracle as O
+    from pandrs_amd import frame as F
+    rng = np.random.default_rng(31)
+    n_left, n_right = 300_000, 20_000
+    rid = rng.permutation(n_right * 3)[:n_right].astype(np.int64) - 7
+    g = rng.integers(-3, 40, n_right).astype(np.int64)
+    lid = rng.choice(np.concatenate([rid, np.arange(10**9, 10**9 + 500)]), n_left)      # ~97 % hits
+    v = rng.normal(10, 3, n_left)
+    left, right = OptimizedDataFrame(), OptimizedDataFrame()
+    left.add_column("id", Int64Column(lid)); left.add_column("v", Float64Column.with_nulls(v, rng.random(n_left) < 0.01))
+    left.add_column("g", Int64Column(np.arange(n_left)))
+    right.add_column("rid", Int64Column(rid)); right.add_column("g", Int64Column(g)); right.add_column("name", StringColumn(["n%d" % (x % 11) for x in g]))
+    calls = []
+    real = F.Context.join_groupby_sum
+    monkeypatch.setattr(F.Context, "join_groupby_sum", lambda self, *a: (calls.append(1), real(self, *a))[1])
+    for gname, rcol in (("g_right", "g"), ("name", "name")):                             # `g` clashes with a left column -> "g_right" (join.rs:478-482)
+        calls.clear()
+        res = LazyFrame.new(left).join(right, "id", "rid", JoinType.Inner).aggregate([gname], [("v", AggregateOp.Sum, "total")]).execute()
+        assert calls == [1]                                                              # the fused operator answered
+        assert res.column_names == [gname, "total"]
+        two = left.inner_join(right, "id", "rid").group_by([gname]).aggregate([("v", AggregateOp.Sum, "total")])
+        a = dict(zip(res.column(gname).to_list(), res.column("total").data.tolist()))
+        b = dict(zip(two.column(gname).to_list(), two.column("total").data.tolist()))
+        assert a.keys() == b.keys() and all(abs(a[k] - b[k]) <= 1e-9 * abs(b[k]) for k in b)
+        rc = right.column(rcol)
+        kc, kn, sums = O.join_groupby_sum(left.column("id").view(), left.column("v").view(), n_left, right.column("rid").view(), rc.view(), n_right)
+        want = dict(zip(F._key_strings(rc.dtype, kc[0], kn[0]), sums[0].tolist()))
+        assert a.keys() == want.keys() and all(abs(a[k] - want[k]) <= 1e-9 * abs(want[k]) for k in want)
+    # shapes that must NOT fuse: another join type, two aggregations, grouping by a left column, a null in g
+    calls.clear()
+    LazyFrame.new(left).join(right, "id", "rid", JoinType.Left).aggregate(["name"], [("v", AggregateOp.Sum, "t")]).execute()
+    LazyFrame.new(left).join(right, "id", "rid", JoinType.Inner).aggregate(["name"], [("v", AggregateOp.Sum, "t"), ("v", AggregateOp.Count, "n")]).execute()
+    LazyFrame.new(left).join(right, "id", "rid", JoinType.Inner).aggregate(["g"], [("v", AggregateOp.Sum, "t")]).execute()     # "g" is the LEFT column
+    rn = OptimizedDataFrame()
+    rn.add_column("rid", Int64Column(rid)); rn.add_column("w", Int64Column.with_nulls(g, np.arange(n_right) % 1000 == 0))
+    res = LazyFrame.new(left).join(rn, "id", "rid", JoinType.Inner).aggregate(["w"], [("v", AggregateOp.Sum, "t")]).execute()
+    assert calls == []
+    assert "NULL" not in res.column("w").to_list()                                       # a null g is the join's fill value 0 (join.rs:304-307)
+
+
+@pytest.mark.gpu
+def test_join_columns_are_gathered_through_the_retained_pairs():
+    """pandrs_hip_join_gather / _join_gather_key (the Rust shim's join seam, patch 0002): every column of the joined frame is one
+    gather through the pairs the context retains — resident or host source, host output — equal to the oracle's gathers over the
+    fetched pairs (join.rs:286-552: misses and nulls become the fill value; the key column takes the right key where there is no
+    left row)."""
+    import ctypes as C
+    from oracle import oracle as O
+    from pandrs_amd import _lib as L
+    from pandrs_amd.frame import get_context
+    rng = np.random.default_rng(77)
+    ctx = get_context()
+    n_left, n_right = 50_000, 30_000
+    lk = rng.integers(0, 40_000, n_left).astype(np.int64)
+    rk = rng.permutation(60_000)[:n_right].astype(np.int64)
+    lmask, rmask = O.pack_mask(rng.random(n_left) < 0.02), O.pack_mask(rng.random(n_right) < 0.02)
+    lpay = rng.normal(0, 1, n_left)
+    lpay_mask = O.pack_mask(rng.random(n_left) < 0.1)
+    rcodes = rng.integers(0, 50, n_right).astype(np.uint32)
+    rbits = np.packbits(rng.random(n_right) < 0.5, bitorder="little")
+    for how in (0, 1, 2, 3):
+        li, ri = ctx.join_indices((lk, lmask, L.I64), n_left, (rk, rmask, L.I64), n_right, how)
+        li, ri = np.asarray(li.cpu() if hasattr(li, "cpu") else li), np.asarray(ri.cpu() if hasattr(ri, "cpu") else ri)
+        n = len(li)
+        wl, wr = O.join_indices((lk, lmask, O.I64), n_left, (rk, rmask, O.I64), n_right, how)
+        assert np.array_equal(li, wl) and np.array_equal(ri, wr)
+
+        def gather(col, n_src, side, fill, out, key_right=None, n_key_right=0, resident=False):
+            keep = []
+            cc, sp = ctx._cols([col], keep)
+            if resident:
+                up = ctx.upload_column(*col)
+                keep = [up]
+                cc, sp = ctx._cols([tuple(up)], keep)
+            if key_right is None:
+                st = ctx.lib.pandrs_hip_join_gather(ctx.h, sp, cc, n_src, side, fill, L.MEM_HOST, out.ctypes.data_as(C.c_void_p))
+            else:
+                kc, _ = ctx._cols([key_right], keep)
+                st = ctx.lib.pandrs_hip_join_gather_key(ctx.h, sp, cc, n_src, kc, n_key_right, fill, L.MEM_HOST, out.ctypes.data_as(C.c_void_p))
+            assert st == 0, ctx.lib.pandrs_hip_last_error()
+            if resident:
+                up.release()
+            return out
+
+        for resident in (False, True):
+            got = gather((lpay, lpay_mask, L.F64), n_left, 0, 0, np.full(n, -1.0), resident=resident)
+            assert np.array_equal(got, O.gather(lpay, lpay_mask, li, 0.0, O.F64))
+        got = gather((rcodes, rmask, L.U32CODE), n_right, 1, 0xFFFFFFFF, np.zeros(n, np.uint32))
+        assert np.array_equal(got, O.gather(rcodes, rmask, ri, 0xFFFFFFFF, O.U32CODE))
+        got = gather((rbits, None, L.BOOLBITS), n_right, 1, 0, np.full(n, 7, np.uint8))
+        assert np.array_equal(got, O.gather(rbits, None, ri, 0, O.BOOLBITS))
+        # the key column: left value (null -> fill), else the right key's value
+        got = gather((lk, lmask, L.I64), n_left, 0, 0, np.full(n, -1, np.int64), key_right=(rk, rmask, L.I64), n_key_right=n_right)
+        a, b = O.gather(lk, lmask, li, 0, O.I64), O.gather(rk, rmask, ri, 0, O.I64)
+        assert np.array_equal(got, np.where(li >= 0, a, b))
+
+
+@pytest.mark.gpu
 def test_joins_like_reference_tests(golden):
     """tests/optimized_join_test.rs:6-232: row / column counts, plus exact contents."""
     left = OptimizedDataFrame()

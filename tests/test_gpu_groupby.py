@@ -1438,6 +1438,50 @@ def test_absorb_and_spill_matches_oracle(ctx, shape):
         assert t["absorbed_rows"] > t3["absorbed_rows"] + 0.03 * n, (t["absorbed_rows"], t3["absorbed_rows"])
 
 
+@pytest.mark.parametrize("case", ["sliced_tail", "underestimated_tail", "late_hot_key", "two_keys"])
+def test_compact_spill_with_nested_runs_and_composite_keys(ctx, case):
+    """The compact spill (a hot set in front of a long tail) groups the spilled rows as the call's RESULT and appends the absorbed hot
+    groups behind them.  The tail's run may itself nest — the slice merge of an oversized partition, the overflow run of a tail whose
+    own estimate is too low — into the result slot the absorbed groups used to sit in (round-3 advisor finding: the hot groups were
+    lost and the nested groups appended twice); and with a composite key the tail's result must be laid out for ALL key columns
+    (it was laid out for one: the unpack wrote past the key arrays).  Same groups as the oracle in every case."""
+    rng = np.random.default_rng({"sliced_tail": 11, "underestimated_tail": 12, "late_hot_key": 13, "two_keys": 14}[case])
+    n, g = 17_000_000, 2_000_000
+    opts = []
+    ids = _skewed_ids(rng, n, g, 0.85, 800)
+    if case == "late_hot_key":
+        # one more heavy key that only shows up in the last tenth of the rows (image or not, it is the same call); a forced tiny
+        # slice size also cuts its partition of the tail into many slices -> nested merge
+        ids[-n // 10:][rng.random(n // 10) < 0.6] = 5_000_000
+    if case in ("sliced_tail", "late_hot_key"):
+        opts = [("slice_rows", 30_000)]
+    if case == "underestimated_tail":
+        opts = [("tail_groups_hint", 50_000)]                   # ~1.4 M groups in the tail: its LDS tables fill up -> overflow run
+    if case == "two_keys":
+        k0 = ((ids % 1000).astype(np.int64) * 7 - 3000, O.pack_mask(rng.random(n) < 0.0005), O.I64)
+        k1 = ((ids // 1000).astype(np.uint32), None, O.U32CODE)
+        keys, kds = [k0, k1], [O.I64, O.U32CODE]
+    else:
+        k = sparse_keys_from(ids)
+        k[::100_003] = -1
+        keys, kds = [(k, O.pack_mask(rng.random(n) < 0.001), O.I64)], [O.I64]
+    v = rng.standard_normal(n)
+    v[::50_021] = np.nan
+    vals = [(v, O.pack_mask(rng.random(n) < 0.02), O.F64), (rng.standard_normal(n), O.pack_mask(rng.random(n) < 0.3), O.F64)]
+    aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.MEAN), (1, O.SUM), (1, O.MIN), (1, O.MAX), (1, O.COUNT)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    for name, val in opts:
+        ctx.set_option(name, val)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+        t = ctx.timings()
+    finally:
+        for name, _ in opts:
+            ctx.set_option(name, 0)
+    assert t["n_partitions"] == -1 and t["absorbed_rows"] > 0.5 * n, t          # the compact spill answered
+    assert_groupby_equal(got, want, kds, int_exact_rows=(1, 2, 5, 6, 7))
+
+
 def test_absorb_is_not_tried_on_uniform_keys(ctx):
     """The decision comes from the estimate's own sample (share of the rows on the most frequent keys): uniform keys
     must keep the ordinary path, at the cost of two small kernels."""
