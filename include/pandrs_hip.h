@@ -209,6 +209,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "test_throw"        tests of the exception firewall (ctx may be NULL): 1 = the entry point's host code throws std::bad_alloc
  *                       (-> PANDRS_HIP_ERR_OUT_OF_MEMORY), 2 = std::out_of_range, 3 = a non-std exception, 4 = an oversized
  *                       std::vector::resize (2 - 4 -> PANDRS_HIP_ERR_COMPUTATION, or OUT_OF_MEMORY for bad_alloc); never a crash
+ *   "no_census"         1 = the group estimate never takes its second stage (a hash-slice census of a tenth of the rows, run when the
+ *                       strided sample shows singletons its repeating keys cannot explain: a long tail behind a broad hot class)
  *   "tail_groups_hint"  tests: the group estimate handed to the tail run of the absorb pass's compact spill (0 = its own sample)
  *   "no_overflow_run"   1 = a full LDS table fails the attempt (the call is retried with 4 x the fan-out) instead of handing the rows it
  *                       could not place to a run of their own, whose groups are appended

@@ -103,6 +103,7 @@ int32_t pandrs_hip_ctx_destroy(pandrs_hip_ctx *c) try {
     (void)hipEventDestroy(c->ev_call_begin); (void)hipEventDestroy(c->ev_call_end);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->est_table) (void)hipFree(c->est_table);
+    if (c->census_table) (void)hipFree(c->census_table);
     if (c->small_table) (void)hipFree(c->small_table);
     for (auto &kv : c->resident) (void)hipFree(kv.second.base);      // columns the caller never released
     (void)hipStreamDestroy(c->stream);
@@ -213,6 +214,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_direct")) c->opt.no_direct = value;
     else if (!std::strcmp(name, "no_absorb")) c->opt.no_absorb = value;
     else if (!std::strcmp(name, "no_chao")) c->opt.no_chao = value;
+    else if (!std::strcmp(name, "no_census")) c->opt.no_census = value;
     else if (!std::strcmp(name, "no_overflow_run")) c->opt.no_overflow_run = value;
     else if (!std::strcmp(name, "tail_groups_hint")) c->opt.tail_groups_hint = value;
     else if (!std::strcmp(name, "sorted_dictionary")) c->opt.sorted_dictionary = value;

@@ -190,6 +190,7 @@ struct Options {
     int64_t sorted_dictionary = 0;   // 1 = a too-wide column of a composite key is dictionary-encoded by ordering its rows (the path that takes any cardinality) instead of a hashed look-up
     int64_t no_overflow_run = 0;     // 1 = a full LDS table fails the attempt (retry with 4 x the fan-out) instead of handing its unplaced rows to a run of their own
     int64_t tail_groups_hint = 0;    // tests: the group estimate handed to the compact spill's tail run (0 = its own estimate); a low value makes its tables overflow
+    int64_t no_census = 0;           // 1 = the group estimate never takes its second stage (the hash-slice census of a tenth of the rows when the sample shows an unresolved tail)
     int64_t no_chao = 0;             // 1 = the group estimate is the uniform-occupancy model alone (no Chao1 term from the sample's singletons / doubletons)
     int64_t no_absorb = 0;           // 1 = never run the hot-key absorb-and-spill pass in front of the radix path
     int64_t no_hot_image = 0;        // 1 = the absorb tables start empty (first come, first served) instead of from the sample's hot keys
@@ -242,6 +243,8 @@ struct pandrs_hip_ctx {
     int small_skip = 0, small_backoff = 0;     // run_small's back-off after a call that did not fit
     void *small_table = nullptr;      // the small path's armed global table (groupby.hip run_small)
     uint64_t *est_table = nullptr;    // estimate_groups' armed hash table + counters (own allocation)
+    uint64_t *census_table = nullptr; // the estimate's second stage (hash-slice census): its own armed table + counters
+    int timings_census = 0;           // the last estimate took its figure from the census
     int64_t reserve_groups = 0;       // result rows the next res_slot-0 engine run keeps free behind its groups (a caller appends there)
     double est_near_same = 0.0;       // of the last estimate's sample: share of adjacent row pairs with equal keys (a dominant key or clustered rows)
     double est_repeat_share = 0.0;    // of the last estimate's sample: rows on keys sighted >= 3 times (a hot set shows here whatever the tail's length)

@@ -316,6 +316,88 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
     estimate_publish(distinct, host_out);
 }
 
+// ---- second stage of the estimate: a hash-slice CENSUS -----------------------------------------------------------------
+// The strided sample cannot size a long tail behind a broad hot class (SURVEY 8d's own 80/20 variant of C2: 200 K keys with 80 % of
+// the rows + 1 M keys sharing the rest): its 256 K rows hold the tail's keys once each, and "seen once" says nothing about how many
+// there are.  What does: take every row of a TENTH of the column (2048-row blocks spread evenly) whose key hashes into one slice of
+// the key space (1 / R of the keys).  A key of that slice is then seen with its FULL multiplicity among the scanned rows — ~2 rows
+// for the tail's keys instead of ~0.003 in the strided sample — so singletons and doubletons of the slice are meaningful for every
+// class of keys at once, Chao1 over them (exact for Poisson counts of any one rate, a lower bound for mixtures) extrapolates from
+// the scanned tenth to the whole column, and R x that is the group count.  The scan is a contiguous read (80 MB for C2: ~20 us), the
+// ~150 K rows that pass the slice filter go through the same CAS table + saturating sighting counters as the first stage.
+// counters: [0] distinct keys of the slice, [1] rows that passed, [4] blocks done, [5] keys sighted twice or more, [6] three times or more.
+constexpr uint32_t CENSUS_BLOCK_ROWS = 2048;
+__global__ __launch_bounds__(1024) void census_kernel(KeyDesc key, int64_t n_rows, int64_t block_stride, uint32_t slice_mask,
+                                                      uint64_t *table, uint32_t table_mask, uint32_t *counters, uint32_t *sight, uint32_t *host_out) {
+    __shared__ uint32_t inserted, twice, thrice, passed;
+    if (threadIdx.x == 0) { inserted = 0; twice = 0; thrice = 0; passed = 0; }
+    __syncthreads();
+    for (uint32_t j = 0; j < CENSUS_BLOCK_ROWS / 1024; j++) {
+        const int64_t i = (int64_t)blockIdx.x * block_stride + j * 1024 + threadIdx.x;
+        bool live = i < n_rows;
+        uint64_t k = 0;
+        if (live) {
+            k = key_cell(key, i);
+            live = !key_is_null(key, i) && k != EMPTY_KEY && (hash32(k, 0x7F4A7C15u) & slice_mask) == 0u;
+        }
+        const unsigned long long pm = __ballot(live);
+        if (!pm) continue;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&passed, (uint32_t)__popcll(pm));
+        // a wave's repeats of one key are represented by one lane (rows clustered by key; a heavy key that falls into the slice)
+        bool peeled = false;
+        uint32_t mult = 1;
+        for (int round = 0; round < 8; round++) {
+            const unsigned long long m = __ballot(live && !peeled);
+            if (!m) break;
+            const int leader = __ffsll((long long)m) - 1;
+            const uint64_t lk = __shfl(k, leader, 64);
+            const unsigned long long same = __ballot(live && !peeled && k == lk);
+            if (live && !peeled && k == lk) {
+                peeled = true;
+                if ((int)(threadIdx.x & 63) != leader) live = false;
+                else mult = (uint32_t)__popcll(same);
+            }
+        }
+        if (live) {
+            uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+            uint32_t seen = 3;
+            bool placed = false;
+            for (uint32_t probe = 0; probe <= table_mask; probe++) {
+                const uint64_t cur = table[slot];
+                seen = __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == k) { placed = true; break; }
+                if (cur == EMPTY_KEY) {
+                    const uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
+                    if (old == EMPTY_KEY) { atomicAdd(&inserted, 1u); placed = true; break; }
+                    if (old == k) { placed = true; break; }
+                }
+                slot = (slot + 1) & table_mask;
+            }
+            if (placed && seen < 3u) {
+                const uint32_t o = atomicAdd(&sight[slot], mult), n2 = o + mult;
+                if (o < 2u && n2 >= 2u) atomicAdd(&twice, 1u);
+                if (o < 3u && n2 >= 3u) atomicAdd(&thrice, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (inserted) atomicAdd(&counters[0], inserted);
+        if (passed) atomicAdd(&counters[1], passed);
+        if (twice) atomicAdd(&counters[5], twice);
+        if (thrice) atomicAdd(&counters[6], thrice);
+        __threadfence();
+        if (atomicAdd(&counters[4], 1u) == gridDim.x - 1) {
+            __threadfence();
+            host_out[0] = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[1] = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[2] = __hip_atomic_load(&counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[4] = __hip_atomic_load(&counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&host_out[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ histogram
 // ------------------------------------------------------------------------------------ scan
 constexpr int SCAN_THREADS = 1024;
@@ -921,6 +1003,51 @@ constexpr uint32_t EST_IMAGE_SLOTS = 1u << 15;            // the hot-key image (
 static uint64_t *est_image(pandrs_hip_ctx *c) { return reinterpret_cast<uint64_t *>(est_cov_hist(c) + 2 * COV_BINS + 64); }
 static uint32_t *est_sight(pandrs_hip_ctx *c) { return reinterpret_cast<uint32_t *>(est_image(c) + EST_IMAGE_SLOTS); }      // [EST_SLOTS] saturating sighting counters
 
+// The census's own table (kept armed like the first stage's: cleared BEHIND a census, not in front of the next one).
+// -> *out_est = 0 when the slice held too few keys to say anything.
+static int32_t census_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, double *out_est) {
+    constexpr uint32_t slots = EST_SLOTS;
+    *out_est = 0.0;
+    if (!c->census_table) {
+        const size_t bytes = size_t(slots) * 8 + 256 + size_t(slots) * 4;
+        HIP_TRY(hipMalloc((void **)&c->census_table, bytes));
+        alloc_events()++;
+        hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->census_table, slots,
+                           reinterpret_cast<uint32_t *>(c->census_table + slots), (uint32_t *)nullptr, reinterpret_cast<uint32_t *>(c->census_table + slots) + 64);
+    }
+    uint32_t *counters = reinterpret_cast<uint32_t *>(c->census_table + slots), *sight = counters + 64;
+    // a tenth of the rows, at least 4 M (all of a smaller column), in 2048-row blocks spread evenly; slice width so that <= ~160 K rows pass
+    const int64_t n_scan = std::min<int64_t>(n_rows, std::max<int64_t>(n_rows / 10, int64_t(4) << 20));
+    const int64_t n_blocks = std::max<int64_t>(1, n_scan / CENSUS_BLOCK_ROWS);
+    const int64_t block_stride = std::max<int64_t>(CENSUS_BLOCK_ROWS, (n_rows / n_blocks) & ~int64_t(15));
+    uint32_t R = 16;
+    while ((double)n_blocks * CENSUS_BLOCK_ROWS / R > 160000.0 && R < (1u << 16)) R *= 2;
+    volatile uint32_t *h = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1200;
+    h[3] = 0;
+    hipLaunchKernelGGL(census_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, c->stream, key, n_rows, block_stride, R - 1, c->census_table, slots - 1,
+                       counters, sight, const_cast<uint32_t *>(h));
+    HIP_TRY(hipGetLastError());
+    for (int spin = 0; spin < 400000 && h[3] != 1; spin++) __builtin_ia32_pause();
+    if (h[3] != 1) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[3] != 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "census kernel did not publish its counters");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const double d = h[0], rows = h[1], twice = h[2], thrice = h[4];
+    hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, c->census_table, slots, counters, (uint32_t *)nullptr, sight);
+    const double scanned = (double)n_blocks * CENSUS_BLOCK_ROWS;
+    if (d >= 256.0 && d < 0.45 * slots) {
+        const double f1 = std::max(0.0, d - twice), f2 = std::max(0.0, twice - thrice);
+        // Chao1 over the slice: from the scanned rows to all rows; every row scanned: the slice's distinct count is exact
+        const double in_slice = scanned >= (double)n_rows ? d : d + f1 * std::max(0.0, f1 - 1.0) / (2.0 * (f2 + 1.0));
+        *out_est = std::min((double)R * in_slice, (double)n_rows);
+    }
+    if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
+        fprintf(stderr, "[census] scanned %.0f rows in %lld blocks, slice 1/%u: %.0f rows passed, %.0f distinct, %.0f twice, %.0f thrice -> %.0f groups\n",
+                scanned, (long long)n_blocks, R, rows, d, twice, thrice, *out_est);
+    return 0;
+}
+
 int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, int64_t *out_est, bool keep_table) {
     PhaseTimer pt(c, PANDRS_HIP_PHASE_ESTIMATE);
     const int64_t n_sample = std::min<int64_t>(n_rows, 1 << 18);
@@ -959,6 +1086,7 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     if (!keep_table) hipLaunchKernelGGL(estimate_clear_kernel, dim3(slots / 256), dim3(256), 0, c->stream, table, slots, distinct, (uint32_t *)nullptr, est_sight(c));
     double d = std::max<uint32_t>(hv[0], 1), s = (double)n_sample;
     double est;
+    bool census_wanted = false;
     c->est_repeat_share = 0.0;
     if (n_sample == n_rows) est = d;
     else if (s - d < 64.0) est = (double)n_rows;                  // too few repeats in the sample to measure: (nearly) all distinct
@@ -984,7 +1112,29 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         // so that uniform keys keep the model's steadier figure)
         if (!c->opt.no_chao && chao > 1.3 * G) G = chao;
         est = std::min<double>(std::max(G, d), (double)n_rows);
+        // An unresolved tail?  Keys sighted three times or more against doubletons give the rate of the class that REPEATS in the
+        // sub-sample (Poisson: P(>= 3) / P(2) is a function of the rate alone), and that class explains 2 f2 / rate singletons.
+        // Singletons far beyond that belong to keys the sample cannot count — rows of a tail whose size neither the model nor Chao1
+        // (a lower bound) can know.  When they are a real share of the rows, the second stage (a hash-slice census) sizes the column.
+        // Uniform keys never get here: their singletons are what their own doubletons predict (or f3 is too small to tell, and then
+        // the model's figure stands).
+        census_wanted = false;
+        if (!c->opt.no_census && thrice >= 150.0 && f2 >= 400.0 && n_rows >= (int64_t(1) << 22)) {
+            const double ratio = thrice / f2;                    // = (e^r - 1 - r - r^2 / 2) / (r^2 / 2)
+            double lo = 1e-4, hi = 30.0;
+            for (int it = 0; it < 60; it++) {
+                const double r = 0.5 * (lo + hi), val = (std::expm1(r) - r - 0.5 * r * r) / (0.5 * r * r);
+                (val < ratio ? lo : hi) = r;
+            }
+            const double rate = 0.5 * (lo + hi), f1_explained = 2.0 * f2 / rate;
+            const double sigma = f1_explained * std::sqrt(1.0 / thrice + 1.0 / f2);      // (the rate's own noise, first order)
+            const double excess = f1 - f1_explained;
+            census_wanted = excess > 0.08 * s_sub && excess > 4.0 * sigma;
+            if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
+                fprintf(stderr, "[estimate] repeat class: rate %.3f explains %.0f of %.0f singletons (sigma %.0f) -> census %d\n", rate, f1_explained, f1, sigma, (int)census_wanted);
+        }
     }
+    double run_bound = (double)n_rows;
     c->clustered_rows = false;
     c->est_near_same = hv[2] >= 1024 ? 1.0 - (double)hv[1] / (double)hv[2] : 0.0;
     if (hv[2] >= 1024) {
@@ -997,7 +1147,15 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         // input); + 3 sigma of the sampled share so that noise cannot push it below the truth
         const double pairs = (double)hv[2], b = (double)hv[1];
         const double share = std::min(1.0, (b + 3.0 * std::sqrt(b + 1.0)) / pairs);
-        est = std::min(est, std::max(d, share * (double)(n_rows - 1) + 1.0));
+        run_bound = std::max(d, share * (double)(n_rows - 1) + 1.0);
+        est = std::min(est, run_bound);
+    }
+    c->timings_census = 0;
+    if (census_wanted && !c->clustered_rows) {
+        double est2 = 0.0;
+        ST_TRY(census_groups(c, key, n_rows, &est2));
+        est2 = std::min(est2, run_bound);
+        if (est2 > est) { est = est2; c->timings_census = 1; }
     }
     if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
         fprintf(stderr, "[estimate] rows %lld sample %lld distinct %u | adjacent pairs %u differing %u (far pairs %u differing %u) | sub-sample %0.f distinct %0.f twice %0.f thrice %0.f | estimate %0.f clustered %d\n",

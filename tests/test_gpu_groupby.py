@@ -684,6 +684,86 @@ def test_full_size_properties():
         c.close()
 
 
+def test_config2_skew_full_size_properties():
+    """C2's own 80/20 variant (/root/reference/benches/enhanced_comprehensive_benchmark.rs:53-59) at full size — 100 M rows,
+    80 % of them on a fifth of the 1 M keys — through the same size-independent properties as the uniform case above.  The strided
+    sample cannot size the tail behind the 200 K hot keys (round 3: estimate 297 K, a third of the groups through an overflow run,
+    4.9 ms); the estimate's second stage — a hash-slice census of a tenth of the rows — does, so the call is planned once with the
+    right fan-out: no retry, no overflow run, estimate within 15 % of the truth; with the census off the old behaviour is still exact."""
+    import torch
+    import pandrs_amd as pa
+    n, g = 100_000_000, 1_000_000
+    d = "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(47)
+    hot = torch.rand(n, device=d, generator=gen) < 0.8
+    ids = torch.where(hot, torch.randint(0, g // 5, (n,), device=d, generator=gen), torch.randint(0, g, (n,), device=d, generator=gen))
+    del hot
+    keys = ids * -7046029254386353131 ^ 0x5555AAAA5555AAAA
+    vals = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100 for _ in range(4)]
+    aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    true_groups = torch.unique(ids).numel()
+    c = pa.Context(0)
+    try:
+        for census in (1, 0):
+            c.set_option("no_census", 1 - census)
+            ng = c.groupby_compute([(keys, None, O.I64)], n, [(v, None, O.F64) for v in vals], aggs)
+            t = c.timings()
+            kc, kn, oa = c.groupby_fetch()
+            assert ng == true_groups
+            assert torch.unique(kc[0]).numel() == ng and int(kn.sum()) == 0
+            cnt = oa[16]
+            assert float(cnt.sum()) == n
+            for col in range(4):
+                s, mean, mn, mx = oa[4 * col:4 * col + 4]
+                tot = float(vals[col].sum())
+                assert abs(float(s.sum()) - tot) <= 1e-9 * abs(tot)
+                assert float(mn.min()) == float(vals[col].min()) and float(mx.max()) == float(vals[col].max())
+                assert torch.allclose(mean * cnt, s, rtol=1e-12, atol=0)
+            if census:
+                assert t["retries"] == 0, t                                  # neither a retry nor an overflow run
+                assert 0.85 * true_groups <= t["estimated_groups"] <= 1.15 * true_groups, (t["estimated_groups"], true_groups)
+            else:
+                assert t["estimated_groups"] < 0.5 * true_groups, t         # what the strided sample alone makes of it
+            del kc, kn, oa
+    finally:
+        c.set_option("no_census", 0)
+        c.close()
+
+
+def test_census_is_not_taken_on_uniform_keys_and_sizes_a_long_tail(ctx):
+    """The census trigger (partition.hip, estimate_groups): singletons that the sample's repeating keys cannot explain.  Uniform keys
+    never trigger it (their estimate is the model's, as before); a broad hot class in front of a long tail does, and the estimate is
+    then within 15 % at a size the oracle checks too."""
+    rng = np.random.default_rng(321)
+    n = 12_000_000
+    v = [(rng.normal(100, 10, n), None, O.F64)]
+    aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.COUNT)]
+    for g in (5_000, 120_000, 2_000_000):
+        keys = [(sparse_keys(rng, n, g), None, O.I64)]
+        ctx.set_option("no_census", 1)
+        ctx.groupby_compute(keys, n, v, aggs)
+        e0 = ctx.timings()["estimated_groups"]
+        ctx.set_option("no_census", 0)
+        ctx.groupby_compute(keys, n, v, aggs)
+        assert ctx.timings()["estimated_groups"] == e0, g           # (the estimate is deterministic: same sample, no second stage)
+    g = 240_000
+    ids = np.where(rng.random(n) < 0.8, rng.integers(0, g // 10, n), rng.integers(0, g, n))    # 24 K keys with 80 % of the rows + 240 K
+    keys = [(sparse_keys_from(ids), None, O.I64)]
+    want = O.groupby_agg(keys, n, v, aggs)
+    true_groups = want[0].shape[1]
+    got = ctx.groupby_agg(keys, n, v, aggs)
+    t = ctx.timings()
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1, 2, 3])
+    assert 0.85 * true_groups <= t["estimated_groups"] <= 1.15 * true_groups, (t["estimated_groups"], true_groups)
+    ctx.set_option("no_census", 1)
+    try:
+        ctx.groupby_compute(keys, n, v, aggs)
+        assert ctx.timings()["estimated_groups"] < 0.6 * true_groups
+    finally:
+        ctx.set_option("no_census", 0)
+
+
 def test_gpu_config_is_honoured():
     """pandrs_hip_config mirrors GpuConfig (reference src/gpu/mod.rs:18-44): enabled / memory_limit."""
     import ctypes as C
