@@ -319,30 +319,74 @@ __global__ void estimate_kernel(KeyDesc key, int64_t n_rows, int64_t stride, int
 // ---- second stage of the estimate: a hash-slice CENSUS -----------------------------------------------------------------
 // The strided sample cannot size a long tail behind a broad hot class (SURVEY 8d's own 80/20 variant of C2: 200 K keys with 80 % of
 // the rows + 1 M keys sharing the rest): its 256 K rows hold the tail's keys once each, and "seen once" says nothing about how many
-// there are.  What does: take every row of a TENTH of the column (2048-row blocks spread evenly) whose key hashes into one slice of
+// there are.  What does: take every row of a TENTH of the column (16 K-row blocks spread evenly) whose key hashes into one slice of
 // the key space (1 / R of the keys).  A key of that slice is then seen with its FULL multiplicity among the scanned rows — ~2 rows
 // for the tail's keys instead of ~0.003 in the strided sample — so singletons and doubletons of the slice are meaningful for every
 // class of keys at once, Chao1 over them (exact for Poisson counts of any one rate, a lower bound for mixtures) extrapolates from
 // the scanned tenth to the whole column, and R x that is the group count.  The scan is a contiguous read (80 MB for C2: ~20 us), the
 // ~150 K rows that pass the slice filter go through the same CAS table + saturating sighting counters as the first stage.
 // counters: [0] distinct keys of the slice, [1] rows that passed, [4] blocks done, [5] keys sighted twice or more, [6] three times or more.
-constexpr uint32_t CENSUS_BLOCK_ROWS = 2048;
+constexpr uint32_t CENSUS_RPT = 16, CENSUS_BLOCK_ROWS = 1024 * CENSUS_RPT, CENSUS_QCAP = 4096;
+// one key of the slice into the census table: CAS insert, then the saturating sighting counter (`mult` sightings at once)
+__device__ __forceinline__ void census_insert(uint64_t k, uint32_t mult, uint64_t *table, uint32_t table_mask, uint32_t *sight,
+                                              uint32_t *inserted, uint32_t *twice, uint32_t *thrice) {
+    uint32_t slot = hash32(k, 0x1234567u) & table_mask;
+    uint32_t seen = 3;
+    bool placed = false;
+    for (uint32_t probe = 0; probe <= table_mask; probe++) {
+        const uint64_t cur = table[slot];
+        seen = __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == k) { placed = true; break; }
+        if (cur == EMPTY_KEY) {
+            const uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { atomicAdd(inserted, 1u); placed = true; break; }
+            if (old == k) { placed = true; break; }
+        }
+        slot = (slot + 1) & table_mask;
+    }
+    if (placed && seen < 3u) {
+        const uint32_t o = atomicAdd(&sight[slot], mult), n2 = o + mult;
+        if (o < 2u && n2 >= 2u) atomicAdd(twice, 1u);
+        if (o < 3u && n2 >= 3u) atomicAdd(thrice, 1u);
+    }
+}
+// A workgroup scans 16 K contiguous rows: 16 independent key loads per thread (the scan is a stream, not a chain of round trips), the
+// ~1 / R of them that fall into the slice are collected in an LDS queue, and the queue is then worked off one key per thread — the
+// table's round trips (load, CAS, counter) are paid once per workgroup, side by side, instead of once per passing row
+// (the first form, 2 K-row blocks and the insert inline: 255 us for C2's 10 M scanned rows; this one: see DESIGN.md).
 __global__ __launch_bounds__(1024) void census_kernel(KeyDesc key, int64_t n_rows, int64_t block_stride, uint32_t slice_mask,
                                                       uint64_t *table, uint32_t table_mask, uint32_t *counters, uint32_t *sight, uint32_t *host_out) {
-    __shared__ uint32_t inserted, twice, thrice, passed;
-    if (threadIdx.x == 0) { inserted = 0; twice = 0; thrice = 0; passed = 0; }
+    __shared__ uint64_t q[CENSUS_QCAP];
+    __shared__ uint32_t qn, inserted, twice, thrice;
+    if (threadIdx.x == 0) { qn = 0; inserted = 0; twice = 0; thrice = 0; }
     __syncthreads();
-    for (uint32_t j = 0; j < CENSUS_BLOCK_ROWS / 1024; j++) {
-        const int64_t i = (int64_t)blockIdx.x * block_stride + j * 1024 + threadIdx.x;
-        bool live = i < n_rows;
-        uint64_t k = 0;
-        if (live) {
-            k = key_cell(key, i);
-            live = !key_is_null(key, i) && k != EMPTY_KEY && (hash32(k, 0x7F4A7C15u) & slice_mask) == 0u;
+    const int64_t base = (int64_t)blockIdx.x * block_stride;
+#pragma unroll
+    for (uint32_t half = 0; half < 2; half++) {
+        uint64_t k[CENSUS_RPT / 2];
+        bool live[CENSUS_RPT / 2];
+#pragma unroll
+        for (uint32_t j = 0; j < CENSUS_RPT / 2; j++) {
+            const int64_t i = base + (int64_t)((half * (CENSUS_RPT / 2) + j) * 1024 + threadIdx.x);
+            live[j] = i < n_rows;
+            k[j] = live[j] ? key_cell(key, i) : 0ull;
+            live[j] = live[j] && !key_is_null(key, i);
         }
-        const unsigned long long pm = __ballot(live);
-        if (!pm) continue;
-        if ((threadIdx.x & 63) == 0) atomicAdd(&passed, (uint32_t)__popcll(pm));
+#pragma unroll
+        for (uint32_t j = 0; j < CENSUS_RPT / 2; j++) {
+            if (live[j] && k[j] != EMPTY_KEY && (hash32(k[j], 0x7F4A7C15u) & slice_mask) == 0u) {
+                const uint32_t pos = atomicAdd(&qn, 1u);
+                if (pos < CENSUS_QCAP) q[pos] = k[j];
+                else census_insert(k[j], 1u, table, table_mask, sight, &inserted, &twice, &thrice);     // (a heavy key in the slice: beyond the queue, inline)
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_q = min(qn, CENSUS_QCAP);
+    for (uint32_t e0 = 0; e0 < n_q; e0 += 1024) {               // (wave-uniform trip count)
+        const uint32_t e = e0 + threadIdx.x;
+        bool live = e < n_q;
+        const uint64_t k = live ? q[e] : 0ull;
         // a wave's repeats of one key are represented by one lane (rows clustered by key; a heavy key that falls into the slice)
         bool peeled = false;
         uint32_t mult = 1;
@@ -358,32 +402,12 @@ __global__ __launch_bounds__(1024) void census_kernel(KeyDesc key, int64_t n_row
                 else mult = (uint32_t)__popcll(same);
             }
         }
-        if (live) {
-            uint32_t slot = hash32(k, 0x1234567u) & table_mask;
-            uint32_t seen = 3;
-            bool placed = false;
-            for (uint32_t probe = 0; probe <= table_mask; probe++) {
-                const uint64_t cur = table[slot];
-                seen = __hip_atomic_load(&sight[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur == k) { placed = true; break; }
-                if (cur == EMPTY_KEY) {
-                    const uint64_t old = atomicCAS((unsigned long long *)&table[slot], EMPTY_KEY, k);
-                    if (old == EMPTY_KEY) { atomicAdd(&inserted, 1u); placed = true; break; }
-                    if (old == k) { placed = true; break; }
-                }
-                slot = (slot + 1) & table_mask;
-            }
-            if (placed && seen < 3u) {
-                const uint32_t o = atomicAdd(&sight[slot], mult), n2 = o + mult;
-                if (o < 2u && n2 >= 2u) atomicAdd(&twice, 1u);
-                if (o < 3u && n2 >= 3u) atomicAdd(&thrice, 1u);
-            }
-        }
+        if (live) census_insert(k, mult, table, table_mask, sight, &inserted, &twice, &thrice);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (inserted) atomicAdd(&counters[0], inserted);
-        if (passed) atomicAdd(&counters[1], passed);
+        if (qn) atomicAdd(&counters[1], qn);
         if (twice) atomicAdd(&counters[5], twice);
         if (thrice) atomicAdd(&counters[6], thrice);
         __threadfence();
@@ -1016,7 +1040,7 @@ static int32_t census_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_ro
                            reinterpret_cast<uint32_t *>(c->census_table + slots), (uint32_t *)nullptr, reinterpret_cast<uint32_t *>(c->census_table + slots) + 64);
     }
     uint32_t *counters = reinterpret_cast<uint32_t *>(c->census_table + slots), *sight = counters + 64;
-    // a tenth of the rows, at least 4 M (all of a smaller column), in 2048-row blocks spread evenly; slice width so that <= ~160 K rows pass
+    // a tenth of the rows, at least 4 M (all of a smaller column), in 16 K-row blocks spread evenly; slice width so that <= ~160 K rows pass
     const int64_t n_scan = std::min<int64_t>(n_rows, std::max<int64_t>(n_rows / 10, int64_t(4) << 20));
     const int64_t n_blocks = std::max<int64_t>(1, n_scan / CENSUS_BLOCK_ROWS);
     const int64_t block_stride = std::max<int64_t>(CENSUS_BLOCK_ROWS, (n_rows / n_blocks) & ~int64_t(15));
@@ -1129,7 +1153,8 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
             const double rate = 0.5 * (lo + hi), f1_explained = 2.0 * f2 / rate;
             const double sigma = f1_explained * std::sqrt(1.0 / thrice + 1.0 / f2);      // (the rate's own noise, first order)
             const double excess = f1 - f1_explained;
-            census_wanted = excess > 0.08 * s_sub && excess > 4.0 * sigma;
+            // (a loose bar: a false alarm on uniform keys — a 2.5 sigma event — costs one census, a miss costs an overflow run)
+            census_wanted = excess > 0.06 * s_sub && excess > 2.5 * sigma;
             if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
                 fprintf(stderr, "[estimate] repeat class: rate %.3f explains %.0f of %.0f singletons (sigma %.0f) -> census %d\n", rate, f1_explained, f1, sigma, (int)census_wanted);
         }
