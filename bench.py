@@ -335,9 +335,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra configs (north-star sum line, C3, C4 shard, C5 shard) reported beside the headline")
-    ap.add_argument("--workload", choices=["groupby", "join"], default="groupby",
+    ap.add_argument("--workload", choices=["groupby", "join", "c4"], default="groupby",
                     help="groupby = BASELINE config 2 (the headline line); join = config 5 shape "
-                         "(probe --rows per GPU, build rows/10 per GPU, inner join -> groupby(g).sum(v))")
+                         "(probe --rows per GPU, build rows/10 per GPU, inner join -> groupby(g).sum(v)); "
+                         "c4 = BASELINE config 4's per-GPU shard (125 M rows/GPU, 10 M groups, one f64 column, sum + count): "
+                         "the configuration north_star names for the 8-GPU radix all-to-all")
     ap.add_argument("--join-strategy", choices=["auto", "allgather", "shuffle"], default="auto",
                     help="N > 1, --workload join: replicate the build side, or shuffle both sides to the owner of their key")
     args = ap.parse_args()
@@ -374,8 +376,11 @@ def main():
         return bench_join(args, torch, pa, dist, rank, local_rank, world, device)
 
     n, g, ncol = args.rows, args.groups, args.cols
-    keys, vals = make_shard(torch, n, g, ncol, 42 + 1 + 1000 * rank, device)
-    aggs = [(c, op) for c in range(ncol) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)]
+    c4 = args.workload == "c4"
+    if c4:       # BASELINE config 4: 1 B rows over 8 GPUs = 125 M per GPU, 10 M groups over the WHOLE job, sum + count of one column
+        n, g, ncol = (125_000_000 if args.rows == 100_000_000 else args.rows), (10_000_000 if args.groups == 1_000_000 else args.groups), 1
+    keys, vals = make_shard(torch, n, g, ncol, 42 + (3 if c4 else 1) + 1000 * rank, device)
+    aggs = [(0, pa.SUM), (0, pa.COUNT)] if c4 else [(c, op) for c in range(ncol) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)]
     key_cols = [(keys, None, pa.I64)]
     val_cols = [(v, None, pa.F64) for v in vals]
     ctx = pa.Context(local_rank)
@@ -433,8 +438,10 @@ def main():
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d rows/GPU, 1 sparse i64 key (%d groups), "
-                                   "sum/mean/min/max over %d f64 cols" % (n, g, ncol),
+            "config": {"workload": ("BASELINE config 4 (per-GPU shard): %d rows/GPU, 1 sparse i64 key (%d groups over the whole job), "
+                                    "sum + count of %d f64 col" if c4 else
+                                    "BASELINE config 2: %d rows/GPU, 1 sparse i64 key (%d groups), "
+                                    "sum/mean/min/max over %d f64 cols") % (n, g, ncol),
                        "rows_per_gpu": n, "groups": g, "value_cols": ncol, "aggregates": len(aggs),
                        "parallelism": "row-range shards + 1 RCCL all-to-all of partial records inside the library (pandrs_hip_dist_groupby_agg)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -454,11 +461,11 @@ def main():
             out["roofline"]["wall_ms_last_step"] = dgb.last_timings.get("wall_ms")
             out["roofline"]["note"] = ("local partial aggregation + split + all-to-all + merge; device_ms = hipEvent time of the "
                                        "local and merge pipelines + wall time of the exchange; B = N(K+8C)+G(K+8A) per GPU")
-        if not args.no_extras and world == 1:
+        if not args.no_extras and world == 1 and not c4:
             del keys, vals, key_cols, val_cols
             torch.cuda.empty_cache()
             out.update(extra_configs(torch, pa, ctx, device))
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not c4:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, g, ncol, aggs)
             out["cpu_baseline_parallel"] = cpu_baseline_parallel(min(n, 2 * args.cpu_sample), g, ncol, aggs)
             out["cpu_baseline_typed"] = cpu_baseline_typed(min(n, 3 * args.cpu_sample), g, ncol)

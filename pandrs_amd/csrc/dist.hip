@@ -33,6 +33,7 @@ struct Rccl {
     int (*GetUniqueId)(RcclUniqueId *) = nullptr;
     int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;            // optional: releases peers blocked in a collective this rank cannot take part in
     const char *(*GetErrorString)(int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -61,6 +62,7 @@ int32_t rccl_load() {
           sym("ncclGetErrorString", r.GetErrorString) && sym("ncclAllGather", r.AllGather) && sym("ncclAllReduce", r.AllReduce) &&
           sym("ncclSend", r.Send) && sym("ncclRecv", r.Recv) && sym("ncclGroupStart", r.GroupStart) && sym("ncclGroupEnd", r.GroupEnd)))
         return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "RCCL lacks a required entry point");
+    r.CommAbort = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclCommAbort"));
     r.handle = h;
     return 0;
 }
@@ -86,6 +88,11 @@ struct pandrs_hip_comm {
     // stage: the join's exported (g, sum) columns, which must outlive the nested groupby exchange
     pandrs::Arena send, recv, small, zeros, stage, crow;
     size_t zeros_valid = 0;                  // bytes of `zeros` known to be zero
+    // the null-mask layout the ranks agreed on in the last dist_groupby call with the same column count (bit i: value column i carries
+    // a non-null count): the next call ASSUMES it and verifies on the count exchange — no collective of its own in the steady state
+    int64_t agreed_flags = 0;
+    int32_t agreed_n_vals = -1;
+    bool aborted = false;                    // a rank-local failure after the count exchange aborted the communicator
     std::vector<int64_t> counts;             // world x (world + 1) matrix of the last count exchange (last column: status)
     std::vector<uint8_t> hsend, hrecv;       // host staging of the callback transport
 };
@@ -129,25 +136,34 @@ static int32_t all_gather_dev(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const void
 // ---- exchange of row-aligned COLUMNS (partial records as columns; the general row shuffle below)
 struct ExCol { const void *send; size_t elem; void *recv; };
 
-// `cols`: row-aligned device columns, rank-contiguous by the same split `send_counts` (rows per rank).  recv pointers are
-// filled in (cm->recv arena).  `local_status`: this rank's status so far; it rides on the count exchange, and when ANY rank
-// reports a failure every rank returns an error together instead of leaving its peers blocked in the all-to-all.
-// `d_count_row` (optional): this rank's counts as a DEVICE row of world + 1 int64 (the split left them there, slot `world` is
-// the status word, written here): the all-gather starts from it and `send_counts` is an OUTPUT — the host first learns its own
-// counts from the gathered matrix, one synchronisation for the whole count exchange.
-static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t *send_counts, std::vector<ExCol> &cols,
-                                int32_t local_status, int64_t *out_n_recv, int64_t *d_count_row = nullptr) {
-    const int world = cm->world, me = cm->rank, row = world + 1;
+// A rank that cannot take part in a collective its peers are about to enter (or are in) aborts the communicator: the peers' calls
+// return an error instead of blocking for ever.  The communicator is unusable afterwards.
+static void abort_comm(pandrs_hip_comm *cm) {
+    if (cm->nccl && cm->world > 1 && rccl().CommAbort) { (void)rccl().CommAbort(cm->nccl); cm->nccl = nullptr; cm->owned = false; }
+    cm->aborted = true;
+}
+
+// The count exchange: ONE all-gather of a row of world + 1 + n_extra int64 per rank — rows for every peer, this rank's status so
+// far, and `extra` words every rank wants the others to see (dist_groupby's null-mask layout).  cm->counts holds the gathered
+// matrix (row stride world + 1 + n_extra).  `local_status` rides on the exchange: when ANY rank reports a failure every rank
+// returns an error together instead of leaving its peers blocked in the all-to-all.
+// `d_count_row` (optional): this rank's counts as a DEVICE row (the split left them there; the status and extra words are written
+// here): the all-gather starts from it and `send_counts` is an OUTPUT — the host first learns its own counts from the gathered
+// matrix, one synchronisation for the whole count exchange.
+static int32_t exchange_counts(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t *send_counts, int32_t local_status,
+                               const int64_t *extra, int n_extra, int64_t *d_count_row = nullptr) {
+    const int world = cm->world, me = cm->rank, row = world + 1 + n_extra;
     std::vector<int64_t> mine((size_t)row, 0);
     if (!d_count_row) for (int p = 0; p < world; p++) mine[p] = local_status ? 0 : send_counts[p];
     mine[world] = local_status;
+    for (int e = 0; e < n_extra; e++) mine[world + 1 + e] = extra[e];
     cm->counts.assign((size_t)world * row, 0);
     if (d_count_row) {
         if (local_status) HIP_TRY(hipMemsetAsync(d_count_row, 0, (size_t)world * 8, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_count_row + world, &mine[world], 8, hipMemcpyHostToDevice, c->stream));   // (pageable source: copied before the call returns)
+        HIP_TRY(hipMemcpyAsync(d_count_row + world, &mine[world], (size_t)(1 + n_extra) * 8, hipMemcpyHostToDevice, c->stream));   // (pageable source: copied before the call returns)
     }
     if (cm->nccl) {
-        ST_TRY(cm->small.ensure(4096 + (size_t)world * row * 8 + (size_t)row * 8, c->stream));
+        if (const int32_t st = cm->small.ensure(4096 + (size_t)world * row * 8 + (size_t)row * 8, c->stream)) { abort_comm(cm); return st; }   // (a few KB, grown once)
         int64_t *d_mine = d_count_row ? d_count_row : cm->small.take<int64_t>(row);
         int64_t *d_all = cm->small.take<int64_t>((size_t)world * row);
         if (!d_count_row) HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), (size_t)row * 8, hipMemcpyHostToDevice, c->stream));
@@ -169,15 +185,27 @@ static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t 
             return fail(PANDRS_HIP_ERR_COMPUTATION, "rank %d failed in its local phase (status %lld): the exchange is abandoned on every rank",
                         r, (long long)cm->counts[(size_t)r * row + world]);
         }
+    return 0;
+}
+
+// The payload: row-aligned device COLUMNS, rank-contiguous by the split `send_counts`, in ONE grouped send / recv.  recv pointers
+// are filled in (cm->recv arena).  `row`: the row stride of cm->counts as the count exchange left it.  A failure here is rank-local
+// and comes AFTER the ranks agreed to exchange (the receive buffer cannot be allocated): the peers are about to block in the
+// all-to-all, so the communicator is aborted (ncclCommAbort) — they return an error instead of waiting for ever — and is unusable
+// afterwards (cm->aborted).
+static int32_t exchange_payload(pandrs_hip_ctx *c, pandrs_hip_comm *cm, const int64_t *send_counts, std::vector<ExCol> &cols, int row, int64_t *out_n_recv) {
+    const int world = cm->world, me = cm->rank;
     int64_t n_recv = 0;
     for (int r = 0; r < world; r++) n_recv += cm->counts[(size_t)r * row + me];
     size_t need = 4096;
     for (auto &col : cols) need += Arena::padded((size_t)std::max<int64_t>(n_recv, 1) * col.elem + 256);
-    ST_TRY(cm->recv.ensure(need, c->stream));
+    int32_t st = cm->recv.ensure(need, c->stream);
     for (auto &col : cols) {
+        if (st) break;
         col.recv = cm->recv.take<uint8_t>((size_t)std::max<int64_t>(n_recv, 1) * col.elem + 256);
-        if (!col.recv) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small");
+        if (!col.recv) st = fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small");
     }
+    if (st) { abort_comm(cm); return st; }
     if (cm->nccl) {
         RCCL_TRY(rccl().GroupStart());
         int rc = 0;
@@ -204,8 +232,8 @@ static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t 
             cm->hsend.resize((size_t)soff + 8); cm->hrecv.resize((size_t)roff + 8);
             if (soff) HIP_TRY(hipMemcpyAsync(cm->hsend.data(), col.send, (size_t)soff, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            const int32_t st = cm->host.all_to_all_v(cm->host.user, cm->hsend.data(), sb.data(), so.data(), cm->hrecv.data(), rb.data(), ro.data());
-            if (st) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_to_all_v failed (%d)", st);
+            const int32_t st2 = cm->host.all_to_all_v(cm->host.user, cm->hsend.data(), sb.data(), so.data(), cm->hrecv.data(), rb.data(), ro.data());
+            if (st2) return fail(PANDRS_HIP_ERR_COMPUTATION, "transport all_to_all_v failed (%d)", st2);
             if (roff) HIP_TRY(hipMemcpyAsync(col.recv, cm->hrecv.data(), (size_t)roff, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
@@ -214,12 +242,19 @@ static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t 
     return 0;
 }
 
+// both steps, for callers without extra words
+static int32_t exchange_columns(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int64_t *send_counts, std::vector<ExCol> &cols,
+                                int32_t local_status, int64_t *out_n_recv, int64_t *d_count_row = nullptr) {
+    ST_TRY(exchange_counts(c, cm, send_counts, local_status, nullptr, 0, d_count_row));
+    return exchange_payload(c, cm, send_counts, cols, cm->world + 1, out_n_recv);
+}
+
 // `prior_status`: a failure of the caller's local phase (the join's fused pass): this rank still takes part in every
 // collective below, contributes nothing, and all ranks return an error together.
 static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t mem_space, const pandrs_hip_column *key,
                                  int64_t n_rows, const pandrs_hip_column *vals, int32_t n_vals, const pandrs_hip_agg_spec *aggs,
                                  int32_t n_aggs, int64_t *out_n_groups, int32_t prior_status = 0) {
-    if (n_vals > 64) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: more than 64 value columns");
+    if (n_vals > 62) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: more than 62 value columns");
     for (int a = 0; a < n_aggs; a++)
         if (aggs[a].op > PANDRS_HIP_AGG_COUNT)
             return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_groupby_agg exchanges partial states: Sum / Mean / Min / Max / Count only "
@@ -234,29 +269,34 @@ static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t
         std::fprintf(stderr, "[dist rank %d] %-28s %8.3f ms\n", cm->rank, what, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
-    // 0. one layout on every rank: a value column has an nn state iff SOME rank passes a null mask for it
-    int64_t flags[65] = {0};
-    for (int i = 0; i < n_vals; i++) flags[i] = (!prior_status && vals[i].null_mask) ? 1 : 0;
-    flags[n_vals] = n_rows > 0 ? 1 : 0;
-    ST_TRY(agree_max(c, cm, flags, n_vals + 1));
-    mark("agree_max");
+    // 0. one layout on every rank: a value column has an nn state iff SOME rank passes a null mask for it.  No collective of its
+    // own: every rank plans with the layout it ASSUMES — the one agreed in the previous call of this shape, plus its own masks — and
+    // puts (its own masks, the layout it used) on the count exchange.  When every rank used the same layout and that layout covers
+    // every rank's masks (the steady state: always), the exchange goes ahead; otherwise every rank repeats its local phase with the
+    // union, which is then the same word everywhere by construction.  (Round 3: a host-synchronous all-reduce in front of every call.)
+    int64_t my_flags = 0;
+    for (int i = 0; i < n_vals; i++) if (!prior_status && vals[i].null_mask) my_flags |= int64_t(1) << i;
+    int64_t used = my_flags | (cm->agreed_n_vals == n_vals ? cm->agreed_flags : 0);
     int32_t status = prior_status;
     int64_t ng = 0;
     int32_t n_state = 0;
     uint64_t *send = nullptr;
+    const int n_extra = 2, row = cm->world + 1 + n_extra;
     std::vector<int64_t> send_counts((size_t)cm->world, 0);
-    ST_TRY(cm->crow.ensure(4096 + (size_t)(cm->world + 1) * 8, c->stream));      // (its own arena: `small` is re-used by every collective)
-    int64_t *d_count_row = cm->crow.take<int64_t>((size_t)cm->world + 1);
-    if (!d_count_row) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small (counts)");
+    // (its own arena, sized when the communicator was made: `small` is re-used by every collective)
+    if (cm->crow.cap < 4096 + (size_t)row * 8) status = status ? status : cm->crow.ensure(4096 + (size_t)row * 8, c->stream);
+    cm->crow.off = 0;
+    int64_t *d_count_row = cm->crow.take<int64_t>((size_t)row);
+    if (!d_count_row && !status) status = fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "exchange buffer too small (counts)");
     std::vector<uint8_t> has_nulls((size_t)std::max(n_vals, 1), 0);
     std::vector<int32_t> dtypes((size_t)std::max(n_vals, 1), 0);
-    for (int i = 0; i < n_vals; i++) { has_nulls[i] = (uint8_t)flags[i]; dtypes[i] = vals[i].dtype; }
+    for (int i = 0; i < n_vals; i++) dtypes[i] = vals[i].dtype;
     // the local phase: a failure here must not return before the count exchange (the peers are waiting in it)
     auto local_phase = [&]() -> int32_t {
         std::vector<pandrs_hip_column> v2(vals, vals + n_vals);
         std::vector<uint8_t> zero_host;
         for (int i = 0; i < n_vals; i++) {
-            if (flags[i] && !vals[i].null_mask) {           // another rank has nulls here: an all-valid bitmap keeps the plan identical
+            if (((used >> i) & 1) && !vals[i].null_mask) {           // another rank has nulls here: an all-valid bitmap keeps the plan identical
                 const size_t nb = (size_t)(n_rows + 7) / 8 + 8;
                 if (mem_space == PANDRS_HIP_MEM_HOST) {
                     if (zero_host.size() < nb) zero_host.assign(nb, 0);
@@ -282,20 +322,38 @@ static int32_t dist_groupby_impl(pandrs_hip_ctx *c, pandrs_hip_comm *cm, int32_t
         mark("owner split");
         return 0;
     };
-    if (!status) status = local_phase();
-    // 3. count exchange (+ status agreement) straight from the device counts + ONE grouped all-to-all, a block per peer.  The block
-    // width is a function of (dtypes, agreed null flags, aggs) alone: identical on every rank.  A rank whose local phase failed
-    // sends nothing and receives nothing: every rank returns the error together.
-    if (!status && n_state <= 0) status = fail(PANDRS_HIP_ERR_COMPUTATION, "dist_groupby_agg: the local phase left no partial states");
+    for (int attempt = 0;; attempt++) {
+        if (!status) status = local_phase();
+        // 3. count exchange (+ status and layout agreement) straight from the device counts.  A rank whose local phase failed sends
+        // nothing and receives nothing: every rank returns the error together.
+        if (!status && n_state <= 0) status = fail(PANDRS_HIP_ERR_COMPUTATION, "dist_groupby_agg: the local phase left no partial states");
+        const int64_t extra[2] = {my_flags, used};
+        ST_TRY(exchange_counts(c, cm, send_counts.data(), status, extra, n_extra, d_count_row));
+        int64_t all_masks = 0, all_used = 0;
+        bool same = true;
+        for (int r = 0; r < cm->world; r++) {
+            all_masks |= cm->counts[(size_t)r * row + cm->world + 1];
+            all_used |= cm->counts[(size_t)r * row + cm->world + 2];
+            same = same && cm->counts[(size_t)r * row + cm->world + 2] == used;
+        }
+        if (same && (all_masks & ~used) == 0) break;              // one layout everywhere, and it covers every rank's masks
+        if (attempt >= 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "dist_groupby_agg: the ranks could not agree on a null-mask layout");
+        used = all_masks | all_used;                               // the same word on every rank: the second round must agree
+        mark("layout disagreement: local phase repeated");
+    }
+    cm->agreed_flags = used; cm->agreed_n_vals = n_vals;
+    for (int i = 0; i < n_vals; i++) has_nulls[i] = (uint8_t)((used >> i) & 1);
+    // ... and ONE grouped all-to-all, a block per peer.  The block width is a function of (dtypes, agreed null flags, aggs) alone:
+    // identical on every rank.
     const size_t W = 2 + (size_t)std::max(n_state, 0);
     std::vector<ExCol> ex;
     ex.push_back(ExCol{send, W * 8, nullptr});
     int64_t n_recv = 0;
-    ST_TRY(exchange_columns(c, cm, send_counts.data(), ex, status, &n_recv, d_count_row));
+    ST_TRY(exchange_payload(c, cm, send_counts.data(), ex, row, &n_recv));
     mark("counts + all-to-all");
     // 4. merge what this rank owns (cardinality bounded by the records received: no sampling pass)
     std::vector<int64_t> roff((size_t)cm->world + 1, 0);
-    for (int r = 0; r < cm->world; r++) roff[(size_t)r + 1] = roff[(size_t)r] + cm->counts[(size_t)r * (cm->world + 1) + cm->rank];
+    for (int r = 0; r < cm->world; r++) roff[(size_t)r + 1] = roff[(size_t)r] + cm->counts[(size_t)r * row + cm->rank];
     const int64_t hint_saved = c->opt.groups_hint;
     c->opt.groups_hint = std::max<int64_t>(n_recv, 1);
     const int32_t st = groupby_merge_blocks_entry(c, key->dtype, (const uint64_t *)ex[0].recv, roff.data(), cm->world, dtypes.data(), n_vals,
@@ -471,6 +529,7 @@ int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, 
                                     const pandrs_hip_agg_spec *aggs, int32_t n_aggs, int64_t *out_n_groups) try {
     if (!ctx || !comm || !keys || !out_n_groups || n_rows < 0 || n_vals < 0 || n_aggs < 0 || (n_vals && !vals) || (n_aggs && !aggs))
         return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "dist_groupby_agg: bad arguments");
+    if (comm->aborted) return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "this communicator was aborted after a rank-local failure: create a new one");
     HIP_TRY(hipSetDevice(ctx->device));
     bool mergeable = n_keys == 1;
     for (int a = 0; a < n_aggs; a++) mergeable = mergeable && aggs[a].op <= PANDRS_HIP_AGG_COUNT;
@@ -491,18 +550,17 @@ int32_t pandrs_hip_dist_join_groupby_sum(pandrs_hip_ctx *ctx, pandrs_hip_comm *c
     if ((right_key->dtype != PANDRS_HIP_I64 && right_key->dtype != PANDRS_HIP_F64 && right_key->dtype != PANDRS_HIP_CELL64) ||
         (right_group->dtype != PANDRS_HIP_I64 && right_group->dtype != PANDRS_HIP_F64 && right_group->dtype != PANDRS_HIP_CELL64))
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "dist_join_groupby_sum: 8-byte build-side columns only");
+    if (cm->aborted) return fail(PANDRS_HIP_ERR_NOT_INITIALIZED, "this communicator was aborted after a rank-local failure: create a new one");
     pandrs_hip_ctx *c = ctx;
     HIP_TRY(hipSetDevice(c->device));
     const int world = cm->world;
     // 1. all-gather the build side; shards are padded to a common length with NULL-key rows
-    int64_t info[3] = {n_right, right_key->null_mask ? 1 : 0, right_group->null_mask ? 1 : 0};
-    int64_t mx[3] = {info[0], info[1], info[2]};
-    ST_TRY(agree_max(c, cm, mx, 3));
+    // (one all-reduce: the longest shard, the mask flags, and — as the max of the negated lengths — the shortest shard: every rank needs
+    // to know whether padding exists anywhere)
+    int64_t mx[4] = {n_right, right_key->null_mask ? 1 : 0, right_group->null_mask ? 1 : 0, -n_right};
+    ST_TRY(agree_max(c, cm, mx, 4));
     const int64_t n_pad = (mx[0] + 7) / 8 * 8, n_all = n_pad * world;
-    // every rank needs its neighbours' true lengths to know whether padding exists anywhere
-    int64_t mn[1] = {-n_right};
-    ST_TRY(agree_max(c, cm, mn, 1));
-    const bool padded = -mn[0] != n_pad;
+    const bool padded = -mx[3] != n_pad;
     const bool key_mask = mx[1] != 0 || padded, grp_mask = mx[2] != 0;
     const size_t mb = (size_t)n_pad / 8;
     ST_TRY(cm->send.ensure(((size_t)n_pad * 16 + 2 * mb) + ((size_t)n_all * 16 + 2 * mb * world) + (1 << 16), c->stream));

@@ -107,6 +107,26 @@ cases = {
         {"cite": "src/optimized/jit/parallel.rs:354-363", "f64_range": [1, 1000], "sum": 500500.0},
         {"cite": "src/optimized/jit/parallel.rs:366-372", "f64_range": [1, 100], "mean": 50.5},
     ],
+    # src/optimized/direct_aggregations.rs:363-382 (create_test_dataframe) and its tests :384-520: the *_direct family is
+    # Float64Column / Int64Column::{sum, mean, min, max} (:30-120), the *_simd family simd_*_{f64,i64} over the raw slice
+    # (:200-356); both are asserted to give the same numbers on this frame (:505-545)
+    "direct_aggregations": {
+        "cite": "src/optimized/direct_aggregations.rs:363-545",
+        "float_col": [1.0, 2.0, 3.0, 4.0, 5.0], "int_col": [10, 20, 30, 40, 50],
+        "expect": {"float_col": {"sum": 15.0, "mean": 3.0, "max": 5.0, "min": 1.0, "count": 5},
+                   "int_col": {"sum": 150.0, "mean": 30.0, "max": 50.0, "min": 10.0, "count": 5}},
+        # :548-593: 10 000 elements, float i * 0.1 and int i * 10 for i = 1..=10000; sum and mean within 1e-10 of the
+        # sequential f64 sum, int max / min exact
+        "large": {"cite": "src/optimized/direct_aggregations.rs:548-593", "n": 10000, "float_scale": 0.1, "int_scale": 10,
+                  "abs_tolerance": 1e-10, "int_max": 100000.0, "int_min": 10.0},
+    },
+    # src/dataframe/pandas_compat/merge.rs:414-460: a non-key column present on both sides takes the suffixes, left then right
+    "merge_suffixes": {
+        "cite": "src/dataframe/pandas_compat/merge.rs:414-460",
+        "left": {"key": ["A", "B"], "value": [1.0, 2.0]}, "right": {"key": ["A", "B"], "value": [10.0, 20.0]},
+        "how": "inner", "suffixes": ["_left", "_right"],
+        "expect": {"value_left": [1.0, 2.0], "value_right": [10.0, 20.0]},
+    },
 }
 
 here = os.path.dirname(os.path.abspath(__file__))

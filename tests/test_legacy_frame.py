@@ -221,6 +221,14 @@ def test_legacy_merge_known_answers_and_restatement(golden):
         assert r.column_names == ["key", "value1", "value2"] and r.get_column_string_values("key") == e["keys"]
         v1 = [float(x) for x in r.get_column_string_values("value1")]
         assert [math.isnan(x) for x in v1] == [i < 0 for i in e["left_idx"]]       # a missing side is NaN (:150)
+    sx = golden["merge_suffixes"]                                  # merge.rs:414-460: overlapping non-key columns take the suffixes
+    ls, rs_ = DataFrame(), DataFrame()
+    ls.add_column("key", sx["left"]["key"]); ls.add_column("value", sx["left"]["value"])
+    rs_.add_column("key", sx["right"]["key"]); rs_.add_column("value", sx["right"]["value"])
+    r = merge(ls, rs_, "key", JoinType.Inner, tuple(sx["suffixes"]))
+    assert r.contains_column("value_left") and r.contains_column("value_right")
+    for name, want in sx["expect"].items():
+        assert [float(x) for x in r.get_column_string_values(name)] == want
     n = golden["join_numeric_key"]                                 # merge.rs:463-507: f64 keys compared by their bits
     l2, r2 = DataFrame(), DataFrame()
     l2.add_column("id", n["left_keys_f64"]); l2.add_column("name", n["left_names"])
