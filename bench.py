@@ -41,7 +41,7 @@ def pmc_traffic(n, g, ncol):
     from inside the process, so the corrected per-launch figure is loaded — a STATIC number measured in a
     separate `rocprofv3 --pmc` run of this command, not in this run — when it was collected on this exact
     workload; otherwise null.  -> (bytes or None, source)"""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
