@@ -13,5 +13,5 @@ for cfg in $cfgs; do
         timeout -k 10 280 rocprofv3 --pmc $ctr --output-format csv -d $out/${cfg}_$ctr -- python3 $root/experiments/one_config.py $cfg 3 > $out/${cfg}_$ctr.json 2> $out/${cfg}_$ctr.err || { echo "$cfg $ctr failed"; tail -3 $out/${cfg}_$ctr.err; }
     done
     f=$(find $out/${cfg}_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/${cfg}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-    python3 $root/experiments/pmc_config_traffic.py $cfg "$f" "$w" 4 > $root/profiles/${tag}_pmc_${cfg}.json && echo "$cfg: $(python3 -c "import json;d=json.load(open('$root/profiles/${tag}_pmc_${cfg}.json'));print('%.2f GB per call, %.2f x algorithmic' % (d['pipeline_hbm_bytes_per_call']/1e9, d['traffic_over_algorithmic']))")"
+    python3 $root/experiments/pmc_config_traffic.py $cfg "$f" "$w" 4 > $root/profiles/${tag}_pmc_${cfg}.json; mkdir -p $root/gpurun_out/profiles_$tag; cp $root/profiles/${tag}_pmc_${cfg}.json $root/gpurun_out/profiles_$tag/ && echo "$cfg: $(python3 -c "import json;d=json.load(open('$root/profiles/${tag}_pmc_${cfg}.json'));print('%.2f GB per call, %.2f x algorithmic' % (d['pipeline_hbm_bytes_per_call']/1e9, d['traffic_over_algorithmic']))")"
 done
