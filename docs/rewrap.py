@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Re-wraps a markdown file to a readable width: paragraphs and list items are wrapped (hanging indent kept), code
 fences are left alone, and table rows with cells too long to read in a table are turned into definition-style bullets.
-usage: rewrap.py IN OUT [width]"""
+usage: rewrap.py IN OUT [width] [longest table cell kept in a table]"""
 import re, sys, textwrap
 
 src, dst = sys.argv[1], sys.argv[2]
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 110
+CELL = int(sys.argv[4]) if len(sys.argv) > 4 else 160
 lines = open(src).read().split("\n")
 out, i, in_code = [], 0, False
 
@@ -16,7 +17,7 @@ def wrap(text, first, rest):
 def flush_table(rows):
     cells = [[c.strip() for c in r.strip().strip("|").split("|")] for r in rows]
     body = [c for c in cells if not all(re.fullmatch(r":?-+:?", x or "-") for x in c)]
-    if max(len(x) for c in body for x in c) <= 160:
+    if max(len(x) for c in body for x in c) <= CELL:
         return rows
     head, res = body[0], []
     for c in body[1:]:
