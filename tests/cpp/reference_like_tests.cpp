@@ -345,6 +345,8 @@ static void test_resident_frame_skips_the_staging() {
     auto jh = copy.inner_join(right, "k", "k");
     right.make_resident();
     auto jd = shared.inner_join(right, "k", "k");
+    const pandrs_hip_timings tj = timings();                  // the join's last library call: one gather of a resident column through the retained pairs
+    CHECK(tj.phase_ms[PANDRS_HIP_PHASE_STAGE_IN] == 0.0 && tj.phase_ms[PANDRS_HIP_PHASE_GATHER] > 0.0);      // nothing staged over PCIe, no index pairs fetched
     CHECK(jh.row_count() == jd.row_count() && jd.row_count() > 0);
     CHECK(std::get<Int64Column>(jh.column("k")).data == std::get<Int64Column>(jd.column("k")).data);
     CHECK(std::get<Float64Column>(jh.column("a")).data == std::get<Float64Column>(jd.column("a")).data);
