@@ -497,9 +497,14 @@ int32_t pandrs_hip_comm_destroy(pandrs_hip_comm *comm);
  * (Std / Var / Median / Nunique, composite keys of up to 8 columns) takes the row shuffle inside the same call: every row
  * goes to the owner of its key (the radix partitioner with P = world; a composite key on a hash cell of the tuple), one count
  * exchange, one grouped all-to-all of all columns, and the owner runs the ordinary groupby on what it received.
- * Null-mask presence may differ between ranks.  A rank whose
- * local phase fails still joins the count exchange with its status: EVERY rank then returns an error (nobody is left
- * blocked in a collective).  The exchange buffers live in the communicator and are only ever grown. */
+ * Null-mask presence may differ between ranks: the layout (which value columns carry a non-null count) is agreed ON the
+ * count exchange — every rank plans with the layout of the previous call of this shape plus its own masks, and the ranks
+ * repeat their local phase once when they find they disagreed — so a steady-state call makes no collective of its own
+ * for it (at most 62 value columns on this path).  A rank whose local phase fails still joins the count exchange with its
+ * status: EVERY rank then returns an error (nobody is left blocked in a collective).  A failure that is rank-local AFTER
+ * the count exchange (the receive buffer cannot be allocated) aborts the communicator (ncclCommAbort) so that the peers
+ * return instead of blocking; the communicator then refuses further calls (PANDRS_HIP_ERR_NOT_INITIALIZED).  The exchange
+ * buffers live in the communicator and are only ever grown. */
 int32_t pandrs_hip_dist_groupby_agg(pandrs_hip_ctx *ctx, pandrs_hip_comm *comm, int32_t mem_space,
                                     const pandrs_hip_column *keys, int32_t n_keys, int64_t n_rows,
                                     const pandrs_hip_column *vals, int32_t n_vals,

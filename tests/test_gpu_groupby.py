@@ -749,19 +749,23 @@ def test_census_is_not_taken_on_uniform_keys_and_sizes_a_long_tail(ctx):
         assert ctx.timings()["estimated_groups"] == e0, g           # (the estimate is deterministic: same sample, no second stage)
     g = 240_000
     ids = np.where(rng.random(n) < 0.8, rng.integers(0, g // 10, n), rng.integers(0, g, n))    # 24 K keys with 80 % of the rows + 240 K
-    keys = [(sparse_keys_from(ids), None, O.I64)]
-    want = O.groupby_agg(keys, n, v, aggs)
-    true_groups = want[0].shape[1]
-    got = ctx.groupby_agg(keys, n, v, aggs)
-    t = ctx.timings()
-    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1, 2, 3])
-    assert 0.85 * true_groups <= t["estimated_groups"] <= 1.15 * true_groups, (t["estimated_groups"], true_groups)
-    ctx.set_option("no_census", 1)
-    try:
-        ctx.groupby_compute(keys, n, v, aggs)
-        assert ctx.timings()["estimated_groups"] < 0.6 * true_groups
-    finally:
-        ctx.set_option("no_census", 0)
+    # every key layout the census reads through key_cell / key_is_null: sparse i64 cells, string-pool codes behind a null mask
+    # (the NULL group and the rows' nulls are not part of the slice), f64 cells
+    for kd, kdata, kmask in ((O.I64, sparse_keys_from(ids), None), (O.U32CODE, ids.astype(np.uint32), O.pack_mask(rng.random(n) < 0.01)),
+                             (O.F64, ids.astype(np.float64) * 0.25 - 1000.0, None)):
+        keys = [(kdata, kmask, kd)]
+        want = O.groupby_agg(keys, n, v, aggs)
+        true_groups = want[0].shape[1]
+        got = ctx.groupby_agg(keys, n, v, aggs)
+        t = ctx.timings()
+        assert_groupby_equal(got, want, [kd], int_exact_rows=[1, 2, 3])
+        assert 0.85 * true_groups <= t["estimated_groups"] <= 1.15 * true_groups, (kd, t["estimated_groups"], true_groups)
+        ctx.set_option("no_census", 1)
+        try:
+            ctx.groupby_compute(keys, n, v, aggs)
+            assert ctx.timings()["estimated_groups"] < 0.6 * true_groups
+        finally:
+            ctx.set_option("no_census", 0)
 
 
 def test_gpu_config_is_honoured():
