@@ -1090,7 +1090,11 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
             c->opt = saved;
             pandrs_hip_timings tnested = c->timings;
             c->timings = tsave;
-            if (st2) return st2;
+            if (st2) {
+                // the tail alone holds more groups than one radix level takes (a nested run cannot go two-level): the ordinary path answers
+                if (c->capacity_exceeded) { c->capacity_exceeded = false; return ABSORB_NOT_TAKEN; }
+                return st2;
+            }
             GroupbyResult &res = c->gb;
             if (n_hot > 0) {
                 ST_TRY(append_groups(c, res, (size_t)res.cap, r2, partials, pl, n_aggs));
@@ -1710,9 +1714,13 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 c->quiet--;
                 c->opt = saved;
                 c->timings = tsave;
-                if (st) return st;
+                // the nested run cannot leave one radix level (it is not the call's own run): when the unplaced rows alone hold more
+                // groups than one level takes, THIS attempt has failed — more partitions, or the two-level path, below — and the call
+                // must not fail with the nested run's error (fuzz, round 4: p_max = 24 with 900 K groups)
+                if (st && !c->capacity_exceeded) return st;
                 GroupbyResult &r2 = res_slot == 0 ? c->gb2 : c->gb3;
-                if ((size_t)res.n_groups + (size_t)r2.n_groups <= cap) {
+                if (st) c->capacity_exceeded = false;
+                else if ((size_t)res.n_groups + (size_t)r2.n_groups <= cap) {
                     ST_TRY(append_groups(c, res, cap, r2, partials, pl, n_aggs));
                     HIP_TRY(hipStreamSynchronize(c->stream));
                     c->timings.retries = attempt + 100;  // (100 + attempt: an overflow run answered)

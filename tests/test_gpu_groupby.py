@@ -1720,6 +1720,30 @@ def test_full_tables_hand_their_unplaced_rows_to_a_run_of_their_own(ctx):
     assert_groupby_equal(got1, want, [O.I64], int_exact_rows=[1, 2, 4, 5, 6])
 
 
+def test_an_overflow_run_that_outgrows_one_radix_level_fails_the_attempt_not_the_call(ctx):
+    """Found by the round-4 fuzz (case 133 of seed 93001): the run over a full table's unplaced rows is a nested run and cannot take
+    the two-level path; when those rows alone hold more groups than one radix level takes it returned "group cardinality exceeds the
+    radix capacity" and the whole CALL failed with it.  It now fails the ATTEMPT: the call goes on to more partitions or the
+    two-level path.  Forced here with a tiny level (p_max = 24: 24 tables) under 900 K groups behind a hot key."""
+    rng = np.random.default_rng(133)
+    n, g = 1_200_000, 900_000
+    ids = rng.integers(0, g, n)
+    ids[rng.random(n) < 0.6] = 0
+    keys = [(sparse_keys_from(ids), None, O.I64)]
+    vals = [(rng.normal(50, 20, n), None, O.F64)]
+    aggs = [(0, O.MEAN), (0, O.MAX), (0, O.MIN)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    opts = {"p_max": 24, "exact_partition": 1, "no_small": 1, "no_absorb": -1, "scatter_wide": 1, "wide_slices": 1}
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+    finally:
+        for k in opts:
+            ctx.set_option(k, 0)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[1, 2])
+
+
 @pytest.mark.parametrize("vkind", [O.F64, O.I64])
 def test_slices_of_a_hot_partition_fold_their_rows_per_wave(ctx, vkind):
     """A slice of an oversized partition is mostly ONE key (a hot key, the NULL group): when all placed rows of a wave sit in one
