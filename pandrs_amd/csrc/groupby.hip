@@ -1143,6 +1143,9 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     c->timings.n_partitions = hs[0] ? (compact ? -1 : PS) : 0;   // nothing spilled: no radix partition took part (the few-groups case); -1: compact spill
     c->timings.table_slots = T;
     c->timings.retries = 0;
+    // (the merge is a nested run: it cannot go two-level.  More groups among the records than one radix level takes — only with a
+    // tiny test level, p_max — hands the call back to the ordinary path instead of failing it)
+    if (st && c->capacity_exceeded) { c->capacity_exceeded = false; return ABSORB_NOT_TAKEN; }
     return st;
 }
 
