@@ -144,6 +144,17 @@ for case in range(first_case, n_cases):
                 ctx.set_option("join_one_pass", 0)
             wl, wr = O.join_indices(lk, nl, rk, nr, how)
             np.testing.assert_array_equal(gl, wl); np.testing.assert_array_equal(gr, wr)
+            if rng.random() < 0.5:      # the joined frame's columns through the retained pairs (join.rs:286-552): a payload of either side, the key column
+                side = int(rng.integers(0, 2))
+                n_src = nr if side else nl
+                pay = rng.normal(size=n_src); pmask = mask(rng, n_src, rng.choice([0, 0.1]))
+                got_p = ctx.join_gather((pay, pmask, O.F64), n_src, len(gl), side, 0.0)
+                np.testing.assert_array_equal(got_p, O.gather(pay, pmask, wr if side else wl, 0.0, O.F64))
+                if kd in (O.I64, O.U32CODE):
+                    fillv = 0 if kd == O.I64 else 0xFFFFFFFF
+                    got_k = ctx.join_gather(lk, nl, len(gl), 0, fillv, key_right=rk, n_right=nr)
+                    a_, b_ = O.gather(lk[0], lk[1], wl, fillv, kd), O.gather(rk[0], rk[1], wr, fillv, kd)
+                    np.testing.assert_array_equal(got_k, np.where(np.asarray(wl) >= 0, a_, b_))
             desc = "join nl=%d nr=%d kd=%d space=%d how=%d generic=%d -> %d rows" % (nl, nr, kd, space, how, jg, len(gl))
         print("ok   %3d %s" % (case, desc), flush=True)
     except pa.PandrsHipError as e:

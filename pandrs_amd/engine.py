@@ -492,6 +492,27 @@ class Context:
             _raise(st)
         return out
 
+    def join_gather(self, col, n_src, n_out, side, fill=0, key_right=None, n_right=0):
+        """One column of the joined frame through the pairs this context retains (the last join_indices / join_indices_compute):
+        pandrs_hip_join_gather (side 0 = the pairs' left rows, 1 = their right rows), or — key_right given — pandrs_hip_join_gather_key
+        (the left key's value, else the right key's: join.rs:364-470).  `col` is a (data, mask, dtype) triple on the host or the
+        device, or a ResidentColumn; -> numpy array of n_out elements (uint8 per row for BOOLBITS sources)."""
+        keep = []
+        cc, sp = self._cols([tuple(col)], keep)
+        dtype = tuple(col)[2]
+        out = np.empty(int(n_out), {L.I64: np.int64, L.F64: np.float64, L.U32CODE: np.uint32, L.BOOLBITS: np.uint8}[dtype])
+        fill_bits = int(np.float64(fill).view(np.uint64)) if dtype == L.F64 else int(fill) & 0xFFFFFFFFFFFFFFFF
+        if key_right is None:
+            st = self.lib.pandrs_hip_join_gather(self.h, sp, cc, int(n_src), int(side), fill_bits, L.MEM_HOST, _ptr(out))
+        else:
+            kc, sp2 = self._cols([tuple(key_right)], keep)
+            if sp2 != sp:
+                raise ValueError("both key columns must live in one memory space")
+            st = self.lib.pandrs_hip_join_gather_key(self.h, sp, cc, int(n_src), kc, int(n_right), fill_bits, L.MEM_HOST, _ptr(out))
+        if st:
+            _raise(st)
+        return out
+
     def join_groupby_sum(self, lkey, lval, n_left, rkey, rgroup, n_right):
         keep = []
         a, sp = self._cols([lkey], keep)
