@@ -35,3 +35,12 @@ def test_fuzz_slice_joins_and_fused():
 def test_fuzz_slice_absorb_forced():
     out = _run("fuzz_absorb.py", 25, 43)
     assert "0 failures" in out
+
+
+def test_fuzz_slice_distributed_real_ranks():
+    """experiments/fuzz_dist.py: the in-library exchange (dist.hip) with three REAL ranks on the one GPU over a host transport —
+    random uneven / empty row ranges, null masks passed by random subsets of the ranks (the layout agreement that rides on the
+    count exchange), host and device shards, mergeable and shuffled aggregate sets, one or two key columns; the owners' results,
+    concatenated, equal the oracle on the whole frame."""
+    out = _run("fuzz_dist.py", 3, 14, 5)
+    assert "fuzz_dist done: world 3, 14 cases, 0 failing rank-cases" in out
