@@ -31,6 +31,42 @@ def worker(rank, world, port, n_cases, seed0):
         rng = np.random.default_rng(seed0 * 104729 + case)          # the SAME stream on every rank
         desc = "?"
         try:
+            if rng.random() < float(os.environ.get("FUZZ_DIST_JOIN_FRAC", "0.3")):
+                # ---- pandrs_hip_dist_join_groupby_sum: both sides row-range-sharded (uneven, possibly empty), device shards
+                nl = int(rng.choice([0, 7, 4000, 300_000])); nr = int(rng.choice([0, 5, 3000, 80_000]))
+                unique = rng.random() < 0.6
+                rcells = (rng.permutation(max(nr * 3, 8))[:nr] if unique else rng.integers(0, max(nr // 2, 3), nr)).astype(np.int64) * 7919 - 5
+                lcells = (rcells[rng.integers(0, nr, nl)] if nr else rng.integers(0, 9, nl).astype(np.int64)).copy()
+                if nl: lcells[rng.random(nl) < 0.15] = 123456789
+                vdt = int(rng.choice([O.I64, O.F64]))
+                rg = rng.integers(0, int(rng.choice([3, 400, 30_000])), nr).astype(np.int64) - 7
+                lv = rng.integers(-1000, 1000, nl).astype(np.int64) if vdt == O.I64 else rng.normal(10, 5, nl)
+                lkm, lvm = rng.random(nl) < rng.choice([0, 0.02]), rng.random(nl) < rng.choice([0, 0.05])
+                rkm, rgm = rng.random(nr) < rng.choice([0, 0.02]), rng.random(nr) < rng.choice([0, 0.02])
+                cut = lambda m: [0] + [int(x) for x in np.sort(rng.integers(0, m + 1, world - 1))] + [m]
+                bl, br = cut(nl), cut(nr)
+                pass_rkm, pass_rgm = rng.random(world) < 0.6, rng.random(world) < 0.6
+                for r in range(world):
+                    if not pass_rkm[r]: rkm[br[r]:br[r + 1]] = False
+                    if not pass_rgm[r]: rgm[br[r]:br[r + 1]] = False
+                d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                l0, l1, r0, r1 = bl[rank], bl[rank + 1], br[rank], br[rank + 1]
+                desc = "JOIN nl=%d nr=%d unique=%d vdt=%d cuts=%s / %s masks=%s %s" % (nl, nr, unique, vdt, bl, br, pass_rkm.astype(int).tolist(), pass_rgm.astype(int).tolist())
+                kc, kn, oa = ctx.dist_join_groupby_sum((d(lcells[l0:l1]), d(O.pack_mask(lkm[l0:l1])) if lkm.any() else None, O.I64),
+                                                       (d(lv[l0:l1]), d(O.pack_mask(lvm[l0:l1])) if lvm.any() else None, vdt), l1 - l0,
+                                                       (d(rcells[r0:r1]), d(O.pack_mask(rkm[r0:r1])) if pass_rkm[rank] else None, O.I64),
+                                                       (d(rg[r0:r1]), d(O.pack_mask(rgm[r0:r1])) if pass_rgm[rank] else None, O.I64), r1 - r0)
+                parts = [None] * world
+                dist.all_gather_object(parts, (kc.cpu().numpy().view(np.uint64), kn.cpu().numpy(), oa.cpu().numpy()))
+                if rank == 0:
+                    got = tuple(np.concatenate([p[i] for p in parts], axis=1) for i in range(3))
+                    want = O.join_groupby_sum((lcells, O.pack_mask(lkm) if lkm.any() else None, O.I64), (lv, O.pack_mask(lvm) if lvm.any() else None, vdt), nl,
+                                              (rcells, O.pack_mask(rkm) if rkm.any() else None, O.I64), (rg, O.pack_mask(rgm) if rgm.any() else None, O.I64), nr)
+                    assert got[0].shape[1] == want[0].shape[1], "groups: %d vs %d" % (got[0].shape[1], want[0].shape[1])
+                    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[0] if vdt == O.I64 else [], rtol=1e-9)
+                    print("ok   %3d %s" % (case, desc), flush=True)
+                dist.barrier()
+                continue
             n = int(rng.choice([0, 5, 3000, 200_000, 900_000]))
             g = int(rng.choice([1, 7, 500, 40_000, 300_000]))
             cuts = np.sort(rng.integers(0, n + 1, world - 1)) if rng.random() < 0.7 else np.array([n * (r + 1) // world for r in range(world - 1)])
