@@ -226,6 +226,10 @@ __global__ void gather_kernel(const void *src, const uint8_t *null_bits, const i
     else reinterpret_cast<uint8_t *>(out)[i] = take ? (uint8_t)bit_at(reinterpret_cast<const uint8_t *>(src), j) : (uint8_t)fill;
 }
 
+// the launch itself; the caller holds the context's mutex
+static int32_t gather_locked(pandrs_hip_ctx *c, int kind, const void *src, const uint8_t *mask, const int64_t *idx, int64_t n,
+                             uint64_t fill_bits, void *out, int64_t n_src, const int64_t *only_where_negative);
+
 int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void *src, const uint8_t *mask,
                      const int64_t *idx, int64_t n, uint64_t fill_bits, void *out, int64_t n_src, const int64_t *only_where_negative) {
     if (!c || n < 0 || (n && (!idx || !out))) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "gather: bad arguments");
@@ -235,6 +239,11 @@ int32_t gather_entry(pandrs_hip_ctx *c, int32_t mem_space, int kind, const void 
                     "gather takes device pointers only (the source length is not part of the ABI); "
                     "stage columns with your allocator and pass PANDRS_HIP_MEM_DEVICE");
     std::lock_guard<std::mutex> lock(c->mu);
+    return gather_locked(c, kind, src, mask, idx, n, fill_bits, out, n_src, only_where_negative);
+}
+
+static int32_t gather_locked(pandrs_hip_ctx *c, int kind, const void *src, const uint8_t *mask, const int64_t *idx, int64_t n,
+                             uint64_t fill_bits, void *out, int64_t n_src, const int64_t *only_where_negative) {
     HIP_TRY(hipSetDevice(c->device));
     timings_begin(c);
     {
@@ -265,8 +274,8 @@ int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_h
         return gather_entry(c, mem_space, kind, src->data, src->null_mask, idx, n, fill_bits, out, n_src);
     const size_t esz = kind == 0 ? 8 : (kind == 1 ? 4 : 1);
     const void *d_src = nullptr; const uint8_t *d_mask = nullptr; int64_t *d_idx = nullptr; void *d_out = nullptr;
+    std::lock_guard<std::mutex> lock(c->mu);          // one critical section: the staged buffers live in the context
     {
-        std::lock_guard<std::mutex> lock(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         const size_t sbytes = dtype_bytes(src->dtype, n_src), mbytes = (size_t)(n_src + 7) / 8;
         ST_TRY(c->staging.ensure(sbytes + mbytes + size_t(n) * (8 + esz) + 4096, c->stream));
@@ -295,8 +304,7 @@ int32_t gather_column_entry(pandrs_hip_ctx *c, int32_t mem_space, const pandrs_h
         }
         return 0;
     }
-    ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, d_src, d_mask, d_idx, n, fill_bits, d_out, n_src));
-    std::lock_guard<std::mutex> lock(c->mu);
+    ST_TRY(gather_locked(c, kind, d_src, d_mask, d_idx, n, fill_bits, d_out, n_src, nullptr));
     HIP_TRY(hipMemcpyAsync(out, d_out, size_t(n) * esz, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -322,8 +330,10 @@ int32_t join_gather_entry(pandrs_hip_ctx *c, int32_t src_mem_space, const pandrs
     const int64_t *d_left = nullptr, *d_right = nullptr;
     void *d_out = out;
     int64_t n = 0;
+    // ONE critical section for the whole call: the retained pairs, the staged source and the staged output all live in the context,
+    // and a concurrent call on the same context between two steps could replace any of them
+    std::lock_guard<std::mutex> lock(c->mu);
     {
-        std::lock_guard<std::mutex> lock(c->mu);
         if (!c->jn.valid) return fail(PANDRS_HIP_ERR_INVALID_ARGUMENT, "no join result retained in this context");
         n = c->jn.n_rows;
         if (n == 0) return 0;
@@ -362,12 +372,11 @@ int32_t join_gather_entry(pandrs_hip_ctx *c, int32_t src_mem_space, const pandrs
         }
     }
     // a source without rows is never dereferenced: the kernel's bounds test (n_src = 0) sends every row to the fill value
-    ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, s0.data ? s0.data : (const void *)d_left, s0.mask, side ? d_right : d_left, n, fill_bits, d_out,
-                        s0.data ? s0.n : 0));
+    ST_TRY(gather_locked(c, kind, s0.data ? s0.data : (const void *)d_left, s0.mask, side ? d_right : d_left, n, fill_bits, d_out,
+                         s0.data ? s0.n : 0, nullptr));
     if (key_right)
-        ST_TRY(gather_entry(c, PANDRS_HIP_MEM_DEVICE, kind, s1.data ? s1.data : (const void *)d_left, s1.mask, d_right, n, fill_bits, d_out, s1.data ? s1.n : 0,
-                            /*only_where_negative=*/d_left));
-    std::lock_guard<std::mutex> lock(c->mu);
+        ST_TRY(gather_locked(c, kind, s1.data ? s1.data : (const void *)d_left, s1.mask, d_right, n, fill_bits, d_out, s1.data ? s1.n : 0,
+                             /*only_where_negative=*/d_left));
     if (out_mem_space == PANDRS_HIP_MEM_HOST) HIP_TRY(hipMemcpyAsync(out, d_out, size_t(n) * esz, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
