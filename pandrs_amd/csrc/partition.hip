@@ -1143,7 +1143,8 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         // Uniform keys never get here: their singletons are what their own doubletons predict (or f3 is too small to tell, and then
         // the model's figure stands).
         census_wanted = false;
-        if (!c->opt.no_census && thrice >= 150.0 && f2 >= 400.0 && n_rows >= (int64_t(1) << 22)) {
+        // (few triple sightings are still evidence when they are many more than the doubletons predict: sigma below carries their noise)
+        if (!c->opt.no_census && thrice >= 16.0 && f2 >= 200.0 && n_rows >= (int64_t(1) << 22)) {
             const double ratio = thrice / f2;                    // = (e^r - 1 - r - r^2 / 2) / (r^2 / 2)
             double lo = 1e-4, hi = 30.0;
             for (int it = 0; it < 60; it++) {
