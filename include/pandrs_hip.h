@@ -191,7 +191,7 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "groups_hint"       expected number of groups (skips the sampled estimate)
  *   "partitions"        force the radix fan-out P
  *   "p_max"             lower the fan-out cap (forces the two-level path above it)
- *   "p_target"          rounds heuristic: take several aggregate rounds only above this fan-out (default 3072)
+ *   "p_target"          rounds heuristic: take several aggregate rounds only above this fan-out (default: 8192 where the lean kernel answers, else 3072)
  *   "src_per_round"     force the number of value columns folded per aggregate round
  *   "load_pct"          LDS table load factor in percent (default 70)
  *  partition (scatter) pass
@@ -223,6 +223,7 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "wide_slices"       1 = the pieces of an oversized partition are as long as the cutting threshold (4 x the average partition) instead of
  *                       average-sized (A/B: a piece is one workgroup's job, long pieces are the aggregate pass's tail)
  *   "slice_over"        experiments: a partition is cut when it holds more than this many average partitions' rows (default 2)
+ *   "no_table_order"    experiments: 1 = the lean aggregate draws its tables in partition order instead of largest first
  *   "fold_min", "fold_min_multi"  experiments: lanes of a wave in one table slot from which the lean aggregate folds them on the VALU
  *                       (ordinary tables: default 40; pieces of an oversized partition: default 8; 65 = never)
  *   "no_small"          1 = never the two-launch path for calls of <= 2 M rows; "small_chunk" rows per workgroup there

@@ -33,6 +33,7 @@ struct AggArgs {
     const AggTask *tasks;        // nullptr: workgroup b = partition b
     const uint32_t *n_tasks;
     const AggTable *tables;      // aggregate2 only; n_tasks[1] = number of tables
+    const uint32_t *order;       // aggregate2, optional: the tables in the order they are handed out (largest first); nullptr = as listed
     uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
     SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     };
     // SMALL: table b = rows [b * s_chunk, (b + 1) * s_chunk) of the original columns; no task list in memory
     auto small_task = [&](uint32_t b) { return AggTask{0u, (uint32_t)min(b * a.s_chunk, a.s_rows), (uint32_t)min((b + 1) * a.s_chunk, a.s_rows), 0u}; };
-    auto get_table = [&](uint32_t b) { return SMALL ? AggTable{b, 1u, 0u, 0u} : a.tables[b]; };
+    auto get_table = [&](uint32_t b) { return SMALL ? AggTable{b, 1u, 0u, 0u} : a.tables[a.order ? a.order[b] : b]; };
     auto get_task = [&](uint32_t i) { return SMALL ? small_task(i) : a.tasks[i]; };
     const uint32_t n_tables = SMALL ? (a.s_rows + a.s_chunk - 1) / a.s_chunk : a.n_tasks[1];
     uint32_t tb = blockIdx.x;
@@ -327,9 +327,10 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     for (int d = 0; d < DEPTH; d++) fetch(d, cur, d);
 
     for (;;) {                                         // one LDS table per iteration
-        const uint32_t tbn = tb + gridDim.x;
-        const bool have_next_tab = tbn < n_tables;
-        const AggTable ntab = get_table(have_next_tab ? tbn : tb);
+        // the NEXT table is drawn from a ticket counter now (its first rows fly under this table's last ones): the first gridDim.x tables
+        // are the workgroups' own, the others go to whoever comes first — partitions differ in size under skewed keys, and a fixed
+        // round-robin's slowest workgroup (the one whose four partitions each hold a hot key) was the kernel's time
+        if (tid == 0) misc[33] = gridDim.x + atomicAdd(&a.counters[10], 1u);
         const bool multi = tab.multi != 0;
         const uint32_t t_end = tab.task_beg + tab.n_tasks;
         cur_multi = multi;
@@ -343,6 +344,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         }
         if (tid < 32) misc[tid] = 0;
         __syncthreads();
+        const uint32_t tbn = misc[33];
+        const bool have_next_tab = tbn < n_tables;
+        const AggTable ntab = get_table(have_next_tab ? tbn : tb);
 
       for (;;) {                                       // the row ranges that feed this table
         const bool more_in_tab = ti + 1 < t_end;

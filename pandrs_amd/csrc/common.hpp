@@ -197,6 +197,7 @@ struct Options {
     int64_t generic_aggregate = 0;   // 1 = force the descriptor-driven aggregate kernel (testing)
     int64_t median_generic = 0;      // 1 = Median / Nunique: skip the LDS group-sort fast path (testing)
     int64_t load_pct = 0;            // 0 = default LDS table load factor (percent)
+    int64_t no_table_order = 0;      // experiments: aggregate2 draws its tables in partition order instead of largest first
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
     int64_t no_runs = 0;             // 1 = never use the run-folding aggregate kernels
     int64_t join_one_pass = 0;       // 1 = probe with the single-pass (decoupled look-back) kernel instead of lookup / scan / emit

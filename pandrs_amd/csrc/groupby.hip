@@ -61,12 +61,19 @@ __global__ __launch_bounds__(1024) void build_tasks_kernel(const uint32_t *offse
 
 // aggregate2's work list: tables (one per partition; an oversized partition is cut into tables of <= slice_rows
 // rows flagged `multi`) and, per table, the row ranges that feed it.  One workgroup; counts[0] = tasks, [1] = tables.
+// `order` (with `trows`, scratch of the same length): the tables' indices by falling size, in 64 classes of an eighth of the average
+// table — aggregate2's workgroups draw tables from a ticket counter in this order, so the large ones (partitions holding hot keys,
+// not far enough above the average to be cut) start first and the small ones fill the gaps behind them.
 __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32_t P1, uint32_t over_rows, uint32_t slice_rows_in, AggTask *tasks,
                                                             AggTable *tables, uint32_t *counts, uint32_t max_tasks,
-                                                            uint32_t max_tables) {
+                                                            uint32_t max_tables, uint32_t *order, uint32_t *trows) {
     __shared__ uint32_t wt[17];
     __shared__ uint32_t carry[2];
+    __shared__ uint32_t cls_n[64];
+    __shared__ unsigned long long all_rows;
     if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    if (threadIdx.x < 64) cls_n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) all_rows = 0;
     __syncthreads();
     for (uint32_t base = 0; base < P1; base += 1024) {
         const uint32_t p = base + threadIdx.x;
@@ -114,8 +121,10 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32
                     if (v0 + len > hi) break;      // the segment continues in the next table
                     v0 += len; g++;
                 }
+                if (trows) trows[tb] = (uint32_t)(hi - lo);
                 tables[tb++] = AggTable{first, ti - first, p, n_tab > 1 ? 1u : 0u};
             }
+            if (trows) atomicAdd(&all_rows, (unsigned long long)R);
         }
         __syncthreads();
         if (threadIdx.x == 0) { carry[0] += tot_task; carry[1] += tot_tab; }
@@ -125,6 +134,19 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32
         counts[0] = min(carry[0], max_tasks); counts[1] = min(carry[1], max_tables);
         counts[2] = (carry[0] > max_tasks || carry[1] > max_tables) ? 1u : 0u;     // cannot happen with the caller's bounds
     }
+    if (!order) return;
+    // counting sort of the table indices by size class (class 0 = the largest); the order inside a class is whatever the cursors give
+    const uint32_t n_tables = min(carry[1], max_tables);
+    const unsigned long long unit = max(all_rows / (8ull * max(n_tables, 1u)), 1ull);       // an eighth of the average table
+    auto cls_of = [&](uint32_t t) { return 63u - (uint32_t)min((unsigned long long)trows[t] / unit, 63ull); };
+    for (uint32_t t = threadIdx.x; t < n_tables; t += 1024) atomicAdd(&cls_n[cls_of(t)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 64; k++) { const uint32_t n = cls_n[k]; cls_n[k] = run; run += n; }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_tables; t += 1024) order[atomicAdd(&cls_n[cls_of(t)], 1u)] = t;
 }
 
 // The reference's finalisation of one aggregate from the group's states
@@ -1363,7 +1385,6 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // re-reading the partition's keys once per extra round.
     const size_t lds_budget = (size_t)c->lds_bytes - 512;
     const double LOAD = c->opt.load_pct > 0 ? c->opt.load_pct / 100.0 : 0.70;
-    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : 3072;   // rounds only when one round would need more partitions than this
     int spr = n_src > 0 ? n_src : 1;           // sources per round
     int n_rounds = 1, round_states = 0, max_spr = 0;
     int64_t T = 0, P = 0, auto_slice_rows = 0;
@@ -1382,6 +1403,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && !c->clustered_rows && !c->opt.agg_v1 &&
                        aggregate2_has(n_src, uni_profile);
     bool use_v2 = false;
+    // rounds only when one round would need more partitions than this.  Where the lean kernel answers, that is the scatter's own limit:
+    // one lean round at a fan-out of 4-7 K beats two or four rounds of the older kernel at 2.5-3 K although the scatter pays for it
+    // (experiments/p_target_sweep.py, C2's 12 states: 4 M uniform groups 5.70 -> 5.05 ms, 7 M 7.28 -> 6.06, 10 M 8.10 -> 7.70;
+    // Zipf(0.8) over 5 M keys 10.8 -> 6.5 — the older kernel has no wave fold for the hot keys' pieces)
+    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : (v2_ok ? P_MAX : 3072);
     for (;; spr = (spr + 1) / 2) {
         if (c->opt.src_per_round > 0 && !pl.needs_second_pass) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
         n_rounds = n_src ? (n_src + spr - 1) / spr : 1;
@@ -1605,15 +1631,16 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             AggTask *tasks = c->work.take<AggTask>(max_tasks + 8);
             AggTable *tables = c->work.take<AggTable>(max_tables + 8);
             uint32_t *n_tasks = c->work.take<uint32_t>(64);
-            if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !tables || !n_tasks)
+            uint32_t *order = use_v2 && !c->opt.no_table_order ? c->work.take<uint32_t>(2 * (size_t)max_tables + 16) : nullptr;
+            if (!aa.side_keys || !aa.side_null || !aa.side_states || !tasks || !tables || !n_tasks || (use_v2 && !c->opt.no_table_order && !order))
                 return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "workspace too small (slices)");
             const uint32_t srows = slicing ? (uint32_t)std::min<int64_t>(slice_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu;
             const uint32_t prows = slicing ? (uint32_t)std::min<int64_t>(piece_rows, 0xFFFFFFFFll) : 0xFFFFFFFFu;
             if (use_v2) {
                 const SegSource ss{offsets, NB, part.gbeg, part.gcur, part.gend};
                 hipLaunchKernelGGL(build_tables_kernel, dim3(1), dim3(1024), 0, c->stream, ss, P1, srows, prows, tasks, tables, n_tasks,
-                                   max_tasks, max_tables);
-                aa.tables = tables; aa.launch_grid = max_tables;
+                                   max_tasks, max_tables, order, order ? order + max_tables + 8 : nullptr);
+                aa.tables = tables; aa.order = order; aa.launch_grid = max_tables;
             } else {
                 hipLaunchKernelGGL(build_tasks_kernel, dim3(1), dim3(1024), 0, c->stream, offsets, NB, P1, srows, prows, tasks, n_tasks, max_tasks);
                 aa.launch_grid = max_tasks;

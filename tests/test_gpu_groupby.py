@@ -1140,8 +1140,8 @@ def test_config3_full_size_properties():
     n, g, d = 100_000_000, 10_000, "cuda:0"
     gen = torch.Generator(device=d)
     gen.manual_seed(45)
-    hot = torch.rand(n, device=d, generator=gen) < hot_share
-    ids = torch.where(hot, torch.randint(0, hot_keys, (n,), device=d, generator=gen), torch.randint(0, g, (n,), device=d, generator=gen))
+    hot = torch.rand(n, device=d, generator=gen) < 0.8
+    ids = torch.where(hot, torch.randint(0, g // 5, (n,), device=d, generator=gen), torch.randint(0, g, (n,), device=d, generator=gen))
     del hot
     codes = ids.to(torch.int32)
     vals = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) * 10 + 100 for _ in range(2)]
@@ -1776,3 +1776,67 @@ def test_slices_of_a_hot_partition_fold_their_rows_per_wave(ctx, vkind):
             ctx.set_option(name, 0)
     exact = [1, 2, 5, 6, 7] + ([0, 4] if vkind == O.I64 else [])
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+
+
+def test_tables_of_unequal_size_are_drawn_largest_first(ctx):
+    """The lean aggregate's workgroups draw their tables from a ticket counter, in the order build_tables_kernel sorts them
+    (groupby.hip: 64 size classes, largest first), so partitions that hold a hot key — not far enough above the average to be cut —
+    start first and do not become the kernel's tail (Zipf(0.8) over 5 M keys, C2's shape: aggregate 7.8 -> 1.6 ms together with the
+    one-round plan below).  Zipf-like keys over 1.5 M groups, 12 states: with the order, in partition order (`no_table_order`), and
+    with small forced pieces (every table a slice, order over pieces) — the oracle's answers each time."""
+    rng = np.random.default_rng(404)
+    n, g, a = 17_000_000, 1_500_000, 0.8
+    u = rng.random(n)
+    ids = np.clip((((g ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))).astype(np.int64), 1, g)
+    keys = [(sparse_keys_from(ids), None, O.I64)]
+    vals = [(rng.normal(100, 10, n), None, O.F64) for _ in range(4)]
+    aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    exact = [2, 3, 6, 7, 10, 11, 14, 15, 16]
+    for opts in ({}, {"no_table_order": 1}, {"slice_rows": 50_000}):
+        for name, val in opts.items():
+            ctx.set_option(name, val)
+        try:
+            got = ctx.groupby_agg(keys, n, vals, aggs)
+            t = ctx.timings()
+        finally:
+            for name in opts:
+                ctx.set_option(name, 0)
+        assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+        assert t["n_partitions"] >= 1024, t                # (the radix path with the lean kernel, not the direct or absorb paths)
+
+
+def test_one_lean_round_is_preferred_to_rounds_up_to_the_scatter_limit():
+    """The rounds heuristic (groupby.hip, P_TARGET): where the lean kernel answers, one round at a fan-out of up to 8192 is planned
+    rather than two or four rounds of the older kernel at <= 3072 (experiments/p_target_sweep.py).  C2's 12 states over 5 M uniform
+    groups: P = 4864 tables of 1408 slots, one attempt; `p_target` = 3072 restores the two-round plan (2396 slots); same group count,
+    counts and sums either way."""
+    import torch
+    import pandrs_amd as pa
+    n, g, d = 60_000_000, 5_000_000, "cuda:0"
+    gen = torch.Generator(device=d)
+    gen.manual_seed(5)
+    ids = torch.randint(0, g, (n,), device=d, generator=gen)
+    keys = ids * -7046029254386353131
+    vals = [torch.randn(n, device=d, generator=gen, dtype=torch.float64) for _ in range(4)]
+    aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(0, O.COUNT)]
+    true_groups = torch.unique(ids).numel()
+    c = pa.Context(0)
+    try:
+        for p_target, slots in ((0, 1408), (3072, 2396)):
+            c.set_option("p_target", p_target)
+            ng = c.groupby_compute([(keys, None, O.I64)], n, [(v, None, O.F64) for v in vals], aggs)
+            t = c.timings()
+            kc, kn, oa = c.groupby_fetch()
+            assert ng == true_groups and torch.unique(kc[0]).numel() == ng
+            assert float(oa[16].sum()) == n
+            for col in range(4):
+                tot = float(vals[col].sum())
+                assert abs(float(oa[4 * col].sum()) - tot) <= 1e-9 * max(abs(tot), 1.0)
+                assert float(oa[4 * col + 2].min()) == float(vals[col].min()) and float(oa[4 * col + 3].max()) == float(vals[col].max())
+            assert t["table_slots"] == slots, t
+            assert (t["n_partitions"] > 3072) == (p_target == 0), t
+            del kc, kn, oa
+    finally:
+        c.set_option("p_target", 0)
+        c.close()
