@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024) void build_tables_kernel(SegSource ss, uint32
     // counting sort of the table indices by size class (class 0 = the largest); the order inside a class is whatever the cursors give
     const uint32_t n_tables = min(carry[1], max_tables);
     const unsigned long long unit = max(all_rows / (8ull * max(n_tables, 1u)), 1ull);       // an eighth of the average table
-    auto cls_of = [&](uint32_t t) { return 63u - (uint32_t)min((unsigned long long)trows[t] / unit, 63ull); };
+    auto cls_of = [&](uint32_t t) { return 63u - (uint32_t)min(((unsigned long long)trows[t] + unit / 2) / unit, 63ull); };   // (rounded: near-equal tables share a class)
     for (uint32_t t = threadIdx.x; t < n_tables; t += 1024) atomicAdd(&cls_n[cls_of(t)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
