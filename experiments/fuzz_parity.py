@@ -13,6 +13,7 @@ from tests.helpers import assert_groupby_equal
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = pa.Context(0)
+n_clustered = 0
 OPS_MERGEABLE = [O.SUM, O.MEAN, O.MIN, O.MAX, O.COUNT]
 OPS_ALL = OPS_MERGEABLE + [O.STD, O.VAR, O.FIRST, O.LAST, O.MEDIAN, O.MEDIAN, O.NUNIQUE, O.NUNIQUE]
 
@@ -50,7 +51,7 @@ for case in range(first_case, n_cases):
             skew = rng.choice(["uniform", "hot", "8020"])
             nk = 1 if rng.random() < 0.8 else 2
             kdata = rand_key(rng, n, kd, g, skew)
-            layout = rng.choice(["any", "any", "any", "sorted", "runs"])
+            layout = rng.choice(os.environ["FUZZ_LAYOUT"].split(",") if "FUZZ_LAYOUT" in os.environ else ["any", "any", "any", "sorted", "runs"])
             if kd != O.BOOLBITS and n > 1:
                 if layout == "sorted":
                     kdata = np.sort(kdata) if kd != O.F64 else kdata[np.argsort(kdata.view(np.uint64), kind="stable")]
@@ -76,14 +77,16 @@ for case in range(first_case, n_cases):
                     "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9),
                     "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15),
                     "no_small": int(rng.random() < 0.4), "no_absorb": int(rng.choice([0, 0, -1, -1, 1])), "no_hot_image": int(rng.random() < 0.3), "scatter_wide": int(rng.choice([0, 1, 1, -1])), "two_pass_min_p": int(rng.choice([0, 0, 96])), "sorted_dictionary": int(rng.random() < 0.3), "wide_slices": int(rng.random() < 0.3), "no_census": int(rng.random() < 0.3),
-                    "no_table_order": int(rng.random() < 0.25), "p_target": int(rng.choice([0, 0, 3072, 64]))}
+                    "no_table_order": int(rng.random() < 0.25), "p_target": int(rng.choice([0, 0, 3072, 64])),
+                    "no_clustered": int(rng.random() < 0.15), "clustered_chunk": int(rng.choice([0, 0, 0, 4096, 1 << 20])), "clustered_max_runs_pct": int(rng.choice([0, 0, 45]))}
             for k, v in opts.items(): ctx.set_option(k, v)
             try:
                 got = ctx.groupby_agg(keys, n, vals, aggs)
                 absorbed = ctx.timings()["absorbed_rows"]
+                n_clustered += ctx.timings()["n_partitions"] == -2
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1,
-                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0, "sorted_dictionary": 0, "wide_slices": 0, "no_census": 0, "no_table_order": 0, "p_target": 0}.items(): ctx.set_option(k, v)
+                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0, "sorted_dictionary": 0, "wide_slices": 0, "no_census": 0, "no_table_order": 0, "p_target": 0, "no_clustered": 0, "clustered_chunk": 0, "clustered_max_runs_pct": 0}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
             if opts["deterministic"] and not any(np.isnan(np.asarray(v[0], np.float64)).any() or np.isinf(np.asarray(v[0], np.float64)).any() for v in vals if v[2] == O.F64):
@@ -165,5 +168,5 @@ for case in range(first_case, n_cases):
             fails += 1; print("FAIL %3d" % case); traceback.print_exc()
     except Exception:
         fails += 1; print("FAIL %3d" % case); traceback.print_exc()
-print("fuzz done: %d cases, %d failures" % (n_cases, fails))
+print("fuzz done: %d cases, %d failures (%d through the clustered-rows pass)" % (n_cases, fails, n_clustered))
 sys.exit(1 if fails else 0)

@@ -140,7 +140,8 @@ typedef struct pandrs_hip_timings {
                                                  of one call may overlap); small calls (the two-launch path) record none */
     int64_t algorithmic_bytes;                /* SURVEY.md §8d formula for this call */
     int64_t n_partitions;                     /* radix fan-out chosen (0: the small-call path; -1: hot-key absorb pass with a COMPACT spill —
-                                                 the rest of the rows went through a run of their own; fused join: the probe side's fan-out,
+                                                 the rest of the rows went through a run of their own; -2: rows clustered by key, one pass
+                                                 over the original columns and no partition at all; fused join: the probe side's fan-out,
                                                  0 = general fallback) */
     int64_t table_slots;                      /* LDS hash-table slots per partition */
     int64_t retries;                          /* overflow retries taken; 100 + retries: full LDS tables handed their unplaced rows to a
@@ -223,6 +224,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "wide_slices"       1 = the pieces of an oversized partition are as long as the cutting threshold (4 x the average partition) instead of
  *                       average-sized (A/B: a piece is one workgroup's job, long pieces are the aggregate pass's tail)
  *   "slice_over"        experiments: a partition is cut when it holds more than this many average partitions' rows (default 2)
+ *   "no_clustered"      1 = never the one-pass path for rows clustered by key (sorted input, input grouped by key); "clustered_chunk"
+ *                       rows per chunk there, "clustered_max_runs_pct" runs per 100 rows up to which it is taken (default 13)
  *   "no_table_order"    experiments: 1 = the lean aggregate draws its tables in partition order instead of largest first
  *   "fold_min", "fold_min_multi"  experiments: lanes of a wave in one table slot from which the lean aggregate folds them on the VALU
  *                       (ordinary tables: default 40; pieces of an oversized partition: default 8; 65 = never)

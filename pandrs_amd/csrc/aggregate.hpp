@@ -61,6 +61,7 @@ struct AggArgs {
     // aggregate2's SMALL mode (few rows: no estimate, no partition): workgroup b folds rows [b * s_chunk, ...) of the
     // ORIGINAL columns (dkey, src[].vals, src[].valid = null BITMAP) into its LDS table and flushes the table into
     // the context's global table with device-scope atomics; small_output_kernel turns that into the result
+    uint32_t s_vec;                           // clustered.hip: every column (8-byte key cells included) starts on a 16-byte boundary: 16-byte loads
     uint32_t s_need_cnt;                      // 0: no output reads a group size (one global atomic less per group and workgroup)
     uint32_t s_rows, s_chunk, g_slots;        // g_slots: power of two; slot g_slots = sentinel-valued key, g_slots + 1 = NULL key
     uint64_t *g_keys;                          // [g_slots + 2], EMPTY_KEY when free
@@ -152,6 +153,9 @@ constexpr size_t AGG2_LDS_EXTRA = 16 * 128 * 4 + 64;   // per-wave retry queues 
 bool aggregate2_has(int n_src, int profile);
 bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
 bool aggregate2_small_has(int n_src, int profile);
+// clustered.hip: rows clustered by key — one pass over the ORIGINAL columns, every row chunk's groups leave as partial records
+bool clustered_has(int n_src, int profile);
+bool launch_clustered(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
 // SMALL mode: false when (n_src, profile) has no small instantiation
 bool launch_aggregate2_small(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid);
 void launch_small_output(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile);

@@ -1171,6 +1171,121 @@ static int32_t run_absorb(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl
     return st;
 }
 
+// ---- rows clustered by key (sorted input, input grouped by key, time-ordered keys) ------------------------------------------------
+// No partition at all: ONE pass over the ORIGINAL columns.  The rows are cut into chunks short enough that a chunk's runs fit one LDS
+// table; clustered_kernel (clustered.hip; any key dtype, null bitmaps in place) folds every thread's consecutive rows in registers and
+// touches the table once per run; a chunk's groups leave as partial records, and one merge of the records — groups + chunk
+// boundaries + keys that come back in a later run — is the result.  100 M sorted rows, 1 M groups, 12 states: 4.9 ms (scatter + the
+// older kernel's RUNS instantiation) -> see experiments/clustered_check.py.  CLUSTERED_NOT_TAKEN: the caller goes on as before
+// (a chunk with more runs than the sample promised fills its table; the record buffer is sized for twice the promised runs).
+constexpr int32_t CLUSTERED_NOT_TAKEN = -1002;
+static int32_t run_clustered(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, const std::vector<EngSrc> &srcs, int64_t est, bool partials,
+                             int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
+    const int64_t N = rs.n_rows;
+    const int n_src = (int)srcs.size();
+    if (n_src < 1 || n_src > 4 || N >= (int64_t(1) << 32) - (int64_t(1) << 22)) return CLUSTERED_NOT_TAKEN;
+    auto prof_of = [](const EngSrc &e) {
+        int ops = (e.st_add >= 0 ? 1 : 0) | (e.st_min >= 0 ? 2 : 0) | (e.st_max >= 0 ? 4 : 0);
+        return (e.kind << 4) | (ops << 1) | (e.null_bits ? 1 : 0);
+    };
+    const int profile = prof_of(srcs[0]);
+    int round_states = 0;
+    for (auto &e : srcs) {
+        if (e.rowidx || e.valid_bytes || !e.data || e.st_fadd >= 0 || e.st_ssq >= 0 || prof_of(e) != profile) return CLUSTERED_NOT_TAKEN;
+        round_states += e.n_states();
+    }
+    if (!clustered_has(n_src, profile)) return CLUSTERED_NOT_TAKEN;
+    const int64_t T = lean_table_slots(c, round_states);
+    if (T < 256) return CLUSTERED_NOT_TAKEN;
+    // runs per row from the estimate's adjacent pairs; only long runs pay (a record per run goes through the merge)
+    const double runs_per_row = std::max(1.0 - c->est_near_same, 1e-7);
+    // (measured up to one run per 8 rows — experiments/clustered_check.py: 100 M rows in runs of 8, 12 states 4.7 -> 4.2 ms, one sum 1.7 -> 0.9)
+    if (runs_per_row > (c->opt.clustered_max_runs_pct > 0 ? c->opt.clustered_max_runs_pct / 100.0 : 0.13)) return CLUSTERED_NOT_TAKEN;
+    // a chunk's runs fill a third of its table (the sample's figure is an average), and there are chunks enough for every CU four times over
+    int64_t chunk = (int64_t)((double)T * 0.33 / runs_per_row);
+    chunk = std::min<int64_t>(chunk, std::max<int64_t>(N / (4 * (int64_t)std::max(c->n_cu, 1)), 16384));
+    if (c->opt.clustered_chunk > 0) chunk = c->opt.clustered_chunk;
+    chunk = std::max<int64_t>((chunk + 1023) / 1024 * 1024, 4096);
+    const int64_t n_tables = (N + chunk - 1) / chunk;
+    const int64_t runs = (int64_t)((double)N * runs_per_row);
+    const size_t dcap = (size_t)std::min<int64_t>(n_tables * (T + 2), 2 * runs + 2 * n_tables + 65536);
+    const size_t n_state = 1 + (size_t)pl.n_states;
+    ST_TRY(c->temp.ensure(Arena::padded(dcap * 8) + Arena::padded(dcap) + n_state * Arena::padded(dcap * 8 + 256) + 65536, c->stream));
+    c->temp.off = 0;
+    uint64_t *rk = c->temp.take<uint64_t>(dcap);
+    uint8_t *rn = c->temp.take<uint8_t>(dcap);
+    uint64_t *rst = c->temp.take<uint64_t>(dcap * n_state + 32);
+    uint32_t *counters = c->temp.take<uint32_t>(64);
+    if (!rk || !rn || !rst || !counters) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "temp arena too small (clustered rows)");
+    HIP_TRY(hipMemsetAsync(counters, 0, 256, c->stream));
+    AggArgs aa{};
+    for (int k = 0; k < MAX_STATES; k++) { aa.st_round[k] = -1; aa.st_lds[k] = -1; }
+    // the lean aggregate's fixed LDS state order: adds of source 0..n-1, per source its min-type states, then the counts
+    const int mm = ((profile >> 2) & 1) + ((profile >> 3) & 1), mbase = ((profile >> 1) & 1) ? n_src : 0;
+    int next_nn = mbase + n_src * mm;
+    for (int s = 0; s < n_src; s++) {
+        const EngSrc &e = srcs[s];
+        SrcDev &sd = aa.src[s];
+        sd = SrcDev{static_cast<const uint64_t *>(e.data), e.null_bits, e.kind, -1, -1, -1, -1, -1, -1, {0}};     // SMALL: valid = the column's null bitmap
+        auto put = [&](int8_t abs_id, int8_t &lds_id, int at) {
+            if (abs_id < 0) return;
+            aa.st_round[abs_id] = 0; aa.st_lds[abs_id] = (int8_t)at; lds_id = (int8_t)at;
+        };
+        put(e.st_add, sd.st_add, s);
+        put(e.st_min, sd.st_min, mbase + s * mm);
+        put(e.st_max, sd.st_max, mbase + s * mm + mm - 1);
+        if (e.st_nn >= 0) put(e.st_nn, sd.st_nn, next_nn++);
+    }
+    aa.dkey = rs.key; aa.s_rows = (uint32_t)N; aa.s_chunk = (uint32_t)chunk;
+    {
+        uintptr_t bits = reinterpret_cast<uintptr_t>(rs.key.data);
+        for (auto &e : srcs) bits |= reinterpret_cast<uintptr_t>(e.data);
+        aa.s_vec = (bits & 15) == 0 ? 1u : 0u;
+    }
+    aa.T = (uint32_t)T; aa.seed = 0x9E3779B9u; aa.n_src = n_src; aa.n_states = pl.n_states;
+    aa.n_fin = 0; aa.partials = 1; aa.n_rounds = 1; aa.round_states = round_states; aa.second_pass = 0;
+    aa.round_src_begin[0] = 0; aa.round_src_begin[1] = (int8_t)n_src;
+    std::memcpy(aa.kinds, pl.kinds, sizeof aa.kinds);
+    aa.out_keys = rk; aa.out_null = rn; aa.out_states = rst; aa.cap = dcap;
+    aa.side_keys = rk; aa.side_null = rn; aa.side_states = rst; aa.side_cap = dcap;
+    aa.counters = counters; aa.launch_grid = (uint32_t)n_tables;
+    volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;
+    hp[4] = 0;
+    aa.host_out = const_cast<uint32_t *>(hp); aa.scatter_flags = nullptr;
+    const size_t lds = (size_t)(T + 3) * (13 + 8 * (size_t)round_states) + 192 + 64;
+    {
+        PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
+        if (!launch_clustered(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, n_tables))) return CLUSTERED_NOT_TAKEN;
+        HIP_TRY(hipGetLastError());
+    }
+    for (int spin = 0; spin < 20000000 && hp[4] != 1; spin++) __builtin_ia32_pause();
+    if (hp[4] != 1) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hp[4] != 1) return fail(PANDRS_HIP_ERR_COMPUTATION, "clustered rows: no completion record");
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const uint32_t failed = hp[1], n_rec = hp[2];
+    if (failed) return CLUSTERED_NOT_TAKEN;          // a chunk held more runs than its table takes, or the record buffer ran out
+    RowSource ms;
+    ms.n_rows = n_rec;
+    ms.key = KeyDesc{rk, nullptr, rn, DT_CELL};
+    ms.merge_states = rst;
+    ms.merge_stride = dcap;
+    Options saved = c->opt;
+    c->opt.no_direct = 1; c->opt.no_absorb = 1;
+    c->opt.groups_hint = std::max<int64_t>(std::min<int64_t>(est, ms.n_rows), 1);
+    pandrs_hip_timings tsave = c->timings;
+    c->quiet++;
+    const int32_t st = run_engine(c, ms, pl, /*merge=*/true, partials, n_aggs, key_dtype, n_keys_out, res_slot);
+    c->quiet--;
+    c->opt = saved;
+    c->timings = tsave;
+    c->timings.estimated_groups = est;
+    c->timings.n_partitions = -2;                    // (reported: no radix partition of the rows; -2 = the clustered-rows pass)
+    c->timings.table_slots = T;
+    c->timings.retries = 0;
+    if (st && c->capacity_exceeded) { c->capacity_exceeded = false; return CLUSTERED_NOT_TAKEN; }
+    return st;
+}
+
 int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool merge,
                           bool partials, int n_aggs, int key_dtype, int n_keys_out, int res_slot) {
     if (res_slot < 0 || res_slot > 2) return fail(PANDRS_HIP_ERR_COMPUTATION, "engine nesting too deep");
@@ -1290,6 +1405,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     if (do_absorb) {
         const int32_t st = run_absorb(c, rs, pl, srcs, absorb_profile, T_abs, est, partials, n_aggs, key_dtype, n_keys_out, res_slot, hot_image);
         if (st != ABSORB_NOT_TAKEN) return st;
+    }
+    if (c->clustered_rows && !merge && !rs.pre && pl.mergeable && !pl.needs_second_pass && res_slot == 0 && !c->quiet && !c->opt.no_clustered &&
+        !c->opt.generic_aggregate && !c->opt.agg_v1 && !c->opt.deterministic && c->opt.partitions <= 0 && N >= (int64_t(1) << 20)) {
+        const int32_t st = run_clustered(c, rs, pl, srcs, est, partials, n_aggs, key_dtype, n_keys_out, res_slot);
+        if (st != CLUSTERED_NOT_TAKEN) return st;
     }
 
     // ---- low-cardinality direct path: when every group fits one LDS table with room to spare,
