@@ -173,6 +173,11 @@ def extra_configs(torch, pa, ctx, device, steps=5):
     timed("c2_skew_80_20", n, "C2 with 80/20 skew: 100M rows, i64 key (1M groups, 80% of the rows on 200K of them), sum/mean/min/max over 4 f64 cols",
           lambda: ctx.groupby_compute([(ks, None, pa.I64)], n, [(x, None, pa.F64) for x in vs], aggs16),
           bytes_alg=n * 40 + g * (8 + 8 * 16))
+    # ... and with the rows SORTED by key (round 4: no partition, one pass over the original columns — clustered.hip)
+    ks = torch.sort(torch.randint(0, g, (n,), device=device, generator=gen))[0] * MIX
+    timed("c2_sorted", n, "C2 with the rows sorted by key: 100M rows, i64 key (1M groups), sum/mean/min/max over 4 f64 cols",
+          lambda: ctx.groupby_compute([(ks, None, pa.I64)], n, [(x, None, pa.F64) for x in vs], aggs16),
+          bytes_alg=n * 40 + g * (8 + 8 * 16))
     del ks, vs
     # C3: 100 M rows, u32 string-pool codes, 10 K groups with 80/20 skew, 2 f64 columns x sum/mean/min/max + count
     g = 10_000

@@ -23,5 +23,5 @@ python3 - <<PY
 import json
 d = json.load(open("profiles/${tag}_bench.json"))
 print("ms_per_step", d["ms_per_step"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "dominant", d["roofline"].get("dominant_kernel", {}).get("frac"))
-for k in ("north_star_sum", "c3", "c4_shard", "c5_shard", "c5_one_gpu", "c1"): print(k, round(d[k]["ms"], 4))
+for k in ("north_star_sum", "c2_skew_80_20", "c2_sorted", "c3", "c4_shard", "c5_shard", "c5_one_gpu", "c1"): print(k, round(d[k]["ms"], 4))
 PY
