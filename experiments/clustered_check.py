@@ -19,6 +19,8 @@ cases = [("random 1M", lambda: ids(1_000_000) * MIX),
          ("sorted mixed key bits 1M", lambda: torch.sort(ids(1_000_000) * MIX)[0]),
          ("runs of 64, 1M keys", lambda: runs(1_000_000, 64) * MIX),
          ("runs of 8, 1M keys", lambda: runs(1_000_000, 8) * MIX),
+         ("runs of 4, 1M keys", lambda: runs(1_000_000, 4) * MIX),
+         ("runs of 3, 1M keys", lambda: runs(1_000_000, 3) * MIX),
          ("runs of 1000, 100K keys", lambda: runs(100_000, 1000) * MIX)]
 agg_sets = {"4x(sum,mean,min,max)": [(c, op) for c in range(ncol) for op in (pa.SUM, pa.MEAN, pa.MIN, pa.MAX)], "sum of one": [(0, pa.SUM)]}
 only = [a for a in sys.argv[1:] if "=" not in a]

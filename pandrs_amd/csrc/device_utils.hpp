@@ -47,6 +47,16 @@ __device__ __forceinline__ uint64_t key_cell(const KeyDesc &k, int64_t i) {
     }
 }
 
+// Row of the estimate's sample: one row per `stride` rows, at a pseudo-random offset inside its stride.  A FIXED stride aliases with
+// periodic row layouts — every entity 3 rows, 24 rows per day: with 3 | stride every sampled row is the first of its run, its
+// neighbour always equal, and the adjacent-pair statistic read "0 of 262144 pairs differ": the run bound collapsed the estimate to the
+// sample's own distinct count (230 K for 1 M groups) and the call paid for it with overflowing tables (49 ms).
+__device__ __forceinline__ int64_t sample_row(int64_t s, int64_t stride) {
+    uint32_t h = (uint32_t)s * 0x9E3779B1u;
+    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+    return s * stride + (int64_t)(((uint64_t)h * (uint64_t)stride) >> 32);
+}
+
 // 32-bit mix of a 64-bit cell: three 32-bit multiplies.  High bits pick the radix partition
 // (mulhi), a re-multiplied copy picks the LDS slot, so the two are decorrelated.
 __device__ __forceinline__ uint32_t hash32(uint64_t k, uint32_t seed) {

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         };
         if constexpr (MERGE) {
             for (uint32_t i = beg + tid; i < end; i += AG_THREADS) {
+                if (*reinterpret_cast<volatile uint32_t *>(&misc[20])) break;      // a table that is full stays full: the attempt is lost, stop walking it (every further unplaced row probed all of its buckets: 44 ms for 100 M rows)
                 const uint32_t slot = find_slot(__builtin_nontemporal_load(a.pkeys + i));
                 if (slot > T) continue;
                 if (round == 0) atomicAdd((unsigned long long *)&gsz[slot], (unsigned long long)a.pgsize[i]);
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         } else if constexpr (RUNS) {
             constexpr int AG_RUN = 4;
             for (uint32_t base = beg + tid * AG_RUN; base < end; base += AG_THREADS * AG_RUN) {
+                if (*reinterpret_cast<volatile uint32_t *>(&misc[20])) break;
                 uint64_t rk[AG_RUN], rv[AG_RUN][NS];
                 bool rok[AG_RUN][NS];
 #pragma unroll
@@ -425,6 +427,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate_kernel(AggArgs a) {
         bool okn[2][NS], knn[2];
         if (beg + tid < end) fetch(beg + tid, k2n, vn, gsn, okn, knn);
         for (uint32_t i0 = beg + tid; i0 < end; i0 += 2 * AG_THREADS) {
+            if (*reinterpret_cast<volatile uint32_t *>(&misc[20])) break;
             const bool has1 = i0 + AG_THREADS < end;
             uint64_t k2[2], v[2][NS], gs[2];
             bool ok[2][NS], kn[2];
@@ -1520,7 +1523,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != uni_profile) uni_profile = -1;
     }
     // the lean persistent kernel (aggregate2.hip): one round of a uniform profile over unclustered raw rows
-    const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && !c->clustered_rows && !c->opt.agg_v1 &&
+    // rows clustered in SHORT runs (fewer than ~11 rows: what the one-pass path above does not take or handed back): 3-10 lanes of a wave
+    // on one slot cost the lean kernel less than the older kernel's RUNS instantiation costs everywhere else (runs of 4, C2's shape:
+    // 3.5 ms lean against 4.9; long runs the other way round: sorted 6.0 against 4.9) — behind the EXACT partition: the sampled region
+    // plan assumes random row order
+    const bool short_runs = c->clustered_rows && 1.0 - c->est_near_same > 0.09;
+    const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs) && !c->opt.agg_v1 &&
                        aggregate2_has(n_src, uni_profile);
     bool use_v2 = false;
     // rounds only when one round would need more partitions than this.  Where the lean kernel answers, that is the scatter's own limit:
@@ -1602,7 +1610,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const uint32_t P1 = (uint32_t)P + 1;
         // capacity mode (no histogram pass): aggregate2 only (it walks a partition's 8 row ranges), unclustered rows
         const bool sampled = rs.pre ? true
-                           : use_v2 && !sampled_failed && !c->opt.exact_partition && c->opt.shared_cursors &&
+                           : use_v2 && !sampled_failed && !c->clustered_rows && !c->opt.exact_partition && c->opt.shared_cursors &&
                              c->opt.scatter_threads != 512 && c->opt.scatter_staged && sampled_partition_ok(N, P);
         if (rs.pre && (!use_v2 || sampled_failed || attempt > 0))      // a full table or a dropped run: the producer must start over
             return fail(PANDRS_HIP_ERR_COMPUTATION, "pre-partitioned rows: a partition did not fit");

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void estimate_count_kernel(KeyDesc key, int64
     bool live = s < n_sample && s * stride < n_rows;
     uint64_t k = 0;
     if (live) {
-        const int64_t i = s * stride;
+        const int64_t i = sample_row(s, stride);
         k = key_cell(key, i);
         live = !key_is_null(key, i) && k != EMPTY_KEY;
     }
@@ -220,7 +220,7 @@ __device__ __forceinline__ void estimate_body(KeyDesc key, int64_t n_rows, int64
     bool pair = false, differs = false, nul = false;
     const bool in_range = live;
     if (live) {
-        int64_t i = s * stride;
+        int64_t i = sample_row(s, stride);
         nul = key_is_null(key, i);
         k = key_cell(key, i);
         if (i + 1 < n_rows) {

@@ -207,3 +207,25 @@ def test_sorted_config2_at_full_size():
             assert torch.allclose(mean * cnt, s, rtol=1e-12, atol=0)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("run", [3, 4])
+def test_fixed_length_runs_do_not_alias_with_the_sample(ctx, run):
+    """Every key exactly `run` consecutive rows (three measurements per subject, …) with the sample's stride a multiple of the run length:
+    a fixed-stride sample only ever saw the FIRST row of a run, read "no adjacent pair differs", and the run bound cut the estimate to
+    the sample's own distinct count (100 M rows, runs of 3: 230 K for 1 M groups, overflowing tables, 49 ms).  The sampled row now
+    sits at a pseudo-random offset inside its stride: the estimate is the truth's size, one attempt; and rows in runs this short take
+    the lean kernel behind the exact partition, not the RUNS instantiation of the older one."""
+    rng = np.random.default_rng(60 + run)
+    n = 262_144 * 12                       # the estimate samples 262 144 rows: stride 12
+    k = mixed(np.repeat(rng.integers(0, 1 << 40, n // run + 1), run)[:n])
+    vals = [(rng.normal(size=n), None, O.F64) for _ in range(4)]
+    aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)]
+    want = O.groupby_agg([(k, None, O.I64)], n, vals, aggs)
+    got = ctx.groupby_agg([(k, None, O.I64)], n, vals, aggs)
+    t = ctx.timings()
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[2, 3, 6, 7, 10, 11, 14, 15])
+    true_groups = want[0].shape[1]
+    assert 0.8 * true_groups <= t["estimated_groups"] <= 1.3 * true_groups, (t, true_groups)
+    assert t["retries"] == 0 and t["n_partitions"] > 0, t
+    assert t["table_slots"] == 1408, t                 # the lean kernel's 109-byte slots (the older kernel: 20 + 8 x states bytes, in rounds)
