@@ -17,7 +17,10 @@ def two_class(hot_share, hot_keys, g):
 def zipf(g, a):
     u = torch.rand(n, device=d, generator=gen, dtype=torch.float64)
     return (((g ** (1 - a) - 1) * u + 1) ** (1 / (1 - a))).to(torch.int64).clamp_(1, g) * MIX
-cases = [("uniform 1M", lambda: uniform(1_000_000)), ("80% on 2K + 1M", lambda: two_class(0.8, 2_000, 1_000_000)),
+def interleaved(g):
+    a = torch.sort(torch.randint(0, g, (n // 2,), device=d, generator=gen))[0]; b = torch.sort(torch.randint(0, g, (n // 2,), device=d, generator=gen))[0]
+    return torch.stack([a, b], 1).reshape(-1) * MIX
+cases = [("uniform 1M", lambda: uniform(1_000_000)), ("two sorted streams interleaved", lambda: interleaved(1_000_000)), ("80% on 2K + 1M", lambda: two_class(0.8, 2_000, 1_000_000)),
          ("50% on 20K + 1M", lambda: two_class(0.5, 20_000, 1_000_000)),
          ("zipf 0.8 over 5M", lambda: zipf(5_000_000, 0.8)), ("zipf 0.6 over 1M", lambda: zipf(1_000_000, 0.6)), ("zipf 1.0 over 1M", lambda: zipf(1_000_000, 0.999))]
 folds = [int(x) for x in os.environ.get("FOLDS", "65,40,24,16,10,6").split(",")]

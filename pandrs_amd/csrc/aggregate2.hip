@@ -80,6 +80,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     const uint32_t n_tables = SMALL ? (a.s_rows + a.s_chunk - 1) / a.s_chunk : a.n_tasks[1];
     uint32_t tb = blockIdx.x;
     if (tb >= n_tables) { finish(); return; }
+    // the capacity-mode scatter dropped rows (its sampled regions were too small: rows clumped by position in a way the estimate's adjacent
+    // pairs do not show): the host repeats the call with the exact histogram whatever happens here — do not aggregate what is incomplete
+    if (!SMALL && a.scatter_flags && __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { finish(); return; }
     AggTable tab = get_table(tb);
     uint32_t ti = tab.task_beg;
     AggTask cur = get_task(ti);

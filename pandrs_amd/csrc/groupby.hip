@@ -1423,7 +1423,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // (below a few million rows the whole call is launch-bound and the two-stage direct path loses)
     bool has_valid_bytes = false;
     for (auto &e : srcs) has_valid_bytes |= e.valid_bytes != nullptr;
-    if (!merge && !rs.pre && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
+    // (pl.n_states <= MAX_SRC: the records' merge takes every state as a source of its own — 8 columns x sum / min / max = 24 states used to
+    // FAIL the call here, "too many states to merge"; such calls stay on the radix path, whose rounds need no merge)
+    if (!merge && !rs.pre && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && pl.n_states <= MAX_SRC &&
+        (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
         int total_states = 0;
         for (auto &e : srcs) total_states += e.n_states();
         const size_t sb = 20 + 8 * (size_t)total_states;
@@ -1571,7 +1574,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // an LDS table with more distinct groups sees fewer same-address atomics (hot keys) - as long as
         // the slices' partial records (slices per partition x groups) stay cheap to merge.
         if (!merge && !c->opt.no_slice && c->opt.slice_rows <= 0 && pl.mergeable && n_rounds == 1 &&
-            N >= (int64_t(1) << 24) && P < p_par && pl.n_states >= 4) {   // (1-2 states: measured 5 % slower)
+            N >= (int64_t(1) << 24) && P < p_par && pl.n_states >= 4 && pl.n_states <= MAX_SRC) {   // (1-2 states: measured 5 % slower; > 16: the slices' records could not be merged)
             int64_t p_rec = 16;
             while (p_rec * 262144 < p_par * est) p_rec *= 2;
             if (std::max(P, p_rec) <= 64) { P = std::max(P, p_rec); auto_slice_rows = N / p_par; p_par = 1; }
@@ -1693,7 +1696,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
         int n_var_src = 0;
         for (int s2 = 0; s2 < pl.n_src; s2++) n_var_src += pl.st_ssq[s2] >= 0;
-        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1;
+        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1 && pl.n_states <= MAX_SRC;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
                                                        : std::max<int64_t>(int64_t(1) << 18, (c->opt.wide_slices ? 4 : (c->opt.slice_over > 0 ? c->opt.slice_over : 2)) * (N / std::max<int64_t>(P, 1)));

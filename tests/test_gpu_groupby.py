@@ -1840,3 +1840,19 @@ def test_one_lean_round_is_preferred_to_rounds_up_to_the_scatter_limit():
     finally:
         c.set_option("p_target", 0)
         c.close()
+
+
+@pytest.mark.parametrize("g", [300, 10_000, 400_000])
+def test_eight_columns_of_sum_min_max_never_need_a_merge_they_cannot_have(ctx, g):
+    """8 value columns x sum / mean / min / max = 24 partial states; a merge of partial records takes every state as a source of its own
+    and at most 16 of them, so the paths that end in a merge (few-groups direct path, sliced partitions) used to FAIL such a call with
+    "too many states to merge (24)" (round 4 cliff hunt: 10 K groups, 50 M rows).  They are not taken beyond 16 states: the radix path's
+    rounds answer.  Few, mid and many groups, oracle-compared."""
+    rng = np.random.default_rng(808 + g)
+    n = 4_500_000
+    keys = [(sparse_keys(rng, n, g), None, O.I64)]
+    vals = [(rng.normal(10 * c, 3, n), O.pack_mask(rng.random(n) < 0.05) if c % 3 == 0 else None, O.F64) for c in range(8)]
+    aggs = [(c, op) for c in range(8) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    got = ctx.groupby_agg(keys, n, vals, aggs)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX)])
