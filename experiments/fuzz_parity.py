@@ -72,13 +72,22 @@ for case in range(first_case, n_cases):
                 else: vals.append((rng.integers(-10**6, 10**6, n).astype(np.int64), mask(rng, n, rng.choice([0, 0.2])), O.I64))
             ops = OPS_ALL if rng.random() < 0.4 else OPS_MERGEABLE
             aggs = [(int(rng.integers(0, nv)), int(rng.choice(ops))) for _ in range(int(rng.integers(1, 9)))]
+            if rng.random() < 0.2:         # a WIDE uniform aggregation: 5-12 columns of one kind, the same ops on each (the lean kernel in rounds)
+                nv = int(rng.integers(5, 13))
+                wkind = O.F64 if rng.random() < 0.7 else O.I64
+                wmask = float(rng.choice([0, 0, 0.1])) if wkind == O.F64 else 0.0
+                vals = [((rng.normal(50, 20, n) if wkind == O.F64 else rng.integers(-10**6, 10**6, n).astype(np.int64)), mask(rng, n, wmask) if wmask else None, wkind) for _ in range(nv)]
+                wops = [[O.SUM], [O.SUM, O.MEAN], [O.SUM, O.MIN, O.MAX], [O.MIN, O.MAX], [O.MAX]][int(rng.integers(0, 5))]
+                if wkind == O.I64 and wops in ([O.MIN, O.MAX], [O.MAX]): wops = [O.SUM, O.MIN, O.MAX]
+                wops = wops if nv * (len([o for o in wops if o != O.MEAN]) + (1 if wmask else 0)) <= 38 else [O.SUM]
+                aggs = [(c, op) for c in range(nv) for op in wops] + ([(0, O.COUNT)] if rng.random() < 0.5 else [])
             opts = {"no_direct": int(rng.random() < 0.3), "slice_rows": int(rng.choice([0, 0, 20_000])),
                     "p_max": int(rng.choice([0, 0, 0, 24])), "generic_aggregate": int(rng.random() < 0.2),
                     "scatter_staged": int(rng.random() < 0.9), "shared_cursors": int(rng.random() < 0.9),
                     "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15),
                     "no_small": int(rng.random() < 0.4), "no_absorb": int(rng.choice([0, 0, -1, -1, 1])), "no_hot_image": int(rng.random() < 0.3), "scatter_wide": int(rng.choice([0, 1, 1, -1])), "two_pass_min_p": int(rng.choice([0, 0, 96])), "sorted_dictionary": int(rng.random() < 0.3), "wide_slices": int(rng.random() < 0.3), "no_census": int(rng.random() < 0.3),
                     "no_table_order": int(rng.random() < 0.25), "p_target": int(rng.choice([0, 0, 3072, 64])),
-                    "no_clustered": int(rng.random() < 0.15), "clustered_chunk": int(rng.choice([0, 0, 0, 4096, 1 << 20])), "clustered_max_runs_pct": int(rng.choice([0, 0, 45]))}
+                    "no_lean_rounds": int(rng.random() < 0.2), "no_clustered": int(rng.random() < 0.15), "clustered_chunk": int(rng.choice([0, 0, 0, 4096, 1 << 20])), "clustered_max_runs_pct": int(rng.choice([0, 0, 45]))}
             for k, v in opts.items(): ctx.set_option(k, v)
             try:
                 got = ctx.groupby_agg(keys, n, vals, aggs)
@@ -86,7 +95,7 @@ for case in range(first_case, n_cases):
                 n_clustered += ctx.timings()["n_partitions"] == -2
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1,
-                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0, "sorted_dictionary": 0, "wide_slices": 0, "no_census": 0, "no_table_order": 0, "p_target": 0, "no_clustered": 0, "clustered_chunk": 0, "clustered_max_runs_pct": 0}.items(): ctx.set_option(k, v)
+                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0, "sorted_dictionary": 0, "wide_slices": 0, "no_census": 0, "no_table_order": 0, "p_target": 0, "no_lean_rounds": 0, "no_clustered": 0, "clustered_chunk": 0, "clustered_max_runs_pct": 0}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
             if opts["deterministic"] and not any(np.isnan(np.asarray(v[0], np.float64)).any() or np.isinf(np.asarray(v[0], np.float64)).any() for v in vals if v[2] == O.F64):

@@ -21,7 +21,7 @@ only = sys.argv[1:]
 for name, make in cases:
     if only and not any(o in name for o in only): continue
     k = make()
-    for pt in (3072, 4608, 6144, 8192):
+    for pt in [int(x) for x in os.environ.get("PTS", "3072,4608,6144,8192").split(",")]:
         ctx.set_option("p_target", pt)
         for i in range(4): ng = ctx.groupby_compute([(k, None, pa.I64)], n, v, aggs)
         t = ctx.timings()

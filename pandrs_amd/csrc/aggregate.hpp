@@ -33,6 +33,14 @@ struct AggArgs {
     const AggTask *tasks;        // nullptr: workgroup b = partition b
     const uint32_t *n_tasks;
     const AggTable *tables;      // aggregate2 only; n_tasks[1] = number of tables
+    // aggregate2 in ROUNDS (more than 4 uniform columns; groupby.hip): launch r folds the sources [src_base, src_base + NSRC) of round
+    // `cur_round` and writes the outputs whose states live in that round.  Launch 0 leaves, per table, a snapshot of its key table (keys,
+    // tags, sentinel flag) and every slot's output position; the later launches start from the snapshot — same slots, same positions, no
+    // second compaction — so the outputs of all rounds line up.  snap_* = nullptr: one round, as before.
+    uint64_t *snap_keys;         // [n_tables][T + 2]
+    uint8_t *snap_ctrl;          // [n_tables][T]
+    uint32_t *snap_pos;          // [n_tables][T + 2] output position of the slot's group, 0xFFFFFFFF = free; [T + 1] = sentinel-key flag
+    int32_t src_base, cur_round;
     const uint32_t *order;       // aggregate2, optional: the tables in the order they are handed out (largest first); nullptr = as listed
     uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])

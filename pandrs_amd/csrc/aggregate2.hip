@@ -53,23 +53,31 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     int nn_idx[NSRC];
 #pragma unroll
     for (int c = 0; c < NSRC; c++) {
-        vals[c] = a.src[c].vals; valid[c] = a.src[c].valid; nn_idx[c] = HAS_V ? a.src[c].st_nn : -1;
+        const SrcDev &sd = a.src[(SMALL ? 0 : a.src_base) + c];
+        vals[c] = sd.vals; valid[c] = sd.valid; nn_idx[c] = HAS_V ? sd.st_nn : -1;
     }
+    const bool resume = !SMALL && a.snap_keys && a.cur_round > 0;      // a later round: tables start from launch 0's snapshot
     const uint64_t *pkeys = a.pkeys;
     const uint32_t seed = a.seed, NG = T >> 4, lane = tid & 63;
 
     // every workgroup ends here: the last one publishes the call's counters to the host
     auto finish = [&]() {
         __syncthreads();
-        if (tid == 0 && a.host_out) {
+        if (tid == 0 && (a.host_out || (!SMALL && a.snap_keys))) {
             __threadfence();
             if (atomicAdd(&a.counters[8], 1u) == gridDim.x - 1) {
                 __threadfence();
-                for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.host_out[6] = __hip_atomic_load(&a.counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ABLATE == 8) a.host_out[5] = __hip_atomic_load(&a.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.host_out[3] = a.scatter_flags ? __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.host_out) {
+                    for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.host_out[6] = __hip_atomic_load(&a.counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ABLATE == 8) a.host_out[5] = __hip_atomic_load(&a.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.host_out[3] = a.scatter_flags ? __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    // rounds: every launch but the last publishes nothing and re-arms the per-launch counters (workgroups done, table tickets)
+                    a.counters[8] = 0; a.counters[10] = 0;
+                    __threadfence();
+                }
             }
         }
     };
@@ -83,6 +91,9 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     // the capacity-mode scatter dropped rows (its sampled regions were too small: rows clumped by position in a way the estimate's adjacent
     // pairs do not show): the host repeats the call with the exact histogram whatever happens here — do not aggregate what is incomplete
     if (!SMALL && a.scatter_flags && __hip_atomic_load(a.scatter_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { finish(); return; }
+    // (rounds: a table of launch 0 filled up — its snapshot is incomplete, the attempt is lost)
+    if (resume && __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { finish(); return; }
+    auto table_id = [&](uint32_t b) { return (SMALL || !a.order) ? b : a.order[b]; };
     AggTable tab = get_table(tb);
     uint32_t ti = tab.task_beg;
     AggTask cur = get_task(ti);
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
     bool cur_multi = false;                            // the table being filled is a slice of an oversized partition
     auto drain = [&](uint32_t n_take) {                // n_take <= 64 entries from the top of the wave's queue
         qn -= n_take;
+        if (!SMALL && a.snap_keys && *reinterpret_cast<volatile uint32_t *>(&misc[20])) return;       // (rounds: the table is full, the attempt is lost)
         if (ABLATE == 8 && lane == 0) atomicAdd(&a.counters[5], n_take);       // experiments: rows that took the retry queue
         bool ovf = false;
         uint64_t ov_k = 0, ov_v[NSRC];
@@ -228,7 +240,8 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             else if (k == EMPTY_KEY) misc[21] = 1;
             // (at most 16 groups = a 256-slot window — 8 overflowed a handful of rows of uniform C2 at load 0.69 —: inserts and lookups obey the same bound, so a key is either inside its window or —
             // consistently, slots never free up — handed to the overflow path; a FULL table is no longer walked end to end per unplaced row)
-            else slot = swiss_find(k, keys, ctrl, T, seed, SMALL ? 8u : 16u);
+            // (rounds: no overflow run behind a full table — the whole table is the window, and the attempt ends when it is really full)
+            else slot = swiss_find(k, keys, ctrl, T, seed, SMALL ? 8u : (a.snap_keys ? 0xFFFFFFFFu : 16u));
             if (slot <= T + 1) update(slot, v, okm);
             else ovf = true;                            // table full
             ov_k = k; ov_okm = okm;
@@ -271,8 +284,16 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         const uint32_t t_end = tab.task_beg + tab.n_tasks;
         cur_multi = multi;
 
-        for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
-        for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;
+        const size_t snap = resume || (!SMALL && a.snap_keys) ? (size_t)table_id(tb) : 0;
+        if (resume) {           // a later round: launch 0's key table — every key of this table has its slot already
+            const uint64_t *sk = a.snap_keys + snap * (T + 2);
+            const uint32_t *sc = reinterpret_cast<const uint32_t *>(a.snap_ctrl + snap * T);
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = sk[s]; gsz[s] = 0; }
+            for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = sc[s];
+        } else {
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
+            for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;
+        }
         for (int k = 0; k < a.round_states; k++) {
             const uint64_t idv = ((uint32_t)k >= m_base && (uint32_t)k < m_base + (uint32_t)(NSRC * MM)) ? M_IDENT : 0ull;
             uint64_t *dst = st + (size_t)k * T1;
@@ -280,6 +301,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         }
         if (tid < 32) misc[tid] = 0;
         __syncthreads();
+        if (resume && tid == 0) misc[21] = a.snap_pos[snap * (T + 2) + T + 1];      // the sentinel-valued key was seen in launch 0
         const uint32_t tbn = misc[33];
         const bool have_next_tab = tbn < n_tables;
         const AggTable ntab = get_table(have_next_tab ? tbn : tb);
@@ -415,17 +437,35 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
         const uint32_t spt = (T1 + AG_THREADS - 1) / AG_THREADS;
         const uint32_t s_beg = min(tid * spt, T1), s_end = min(s_beg + spt, T1);
         auto occupied = [&](uint32_t s) { return s < T ? keys[s] != EMPTY_KEY : (s == T && sentinel); };
-        uint32_t mine = 0;
-        for (uint32_t s = s_beg; s < s_end; s++) mine += occupied(s) ? 1u : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<AG_THREADS>(mine, misc, &total);
-        if (tid == 0) misc[22] = atomicAdd(&a.counters[multi ? 2 : 0], total);
-        __syncthreads();
-        size_t pos = (size_t)misc[22] + ex;
+        const bool rounds = !SMALL && a.snap_keys != nullptr;
+        size_t pos = 0;
+        if (!resume) {
+            uint32_t mine = 0;
+            for (uint32_t s = s_beg; s < s_end; s++) mine += occupied(s) ? 1u : 0u;
+            uint32_t total;
+            const uint32_t ex = block_exclusive_scan<AG_THREADS>(mine, misc, &total);
+            if (tid == 0) misc[22] = atomicAdd(&a.counters[multi ? 2 : 0], total);
+            __syncthreads();
+            pos = (size_t)misc[22] + ex;
+        }
+        if (rounds && !resume) {            // launch 0 of several: the key table and every slot's output position for the launches to come
+            uint64_t *sk = a.snap_keys + snap * (T + 2);
+            uint32_t *sc = reinterpret_cast<uint32_t *>(a.snap_ctrl + snap * T);
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) sk[s] = keys[s];
+            for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) sc[s] = reinterpret_cast<const uint32_t *>(ctrl)[s];
+            if (tid == 0) a.snap_pos[snap * (T + 2) + T + 1] = sentinel ? 1u : 0u;
+        }
         for (uint32_t s = s_beg; s < s_end; s++) {
+            if (rounds && s <= T) {
+                uint32_t *sp = a.snap_pos + snap * (T + 2) + s;
+                if (resume) { if (!occupied(s)) continue; pos = *sp; }
+                else *sp = occupied(s) ? (uint32_t)pos : 0xFFFFFFFFu;
+            }
             if (!occupied(s)) continue;
-            o_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
-            o_null[pos] = null_part ? 1 : 0;
+            if (!resume) {
+                o_keys[pos] = null_part ? 0ull : (s < T ? keys[s] : EMPTY_KEY);
+                o_null[pos] = null_part ? 1 : 0;
+            }
             const uint64_t g = gsz[s];
             if (emit_partials) {
                 o_states[pos] = g;
@@ -439,6 +479,7 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
             } else {
                 for (int f = 0; f < a.n_fin; f++) {
                     const FinDev &fd = a.fin[f];
+                    if (rounds && fd.round != a.cur_round) continue;        // this output's states live in another launch's tables
                     auto cell = [&](int8_t l) { return st[(size_t)l * T1 + s]; };
                     double r = 0.0;
                     switch (fd.op) {

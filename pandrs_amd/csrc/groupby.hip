@@ -1531,14 +1531,21 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // 3.5 ms lean against 4.9; long runs the other way round: sorted 6.0 against 4.9) — behind the EXACT partition: the sampled region
     // plan assumes random row order
     const bool short_runs = c->clustered_rows && 1.0 - c->est_near_same > 0.09;
+    // ROUNDS of the lean kernel (round 4, late): more than 4 uniform columns, or 4 whose states need more tables than the scatter can
+    // feed, are folded 4 (2, 1) columns at a time by one launch each over the same partitions; launch 0 leaves every table's keys and
+    // output positions behind and the later launches start from them (aggregate.hpp, snap_*).  8 columns x sum / mean / min / max over
+    // 1 M groups, 50 M rows: 9.2 ms (the older kernel, one round of 24 states in 764-slot tables) -> see experiments/cliff_hunt.py.
+    // Not for partial states (a record of more than 16 states cannot be merged anyway), merges and pre-partitioned rows.
+    const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds;
     const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs) && !c->opt.agg_v1 &&
-                       aggregate2_has(n_src, uni_profile);
+                       aggregate2_has(std::min(n_src, 4), uni_profile) && (n_src <= 4 || lean_rounds_ok);
+    if (v2_ok && n_src > 4) spr = 4;
     bool use_v2 = false;
-    // rounds only when one round would need more partitions than this.  Where the lean kernel answers, that is the scatter's own limit:
-    // one lean round at a fan-out of 4-7 K beats two or four rounds of the older kernel at 2.5-3 K although the scatter pays for it
-    // (experiments/p_target_sweep.py, C2's 12 states: 4 M uniform groups 5.70 -> 5.05 ms, 7 M 7.28 -> 6.06, 10 M 8.10 -> 7.70;
-    // Zipf(0.8) over 5 M keys 10.8 -> 6.5 — the older kernel has no wave fold for the hot keys' pieces)
-    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : (v2_ok ? P_MAX : 3072);
+    // rounds only when one round would need more partitions than this.  The older kernel's rounds are dear (3072); the lean kernel's cost
+    // one more pass over the key column per round, which a fan-out beyond ~4 K costs the scatter too (experiments/p_target_sweep.py,
+    // C2's 12 states, 100 M rows: 5 M uniform groups one round at P = 5120 5.43 ms, two rounds at 2816 4.82; 7 M: 6.05 / 5.37; 4 M: a tie;
+    // before the lean kernel had rounds, one lean round up to 8192 was the better plan: 5.9 and 7.3 ms with the older kernel's rounds)
+    const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : (v2_ok ? (lean_rounds_ok ? 4096 : P_MAX) : 3072);
     for (;; spr = (spr + 1) / 2) {
         if (c->opt.src_per_round > 0 && !pl.needs_second_pass) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
         n_rounds = n_src ? (n_src + spr - 1) / spr : 1;
@@ -1552,7 +1559,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             max_spr = std::max(max_spr, b1 - b0);
         }
         if (n_src == 0) { round_begin[0] = round_begin[1] = 0; }
-        use_v2 = v2_ok && n_rounds == 1;
+        use_v2 = v2_ok && max_spr <= 4 && (n_rounds == 1 || lean_rounds_ok);
         const size_t slot_bytes = (use_v2 ? 13 : 20) + 8 * (size_t)round_states;    // aggregate2: u32 group sizes, one tag byte, no position map
         T = (int64_t)((lds_budget - 192 - (use_v2 ? AGG2_LDS_EXTRA : 0)) / slot_bytes) - 3;
         T = std::min<int64_t>(T, 32768) & (use_v2 ? ~int64_t(15) : ~int64_t(3));   // 16-slot groups / 4-key buckets
@@ -1638,10 +1645,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // aggregate2's fixed LDS state order: the adds of source 0..n-1, then per source its min-type states
         // (min, ~max), then the non-null counts
         const int v2_mm = use_v2 ? ((uni_profile >> 2) & 1) + ((uni_profile >> 3) & 1) : 0;
-        const int v2_mbase = use_v2 && ((uni_profile >> 1) & 1) ? n_src : 0;
-        int v2_next_nn = v2_mbase + n_src * v2_mm;
         for (int r = 0; r < n_rounds; r++) {
             int next = 0;
+            const int n_r = round_begin[r + 1] - round_begin[r];          // (the order holds inside every round of the lean kernel)
+            const int v2_mbase = use_v2 && ((uni_profile >> 1) & 1) ? n_r : 0;
+            int v2_next_nn = v2_mbase + n_r * v2_mm;
             for (int s = round_begin[r]; s < round_begin[r + 1]; s++) {
                 EngSrc &e = srcs[s];
                 uint64_t *pv = rs.pre ? const_cast<uint64_t *>(rs.pre->pvals[s]) : c->work.take<uint64_t>(NP);
@@ -1662,11 +1670,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 if (use_v2) {
                     auto put = [&](int8_t abs_id, int8_t &lds_id, int at) {
                         if (abs_id < 0) return;
-                        st_round[abs_id] = 0; st_lds[abs_id] = (int8_t)at; lds_id = (int8_t)at;
+                        st_round[abs_id] = (int8_t)r; st_lds[abs_id] = (int8_t)at; lds_id = (int8_t)at;
                     };
-                    put(e.st_add, sd.st_add, s);
-                    put(e.st_min, sd.st_min, v2_mbase + s * v2_mm);
-                    put(e.st_max, sd.st_max, v2_mbase + s * v2_mm + v2_mm - 1);
+                    const int sl = s - round_begin[r];
+                    put(e.st_add, sd.st_add, sl);
+                    put(e.st_min, sd.st_min, v2_mbase + sl * v2_mm);
+                    put(e.st_max, sd.st_max, v2_mbase + sl * v2_mm + v2_mm - 1);
                     if (e.st_nn >= 0) put(e.st_nn, sd.st_nn, v2_next_nn++);
                     continue;
                 }
@@ -1707,7 +1716,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const int64_t max_slices = slicing ? N / piece_rows + N / slice_rows + 2 : 0;       // slices of multi-slice partitions
         const size_t side_cap = (size_t)max_slices * (size_t)(T + 2);
         // (rows that full tables hand to an overflow run may bring up to one group each: room for them, bounded by what is likely)
-        const bool want_ov = use_v2 && !merge && res_slot == 0 && !c->opt.no_overflow_run && n_src >= 1 && n_src <= 4 && N >= (int64_t(1) << 16);
+        const bool want_ov = use_v2 && n_rounds == 1 && !merge && res_slot == 0 && !c->opt.no_overflow_run && n_src >= 1 && n_src <= 4 && N >= (int64_t(1) << 16);
         const int64_t ov_rows = want_ov ? std::min<int64_t>(std::max<int64_t>(N / 4, 65536), int64_t(1) << 30) : 0;
         size_t cap = (size_t)std::min<int64_t>(N, (int64_t)P1 * (T + 2) + std::min<int64_t>(ov_rows, std::max<int64_t>(4 * est, int64_t(1) << 20))) + (slicing ? side_cap : 0) +
                      (res_slot == 0 ? (size_t)c->reserve_groups : 0);       // (+ groups a caller will append: the absorb pass's compact spill)
@@ -1754,11 +1763,20 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             const uint32_t max_tables = (uint32_t)(P1 + max_slices);
             const uint32_t max_tasks = use_v2 ? 8 * P1 + max_tables : max_tables;
             const size_t n_state_all = 1 + (size_t)pl.n_states;
-            ST_TRY(c->side.ensure(Arena::padded(side_cap * 8) + Arena::padded(side_cap) + n_state_all * Arena::padded(side_cap * 8 + 256) + 8192, c->stream));
+            const bool lean_rounds = use_v2 && n_rounds > 1;
+            const size_t snap_slots = lean_rounds ? (size_t)max_tables * (size_t)(T + 2) : 0;      // every table's key snapshot (launch 0 -> the later rounds)
+            ST_TRY(c->side.ensure(Arena::padded(side_cap * 8) + Arena::padded(side_cap) + n_state_all * Arena::padded(side_cap * 8 + 256) + 8192 +
+                                  Arena::padded(snap_slots * 8 + 256) + Arena::padded(snap_slots * 4 + 256) + Arena::padded(snap_slots + 256), c->stream));
             aa.side_keys = c->side.take<uint64_t>(side_cap);
             aa.side_null = c->side.take<uint8_t>(side_cap);
             aa.side_states = c->side.take<uint64_t>(side_cap * n_state_all + 32);
             aa.side_cap = side_cap;
+            if (lean_rounds) {
+                aa.snap_keys = c->side.take<uint64_t>(snap_slots + 16);
+                aa.snap_pos = c->side.take<uint32_t>(snap_slots + 16);
+                aa.snap_ctrl = c->side.take<uint8_t>(snap_slots + 16);
+                if (!aa.snap_keys || !aa.snap_pos || !aa.snap_ctrl) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "side arena too small (rounds)");
+            }
             AggTask *tasks = c->work.take<AggTask>(max_tasks + 8);
             AggTable *tables = c->work.take<AggTable>(max_tables + 8);
             uint32_t *n_tasks = c->work.take<uint32_t>(64);
@@ -1781,7 +1799,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         {
             PhaseTimer pt(c, PANDRS_HIP_PHASE_AGGREGATE);
             size_t lds = (size_t)(T + 3) * slot_bytes + 192 + (use_v2 ? AGG2_LDS_EXTRA : 0);
-            const int profile = n_rounds == 1 ? uni_profile : -1;
+            const int profile = (n_rounds == 1 || use_v2) ? uni_profile : -1;
             volatile uint32_t *hp = reinterpret_cast<volatile uint32_t *>(c->pinned) + 1040;      // aggregate2's own corner
             if (use_v2) { hp[4] = 0; aa.host_out = const_cast<uint32_t *>(hp); aa.scatter_flags = sampled ? part.flags : nullptr; }
             // a full table's unplaced rows go to a buffer and are grouped in a run of their own (AggArgs::ov_keys): an estimate that
@@ -1799,8 +1817,20 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 if (!aa.ov_keys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "overflow arena too small");
                 aa.ov_cap = ov_cap;
             } else { aa.ov_keys = nullptr; aa.ov_cap = 0; }
+            if (use_v2 && n_rounds > 1) {
+                // one launch per round over the same tables; only the last one publishes (host_out), the others re-arm the launch counters
+                uint32_t *const publish = aa.host_out;
+                polled = true;
+                for (int r = 0; r < n_rounds && polled; r++) {
+                    aa.cur_round = r; aa.src_base = round_begin[r];
+                    aa.host_out = r + 1 == n_rounds ? publish : nullptr;
+                    polled = launch_aggregate2(c, aa, round_begin[r + 1] - round_begin[r], profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
+                }
+                if (!polled) return fail(PANDRS_HIP_ERR_COMPUTATION, "lean aggregate: no instantiation for a round of this profile");
+            } else {
             polled = use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
             if (!polled) launch_aggregate(c, aa, max_spr, profile, lds);
+            }
             HIP_TRY(hipGetLastError());
         }
         uint32_t *h = reinterpret_cast<uint32_t *>(c->pinned);

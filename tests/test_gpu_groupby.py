@@ -1807,10 +1807,11 @@ def test_tables_of_unequal_size_are_drawn_largest_first(ctx):
 
 
 def test_one_lean_round_is_preferred_to_rounds_up_to_the_scatter_limit():
-    """The rounds heuristic (groupby.hip, P_TARGET): where the lean kernel answers, one round at a fan-out of up to 8192 is planned
-    rather than two or four rounds of the older kernel at <= 3072 (experiments/p_target_sweep.py).  C2's 12 states over 5 M uniform
-    groups: P = 4864 tables of 1408 slots, one attempt; `p_target` = 3072 restores the two-round plan (2396 slots); same group count,
-    counts and sums either way."""
+    """The rounds heuristic (groupby.hip, P_TARGET; experiments/p_target_sweep.py).  C2's 12 states over 5 M uniform groups: the lean
+    kernel in two rounds (two columns per launch over the same 2816 partitions, 2528-slot tables) — the default since the lean kernel has
+    rounds; one lean round at a fan-out of 4864 (1408 slots) with `p_target` = 8192, and without lean rounds (`no_lean_rounds`: one lean
+    round up to the scatter's limit, the plan before); the older kernel's two rounds (2396 slots) with `p_target` = 3072 on top.  Same
+    group count, counts, sums and extremes every way."""
     import torch
     import pandrs_amd as pa
     n, g, d = 60_000_000, 5_000_000, "cuda:0"
@@ -1823,8 +1824,9 @@ def test_one_lean_round_is_preferred_to_rounds_up_to_the_scatter_limit():
     true_groups = torch.unique(ids).numel()
     c = pa.Context(0)
     try:
-        for p_target, slots in ((0, 1408), (3072, 2396)):
+        for p_target, no_lean_rounds, slots in ((8192, 0, 1408), (0, 0, 2528), (0, 1, 1408), (3072, 1, 2396)):
             c.set_option("p_target", p_target)
+            c.set_option("no_lean_rounds", no_lean_rounds)
             ng = c.groupby_compute([(keys, None, O.I64)], n, [(v, None, O.F64) for v in vals], aggs)
             t = c.timings()
             kc, kn, oa = c.groupby_fetch()
@@ -1835,10 +1837,11 @@ def test_one_lean_round_is_preferred_to_rounds_up_to_the_scatter_limit():
                 assert abs(float(oa[4 * col].sum()) - tot) <= 1e-9 * max(abs(tot), 1.0)
                 assert float(oa[4 * col + 2].min()) == float(vals[col].min()) and float(oa[4 * col + 3].max()) == float(vals[col].max())
             assert t["table_slots"] == slots, t
-            assert (t["n_partitions"] > 3072) == (p_target == 0), t
+            assert (t["n_partitions"] > 4096) == (slots == 1408), t
             del kc, kn, oa
     finally:
         c.set_option("p_target", 0)
+        c.set_option("no_lean_rounds", 0)
         c.close()
 
 
@@ -1856,3 +1859,56 @@ def test_eight_columns_of_sum_min_max_never_need_a_merge_they_cannot_have(ctx, g
     want = O.groupby_agg(keys, n, vals, aggs)
     got = ctx.groupby_agg(keys, n, vals, aggs)
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX)])
+
+
+@pytest.mark.parametrize("ncol,kind,masked", [(5, "f64", False), (6, "f64", True), (7, "i64", False), (9, "f64", True), (13, "f64", False), (16, "f64sum", False)])
+def test_wide_aggregations_run_the_lean_kernel_in_rounds(ctx, ncol, kind, masked):
+    """More than 4 uniform columns: the lean kernel folds them 4 at a time, one launch per round over the same partitions; launch 0's key
+    table and output positions are what the later launches start from, so every round's outputs land on the same group rows
+    (aggregate2.hip, snap_*).  Sum / mean / min / max (+ count) over 5-16 columns, null masks, i64 columns, NULL keys and the table's
+    sentinel bits among the keys — the oracle's answers; the same with the older kernel's rounds (`no_lean_rounds`)."""
+    rng = np.random.default_rng(900 + ncol)
+    n, g = 3_000_000, 150_000
+    k = sparse_keys(rng, n, g)
+    k[rng.random(n) < 0.001] = -1                     # the table sentinel's bits
+    keys = [(k, O.pack_mask(rng.random(n) < 0.01), O.I64)]
+    dt = O.I64 if kind == "i64" else O.F64
+    vals = []
+    for c in range(ncol):
+        x = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "i64" else rng.normal(5 * c, 2, n)
+        vals.append((x, O.pack_mask(rng.random(n) < 0.1) if masked else None, dt))
+    ops = {"f64": (O.SUM, O.MEAN, O.MIN, O.MAX), "i64": (O.SUM, O.MIN, O.MAX), "f64sum": (O.SUM, O.MEAN)}[kind]       # (at most 40 states per call)
+    aggs = [(c, op) for c in range(ncol) for op in ops][:60] + [(ncol - 1, O.COUNT)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT) or (kind == "i64" and op == O.SUM)]
+    for no_lean in (0, 1):
+        ctx.set_option("no_lean_rounds", no_lean)
+        try:
+            got = ctx.groupby_agg(keys, n, vals, aggs)
+            t = ctx.timings()
+        finally:
+            ctx.set_option("no_lean_rounds", 0)
+        assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+        if not no_lean:
+            assert t["table_slots"] % 16 == 0 and t["n_partitions"] > 0, t      # the lean kernel's 16-slot groups, the radix path
+
+
+def test_a_full_table_in_the_first_round_fails_the_attempt_for_all_rounds(ctx):
+    """Rounds of the lean kernel with an estimate far too low (`groups_hint`): launch 0's tables fill up, its snapshots are incomplete,
+    the later launches must not touch them — the attempt is repeated with more partitions and the answers are the oracle's."""
+    rng = np.random.default_rng(77)
+    n, g = 2_500_000, 600_000
+    keys = [(sparse_keys(rng, n, g), None, O.I64)]
+    vals = [(rng.normal(size=n), None, O.F64) for _ in range(6)]
+    aggs = [(c, op) for c in range(6) for op in (O.SUM, O.MIN, O.MAX)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    ctx.set_option("groups_hint", 120_000)
+    ctx.set_option("no_small", 1)
+    try:
+        got = ctx.groupby_agg(keys, n, vals, aggs)
+        t = ctx.timings()
+    finally:
+        ctx.set_option("groups_hint", 0)
+        ctx.set_option("no_small", 0)
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=[i for i, (c, op) in enumerate(aggs) if op != O.SUM])
+    assert t["retries"] >= 1, t
