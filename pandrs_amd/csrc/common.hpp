@@ -200,6 +200,7 @@ struct Options {
     int64_t no_clustered = 0;        // 1 = never the one-pass path for rows clustered by key (groupby.hip, run_clustered)
     int64_t clustered_chunk = 0;     // experiments / tests: rows per chunk there (0 = from the sample's runs per row)
     int64_t clustered_max_runs_pct = 0;   // experiments / tests: the path is taken up to this many runs per 100 rows (0 = default 13)
+    int64_t no_window_bound = 0;     // 1 = the estimate never looks at windows of consecutive rows (keys local in position)
     int64_t no_lean_rounds = 0;      // 1 = more than one round always means the older kernel (before: the only choice)
     int64_t no_table_order = 0;      // experiments: aggregate2 draws its tables in partition order instead of largest first
     int64_t p_target = 0;            // 0 = default fan-out target for the rounds heuristic
@@ -255,6 +256,7 @@ struct pandrs_hip_ctx {
     double est_repeat_share = 0.0;    // of the last estimate's sample: rows on keys sighted >= 3 times (a hot set shows here whatever the tail's length)
     bool est_kept = false;            // the table still holds the last estimate's keys (estimate_coverage / estimate_release pending)
     bool clustered_rows = false;      // last estimate: most adjacent rows share their key (sorted / grouped input)
+    bool clumped_rows = false;        // last estimate: keys are local in position without neighbours being equal (nearly sorted input): no sampled region plan
     bool capacity_exceeded = false;   // set when a run needed more radix partitions than allowed
     // resident columns (pandrs_hip_column_upload): device data pointer -> {allocation, bytes}; freed by _release / ctx_destroy
     struct Resident { void *base; size_t bytes; };

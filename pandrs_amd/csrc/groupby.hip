@@ -1379,7 +1379,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
     }
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est, /*keep_table=*/absorb_profile >= 0));
-    else { c->clustered_rows = false; c->est_near_same = 0.0; }          // no sample taken: nothing known about the row order
+    else { c->clustered_rows = false; c->clumped_rows = false; c->est_near_same = 0.0; }          // no sample taken: nothing known about the row order
     c->timings.estimated_groups = est;
     int64_t T_abs = 0;
     bool do_absorb = false;
@@ -1625,7 +1625,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const uint32_t P1 = (uint32_t)P + 1;
         // capacity mode (no histogram pass): aggregate2 only (it walks a partition's 8 row ranges), unclustered rows
         const bool sampled = rs.pre ? true
-                           : use_v2 && !sampled_failed && !c->clustered_rows && !c->opt.exact_partition && c->opt.shared_cursors &&
+                           : use_v2 && !sampled_failed && !c->clustered_rows && !c->clumped_rows && !c->opt.exact_partition && c->opt.shared_cursors &&
                              c->opt.scatter_threads != 512 && c->opt.scatter_staged && sampled_partition_ok(N, P);
         if (rs.pre && (!use_v2 || sampled_failed || attempt > 0))      // a full table or a dropped run: the producer must start over
             return fail(PANDRS_HIP_ERR_COMPUTATION, "pre-partitioned rows: a partition did not fit");

@@ -1027,6 +1027,49 @@ constexpr uint32_t EST_IMAGE_SLOTS = 1u << 15;            // the hot-key image (
 static uint64_t *est_image(pandrs_hip_ctx *c) { return reinterpret_cast<uint64_t *>(est_cov_hist(c) + 2 * COV_BINS + 64); }
 static uint32_t *est_sight(pandrs_hip_ctx *c) { return reinterpret_cast<uint32_t *>(est_image(c) + EST_IMAGE_SLOTS); }      // [EST_SLOTS] saturating sighting counters
 
+// ---- keys that are LOCAL in position (nearly sorted input: event times arriving slightly out of order) -------------------------
+// One sampled row per stride cannot see them repeat — a key's rows all lie inside one or two strides — so the sample reads "all
+// distinct" and the model extrapolates far beyond the truth (100 rows per key shuffled within +-50 rows: 8.2 M for 1 M groups; 10 rows
+// per key: 91 M for 10 M, the two-level path); the run bound does not help either, neighbours mostly differ.  What does: the distinct
+// keys inside WINDOWS of consecutive rows.  Every key lies in at least one window, so (windows in the column) x (mean distinct keys
+// per window) bounds the group count from above in ANY row order — loosely for random order (every window all distinct: the bound is N),
+// tightly when keys are local.  256 windows of 4096 rows: 8 MB read, one LDS hash set per workgroup.
+constexpr uint32_t WIN_ROWS = 4096, WIN_COUNT = 256, WIN_SLOTS = 8192;
+__global__ __launch_bounds__(1024) void window_distinct_kernel(KeyDesc key, int64_t n_rows, int64_t win_stride, uint32_t *out /* [0] distinct, [1] rows */) {
+    __shared__ uint64_t set[WIN_SLOTS];
+    __shared__ uint32_t cnt[3];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t s = tid; s < WIN_SLOTS; s += 1024) set[s] = EMPTY_KEY;
+    if (tid < 3) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * win_stride;
+    uint32_t fresh = 0, rows = 0;
+    bool saw_null = false, saw_sentinel = false;
+    for (uint32_t r = tid; r < WIN_ROWS; r += 1024) {
+        const int64_t i = base + r;
+        if (i >= n_rows) break;
+        rows++;
+        if (key_is_null(key, i)) { saw_null = true; continue; }
+        const uint64_t k = key_cell(key, i);
+        if (k == EMPTY_KEY) { saw_sentinel = true; continue; }
+        uint32_t slot = hash32(k, 0x3C6EF372u) & (WIN_SLOTS - 1);
+        for (;;) {                                   // (4096 keys at most in 8192 slots: the set never fills)
+            const uint64_t old = atomicCAS((unsigned long long *)&set[slot], EMPTY_KEY, k);
+            if (old == EMPTY_KEY) { fresh++; break; }
+            if (old == k) break;
+            slot = (slot + 1) & (WIN_SLOTS - 1);
+        }
+    }
+    if (saw_null) cnt[1] = 1;
+    if (saw_sentinel) cnt[2] = 1;
+    uint32_t w = fresh, rw = rows;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { w += __shfl_down(w, d, 64); rw += __shfl_down(rw, d, 64); }
+    if ((tid & 63) == 0 && rw) { atomicAdd(&cnt[0], w); atomicAdd(&out[1], rw); }
+    __syncthreads();
+    if (tid == 0) atomicAdd(&out[0], cnt[0] + cnt[1] + cnt[2]);
+}
+
 // The census's own table (kept armed like the first stage's: cleared BEHIND a census, not in front of the next one).
 // -> *out_est = 0 when the slice held too few keys to say anything.
 static int32_t census_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, double *out_est) {
@@ -1175,6 +1218,34 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         const double share = std::min(1.0, (b + 3.0 * std::sqrt(b + 1.0)) / pairs);
         run_bound = std::max(d, share * (double)(n_rows - 1) + 1.0);
         est = std::min(est, run_bound);
+    }
+    // keys local in position (see window_distinct_kernel): looked for when neighbours share their key far more often than chance allows
+    // although the sample is (nearly) all distinct — i.e. the estimate is an extrapolation — and the run bound did not already settle it
+    c->clumped_rows = false;
+    // (neighbours equal 20 x more often than `est` equally likely keys would make them: a dominant key does that too — its windows then
+    // simply look like the sample, see below — at the price of this one small kernel and its read-back)
+    if (n_sample < n_rows && n_rows >= (int64_t(1) << 22) && c->est_near_same * est > 20.0 && !(c->clustered_rows && c->est_near_same > 0.87) && !c->opt.no_window_bound) {
+        const int64_t win_stride = std::max<int64_t>(WIN_ROWS, (n_rows / WIN_COUNT) & ~int64_t(15));
+        const uint32_t n_win = (uint32_t)std::min<int64_t>(WIN_COUNT, (n_rows + win_stride - 1) / win_stride);
+        uint32_t *wout = distinct + 16;                   // (two spare words of the estimate's counter block)
+        HIP_TRY(hipMemsetAsync(wout, 0, 8, c->stream));
+        hipLaunchKernelGGL(window_distinct_kernel, dim3(n_win), dim3(1024), 0, c->stream, key, n_rows, win_stride, wout);
+        uint32_t *hw = reinterpret_cast<uint32_t *>(c->pinned) + 1232;
+        HIP_TRY(hipMemcpyAsync(hw, wout, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hw[1] > 0) {
+            const double per_row = (double)hw[0] / (double)hw[1];                   // distinct keys per row inside a window
+            // + 3 sigma of the windows' spread, taken as Poisson on the count, and the windows' edges (a key cut by a window's edge counts twice)
+            const double bound = (double)n_rows * std::min(1.0, (hw[0] + 3.0 * std::sqrt((double)hw[0] + 1.0)) / (double)hw[1]);
+            // what windows of a RANDOMLY ordered column would hold: at least the sub-sample's share of distinct keys (65536 rows taken at
+            // random repeat their keys more often than 4096 do, whatever the key distribution); far fewer = keys local in position
+            const double expect = s_sub > 0 ? d_sub / s_sub : 1.0;
+            c->clumped_rows = per_row < 0.5 * expect;
+            if (std::getenv("PANDRS_HIP_ENGINE_TRACE"))
+                fprintf(stderr, "[estimate] windows: %u distinct keys in %u rows of %u windows -> bound %.0f (estimate before %.0f); random order would show %.3f per row: clumped %d\n",
+                        hw[0], hw[1], n_win, bound, est, expect, (int)c->clumped_rows);
+            if (bound * 1.5 < est) est = std::max(bound, d);             // (a bound in any row order; taken when it says something)
+        }
     }
     c->timings_census = 0;
     if (census_wanted && !c->clustered_rows) {
