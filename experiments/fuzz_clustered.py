@@ -15,14 +15,14 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 first_case = int(os.environ.get("FUZZ_FIRST", "0"))
 ctx = pa.Context(0)
 ctx.set_option("no_small", 1)
-fails = taken = 0
+fails = taken = n_bursts = 0
 for case in range(first_case, n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     try:
         n = int(rng.integers(1_050_000, 6_000_000))
         g = int(rng.choice([3, 500, 20_000, 300_000, 2_000_000]))
         kd = int(rng.choice([O.I64, O.I64, O.F64, O.U32CODE]))
-        layout = str(rng.choice(["sorted", "runs", "runs", "blocks", "stray"]))
+        layout = str(rng.choice(["sorted", "runs", "runs", "blocks", "stray", "nearly", "nearly"]))
         run = int(rng.choice([8, 12, 30, 100, 2000]))
         if layout == "runs":
             ids = np.repeat(rng.integers(0, g, (n + run - 1) // run), run)[:n]
@@ -30,6 +30,9 @@ for case in range(first_case, n_cases):
             ids = np.sort(rng.integers(0, g, n))
             if layout == "blocks":                      # sorted inside blocks of ~n/7 rows: every key comes back in every block
                 for b in np.array_split(np.arange(n), 7): ids[b] = np.sort(rng.integers(0, g, len(b)))
+            elif layout == "nearly":                    # keys local in position: bucket of (i + noise)
+                jit = int(rng.choice([5, 50, 3000]))
+                ids = (np.clip(np.arange(n) + rng.integers(-jit, jit + 1, n), 0, n - 1) // max(run, 2)) % max(g, 2)
             elif layout == "stray":                     # 1 % of the rows carry a random key
                 stray = rng.random(n) < 0.01
                 ids[stray] = rng.integers(0, g, int(stray.sum()))
@@ -63,7 +66,8 @@ for case in range(first_case, n_cases):
         aggs = [(c, op) for c in range(nv) for op in (ops if prof != "sum" else ops[:1 + int(rng.random() < 0.5)])]
         if prof in ("sum", "all") and rng.random() < 0.5: aggs.append((0, O.COUNT))
         opts = {"clustered_chunk": int(rng.choice([0, 0, 0, 4096, 65536, 1 << 20])), "clustered_max_runs_pct": int(rng.choice([0, 0, 45])),
-                "no_clustered": int(rng.random() < 0.05), "fold_min_multi": 0}
+                "no_clustered": int(rng.random() < 0.05), "fold_min_multi": 0, "no_burst_kernel": int(rng.random() < 0.15),
+                "slice_rows": int(rng.choice([0, 0, 0, 30_000])), "p_max": int(rng.choice([0, 0, 0, 24]))}
         for k, v in opts.items(): ctx.set_option(k, v)
         try:
             got = ctx.groupby_agg(keys, n, vals, aggs)
@@ -75,10 +79,11 @@ for case in range(first_case, n_cases):
         assert_groupby_equal(got, want, kdts, int_exact_rows=exact, rtol=1e-9)
         took = t["n_partitions"] == -2
         taken += took
+        n_bursts += t["n_partitions"] > 0
         print("ok   %3d n=%d g=%d kd=%d %s run=%d nk=%d nv=%d kind=%d %s knull=%g vnull=%g opts=%s groups=%d clustered=%d" %
               (case, n, g, kd, layout, run, len(keys), nv, kind, prof, p_null, v_null, opts, got[0].shape[1], took), flush=True)
     except Exception:
         fails += 1
         print("FAIL %3d" % case, flush=True)
         traceback.print_exc()
-print("fuzz_clustered done: %d cases, %d took the clustered-rows pass, %d failures" % (n_cases - first_case, taken, fails))
+print("fuzz_clustered done: %d cases, %d took the clustered-rows pass, %d a radix partition, %d failures" % (n_cases - first_case, taken, n_bursts, fails))

@@ -12,6 +12,12 @@
 //     counter; one merge of the records — groups + chunk boundaries + keys that come back in a later run — is the result
 //     (groupby.hip, run_clustered).
 // Same uniform profiles, LDS layout and state encodings as the lean aggregate (aggregate2.hip), whose Swiss table this shares.
+//
+// PARTS: the same fold over the rows of radix PARTITIONS instead of chunks of the original columns — for keys that arrive in BURSTS
+// inside their partition (keys local in position: nearly sorted input; short runs).  There the lean aggregate's fast path never gets
+// going: a key is new when its burst arrives, its first 64 rows take the retry queue, and the rest of a 100-row burst is one more wave.
+// Drop-in for aggregate2_kernel behind the exact partition: same work list (tables / tasks / order), same outputs (final aggregates or
+// partial records at counters[0], partial records of an oversized partition's pieces at side_* / counters[2]).
 #include "aggregate.hpp"
 #include "swiss.hpp"
 #include <atomic>
@@ -22,7 +28,7 @@ namespace {
 
 constexpr int CL_R = 8;        // consecutive rows per thread: 32 bytes of every column (two 16-byte loads when the columns are 16-byte aligned)
 
-template <int NSRC, int PROFILE>
+template <int NSRC, int PROFILE, bool PARTS>
 __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
     constexpr bool HAS_V = (PROFILE & 1) != 0, OP_ADD = ((PROFILE >> 1) & 1) != 0;
     constexpr bool OP_MIN = ((PROFILE >> 2) & 1) != 0, OP_MAX = ((PROFILE >> 3) & 1) != 0;
@@ -56,12 +62,12 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
             if (atomicAdd(&a.counters[8], 1u) == gridDim.x - 1) {
                 __threadfence();
                 for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.host_out[3] = 0;
+                a.host_out[3] = 0; a.host_out[6] = 0;
                 __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     };
-    const uint32_t n_chunks = (a.s_rows + a.s_chunk - 1) / a.s_chunk;
+    const uint32_t n_chunks = PARTS ? a.n_tasks[1] : (a.s_rows + a.s_chunk - 1) / a.s_chunk;       // PARTS: the work list's tables
     uint32_t cb = blockIdx.x;
     if (cb >= n_chunks) { finish(); return; }
 
@@ -72,7 +78,9 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
         uint32_t slot = T;
         if (knull) { slot = T + 1; misc[23] = 1; }               // NULL key: its own group (grouping.rs:74)
         else if (k == EMPTY_KEY) misc[21] = 1;
-        else slot = swiss_find(k, keys, ctrl, T, seed, 8u);
+        // (chunks: a probe chain of 8 groups means the table is nearly full — the sample's runs per row were off, the host falls back;
+        // PARTS: the tables are planned at load 0.7 and there is no overflow run behind them: the whole table is the window)
+        else slot = swiss_find(k, keys, ctrl, T, seed, PARTS ? 0xFFFFFFFFu : 8u);
         if (slot > T + 1) { misc[20] = 1; return; }              // table full: the host takes the ordinary path
         atomicAdd(&gsz[slot], cnt);
 #pragma unroll
@@ -100,17 +108,25 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
         if (tid < 32) misc[tid] = 0;
         __syncthreads();
         const uint32_t cbn = misc[33];
-        const uint32_t r_beg = cb * a.s_chunk, r_end = min(r_beg + a.s_chunk, a.s_rows);
+        const AggTable tab = PARTS ? a.tables[a.order ? a.order[cb] : cb] : AggTable{0u, 1u, 0u, 0u};
+        const bool multi = PARTS && tab.multi != 0, part_null = PARTS && tab.part == a.P;
+      for (uint32_t ti = 0; ti < tab.n_tasks; ti++) {          // the row ranges that feed this table (chunks: one)
+        uint32_t r_beg, r_end;
+        if (PARTS) { const AggTask tk = a.tasks[tab.task_beg + ti]; r_beg = tk.beg; r_end = tk.end; }
+        else { r_beg = cb * a.s_chunk; r_end = min(r_beg + a.s_chunk, a.s_rows); }
 
         // tiles of AG_THREADS x CL_R rows; no barrier inside a chunk: the waves drift apart and hide each other's loads
-        for (uint32_t t0 = r_beg; t0 < r_end; t0 += AG_THREADS * CL_R) {
+        // (PARTS: a range starts anywhere — the tiles start at the 64-byte boundary below it and the rows in front are masked)
+        for (uint32_t t0 = PARTS ? (r_beg & ~(uint32_t)(CL_R - 1)) : r_beg; t0 < r_end; t0 += AG_THREADS * CL_R) {
             if (*reinterpret_cast<volatile uint32_t *>(&misc[20])) break;
             const uint32_t i0 = t0 + tid * CL_R;
             if (i0 >= r_end) continue;
             const uint32_t nrow = min((uint32_t)CL_R, r_end - i0);
+            const uint32_t lo = (PARTS && r_beg > i0) ? r_beg - i0 : 0u;         // the thread's rows [lo, nrow) belong to the range
+            if (lo >= nrow) continue;
             uint64_t k[CL_R], v[CL_R][NSRC];
             uint32_t okm[CL_R];              // bit c: value c is valid; bit 31: the key is NULL
-            if (a.s_vec && nrow == CL_R) {
+            if (PARTS || (a.s_vec && nrow == CL_R)) {
                 // (s_chunk is a multiple of 1024 and the host checked the columns' 16-byte alignment: i0 is a multiple of 4)
                 if (key8) {
                     const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint64_t *>(a.dkey.data) + i0);
@@ -147,12 +163,12 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < CL_R; r++) {
-                const uint32_t i = min(i0 + r, r_end - 1);
+                const uint32_t i = min(max(i0 + r, r_beg), r_end - 1);
                 okm[r] = 0x7FFFFFFFu;
-                if (key_nulls && key_is_null(a.dkey, i)) okm[r] |= 0x80000000u;
+                if (PARTS ? part_null : (key_nulls && key_is_null(a.dkey, i))) okm[r] |= 0x80000000u;
                 if (HAS_V) {
 #pragma unroll
-                    for (int c = 0; c < NSRC; c++) if (bit_at(valid[c], i)) okm[r] &= ~(1u << c);
+                    for (int c = 0; c < NSRC; c++) if (PARTS ? valid[c][i] == 0 : bit_at(valid[c], i)) okm[r] &= ~(1u << c);       // PARTS: validity bytes, 1 = valid
                 }
             }
             // ---- the thread's rows in order: equal neighbours fold in registers, a run that ends goes to the table
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
             for (int c = 0; c < NSRC; c++) { add[c] = 0; mn[c] = ~0ull; mx[c] = 0; nn[c] = 0; }
 #pragma unroll
             for (int r = 0; r <= CL_R; r++) {
-                const bool in = r < CL_R && (uint32_t)r < nrow;
+                const bool in = r < CL_R && (uint32_t)r < nrow && (uint32_t)r >= lo;
                 const bool rnull = in && (okm[r < CL_R ? r : 0] >> 31) != 0;
                 const uint64_t rk = k[r < CL_R ? r : 0];
                 const bool same = in && cnt > 0 && (rnull ? cnull : (!cnull && rk == ck));
@@ -199,34 +215,76 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
                 }
             }
         }
+      }
         __syncthreads();
         if (misc[20]) { if (tid == 0) a.counters[1] = 1; finish(); return; }
 
-        // ---- compaction: the chunk's groups as partial records at counters[2] (one block scan, every thread a run of slots)
+        // ---- compaction (one block scan, every thread a run of slots).  Chunks: the groups as partial records at counters[2].
+        // PARTS: as aggregate2_kernel — final aggregates or partial records at counters[0]; a piece of an oversized partition: records at counters[2]
         const bool sentinel = misc[21] != 0, nullseen = misc[23] != 0;
         const uint32_t spt = (T1 + AG_THREADS - 1) / AG_THREADS;
         const uint32_t s_beg = min(tid * spt, T1), s_end = min(s_beg + spt, T1);
         auto occupied = [&](uint32_t s) { return s < T ? keys[s] != EMPTY_KEY : (s == T ? sentinel : (s == T + 1 && nullseen)); };
+        const bool to_out = PARTS && !multi;
+        uint64_t *const o_keys = to_out ? a.out_keys : a.side_keys;
+        uint8_t *const o_null = to_out ? a.out_null : a.side_null;
+        uint64_t *const o_states = to_out ? a.out_states : a.side_states;
+        const size_t o_cap = to_out ? a.cap : a.side_cap;
+        const bool emit_partials = !PARTS || a.partials != 0 || multi;
         uint32_t mine = 0;
         for (uint32_t s = s_beg; s < s_end; s++) mine += occupied(s) ? 1u : 0u;
         uint32_t total;
         const uint32_t ex = block_exclusive_scan<AG_THREADS>(mine, misc, &total);
-        if (tid == 0) misc[22] = atomicAdd(&a.counters[2], total);
+        if (tid == 0) misc[22] = atomicAdd(&a.counters[to_out ? 0 : 2], total);
         __syncthreads();
-        // (the record buffer is sized for the runs the sample promised, not for every chunk's full table)
-        if ((size_t)misc[22] + total > a.side_cap) { if (tid == 0) a.counters[1] = 1; finish(); return; }
+        // (chunks: the record buffer is sized for the runs the sample promised, not for every chunk's full table)
+        if ((size_t)misc[22] + total > o_cap) { if (tid == 0) a.counters[1] = 1; finish(); return; }
         size_t pos = (size_t)misc[22] + ex;
         for (uint32_t s = s_beg; s < s_end; s++) {
             if (!occupied(s)) continue;
-            a.side_keys[pos] = s < T ? keys[s] : (s == T ? EMPTY_KEY : 0ull);
-            a.side_null[pos] = s == T + 1 ? 1 : 0;
-            a.side_states[pos] = gsz[s];
-            for (int k = 0; k < a.n_states; k++) {
-                const uint32_t l = (uint32_t)a.st_lds[k];
-                uint64_t cell = st[(size_t)l * T1 + s];
-                const int8_t kd = a.kinds[k];
-                if (kd == SK_MAX_F64 || kd == SK_MAX_I64) cell = ~cell;
-                a.side_states[(size_t)(k + 1) * a.side_cap + pos] = state_natural(kd, cell);
+            o_keys[pos] = s < T ? keys[s] : (s == T ? EMPTY_KEY : 0ull);
+            o_null[pos] = s == T + 1 ? 1 : 0;
+            const uint64_t g = gsz[s];
+            if (emit_partials) {
+                o_states[pos] = g;
+                for (int k = 0; k < a.n_states; k++) {
+                    const uint32_t l = (uint32_t)a.st_lds[k];
+                    uint64_t cell = st[(size_t)l * T1 + s];
+                    const int8_t kd = a.kinds[k];
+                    if (kd == SK_MAX_F64 || kd == SK_MAX_I64) cell = ~cell;
+                    o_states[(size_t)(k + 1) * o_cap + pos] = state_natural(kd, cell);
+                }
+            } else {
+                // the reference's finalisation (aggregation.rs:507-556, :625-674, :743), as in aggregate2_kernel
+                for (int f = 0; f < a.n_fin; f++) {
+                    const FinDev &fd = a.fin[f];
+                    auto cell = [&](int8_t l) { return st[(size_t)l * T1 + s]; };
+                    double r = 0.0;
+                    switch (fd.op) {
+                    case PANDRS_HIP_AGG_COUNT: r = (double)g; break;
+                    case PANDRS_HIP_AGG_SUM:
+                        r = KIND == 0 ? __longlong_as_double((long long)cell(fd.st_add)) : (double)(int64_t)cell(fd.st_add);
+                        break;
+                    case PANDRS_HIP_AGG_MEAN: {
+                        const uint64_t nn = fd.st_nn >= 0 ? cell(fd.st_nn) : g;
+                        const double sum = KIND == 0 ? __longlong_as_double((long long)cell(fd.st_add)) : (double)(int64_t)cell(fd.st_add);
+                        r = nn ? sum / (double)nn : 0.0;
+                        break;
+                    }
+                    case PANDRS_HIP_AGG_MIN:
+                    case PANDRS_HIP_AGG_MAX: {
+                        // untouched identity => the reference's sentinel rule: 0.0 (aggregation.rs:640-674)
+                        const bool mx = fd.op == PANDRS_HIP_AGG_MAX;
+                        const uint64_t raw = cell(mx ? fd.st_max : fd.st_min);
+                        if (raw != M_IDENT) {
+                            const uint64_t ce = mx ? ~raw : raw;
+                            r = KIND == 0 ? dec_f64(ce) : (double)dec_i64(ce);
+                        }
+                        break;
+                    }
+                    }
+                    a.out_aggs[(size_t)f * a.cap + pos] = r;
+                }
             }
             pos++;
         }
@@ -237,21 +295,21 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
     finish();
 }
 
-template <int NSRC, int PROFILE>
+template <int NSRC, int PROFILE, bool PARTS>
 void launch_one(pandrs_hip_ctx *c, const AggArgs &a, size_t lds, uint32_t grid) {
     static std::atomic<uint64_t> attr_done{0};             // per device: the attribute call costs a driver round trip
     const uint64_t bit = 1ull << (c->device & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(clustered_kernel<NSRC, PROFILE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->lds_bytes));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(clustered_kernel<NSRC, PROFILE, PARTS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->lds_bytes));
         attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((clustered_kernel<NSRC, PROFILE>), dim3(grid), dim3(AG_THREADS), lds, c->stream, a);
+    hipLaunchKernelGGL((clustered_kernel<NSRC, PROFILE, PARTS>), dim3(grid), dim3(AG_THREADS), lds, c->stream, a);
 }
 
-template <int NSRC>
+template <int NSRC, bool PARTS>
 bool launch_profile(pandrs_hip_ctx *c, const AggArgs &a, int profile, size_t lds, uint32_t grid) {
     switch (profile) {      // {f64, i64} x {sum, sum+min+max} (+ null masks for f64), f64 min+max, min alone, max alone
-#define PROF(K, OPS, V) case ((K) << 4 | (OPS) << 1 | (V)): launch_one<NSRC, ((K) << 4 | (OPS) << 1 | (V))>(c, a, lds, grid); return true;
+#define PROF(K, OPS, V) case ((K) << 4 | (OPS) << 1 | (V)): launch_one<NSRC, ((K) << 4 | (OPS) << 1 | (V)), PARTS>(c, a, lds, grid); return true;
         PROF(0, 1, 0) PROF(0, 1, 1) PROF(0, 7, 0) PROF(0, 7, 1) PROF(0, 6, 0) PROF(0, 2, 0) PROF(0, 4, 0) PROF(1, 1, 0) PROF(1, 7, 0)
 #undef PROF
     default: return false;
@@ -267,10 +325,23 @@ bool clustered_has(int n_src, int profile) {
 
 bool launch_clustered(pandrs_hip_ctx *c, const AggArgs &a, int n_src, int profile, size_t lds, uint32_t grid) {
     switch (n_src) {
-    case 1: return launch_profile<1>(c, a, profile, lds, grid);
-    case 2: return launch_profile<2>(c, a, profile, lds, grid);
-    case 3: return launch_profile<3>(c, a, profile, lds, grid);
-    case 4: return launch_profile<4>(c, a, profile, lds, grid);
+    case 1: return launch_profile<1, false>(c, a, profile, lds, grid);
+    case 2: return launch_profile<2, false>(c, a, profile, lds, grid);
+    case 3: return launch_profile<3, false>(c, a, profile, lds, grid);
+    case 4: return launch_profile<4, false>(c, a, profile, lds, grid);
+    default: return false;
+    }
+}
+
+// the same fold over the rows of radix partitions (the lean aggregate's work list and outputs): keys that arrive in bursts
+bool launch_clustered_parts(pandrs_hip_ctx *c, const AggArgs &a_in, int n_src, int profile, size_t lds, uint32_t grid) {
+    AggArgs a = a_in;
+    a.dkey = KeyDesc{a.pkeys, nullptr, nullptr, DT_CELL};
+    switch (n_src) {
+    case 1: return launch_profile<1, true>(c, a, profile, lds, grid);
+    case 2: return launch_profile<2, true>(c, a, profile, lds, grid);
+    case 3: return launch_profile<3, true>(c, a, profile, lds, grid);
+    case 4: return launch_profile<4, true>(c, a, profile, lds, grid);
     default: return false;
     }
 }

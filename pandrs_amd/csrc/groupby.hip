@@ -1833,7 +1833,13 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 }
                 if (!polled) return fail(PANDRS_HIP_ERR_COMPUTATION, "lean aggregate: no instantiation for a round of this profile");
             } else {
-            polled = use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
+            // keys that arrive in bursts inside their partition (rows clustered in short runs, keys local in position — both behind the exact
+            // partition): every thread folds 8 consecutive rows of the partition in registers (clustered.hip, PARTS) instead of the lean
+            // kernel's row per lane, whose fast path never gets going when a key is new as its burst arrives
+            const bool bursts = use_v2 && !sampled && !rs.pre && (c->clumped_rows || c->clustered_rows) && clustered_has(n_src, uni_profile) &&
+                                !c->opt.no_burst_kernel;
+            polled = bursts ? launch_clustered_parts(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))
+                            : (use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid)));
             if (!polled) launch_aggregate(c, aa, max_spr, profile, lds);
             }
             HIP_TRY(hipGetLastError());
