@@ -49,7 +49,11 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
     const uint8_t *valid[NSRC];
     int nn_idx[NSRC];
 #pragma unroll
-    for (int c = 0; c < NSRC; c++) { vals[c] = a.src[c].vals; valid[c] = a.src[c].valid; nn_idx[c] = HAS_V ? a.src[c].st_nn : -1; }
+    for (int c = 0; c < NSRC; c++) {
+        const SrcDev &sd = a.src[(PARTS ? a.src_base : 0) + c];       // (PARTS in rounds: this launch's columns)
+        vals[c] = sd.vals; valid[c] = sd.valid; nn_idx[c] = HAS_V ? sd.st_nn : -1;
+    }
+    const bool rounds = PARTS && a.snap_keys != nullptr, resume = rounds && a.cur_round > 0;      // as in aggregate2_kernel (aggregate.hpp, snap_*)
     const uint32_t seed = a.seed;
     const bool key8 = a.dkey.dtype == PANDRS_HIP_I64 || a.dkey.dtype == DT_CELL || a.dkey.dtype == PANDRS_HIP_F64;
     const bool key_nulls = a.dkey.null_bits != nullptr || a.dkey.null_bytes != nullptr;
@@ -57,19 +61,22 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
     // every workgroup ends here: the last one publishes the call's counters to the host
     auto finish = [&]() {
         __syncthreads();
-        if (tid == 0 && a.host_out) {
+        if (tid == 0 && (a.host_out || rounds)) {
             __threadfence();
             if (atomicAdd(&a.counters[8], 1u) == gridDim.x - 1) {
                 __threadfence();
-                for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.host_out[3] = 0; a.host_out[6] = 0;
-                __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.host_out) {
+                    for (int i = 0; i < 3; i++) a.host_out[i] = __hip_atomic_load(&a.counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.host_out[3] = 0; a.host_out[6] = 0;
+                    __hip_atomic_store(&a.host_out[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else { a.counters[8] = 0; a.counters[10] = 0; __threadfence(); }       // rounds: every launch but the last re-arms the launch counters
             }
         }
     };
     const uint32_t n_chunks = PARTS ? a.n_tasks[1] : (a.s_rows + a.s_chunk - 1) / a.s_chunk;       // PARTS: the work list's tables
     uint32_t cb = blockIdx.x;
     if (cb >= n_chunks) { finish(); return; }
+    if (resume && __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { finish(); return; }      // launch 0 lost the attempt
 
     // one finished run of a thread -> its group's states: find or claim the key's slot, one LDS atomic per state
     // (the fold of aggregation.rs:625-674 with the run's totals in place of one row)
@@ -98,8 +105,16 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
 
     for (;;) {                                         // one LDS table per chunk
         if (tid == 0) misc[33] = gridDim.x + atomicAdd(&a.counters[10], 1u);       // the next chunk: whoever comes first
-        for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
-        for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;
+        const size_t snap = rounds ? (size_t)(a.order ? a.order[cb] : cb) : 0;
+        if (resume) {           // a later round: launch 0's key table — every key of this table has its slot already
+            const uint64_t *sk = a.snap_keys + snap * (T + 2);
+            const uint32_t *sc = reinterpret_cast<const uint32_t *>(a.snap_ctrl + snap * T);
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = s < T + 2 ? sk[s] : EMPTY_KEY; gsz[s] = 0; }
+            for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = sc[s];
+        } else {
+            for (uint32_t s = tid; s < T1; s += AG_THREADS) { keys[s] = EMPTY_KEY; gsz[s] = 0; }
+            for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) reinterpret_cast<uint32_t *>(ctrl)[s] = 0;
+        }
         for (int k = 0; k < a.round_states; k++) {
             const uint64_t idv = ((uint32_t)k >= m_base && (uint32_t)k < m_base + (uint32_t)(NSRC * MM)) ? M_IDENT : 0ull;
             uint64_t *dst = st + (size_t)k * T1;
@@ -231,19 +246,35 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
         uint64_t *const o_states = to_out ? a.out_states : a.side_states;
         const size_t o_cap = to_out ? a.cap : a.side_cap;
         const bool emit_partials = !PARTS || a.partials != 0 || multi;
-        uint32_t mine = 0;
-        for (uint32_t s = s_beg; s < s_end; s++) mine += occupied(s) ? 1u : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<AG_THREADS>(mine, misc, &total);
-        if (tid == 0) misc[22] = atomicAdd(&a.counters[to_out ? 0 : 2], total);
-        __syncthreads();
-        // (chunks: the record buffer is sized for the runs the sample promised, not for every chunk's full table)
-        if ((size_t)misc[22] + total > o_cap) { if (tid == 0) a.counters[1] = 1; finish(); return; }
-        size_t pos = (size_t)misc[22] + ex;
+        size_t pos = 0;
+        if (!resume) {
+            uint32_t mine = 0;
+            for (uint32_t s = s_beg; s < s_end; s++) mine += occupied(s) ? 1u : 0u;
+            uint32_t total;
+            const uint32_t ex = block_exclusive_scan<AG_THREADS>(mine, misc, &total);
+            if (tid == 0) misc[22] = atomicAdd(&a.counters[to_out ? 0 : 2], total);
+            __syncthreads();
+            // (chunks: the record buffer is sized for the runs the sample promised, not for every chunk's full table)
+            if ((size_t)misc[22] + total > o_cap) { if (tid == 0) a.counters[1] = 1; finish(); return; }
+            pos = (size_t)misc[22] + ex;
+        }
+        if (rounds && !resume) {            // launch 0 of several: the key table for the launches to come (the positions follow below)
+            uint64_t *sk = a.snap_keys + snap * (T + 2);
+            uint32_t *sc = reinterpret_cast<uint32_t *>(a.snap_ctrl + snap * T);
+            for (uint32_t s = tid; s < T + 2; s += AG_THREADS) sk[s] = keys[s];
+            for (uint32_t s = tid; s < (T >> 2); s += AG_THREADS) sc[s] = reinterpret_cast<const uint32_t *>(ctrl)[s];
+        }
         for (uint32_t s = s_beg; s < s_end; s++) {
-            if (!occupied(s)) continue;
-            o_keys[pos] = s < T ? keys[s] : (s == T ? EMPTY_KEY : 0ull);
-            o_null[pos] = s == T + 1 ? 1 : 0;
+            if (rounds && s < T + 2) {
+                uint32_t *sp = a.snap_pos + snap * (T + 2) + s;
+                if (resume) { const uint32_t p = *sp; if (p == 0xFFFFFFFFu) continue; pos = p; }
+                else *sp = occupied(s) ? (uint32_t)pos : 0xFFFFFFFFu;
+            }
+            if (resume ? s >= T + 2 : !occupied(s)) continue;
+            if (!resume) {
+                o_keys[pos] = s < T ? keys[s] : (s == T ? EMPTY_KEY : 0ull);
+                o_null[pos] = s == T + 1 ? 1 : 0;
+            }
             const uint64_t g = gsz[s];
             if (emit_partials) {
                 o_states[pos] = g;
@@ -258,6 +289,7 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
                 // the reference's finalisation (aggregation.rs:507-556, :625-674, :743), as in aggregate2_kernel
                 for (int f = 0; f < a.n_fin; f++) {
                     const FinDev &fd = a.fin[f];
+                    if (rounds && fd.round != a.cur_round) continue;        // this output's states live in another launch's tables
                     auto cell = [&](int8_t l) { return st[(size_t)l * T1 + s]; };
                     double r = 0.0;
                     switch (fd.op) {

@@ -1542,7 +1542,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // 1 M groups, 50 M rows: 9.2 ms (the older kernel, one round of 24 states in 764-slot tables) -> see experiments/cliff_hunt.py.
     // Not for partial states (a record of more than 16 states cannot be merged anyway), merges and pre-partitioned rows.
     const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds;
-    const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs) && !c->opt.agg_v1 &&
+    // (long runs too when there are more than 4 columns: the one-pass path takes at most 4, and the burst kernel in rounds behind the exact
+    // partition — sorted rows, 8 columns x 4 aggregates, 50 M rows: 3.3 ms — beats the older kernel's 24 states in one table: 9.6)
+    const bool wide_clustered = c->clustered_rows && n_src > 4 && clustered_has(4, uni_profile) && !c->opt.no_burst_kernel;
+    const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs || wide_clustered) && !c->opt.agg_v1 &&
                        aggregate2_has(std::min(n_src, 4), uni_profile) && (n_src <= 4 || lean_rounds_ok);
     if (v2_ok && n_src > 4) spr = 4;
     bool use_v2 = false;
@@ -1822,6 +1825,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 if (!aa.ov_keys) return fail(PANDRS_HIP_ERR_OUT_OF_MEMORY, "overflow arena too small");
                 aa.ov_cap = ov_cap;
             } else { aa.ov_keys = nullptr; aa.ov_cap = 0; }
+            // keys that arrive in bursts inside their partition (rows clustered in short runs, keys local in position — both behind the exact
+            // partition): every thread folds 8 consecutive rows of the partition in registers (clustered.hip, PARTS) instead of the lean
+            // kernel's row per lane, whose fast path never gets going when a key is new as its burst arrives
+            const bool bursts = use_v2 && !sampled && !rs.pre && (c->clumped_rows || c->clustered_rows) && clustered_has(std::min(n_src, 4), uni_profile) &&
+                                !c->opt.no_burst_kernel;
             if (use_v2 && n_rounds > 1) {
                 // one launch per round over the same tables; only the last one publishes (host_out), the others re-arm the launch counters
                 uint32_t *const publish = aa.host_out;
@@ -1829,15 +1837,11 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 for (int r = 0; r < n_rounds && polled; r++) {
                     aa.cur_round = r; aa.src_base = round_begin[r];
                     aa.host_out = r + 1 == n_rounds ? publish : nullptr;
-                    polled = launch_aggregate2(c, aa, round_begin[r + 1] - round_begin[r], profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
+                    polled = bursts ? launch_clustered_parts(c, aa, round_begin[r + 1] - round_begin[r], profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))
+                                    : launch_aggregate2(c, aa, round_begin[r + 1] - round_begin[r], profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
                 }
                 if (!polled) return fail(PANDRS_HIP_ERR_COMPUTATION, "lean aggregate: no instantiation for a round of this profile");
             } else {
-            // keys that arrive in bursts inside their partition (rows clustered in short runs, keys local in position — both behind the exact
-            // partition): every thread folds 8 consecutive rows of the partition in registers (clustered.hip, PARTS) instead of the lean
-            // kernel's row per lane, whose fast path never gets going when a key is new as its burst arrives
-            const bool bursts = use_v2 && !sampled && !rs.pre && (c->clumped_rows || c->clustered_rows) && clustered_has(n_src, uni_profile) &&
-                                !c->opt.no_burst_kernel;
             polled = bursts ? launch_clustered_parts(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))
                             : (use_v2 && launch_aggregate2(c, aa, n_src, profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid)));
             if (!polled) launch_aggregate(c, aa, max_spr, profile, lds);
