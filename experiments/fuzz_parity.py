@@ -76,9 +76,11 @@ for case in range(first_case, n_cases):
                 nv = int(rng.integers(5, 13))
                 wkind = O.F64 if rng.random() < 0.7 else O.I64
                 wmask = float(rng.choice([0, 0, 0.1])) if wkind == O.F64 else 0.0
-                vals = [((rng.normal(50, 20, n) if wkind == O.F64 else rng.integers(-10**6, 10**6, n).astype(np.int64)), mask(rng, n, wmask) if wmask else None, wkind) for _ in range(nv)]
+                mixed_kinds = rng.random() < 0.3          # f64 and i64 columns side by side: no uniform profile, the older kernel in rounds of 4
+                kinds = [(O.I64 if (mixed_kinds and rng.random() < 0.5) else wkind) for _ in range(nv)]
+                vals = [((rng.normal(50, 20, n) if kd_ == O.F64 else rng.integers(-10**6, 10**6, n).astype(np.int64)), mask(rng, n, wmask) if (wmask and kd_ == O.F64) else None, kd_) for kd_ in kinds]
                 wops = [[O.SUM], [O.SUM, O.MEAN], [O.SUM, O.MIN, O.MAX], [O.MIN, O.MAX], [O.MAX]][int(rng.integers(0, 5))]
-                if wkind == O.I64 and wops in ([O.MIN, O.MAX], [O.MAX]): wops = [O.SUM, O.MIN, O.MAX]
+                if (wkind == O.I64 or mixed_kinds) and wops in ([O.MIN, O.MAX], [O.MAX]): wops = [O.SUM, O.MIN, O.MAX]
                 wops = wops if nv * (len([o for o in wops if o != O.MEAN]) + (1 if wmask else 0)) <= 38 else [O.SUM]
                 aggs = [(c, op) for c in range(nv) for op in wops] + ([(0, O.COUNT)] if rng.random() < 0.5 else [])
             opts = {"no_direct": int(rng.random() < 0.3), "slice_rows": int(rng.choice([0, 0, 20_000])),

@@ -1548,6 +1548,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs || wide_clustered) && !c->opt.agg_v1 &&
                        aggregate2_has(std::min(n_src, 4), uni_profile) && (n_src <= 4 || lean_rounds_ok);
     if (v2_ok && n_src > 4) spr = 4;
+    // the older kernel with more than 4 sources in a round is its catch-all instantiation (register arrays for 16 sources: it spills):
+    // 4 f64 + 4 i64 columns x sum, 50 M rows, 8.3 ms in one round, 3.8 in two (experiments/mixed_wide.py).  Merges have their own loop.
+    if (!v2_ok && !merge && n_src > 4 && !pl.needs_second_pass) spr = 4;
     bool use_v2 = false;
     // rounds only when one round would need more partitions than this.  The older kernel's rounds are dear (3072); the lean kernel's cost
     // one more pass over the key column per round, which a fan-out beyond ~4 K costs the scatter too (experiments/p_target_sweep.py,

@@ -1912,3 +1912,25 @@ def test_a_full_table_in_the_first_round_fails_the_attempt_for_all_rounds(ctx):
         ctx.set_option("no_small", 0)
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=[i for i, (c, op) in enumerate(aggs) if op != O.SUM])
     assert t["retries"] >= 1, t
+
+
+def test_wide_aggregations_of_mixed_kinds_take_rounds_of_four(ctx):
+    """f64 and i64 columns side by side, sums on some and min / max on others: no uniform profile, so the older kernel answers — in rounds of
+    at most 4 columns since the round-4 cliff hunt (its catch-all instantiation for more sources keeps register arrays for 16 and spills:
+    4 f64 + 4 i64 columns x sum, 50 M rows: 8.3 ms in one round, 3.8 in two).  9 columns, the oracle's answers."""
+    rng = np.random.default_rng(4242)
+    n, g = 3_200_000, 200_000
+    keys = [(sparse_keys(rng, n, g), O.pack_mask(rng.random(n) < 0.01), O.I64)]
+    vals, aggs = [], []
+    for c in range(9):
+        if c % 2 == 0:
+            vals.append((rng.normal(c, 3, n), O.pack_mask(rng.random(n) < 0.1) if c % 4 == 0 else None, O.F64))
+            aggs += [(c, O.SUM), (c, O.MEAN)] if c % 3 else [(c, O.MIN), (c, O.MAX)]
+        else:
+            vals.append((rng.integers(-10**7, 10**7, n).astype(np.int64), None, O.I64))
+            aggs += [(c, O.SUM), (c, O.MAX)]
+    aggs.append((0, O.COUNT))
+    want = O.groupby_agg(keys, n, vals, aggs)
+    got = ctx.groupby_agg(keys, n, vals, aggs)
+    exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT) or (vals[c][2] == O.I64 and op == O.SUM)]
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
