@@ -44,7 +44,7 @@ struct AggArgs {
     const uint32_t *order;       // aggregate2, optional: the tables in the order they are handed out (largest first); nullptr = as listed
     uint64_t *side_keys; uint8_t *side_null; uint64_t *side_states; size_t side_cap;
     int8_t round_src_begin[MAX_ROUNDS + 1];   // sources of round r = [begin[r], begin[r+1])
-    SrcDev src[MAX_SRC];         // st_* = LDS state index inside the source's round
+    SrcDev src[MAX_STATES];      // st_* = LDS state index inside the source's round (raw rows: <= MAX_SRC columns; merges: one per state)
     int8_t kinds[MAX_STATES];    // by absolute state index (ABI / partial order)
     int8_t st_round[MAX_STATES], st_lds[MAX_STATES];
     FinDev fin[MAX_AGGS];

@@ -253,6 +253,8 @@ struct pandrs_hip_ctx {
     uint64_t *census_table = nullptr; // the estimate's second stage (hash-slice census): its own armed table + counters
     int timings_census = 0;           // the last estimate took its figure from the census
     int64_t reserve_groups = 0;       // result rows the next res_slot-0 engine run keeps free behind its groups (a caller appends there)
+    double est_far_same = 0.0;        // ... and of rows 32 sample strides apart (a dominant key: equal keys in any row order)
+    int64_t est_far_equal = 0;        // the count behind it
     double est_near_same = 0.0;       // of the last estimate's sample: share of adjacent row pairs with equal keys (a dominant key or clustered rows)
     double est_repeat_share = 0.0;    // of the last estimate's sample: rows on keys sighted >= 3 times (a hot set shows here whatever the tail's length)
     bool est_kept = false;            // the table still holds the last estimate's keys (estimate_coverage / estimate_release pending)

@@ -5,7 +5,8 @@
 
 namespace pandrs {
 
-constexpr int MAX_SRC = 16;
+constexpr int MAX_SRC = 16;        // aggregated columns of a call (and sources per round of the older kernel's catch-all instantiation)
+constexpr int MAX_MERGE_SRC = 39;  // states a merge of partial records takes (every state is a source of its own; + the group size <= MAX_MOVE)
 constexpr int MAX_STATES = 40;
 constexpr int MAX_AGGS = 64;
 constexpr int MAX_MOVE = 40;

@@ -1346,7 +1346,10 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         return fail(PANDRS_HIP_ERR_OPERATION_FAILED,
                     "Std/Var/Median/First/Last partial states are not mergeable across shards yet");
     const int n_src = (int)srcs.size();
-    if (n_src > MAX_SRC) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
+    // (merges of more than 16 states: the record loop of aggregate_kernel<.., MERGE> walks the states at run time; the catch-all instantiation a
+    // Std / Var merge needs keeps register arrays for 16 sources)
+    if (n_src > (merge ? MAX_MERGE_SRC : MAX_SRC) || (merge && n_src > MAX_SRC && pl.needs_second_pass))
+        return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many states to merge (%d)", n_src);
 
     // ---- small calls (launch-bound: the reference's 1 M-row case): two launches, no estimate, no partition
     if (!merge && !partials && res_slot == 0 && !c->quiet && c->opt.groups_hint <= 0 && !rs.pre) {
@@ -1379,7 +1382,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         }
     }
     if (est <= 0) ST_TRY(estimate_groups(c, rs.key, N, &est, /*keep_table=*/absorb_profile >= 0));
-    else { c->clustered_rows = false; c->clumped_rows = false; c->est_near_same = 0.0; }          // no sample taken: nothing known about the row order
+    else { c->clustered_rows = false; c->clumped_rows = false; c->est_near_same = 0.0; c->est_far_same = 0.0; c->est_far_equal = 0; }          // no sample taken: nothing known about the row order
     c->timings.estimated_groups = est;
     int64_t T_abs = 0;
     bool do_absorb = false;
@@ -1428,9 +1431,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // (below a few million rows the whole call is launch-bound and the two-stage direct path loses)
     bool has_valid_bytes = false;
     for (auto &e : srcs) has_valid_bytes |= e.valid_bytes != nullptr;
-    // (pl.n_states <= MAX_SRC: the records' merge takes every state as a source of its own — 8 columns x sum / min / max = 24 states used to
-    // FAIL the call here, "too many states to merge"; such calls stay on the radix path, whose rounds need no merge)
-    if (!merge && !rs.pre && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && pl.n_states <= MAX_SRC &&
+    // (pl.n_states <= MAX_MERGE_SRC: the records' merge takes every state as a source of its own — 8 columns x sum / min / max = 24 states
+    // used to FAIL the call here, "too many states to merge", when a merge took 16)
+    if (!merge && !rs.pre && pl.mergeable && !c->opt.no_direct && !has_valid_bytes && n_src <= MAX_SRC && pl.n_states <= MAX_MERGE_SRC &&
         (N >= (int64_t(1) << 22) || c->opt.no_direct < 0)) {
         int total_states = 0;
         for (auto &e : srcs) total_states += e.n_states();
@@ -1541,7 +1544,14 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // output positions behind and the later launches start from them (aggregate.hpp, snap_*).  8 columns x sum / mean / min / max over
     // 1 M groups, 50 M rows: 9.2 ms (the older kernel, one round of 24 states in 764-slot tables) -> see experiments/cliff_hunt.py.
     // Not for partial states (a record of more than 16 states cannot be merged anyway), merges and pre-partitioned rows.
-    const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds;
+    // A DOMINANT key (rows far apart share their key far more often than `est` equally likely keys would: a key with >= ~1 % of the rows)
+    // needs its partition cut into row slices, and rounds switch the slicing off (a piece's records would hold one round's states): half the
+    // rows on one key, 4 f64 + 4 i64 columns x sum, 50 M rows — 248 ms in rounds (one workgroup walks 25 M rows), 8.2 in one round of the older
+    // kernel with slices.  So no rounds then (a merge takes up to 39 states since the same day: 8 columns x sum / min / max, 222 -> see
+    // experiments/wide_hot.py).
+    const bool dominant_key = c->est_far_equal >= 8 && c->est_far_same * (double)est > 20.0;
+    const bool rounds_ok = !(dominant_key && pl.n_states <= MAX_MERGE_SRC) || c->opt.src_per_round > 0;
+    const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds && rounds_ok;
     // (long runs too when there are more than 4 columns: the one-pass path takes at most 4, and the burst kernel in rounds behind the exact
     // partition — sorted rows, 8 columns x 4 aggregates, 50 M rows: 3.3 ms — beats the older kernel's 24 states in one table: 9.6)
     const bool wide_clustered = c->clustered_rows && n_src > 4 && clustered_has(4, uni_profile) && !c->opt.no_burst_kernel;
@@ -1550,7 +1560,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     if (v2_ok && n_src > 4) spr = 4;
     // the older kernel with more than 4 sources in a round is its catch-all instantiation (register arrays for 16 sources: it spills):
     // 4 f64 + 4 i64 columns x sum, 50 M rows, 8.3 ms in one round, 3.8 in two (experiments/mixed_wide.py).  Merges have their own loop.
-    if (!v2_ok && !merge && n_src > 4 && !pl.needs_second_pass) spr = 4;
+    if (!v2_ok && !merge && n_src > 4 && !pl.needs_second_pass && rounds_ok) spr = 4;
     bool use_v2 = false;
     // rounds only when one round would need more partitions than this.  The older kernel's rounds are dear (3072); the lean kernel's cost
     // one more pass over the key column per round, which a fan-out beyond ~4 K costs the scatter too (experiments/p_target_sweep.py,
@@ -1592,7 +1602,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // an LDS table with more distinct groups sees fewer same-address atomics (hot keys) - as long as
         // the slices' partial records (slices per partition x groups) stay cheap to merge.
         if (!merge && !c->opt.no_slice && c->opt.slice_rows <= 0 && pl.mergeable && n_rounds == 1 &&
-            N >= (int64_t(1) << 24) && P < p_par && pl.n_states >= 4 && pl.n_states <= MAX_SRC) {   // (1-2 states: measured 5 % slower; > 16: the slices' records could not be merged)
+            N >= (int64_t(1) << 24) && P < p_par && pl.n_states >= 4 && pl.n_states <= MAX_MERGE_SRC) {   // (1-2 states: measured 5 % slower; > 16: the slices' records could not be merged)
             int64_t p_rec = 16;
             while (p_rec * 262144 < p_par * est) p_rec *= 2;
             if (std::max(P, p_rec) <= 64) { P = std::max(P, p_rec); auto_slice_rows = N / p_par; p_par = 1; }
@@ -1716,7 +1726,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
         int n_var_src = 0;
         for (int s2 = 0; s2 < pl.n_src; s2++) n_var_src += pl.st_ssq[s2] >= 0;
-        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1 && pl.n_states <= MAX_SRC;
+        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1 && pl.n_states <= MAX_MERGE_SRC;
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
                                                        : std::max<int64_t>(int64_t(1) << 18, (c->opt.wide_slices ? 4 : (c->opt.slice_over > 0 ? c->opt.slice_over : 2)) * (N / std::max<int64_t>(P, 1)));

@@ -1205,6 +1205,7 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
     }
     double run_bound = (double)n_rows;
     c->clustered_rows = false;
+    c->est_far_same = 0.0; c->est_far_equal = 0;
     c->est_near_same = hv[2] >= 1024 ? 1.0 - (double)hv[1] / (double)hv[2] : 0.0;
     if (hv[2] >= 1024) {
         // most neighbours share their key — and far more often than rows far apart do (a dominant key alone puts equal keys next to
@@ -1212,6 +1213,7 @@ int32_t estimate_groups(pandrs_hip_ctx *c, const KeyDesc &key, int64_t n_rows, i
         const double near_same = 1.0 - (double)hv[1] / (double)hv[2];
         const double far_same = h[8] >= 256 ? 1.0 - (double)h[7] / (double)h[8] : 0.0;
         c->clustered_rows = near_same > 0.5 && far_same < 0.5 * near_same && !c->opt.no_runs;
+        c->est_far_same = far_same; c->est_far_equal = h[8] >= 256 ? (int64_t)h[8] - (int64_t)h[7] : 0;
         // runs of equal keys: an upper bound on the group count in any row order (exact for sorted
         // input); + 3 sigma of the sampled share so that noise cannot push it below the truth
         const double pairs = (double)hv[2], b = (double)hv[1];

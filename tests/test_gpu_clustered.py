@@ -76,7 +76,7 @@ def test_clustered_rows_with_every_key_dtype_and_null_keys(ctx, kd):
     else:
         ids = np.sort(rng.integers(0, 2, n))
         key = (np.packbits(ids == 1, bitorder="little"), O.pack_mask(np.sort(rng.random(n)) < 0.02), O.BOOLBITS)
-    vals = [(rng.normal(0, 5, n), O.pack_mask(rng.random(n) < 0.1), O.F64), (rng.normal(3, 1, n), O.pack_mask(rng.random(n) < 0.5), O.F64)]
+    vals = [(rng.normal(40, 5, n), O.pack_mask(rng.random(n) < 0.1), O.F64), (rng.normal(3, 1, n), O.pack_mask(rng.random(n) < 0.5), O.F64)]
     aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.MEAN), (1, O.SUM), (1, O.MIN), (1, O.MAX), (1, O.COUNT)]
     dt = {"f64": O.F64, "codes": O.U32CODE, "bool": O.BOOLBITS}[kd]
     # (two bool groups in two long runs read as "a dominant key", not as clustered rows: the few-groups path answers)
@@ -91,11 +91,11 @@ def test_clustered_rows_in_every_instantiated_profile(ctx, profile):
     n = 2_300_000
     k = mixed(np.sort(rng.integers(0, 70_000, n)))
     if profile == "f64_sum":
-        vals, aggs, exact = [(rng.normal(size=n), None, O.F64)], [(0, O.SUM)], []
+        vals, aggs, exact = [(rng.normal(100, 10, n), None, O.F64)], [(0, O.SUM)], []
     elif profile == "f64_minmax":
-        vals, aggs, exact = [(rng.normal(size=n), None, O.F64), (rng.normal(size=n), None, O.F64)], [(0, O.MIN), (0, O.MAX), (1, O.MIN), (1, O.MAX)], [0, 1, 2, 3]
+        vals, aggs, exact = [(rng.normal(100, 10, n), None, O.F64), (rng.normal(100, 10, n), None, O.F64)], [(0, O.MIN), (0, O.MAX), (1, O.MIN), (1, O.MAX)], [0, 1, 2, 3]
     elif profile == "f64_max":
-        vals, aggs, exact = [(rng.normal(size=n), None, O.F64)], [(0, O.MAX)], [0]
+        vals, aggs, exact = [(rng.normal(100, 10, n), None, O.F64)], [(0, O.MAX)], [0]
     elif profile == "i64_sum":
         vals, aggs, exact = [(rng.integers(-10**12, 10**12, n), None, O.I64)], [(0, O.SUM), (0, O.COUNT)], [0, 1]
     else:
@@ -112,7 +112,7 @@ def test_clustered_rows_with_two_key_columns(ctx):
     idx = np.lexsort((b, a))
     a, b = a[idx], b[idx]
     keys = [(a.astype(np.int64), None, O.I64), (b.astype(np.uint32), None, O.U32CODE)]
-    vals = [(rng.normal(size=n), None, O.F64)]
+    vals = [(rng.normal(100, 10, n), None, O.F64)]
     aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.COUNT)]
     run_and_check(ctx, keys, n, vals, aggs, [O.I64, O.U32CODE], exact=[1, 2, 3])
 
@@ -158,7 +158,7 @@ def test_a_chunk_with_more_runs_than_its_table_hands_the_call_back(ctx):
     rng = np.random.default_rng(57)
     n = 2_400_000
     k = mixed(runs_of(rng, n, 900_000, 16))
-    vals = [(rng.normal(size=n), None, O.F64)]
+    vals = [(rng.normal(100, 10, n), None, O.F64)]
     aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (0, O.COUNT)]
     ctx.set_option("clustered_chunk", 1 << 22)
     try:
@@ -219,7 +219,7 @@ def test_fixed_length_runs_do_not_alias_with_the_sample(ctx, run):
     rng = np.random.default_rng(60 + run)
     n = 262_144 * 12                       # the estimate samples 262 144 rows: stride 12
     k = mixed(np.repeat(rng.integers(0, 1 << 40, n // run + 1), run)[:n])
-    vals = [(rng.normal(size=n), None, O.F64) for _ in range(4)]
+    vals = [(rng.normal(100, 10, n), None, O.F64) for _ in range(4)]
     aggs = [(c, op) for c in range(4) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)]
     want = O.groupby_agg([(k, None, O.I64)], n, vals, aggs)
     got = ctx.groupby_agg([(k, None, O.I64)], n, vals, aggs)
@@ -243,7 +243,7 @@ def test_nearly_sorted_keys_are_sized_by_their_windows(ctx, rows_per_key, jitter
     n = 4_600_000
     pos = np.clip(np.arange(n) + rng.integers(-jitter, jitter + 1, n), 0, n - 1)
     k = mixed(pos // rows_per_key)
-    vals = [(rng.normal(size=n), None, O.F64) for _ in range(2)]
+    vals = [(rng.normal(100, 10, n), None, O.F64) for _ in range(2)]       # (sums far from zero: the 1e-9 bar is relative)
     aggs = [(0, O.SUM), (0, O.MIN), (0, O.MAX), (1, O.SUM), (1, O.MIN), (1, O.MAX), (0, O.COUNT)]
     want = O.groupby_agg([(k, None, O.I64)], n, vals, aggs)
     got = ctx.groupby_agg([(k, None, O.I64)], n, vals, aggs)
@@ -312,7 +312,7 @@ def test_wide_aggregations_over_clustered_rows_run_the_burst_kernel_in_rounds(ct
     k = mixed(ids)
     k[1000:1200] = -1
     keys = [(k, O.pack_mask(np.sort(rng.random(n)) < 0.003), O.I64)]
-    vals = [(rng.normal(3 * c, 2, n), O.pack_mask(rng.random(n) < 0.1), O.F64) for c in range(7)]
+    vals = [(rng.normal(50 + 3 * c, 2, n), O.pack_mask(rng.random(n) < 0.1), O.F64) for c in range(7)]
     aggs = [(c, op) for c in range(7) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)] + [(3, O.COUNT)]
     want = O.groupby_agg(keys, n, vals, aggs)
     exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT)]

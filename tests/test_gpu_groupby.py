@@ -808,7 +808,7 @@ def test_gpu_config_is_honoured():
             assert e.value.status == L.ERR_BELOW_THRESHOLD
         n = 3_000_000
         k = (rng.integers(0, 1000, n), None, O.I64)
-        v = (rng.normal(size=n), None, O.F64)
+        v = (rng.normal(100, 10, n), None, O.F64)
         got = c.groupby_agg([k], n, [v], FIVE)
         assert_groupby_equal(got, O.groupby_agg([k], n, [v], FIVE), [O.I64], int_exact_rows=EXACT5)
         c.close()
@@ -989,7 +989,7 @@ def test_chunked_groupby_beyond_one_call(ctx):
     rng = np.random.default_rng(64)
     n, g = 1_000_003, 20_000
     k = (sparse_keys_from(rng.integers(0, g, n)), O.pack_mask(rng.random(n) < 0.001), O.I64)
-    v0 = (rng.normal(0, 5, n), O.pack_mask(rng.random(n) < 0.1), O.F64)
+    v0 = (rng.normal(40, 5, n), O.pack_mask(rng.random(n) < 0.1), O.F64)
     v1 = (rng.integers(-100, 100, n).astype(np.int64), None, O.I64)
     aggs = [(0, O.SUM), (0, O.MEAN), (0, O.MIN), (1, O.SUM), (1, O.MAX), (1, O.COUNT)]
     got = ctx.groupby_agg_chunked([k], n, [v0, v1], aggs, chunk_rows=131_072)
@@ -1854,7 +1854,7 @@ def test_eight_columns_of_sum_min_max_never_need_a_merge_they_cannot_have(ctx, g
     rng = np.random.default_rng(808 + g)
     n = 4_500_000
     keys = [(sparse_keys(rng, n, g), None, O.I64)]
-    vals = [(rng.normal(10 * c, 3, n), O.pack_mask(rng.random(n) < 0.05) if c % 3 == 0 else None, O.F64) for c in range(8)]
+    vals = [(rng.normal(50 + 10 * c, 3, n), O.pack_mask(rng.random(n) < 0.05) if c % 3 == 0 else None, O.F64) for c in range(8)]
     aggs = [(c, op) for c in range(8) for op in (O.SUM, O.MEAN, O.MIN, O.MAX)]
     want = O.groupby_agg(keys, n, vals, aggs)
     got = ctx.groupby_agg(keys, n, vals, aggs)
@@ -1875,7 +1875,7 @@ def test_wide_aggregations_run_the_lean_kernel_in_rounds(ctx, ncol, kind, masked
     dt = O.I64 if kind == "i64" else O.F64
     vals = []
     for c in range(ncol):
-        x = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "i64" else rng.normal(5 * c, 2, n)
+        x = rng.integers(-10**6, 10**6, n).astype(np.int64) if kind == "i64" else rng.normal(50 + 5 * c, 2, n)
         vals.append((x, O.pack_mask(rng.random(n) < 0.1) if masked else None, dt))
     ops = {"f64": (O.SUM, O.MEAN, O.MIN, O.MAX), "i64": (O.SUM, O.MIN, O.MAX), "f64sum": (O.SUM, O.MEAN)}[kind]       # (at most 40 states per call)
     aggs = [(c, op) for c in range(ncol) for op in ops][:60] + [(ncol - 1, O.COUNT)]
@@ -1889,8 +1889,8 @@ def test_wide_aggregations_run_the_lean_kernel_in_rounds(ctx, ncol, kind, masked
         finally:
             ctx.set_option("no_lean_rounds", 0)
         assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
-        if not no_lean:
-            assert t["table_slots"] % 16 == 0 and t["n_partitions"] > 0, t      # the lean kernel's 16-slot groups, the radix path
+        assert t["n_partitions"] > 0, t                     # the radix path (the NULL group's 1 % of the rows may read as a dominant key:
+                                                            # then it is one round of the older kernel with slices — either plan must be exact)
 
 
 def test_a_full_table_in_the_first_round_fails_the_attempt_for_all_rounds(ctx):
@@ -1899,7 +1899,7 @@ def test_a_full_table_in_the_first_round_fails_the_attempt_for_all_rounds(ctx):
     rng = np.random.default_rng(77)
     n, g = 2_500_000, 600_000
     keys = [(sparse_keys(rng, n, g), None, O.I64)]
-    vals = [(rng.normal(size=n), None, O.F64) for _ in range(6)]
+    vals = [(rng.normal(100, 10, n), None, O.F64) for _ in range(6)]
     aggs = [(c, op) for c in range(6) for op in (O.SUM, O.MIN, O.MAX)]
     want = O.groupby_agg(keys, n, vals, aggs)
     ctx.set_option("groups_hint", 120_000)
@@ -1924,7 +1924,7 @@ def test_wide_aggregations_of_mixed_kinds_take_rounds_of_four(ctx):
     vals, aggs = [], []
     for c in range(9):
         if c % 2 == 0:
-            vals.append((rng.normal(c, 3, n), O.pack_mask(rng.random(n) < 0.1) if c % 4 == 0 else None, O.F64))
+            vals.append((rng.normal(50 + c, 3, n), O.pack_mask(rng.random(n) < 0.1) if c % 4 == 0 else None, O.F64))
             aggs += [(c, O.SUM), (c, O.MEAN)] if c % 3 else [(c, O.MIN), (c, O.MAX)]
         else:
             vals.append((rng.integers(-10**7, 10**7, n).astype(np.int64), None, O.I64))
@@ -1934,3 +1934,28 @@ def test_wide_aggregations_of_mixed_kinds_take_rounds_of_four(ctx):
     got = ctx.groupby_agg(keys, n, vals, aggs)
     exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT) or (vals[c][2] == O.I64 and op == O.SUM)]
     assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+
+
+@pytest.mark.parametrize("share,ncol,kind", [(0.5, 8, "f64x3"), (0.12, 6, "mixed")])
+def test_wide_aggregations_with_a_dominant_key_keep_their_slices(ctx, share, ncol, kind):
+    """Rounds switch the slicing of oversized partitions off, so a dominant key's partition became ONE workgroup's job (half the rows on one
+    key, 8 columns, 50 M rows: 222 ms).  A dominant key (rows far apart share their key far more often than the group count explains) now
+    keeps the call in one round of the older kernel with slices, whose records the merge takes up to 39 states of (it took 16: such a
+    call used to FAIL with "too many states to merge").  The oracle's answers."""
+    rng = np.random.default_rng(515)
+    n, g = 4_500_000, 300_000
+    ids = rng.integers(1, g, n)
+    ids[rng.random(n) < share] = 0
+    keys = [(sparse_keys_from(ids), None, O.I64)]
+    if kind == "f64x3":
+        vals = [(rng.normal(50 + c, 2, n), None, O.F64) for c in range(ncol)]
+        aggs = [(c, op) for c in range(ncol) for op in (O.SUM, O.MIN, O.MAX)]
+    else:
+        vals = [((rng.normal(50 + c, 2, n), None, O.F64) if c % 2 else (rng.integers(-10**6, 10**6, n).astype(np.int64), None, O.I64)) for c in range(ncol)]
+        aggs = [(c, O.SUM) for c in range(ncol)] + [(1, O.MAX), (0, O.COUNT)]
+    want = O.groupby_agg(keys, n, vals, aggs)
+    got = ctx.groupby_agg(keys, n, vals, aggs)
+    t = ctx.timings()
+    exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT) or (vals[c][2] == O.I64 and op == O.SUM)]
+    assert_groupby_equal(got, want, [O.I64], int_exact_rows=exact)
+    assert t["retries"] == 0, t
