@@ -277,8 +277,9 @@ __global__ __launch_bounds__(AG_THREADS) void clustered_kernel(AggArgs a) {
             }
             const uint64_t g = gsz[s];
             if (emit_partials) {
-                o_states[pos] = g;
+                if (!resume) o_states[pos] = g;
                 for (int k = 0; k < a.n_states; k++) {
+                    if (rounds && a.st_round[k] != a.cur_round) continue;       // (a piece's record is filled in round by round, at launch 0's position)
                     const uint32_t l = (uint32_t)a.st_lds[k];
                     uint64_t cell = st[(size_t)l * T1 + s];
                     const int8_t kd = a.kinds[k];

@@ -1551,7 +1551,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // experiments/wide_hot.py).
     const bool dominant_key = c->est_far_equal >= 8 && c->est_far_same * (double)est > 20.0;
     const bool rounds_ok = !(dominant_key && pl.n_states <= MAX_MERGE_SRC) || c->opt.src_per_round > 0;
-    const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds && rounds_ok;
+    const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds;            // (slices work inside the lean kernel's rounds)
     // (long runs too when there are more than 4 columns: the one-pass path takes at most 4, and the burst kernel in rounds behind the exact
     // partition — sorted rows, 8 columns x 4 aggregates, 50 M rows: 3.3 ms — beats the older kernel's 24 states in one table: 9.6)
     const bool wide_clustered = c->clustered_rows && n_src > 4 && clustered_has(4, uni_profile) && !c->opt.no_burst_kernel;
@@ -1726,7 +1726,7 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         // oversized partitions (a hot key, heavy skew) are cut into row slices for separate workgroups
         int n_var_src = 0;
         for (int s2 = 0; s2 < pl.n_src; s2++) n_var_src += pl.st_ssq[s2] >= 0;
-        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && n_rounds == 1 && pl.n_states <= MAX_MERGE_SRC;
+        const bool slicing = !c->opt.no_slice && (pl.mergeable || (!partials && !merge && n_var_src <= MAX_MERGE_VAR)) && (n_rounds == 1 || (use_v2 && !partials)) && pl.n_states <= MAX_MERGE_SRC;      // (the lean kernel's rounds fill a piece's record round by round)
         const int64_t slice_rows = c->opt.slice_rows > 0 ? c->opt.slice_rows
                                  : auto_slice_rows > 0 ? auto_slice_rows
                                                        : std::max<int64_t>(int64_t(1) << 18, (c->opt.wide_slices ? 4 : (c->opt.slice_over > 0 ? c->opt.slice_over : 2)) * (N / std::max<int64_t>(P, 1)));
