@@ -1584,7 +1584,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         const size_t slot_bytes = (use_v2 ? 13 : 20) + 8 * (size_t)round_states;    // aggregate2: u32 group sizes, one tag byte, no position map
         T = (int64_t)((lds_budget - 192 - (use_v2 ? AGG2_LDS_EXTRA : 0)) / slot_bytes) - 3;
         T = std::min<int64_t>(T, 32768) & (use_v2 ? ~int64_t(15) : ~int64_t(3));   // 16-slot groups / 4-key buckets
-        P = (int64_t)std::ceil((double)est / ((double)T * LOAD));
+        // (the lean kernel's rounds have no overflow run behind a full table: planned at load 0.6, an estimate 35 % too low still fits —
+        // at 0.7 one that was 25 % too low cost the attempt: 6 M groups estimated as 4.5 M, 10.9 ms against 6.8 for the single round)
+        P = (int64_t)std::ceil((double)est / ((double)T * ((use_v2 && n_rounds > 1 && c->opt.load_pct <= 0) ? 0.6 : LOAD)));
         if (c->opt.src_per_round > 0 || spr <= 1 || P <= P_TARGET || pl.needs_second_pass) break;
     }
     if (T < 64) return fail(PANDRS_HIP_ERR_OPERATION_FAILED, "too many aggregate states for one LDS table");
