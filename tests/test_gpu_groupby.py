@@ -1938,10 +1938,11 @@ def test_wide_aggregations_of_mixed_kinds_take_rounds_of_four(ctx):
 
 @pytest.mark.parametrize("share,ncol,kind", [(0.5, 8, "f64x3"), (0.12, 6, "mixed")])
 def test_wide_aggregations_with_a_dominant_key_keep_their_slices(ctx, share, ncol, kind):
-    """Rounds switch the slicing of oversized partitions off, so a dominant key's partition became ONE workgroup's job (half the rows on one
-    key, 8 columns, 50 M rows: 222 ms).  A dominant key (rows far apart share their key far more often than the group count explains) now
-    keeps the call in one round of the older kernel with slices, whose records the merge takes up to 39 states of (it took 16: such a
-    call used to FAIL with "too many states to merge").  The oracle's answers."""
+    """A dominant key's partition must be cut into row slices whatever the plan — in rounds it was not, and became ONE workgroup's job (half
+    the rows on one key, 8 columns, 50 M rows: 222 ms).  The lean kernel's rounds cut it now (a piece's partial record is filled in round
+    by round at the position launch 0 recorded; one merge at the end — of up to 39 states, it took 16 and such a call used to FAIL with
+    "too many states to merge"); columns of mixed kinds stay in one round of the older kernel with slices when the estimate's far pairs
+    show a dominant key.  Both shapes, the oracle's answers, one attempt."""
     rng = np.random.default_rng(515)
     n, g = 4_500_000, 300_000
     ids = rng.integers(1, g, n)
