@@ -63,7 +63,6 @@ struct AggArgs {
     // is appended — key cell, values, validity bytes — at counters[6] instead of failing the call.  The keys of such rows are
     // in no table (a full table stays full), so they are a disjoint sub-problem: the host groups them on their own and appends
     // the groups.  Not for `multi` tables (another slice may hold the key); more than ov_cap rows => the overflow flag as before.
-    uint32_t fold_last;                            // aggregate2: 1 = also look at the last placed lane's slot for a fold (keys arrive in bursts)
     uint32_t fold_min, fold_min_multi;             // aggregate2: lanes in one slot from which a wave folds them on the VALU (ordinary tables, pieces)
     MergeVar mvar[MAX_MERGE_VAR]; int n_mvar;      // merge mode with a second pass
     uint64_t *ov_keys; uint64_t *ov_vals[4]; uint8_t *ov_valid[4]; uint32_t ov_cap;      // (aggregate2 instantiates 1..4 sources)

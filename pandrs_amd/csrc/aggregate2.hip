@@ -394,18 +394,6 @@ __global__ __launch_bounds__(AG_THREADS) void aggregate2_kernel(AggArgs a) {
                             if (ok && !same) update(idx, v, okm);
                             continue;
                         }
-                        if (a.fold_last) {
-                            // keys that arrive in bursts (rows clustered or local in position: the host sets this): a wave that straddles two
-                            // bursts has the smaller one in front half of the time — look at the LAST placed lane's slot too
-                            const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)idx, __builtin_amdgcn_readfirstlane(63 - __clzll((long long)okw)));
-                            const bool same1 = ok && idx == s1;
-                            const unsigned long long same1w = __ballot(same1);
-                            if ((uint32_t)__popcll(same1w) >= (cur_multi ? a.fold_min_multi : a.fold_min)) {
-                                wave_fold(s1, same1w, same1, v, okm);
-                                if (ok && !same1) update(idx, v, okm);
-                                continue;
-                            }
-                        }
                     }
                 }
                 if (ok) update(idx, v, okm);
@@ -710,8 +698,6 @@ bool launch_aggregate2(pandrs_hip_ctx *c, const AggArgs &a_in, int n_src, int pr
     AggArgs a = a_in;
     a.fold_min = c->opt.fold_min > 0 ? (uint32_t)c->opt.fold_min : FOLD_MIN;
     a.fold_min_multi = c->opt.fold_min_multi > 0 ? (uint32_t)c->opt.fold_min_multi : FOLD_MIN_MULTI;
-    a.fold_last = (c->clustered_rows || c->clumped_rows) ? 1u : 0u;
-    if (a.fold_last && c->opt.fold_min <= 0) a.fold_min = 32;          // (bursts: the other lanes of the wave are mostly ONE other key)
     if ((c->opt.agg_depth > 0 || c->opt.agg_ablate > 0) && profile == 14 && (n_src == 4 || n_src == 2)) {
         // experiments only: what the kernel's time is made of (ablate: 1 no min / max work, 2 key lookup + group
         // size only, 3 the HBM stream alone, 4 ... without epilogue, 6 full work on L2-resident rows) and the ring depth
