@@ -89,7 +89,7 @@ for case in range(first_case, n_cases):
                     "agg_v1": int(rng.random() < 0.15), "exact_partition": int(rng.random() < 0.2), "deterministic": int(rng.random() < 0.15),
                     "no_small": int(rng.random() < 0.4), "no_absorb": int(rng.choice([0, 0, -1, -1, 1])), "no_hot_image": int(rng.random() < 0.3), "scatter_wide": int(rng.choice([0, 1, 1, -1])), "two_pass_min_p": int(rng.choice([0, 0, 96])), "sorted_dictionary": int(rng.random() < 0.3), "wide_slices": int(rng.random() < 0.3), "no_census": int(rng.random() < 0.3),
                     "no_table_order": int(rng.random() < 0.25), "p_target": int(rng.choice([0, 0, 3072, 64])),
-                    "no_lean_rounds": int(rng.random() < 0.2), "no_burst_kernel": int(rng.random() < 0.2), "no_window_bound": int(rng.random() < 0.1), "no_clustered": int(rng.random() < 0.15), "clustered_chunk": int(rng.choice([0, 0, 0, 4096, 1 << 20])), "clustered_max_runs_pct": int(rng.choice([0, 0, 45]))}
+                    "no_lean_rounds": int(rng.random() < 0.2), "no_profile_rounds": int(rng.random() < 0.25), "no_burst_kernel": int(rng.random() < 0.2), "no_window_bound": int(rng.random() < 0.1), "no_clustered": int(rng.random() < 0.15), "clustered_chunk": int(rng.choice([0, 0, 0, 4096, 1 << 20])), "clustered_max_runs_pct": int(rng.choice([0, 0, 45]))}
             for k, v in opts.items(): ctx.set_option(k, v)
             try:
                 got = ctx.groupby_agg(keys, n, vals, aggs)
@@ -97,7 +97,7 @@ for case in range(first_case, n_cases):
                 n_clustered += ctx.timings()["n_partitions"] == -2
             finally:
                 for k, v in {"no_direct": 0, "slice_rows": 0, "p_max": 0, "generic_aggregate": 0, "scatter_staged": 1, "shared_cursors": 1,
-                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0, "sorted_dictionary": 0, "wide_slices": 0, "no_census": 0, "no_table_order": 0, "p_target": 0, "no_lean_rounds": 0, "no_burst_kernel": 0, "no_window_bound": 0, "no_clustered": 0, "clustered_chunk": 0, "clustered_max_runs_pct": 0}.items(): ctx.set_option(k, v)
+                             "agg_v1": 0, "exact_partition": 0, "deterministic": 0, "no_small": 0, "no_absorb": 0, "no_hot_image": 0, "scatter_wide": 0, "two_pass_min_p": 0, "sorted_dictionary": 0, "wide_slices": 0, "no_census": 0, "no_table_order": 0, "p_target": 0, "no_lean_rounds": 0, "no_profile_rounds": 0, "no_burst_kernel": 0, "no_window_bound": 0, "no_clustered": 0, "clustered_chunk": 0, "clustered_max_runs_pct": 0}.items(): ctx.set_option(k, v)
             want = O.groupby_agg(keys, n, vals, aggs)
             exact = [i for i, (c, op) in enumerate(aggs) if op in (O.MIN, O.MAX, O.COUNT, O.FIRST, O.LAST, O.MEDIAN, O.NUNIQUE) or (vals[c][2] == O.I64 and op == O.SUM)]
             if opts["deterministic"] and not any(np.isnan(np.asarray(v[0], np.float64)).any() or np.isinf(np.asarray(v[0], np.float64)).any() for v in vals if v[2] == O.F64):

@@ -226,6 +226,8 @@ int32_t pandrs_hip_alloc_events(int64_t *out_device_allocations);
  *   "slice_over"        experiments: a partition is cut when it holds more than this many average partitions' rows (default 2)
  *   "no_clustered"      1 = never the one-pass path for rows clustered by key (sorted input, input grouped by key); "clustered_chunk"
  *                       rows per chunk there, "clustered_max_runs_pct" runs per 100 rows up to which it is taken (default 13)
+ *   "no_profile_rounds" 1 = aggregated columns of mixed kinds / op sets go to the older kernel (default: ordered by profile, the lean kernel
+ *                       takes up to 4 columns of one profile per round)
  *   "no_burst_kernel"   1 = partitions whose keys arrive in bursts (short runs, keys local in position) are aggregated row per lane by the
  *                       lean kernel instead of 8 consecutive rows per thread
  *   "no_window_bound"   1 = the group estimate never counts distinct keys in windows of consecutive rows (its bound for keys that are

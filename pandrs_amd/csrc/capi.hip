@@ -223,6 +223,7 @@ int32_t pandrs_hip_ctx_set_option(pandrs_hip_ctx *c, const char *name, int64_t v
     else if (!std::strcmp(name, "no_lean_rounds")) c->opt.no_lean_rounds = value;
     else if (!std::strcmp(name, "no_window_bound")) c->opt.no_window_bound = value;
     else if (!std::strcmp(name, "no_burst_kernel")) c->opt.no_burst_kernel = value;
+    else if (!std::strcmp(name, "no_profile_rounds")) c->opt.no_profile_rounds = value;
     else if (!std::strcmp(name, "no_clustered")) c->opt.no_clustered = value;
     else if (!std::strcmp(name, "clustered_chunk")) c->opt.clustered_chunk = value;
     else if (!std::strcmp(name, "clustered_max_runs_pct")) c->opt.clustered_max_runs_pct = value;

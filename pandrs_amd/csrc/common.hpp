@@ -200,6 +200,7 @@ struct Options {
     int64_t no_clustered = 0;        // 1 = never the one-pass path for rows clustered by key (groupby.hip, run_clustered)
     int64_t clustered_chunk = 0;     // experiments / tests: rows per chunk there (0 = from the sample's runs per row)
     int64_t clustered_max_runs_pct = 0;   // experiments / tests: the path is taken up to this many runs per 100 rows (0 = default 13)
+    int64_t no_profile_rounds = 0;   // 1 = columns without a uniform profile always go to the older kernel (before: the only choice)
     int64_t no_burst_kernel = 0;     // 1 = partitions whose keys arrive in bursts still go to the lean kernel (row per lane)
     int64_t no_window_bound = 0;     // 1 = the estimate never looks at windows of consecutive rows (keys local in position)
     int64_t no_lean_rounds = 0;      // 1 = more than one round always means the older kernel (before: the only choice)

@@ -1533,6 +1533,24 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         uni_profile = prof_of(srcs[0]);
         for (int s = 1; s < n_src; s++) if (prof_of(srcs[s]) != uni_profile) uni_profile = -1;
     }
+    // Columns of MIXED kinds / op sets (f64 and i64 side by side, sums on some and min / max on others): no uniform profile, but the lean
+    // kernel's rounds hand on nothing that depends on the profile (keys, tags, output positions) — so the sources are ordered by profile
+    // and every round takes up to 4 sources of ONE profile, with that profile's instantiation.  (Before: the older kernel; 4 f64 + 4 i64
+    // columns x sum, 50 M rows, 3.8 ms in its rounds of 4, 8-13 ms with a dominant key — experiments/mixed_wide.py, wide_hot.py.)
+    int round_prof[MAX_ROUNDS];
+    for (int r = 0; r < MAX_ROUNDS; r++) round_prof[r] = uni_profile;
+    bool grouped = false;
+    if (uni_profile < 0 && !merge && !rs.pre && !partials && n_src >= 2 && !c->opt.generic_aggregate && pl.mergeable && !pl.needs_second_pass &&
+        !c->opt.no_lean_rounds && !c->opt.no_profile_rounds && !c->opt.agg_v1 && c->opt.src_per_round <= 0 && c->opt.partitions <= 0 &&
+        (!c->clustered_rows || 1.0 - c->est_near_same > 0.09)) {
+        bool all_ok = true;
+        for (auto &e : srcs)
+            all_ok = all_ok && !e.rowidx && e.data && e.st_fadd < 0 && e.st_ssq < 0 && !(e.null_bits && e.valid_bytes) && aggregate2_has(1, prof_of(e));
+        if (all_ok) {
+            std::stable_sort(srcs.begin(), srcs.end(), [&](const EngSrc &x, const EngSrc &y) { return prof_of(x) < prof_of(y); });
+            grouped = true;
+        }
+    }
     // the lean persistent kernel (aggregate2.hip): one round of a uniform profile over unclustered raw rows
     // rows clustered in SHORT runs (fewer than ~11 rows: what the one-pass path above does not take or handed back): 3-10 lanes of a wave
     // on one slot cost the lean kernel less than the older kernel's RUNS instantiation costs everywhere else (runs of 4, C2's shape:
@@ -1555,8 +1573,9 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // (long runs too when there are more than 4 columns: the one-pass path takes at most 4, and the burst kernel in rounds behind the exact
     // partition — sorted rows, 8 columns x 4 aggregates, 50 M rows: 3.3 ms — beats the older kernel's 24 states in one table: 9.6)
     const bool wide_clustered = c->clustered_rows && n_src > 4 && clustered_has(4, uni_profile) && !c->opt.no_burst_kernel;
-    const bool v2_ok = uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs || wide_clustered) && !c->opt.agg_v1 &&
-                       aggregate2_has(std::min(n_src, 4), uni_profile) && (n_src <= 4 || lean_rounds_ok);
+    const bool v2_ok = grouped ? lean_rounds_ok
+                     : (uni_profile >= 0 && !pl.needs_second_pass && (!c->clustered_rows || short_runs || wide_clustered) && !c->opt.agg_v1 &&
+                        aggregate2_has(std::min(n_src, 4), uni_profile) && (n_src <= 4 || lean_rounds_ok));
     if (v2_ok && n_src > 4) spr = 4;
     // the older kernel with more than 4 sources in a round is its catch-all instantiation (register arrays for 16 sources: it spills):
     // 4 f64 + 4 i64 columns x sum, 50 M rows, 8.3 ms in one round, 3.8 in two (experiments/mixed_wide.py).  Merges have their own loop.
@@ -1567,6 +1586,23 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // C2's 12 states, 100 M rows: 5 M uniform groups one round at P = 5120 5.43 ms, two rounds at 2816 4.82; 7 M: 6.05 / 5.37; 4 M: a tie;
     // before the lean kernel had rounds, one lean round up to 8192 was the better plan: 5.9 and 7.3 ms with the older kernel's rounds)
     const int64_t P_TARGET = c->opt.p_target > 0 ? c->opt.p_target : (v2_ok ? (lean_rounds_ok ? 4096 : P_MAX) : 3072);
+    if (grouped && v2_ok) {
+        // one round per run of up to 4 sources of one profile
+        n_rounds = 0; round_states = 0; max_spr = 0;
+        for (int b = 0; b < n_src;) {
+            const int p = prof_of(srcs[b]);
+            int e2 = b, ns = 0;
+            while (e2 < n_src && e2 - b < 4 && prof_of(srcs[e2]) == p) { ns += srcs[e2].n_states(); e2++; }
+            round_begin[n_rounds] = (int8_t)b; round_prof[n_rounds] = p; n_rounds++; round_begin[n_rounds] = (int8_t)e2;
+            round_states = std::max(round_states, ns); max_spr = std::max(max_spr, e2 - b);
+            b = e2;
+        }
+        use_v2 = true;
+        const size_t sb = 13 + 8 * (size_t)round_states;
+        T = (int64_t)((lds_budget - 192 - AGG2_LDS_EXTRA) / sb) - 3;
+        T = std::min<int64_t>(T, 32768) & ~int64_t(15);
+        P = (int64_t)std::ceil((double)est / ((double)T * (c->opt.load_pct > 0 ? LOAD : 0.6)));
+    } else
     for (;; spr = (spr + 1) / 2) {
         if (c->opt.src_per_round > 0 && !pl.needs_second_pass) spr = (int)std::min<int64_t>(c->opt.src_per_round, std::max(n_src, 1));
         n_rounds = n_src ? (n_src + spr - 1) / spr : 1;
@@ -1667,11 +1703,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
         for (int k = 0; k < MAX_STATES; k++) { st_round[k] = -1; st_lds[k] = -1; }
         // aggregate2's fixed LDS state order: the adds of source 0..n-1, then per source its min-type states
         // (min, ~max), then the non-null counts
-        const int v2_mm = use_v2 ? ((uni_profile >> 2) & 1) + ((uni_profile >> 3) & 1) : 0;
         for (int r = 0; r < n_rounds; r++) {
             int next = 0;
             const int n_r = round_begin[r + 1] - round_begin[r];          // (the order holds inside every round of the lean kernel)
-            const int v2_mbase = use_v2 && ((uni_profile >> 1) & 1) ? n_r : 0;
+            const int rp = round_prof[r];                                   // (rounds grouped by profile: each round its own)
+            const int v2_mm = use_v2 ? ((rp >> 2) & 1) + ((rp >> 3) & 1) : 0;
+            const int v2_mbase = use_v2 && ((rp >> 1) & 1) ? n_r : 0;
             int v2_next_nn = v2_mbase + n_r * v2_mm;
             for (int s = round_begin[r]; s < round_begin[r + 1]; s++) {
                 EngSrc &e = srcs[s];
@@ -1843,8 +1880,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
             // keys that arrive in bursts inside their partition (rows clustered in short runs, keys local in position — both behind the exact
             // partition): every thread folds 8 consecutive rows of the partition in registers (clustered.hip, PARTS) instead of the lean
             // kernel's row per lane, whose fast path never gets going when a key is new as its burst arrives
-            const bool bursts = use_v2 && !sampled && !rs.pre && (c->clumped_rows || c->clustered_rows) && clustered_has(std::min(n_src, 4), uni_profile) &&
-                                !c->opt.no_burst_kernel;
+            bool bursts = use_v2 && !sampled && !rs.pre && (c->clumped_rows || c->clustered_rows) && !c->opt.no_burst_kernel;
+            for (int r = 0; r < n_rounds && bursts; r++) bursts = clustered_has(round_begin[r + 1] - round_begin[r], round_prof[r]);
             if (use_v2 && n_rounds > 1) {
                 // one launch per round over the same tables; only the last one publishes (host_out), the others re-arm the launch counters
                 uint32_t *const publish = aa.host_out;
@@ -1852,8 +1889,8 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
                 for (int r = 0; r < n_rounds && polled; r++) {
                     aa.cur_round = r; aa.src_base = round_begin[r];
                     aa.host_out = r + 1 == n_rounds ? publish : nullptr;
-                    polled = bursts ? launch_clustered_parts(c, aa, round_begin[r + 1] - round_begin[r], profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))
-                                    : launch_aggregate2(c, aa, round_begin[r + 1] - round_begin[r], profile, lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
+                    polled = bursts ? launch_clustered_parts(c, aa, round_begin[r + 1] - round_begin[r], round_prof[r], lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid))
+                                    : launch_aggregate2(c, aa, round_begin[r + 1] - round_begin[r], round_prof[r], lds, (uint32_t)std::min<int64_t>(c->n_cu, aa.launch_grid));
                 }
                 if (!polled) return fail(PANDRS_HIP_ERR_COMPUTATION, "lean aggregate: no instantiation for a round of this profile");
             } else {
