@@ -1561,12 +1561,12 @@ int32_t run_engine(pandrs_hip_ctx *c, const RowSource &rs, const Plan &pl, bool 
     // feed, are folded 4 (2, 1) columns at a time by one launch each over the same partitions; launch 0 leaves every table's keys and
     // output positions behind and the later launches start from them (aggregate.hpp, snap_*).  8 columns x sum / mean / min / max over
     // 1 M groups, 50 M rows: 9.2 ms (the older kernel, one round of 24 states in 764-slot tables) -> see experiments/cliff_hunt.py.
-    // Not for partial states (a record of more than 16 states cannot be merged anyway), merges and pre-partitioned rows.
+    // Not for partial states, merges and pre-partitioned rows.
     // A DOMINANT key (rows far apart share their key far more often than `est` equally likely keys would: a key with >= ~1 % of the rows)
-    // needs its partition cut into row slices, and rounds switch the slicing off (a piece's records would hold one round's states): half the
-    // rows on one key, 4 f64 + 4 i64 columns x sum, 50 M rows — 248 ms in rounds (one workgroup walks 25 M rows), 8.2 in one round of the older
-    // kernel with slices.  So no rounds then (a merge takes up to 39 states since the same day: 8 columns x sum / min / max, 222 -> see
-    // experiments/wide_hot.py).
+    // needs its partition cut into row slices.  The lean kernel's rounds cut it (a piece's partial record is filled in round by round at
+    // launch 0's position, one merge of up to 39 states at the end); the OLDER kernel's rounds do not — half the rows on one key, 4 f64 +
+    // 4 i64 columns x sum, 50 M rows: 248 ms in its rounds (one workgroup walks 25 M rows), 8.2 in one round with slices — so `rounds_ok`
+    // keeps it to one round then (experiments/wide_hot.py; what still gets there: Std / Var, First / Last, forced plans).
     const bool dominant_key = c->est_far_equal >= 8 && c->est_far_same * (double)est > 20.0;
     const bool rounds_ok = !(dominant_key && pl.n_states <= MAX_MERGE_SRC) || c->opt.src_per_round > 0;
     const bool lean_rounds_ok = !partials && !merge && !rs.pre && !c->opt.no_lean_rounds;            // (slices work inside the lean kernel's rounds)
